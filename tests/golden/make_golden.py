@@ -1,0 +1,327 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference on seeded inputs (CPU).
+
+Run only in the build container, where ``/root/reference`` exists:
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules (never copied into this repo), feeds them
+numpy-seeded inputs, and stores inputs' seeds + outputs as small ``.npz`` vectors.
+The GPU box has no ``/root/reference``; tests there read only the committed vectors.
+
+Import shims: ``Tensor.cuda``/``Module.cuda`` become
+no-ops (the reference calls ``.cuda()`` unconditionally, ``geomloss/utils.py:80-81``,
+``GenProjector/util.py:357``), and absent third-party modules that the reference
+imports at file top but that the hot path never touches (cv2, OpenEXR, Imath,
+imageio, vtk) are stubbed with ``MagicMock``.
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.set_num_threads(8)
+
+
+def rng(*seed):
+    return np.random.default_rng(list(seed))
+
+
+def softmax_np(v, axis=-1):
+    v = v - v.max(axis=axis, keepdims=True)
+    e = np.exp(v)
+    return (e / e.sum(axis=axis, keepdims=True)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- sinkhorn
+def ref_geomloss():
+    sys.path.insert(0, os.path.join(REF, "RegressionNetwork"))
+    import geomloss  # noqa: the reference package
+    from geomloss import utils as gutils
+    return geomloss, gutils
+
+
+def ref_samples_loss(geomloss, gutils, n, batch, blur, diameter=None):
+    """A reference SamplesLoss whose `distance` has N == n.
+
+    n == 96 uses the reference constructor verbatim.  For other n the reference
+    hard-codes N (utils.py:66), so the `distance` object is allocated without running
+    its __init__ and given M built by the reference's own recipe (sphere_points ->
+    f32 -> pairwise torch.norm, utils.py:67-76); every other line that runs
+    (spherical_distance, sinkhorn_loop, softmin_tensorized, ...) is the reference's.
+    """
+    if n == 96:
+        return geomloss.SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, batchsize=batch)
+    anchors = torch.from_numpy(gutils.sphere_points(n)).float()
+    M = torch.ones((n, n))
+    for i in range(n):
+        M[i] = torch.norm(anchors[i][None, :] - anchors, dim=1)
+        for j in (0, n // 3, n - 1):  # spot-check the vectorised row against the scalar form
+            assert M[i, j] == torch.norm(anchors[i] - anchors[j])
+    M[M < 0] = 0
+    d = gutils.distance.__new__(gutils.distance)
+    d.N = n
+    d.anchors = anchors.unsqueeze(0).repeat(batch, 1, 1)
+    d.M = M.unsqueeze(0).repeat(batch, 1, 1)
+    loss = geomloss.SamplesLoss.__new__(geomloss.SamplesLoss)
+    torch.nn.Module.__init__(loss)
+    loss.loss, loss.p, loss.blur, loss.reach = "sinkhorn", 2, blur, None
+    loss.diameter, loss.scaling, loss.distance = diameter, .5, d
+    return loss
+
+
+def sinkhorn_inputs(kind, B, n, seed):
+    g = rng(seed, n, B)
+    if kind == "softmax":
+        x = softmax_np(g.standard_normal((B, n)))
+        y = softmax_np(2.0 * g.standard_normal((B, n)))
+    elif kind == "sparse":  # GT-like: sparse simplex target
+        x = softmax_np(g.standard_normal((B, n)))
+        y = softmax_np(4.0 * g.standard_normal((B, n)))
+        thr = np.quantile(y, 0.75, axis=1, keepdims=True)
+        y = np.where(y < thr, 0.0, y)
+        y = (y / y.sum(1, keepdims=True)).astype(np.float32)
+    elif kind == "logits":
+        x = g.standard_normal((B, n)).astype(np.float32)
+        y = g.standard_normal((B, n)).astype(np.float32)
+    elif kind == "tiny":  # diameter < blur: schedule collapses to 2 entries
+        x = (0.01 + 1e-3 * g.random((B, n))).astype(np.float32)
+        y = (0.01 + 1e-3 * g.random((B, n))).astype(np.float32)
+    else:
+        raise ValueError(kind)
+    return x, y
+
+
+SINKHORN_CASES = [
+    # name, kind, B, N, blur, diameter
+    ("n96_blur025", "softmax", 4, 96, .025, None),   # train.py:61 setting
+    ("n96_blur05", "softmax", 4, 96, .05, None),     # SamplesLoss default
+    ("n96_sparse", "sparse", 4, 96, .05, None),
+    ("n96_logits", "logits", 3, 96, .025, None),     # raw +-3 sigma logits: ~12 eps steps
+    ("n96_tiny", "tiny", 2, 96, .05, None),          # diameter < blur edge
+    ("n96_fixdiam", "softmax", 4, 96, .05, 1.0),
+    ("n128_blur05", "sparse", 4, 128, .05, None),    # BASELINE cfg2 shape
+    ("n128_blur025", "softmax", 2, 128, .025, None),
+    ("n256_blur05", "sparse", 2, 256, .05, None),    # BASELINE cfg5 shape
+    ("n64_blur05", "softmax", 3, 64, .05, None),
+    ("n50_blur05", "softmax", 2, 50, .05, None),     # ragged N (not a multiple of 32)
+]
+
+
+def gen_sinkhorn():
+    geomloss, gutils = ref_geomloss()
+    from geomloss import sinkhorn_divergence as sd
+    out = {}
+    for name, kind, B, n, blur, diam in SINKHORN_CASES:
+        x_np, y_np = sinkhorn_inputs(kind, B, n, 7)
+        x = torch.from_numpy(x_np).view(B, n, 1).requires_grad_(True)
+        y = torch.from_numpy(y_np).view(B, n, 1)
+        crit = ref_samples_loss(geomloss, gutils, n, B, blur, diam)
+        # capture the schedule and the duals the reference computes internally
+        cap = {}
+        orig_sp, orig_cost = sd.scaling_parameters, sd.sinkhorn_cost
+        import geomloss.samples_loss as sl
+
+        def sp(*a, **k):
+            r = orig_sp(*a, **k)
+            cap["diameter"], cap["eps_s"] = r[0], list(r[2])
+            return r
+
+        def sc(eps, rho, a, b, a_x, b_y, a_y, b_x):
+            cap["duals"] = [t.detach().numpy().copy() for t in (a_x, b_y, a_y, b_x)]
+            return orig_cost(eps, rho, a, b, a_x, b_y, a_y, b_x)
+
+        sl.scaling_parameters, sl.sinkhorn_cost = sp, sc
+        try:
+            loss = crit(x, y)
+        finally:
+            sl.scaling_parameters, sl.sinkhorn_cost = orig_sp, orig_cost
+        loss.sum().backward()
+        out[name + "/x"] = x_np
+        out[name + "/y"] = y_np
+        out[name + "/loss"] = loss.detach().numpy()
+        out[name + "/grad_x"] = x.grad.numpy().reshape(B, n)
+        out[name + "/eps_s"] = np.asarray(cap["eps_s"], dtype=np.float64)
+        out[name + "/diameter"] = np.float64(cap["diameter"])
+        out[name + "/duals"] = np.stack(cap["duals"])
+        out[name + "/blur"] = np.float64(blur)
+        out[name + "/fixed_diameter"] = np.float64(-1.0 if diam is None else diam)
+        if name in ("n96_blur025", "n128_blur05"):
+            out[name + "/M"] = crit.distance.M[0].numpy()
+            C = crit.distance.spherical_distance(x.detach(), y) / 2
+            out[name + "/C_xy"] = C.numpy()
+        print("sinkhorn", name, "n_eps", len(cap["eps_s"]), "loss0 %.4e" % float(loss[0]))
+    # reference M checksums for N=256 (full matrix is 256 KB: store every 16th row)
+    crit = ref_samples_loss(geomloss, gutils, 256, 1, .05)
+    out["M256_rows16"] = crit.distance.M[0, ::16].numpy()
+    out["sphere_points_96"] = gutils.sphere_points(96)
+    out["sphere_points_128"] = gutils.sphere_points(128)
+    np.savez_compressed(os.path.join(HERE, "sinkhorn.npz"), **out)
+
+
+# --------------------------------------------------------------------------- rasteriser
+def stub_io_modules():
+    for m in ["cv2", "OpenEXR", "Imath", "imageio", "imageio.plugins",
+              "imageio.plugins.freeimage", "vtk", "vtk.util", "vtk.util.numpy_support",
+              "torchvision", "torchvision.transforms", "torchvision.models",
+              "matplotlib", "matplotlib.pyplot"]:
+        sys.modules.setdefault(m, MagicMock())
+
+
+def raster_inputs(B, n, seed, anchors):
+    g = rng(seed, B, n)
+    dirs = np.tile(anchors.reshape(1, 3 * n), (B, 1)).astype(np.float32)
+    sizes = np.full((B, n), 0.0025, dtype=np.float32)
+    dist = softmax_np(3.0 * g.standard_normal((B, n)))
+    inten = g.uniform(50, 500, (B, 1, 1))
+    rgb = g.uniform(0.4, 0.7, (B, 1, 3))
+    colors = (dist[:, :, None] * inten * rgb).reshape(B, 3 * n).astype(np.float32)
+    return dirs, sizes, colors
+
+
+def gen_rasteriser():
+    stub_io_modules()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_gp_util", os.path.join(REF, "GenProjector", "util.py"))
+    gp_util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp_util)
+    out = {}
+    _, gutils = ref_geomloss()
+    for name, B, n, rows in [("b1_n128", 1, 128, 1), ("b2_n96", 2, 96, 4), ("b3_n42", 3, 42, 8)]:
+        dirs, sizes, colors = raster_inputs(B, n, 11, gutils.sphere_points(n))
+        if name == "b3_n42":  # varied lobe widths + off-anchor directions
+            g = rng(5)
+            sizes = g.uniform(0.002, 0.3, sizes.shape).astype(np.float32)
+            d = g.standard_normal((B, n, 3))
+            dirs = (d / np.linalg.norm(d, axis=2, keepdims=True)).reshape(B, 3 * n).astype(np.float32)
+        pano = gp_util.convert_to_panorama(torch.from_numpy(dirs), torch.from_numpy(sizes),
+                                           torch.from_numpy(colors)).numpy()
+        out[name + "/dirs"], out[name + "/sizes"], out[name + "/colors"] = dirs, sizes, colors
+        out[name + "/pano_rows"] = pano[:, :, ::rows]
+        out[name + "/row_stride"] = np.int64(rows)
+        out[name + "/sum"] = np.float64(pano.astype(np.float64).sum())
+        print("raster", name, pano.shape, "sum %.3f max %.4f" % (pano.sum(), pano.max()))
+    # variable-latitude form (panorama.py:68-82,142-152) at 256x512 -- BASELINE cfg5
+    spec = importlib.util.spec_from_file_location("ref_panorama", os.path.join(REF, "RegressionNetwork", "panorama.py"))
+    sys.modules.setdefault("util", MagicMock())
+    pano_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pano_mod)
+    P = pano_mod.Panorama(N=256, latitude=256)
+    dirs, sizes, colors = raster_inputs(1, 256, 13, gutils.sphere_points(256))
+    pano = P.convert_to_panorama(torch.from_numpy(dirs), torch.from_numpy(sizes),
+                                 torch.from_numpy(colors)).detach().numpy()
+    out["lat256/dirs"], out["lat256/sizes"], out["lat256/colors"] = dirs, sizes, colors
+    out["lat256/pano_rows"] = pano[:, :, ::16]
+    out["lat256/row_stride"] = np.int64(16)
+    out["lat256/sum"] = np.float64(pano.astype(np.float64).sum())
+    print("raster lat256", pano.shape, "sum %.3f" % pano.sum())
+    np.savez_compressed(os.path.join(HERE, "rasteriser.npz"), **out)
+
+
+# --------------------------------------------------------------------------- densenet
+def gen_densenet():
+    sys.path.insert(0, os.path.join(REF, "RegressionNetwork"))
+    import DenseNet as refnet
+    from oracle.densenet import deterministic_state_dict
+    geomloss, gutils = ref_geomloss()
+    out = {}
+
+    def sample(t, k=64):
+        flat = t.detach().reshape(-1)
+        idx = np.linspace(0, flat.numel() - 1, k).astype(np.int64)
+        return flat[idx].numpy(), idx
+
+    # -- reference-native geometry: 192x256 crops, 96 anchors, B=2
+    torch.manual_seed(0)
+    net = refnet.DenseNet()
+    net.load_state_dict(deterministic_state_dict(net.state_dict(), seed=0))
+    x = torch.from_numpy(rng(0).random((2, 3, 192, 256), dtype=np.float32))
+    net.eval()
+    with torch.no_grad():
+        pe = net(x)
+        fe = net.features(x)
+    for k, v in pe.items():
+        out["eval/" + k] = v.numpy()
+    out["eval/features_sample"], out["eval/features_idx"] = sample(fe)
+    out["eval/features_mean_abs"] = np.float64(fe.abs().double().mean())
+
+    # -- one full training step (train.py:81-102): train-mode BN, Sinkhorn blur .025
+    net.train()
+    crit = ref_samples_loss(geomloss, gutils, 96, 2, .025)
+    g = rng(1)
+    gt = {
+        "distribution": torch.from_numpy(sinkhorn_inputs("sparse", 2, 96, 3)[1]),
+        "intensity": torch.from_numpy(g.uniform(.05, 2, (2, 1)).astype(np.float32)),
+        "rgb_ratio": torch.from_numpy(g.uniform(.4, .7, (2, 3)).astype(np.float32)),
+        "ambient": torch.from_numpy(g.uniform(0, .3, (2, 3)).astype(np.float32)),
+    }
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    pred = net(x)
+    l2 = torch.nn.MSELoss()
+    dp, dg = pred["distribution"].view(-1, 96, 1), gt["distribution"].view(-1, 96, 1)
+    terms = [crit(dp, dg).sum() * 1000.0, l2(dp, dg) * 1000.0,
+             l2(pred["intensity"], gt["intensity"]) * 0.1,
+             l2(pred["rgb_ratio"], gt["rgb_ratio"]) * 100.0,
+             l2(pred["ambient"], gt["ambient"]) * 1.0]
+    loss = sum(terms)
+    opt.zero_grad()
+    loss.backward()
+    for k, v in pred.items():
+        out["train/" + k] = v.detach().numpy()
+    for k, v in gt.items():
+        out["train/gt_" + k] = v.numpy()
+    out["train/loss_terms"] = np.array([float(t) for t in terms], dtype=np.float64)
+    named = dict(net.named_parameters())
+    for key in ["features.conv0.weight", "features.norm0.weight",
+                "features.denseblock1.denselayer1.conv1.weight",
+                "features.denseblock1.denselayer1.norm1.bias",
+                "features.denseblock1.denselayer16.conv2.weight",
+                "features.denseblock2.denselayer7.norm2.weight",
+                "features.denseblock3.denselayer16.conv1.weight",
+                "features.transition1.conv.weight", "features.transition3.norm.weight",
+                "features.last_norm3.bias", "fc_dist.bias", "fc_intensity.weight"]:
+        gsmp, gidx = sample(named[key].grad, 48)
+        out["train/grad/" + key] = gsmp
+        out["train/grad_idx/" + key] = gidx
+        out["train/grad_l2/" + key] = np.float64(named[key].grad.double().norm())
+    out["train/running_mean/features.norm0"] = net.features.norm0.running_mean.numpy().copy()
+    out["train/running_var/features.last_norm3"] = net.features.last_norm3.running_var.numpy().copy()
+    opt.step()
+    out["train/post_step/fc_dist.bias"] = net.fc_dist.bias.detach().numpy().copy()
+    out["train/post_step/conv0_sample"], _ = sample(net.features.conv0.weight, 48)
+    print("densenet train terms", out["train/loss_terms"])
+
+    # -- BASELINE cfg1: 1x240x320 crop -> 128 anchors, CPU forward only.  The reference
+    # class raises at 240x320 (fc is 8208-wide, DenseNet.py:125); the oracle is the same
+    # class with fc / fc_dist swapped for matching nn.Linear.
+    torch.manual_seed(0)
+    net2 = refnet.DenseNet()
+    net2.fc = torch.nn.Linear(171 * 7 * 10, 1024)
+    net2.fc_dist = torch.nn.Linear(1024, 128)
+    net2.load_state_dict(deterministic_state_dict(net2.state_dict(), seed=1))
+    net2.eval()
+    x2 = torch.from_numpy(rng(2).random((1, 3, 240, 320), dtype=np.float32))
+    with torch.no_grad():
+        p2 = net2(x2)
+    for k, v in p2.items():
+        out["cfg1/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "densenet.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet"]
+    if "sinkhorn" in which:
+        gen_sinkhorn()
+    if "rasteriser" in which:
+        gen_rasteriser()
+    if "densenet" in which:
+        gen_densenet()
