@@ -1,0 +1,152 @@
+"""``SamplesLoss`` -- EMLight's spherical mover's (Sinkhorn) loss on the MI355X.
+
+Same constructor and ``forward`` as the reference class
+(``RegressionNetwork/geomloss/samples_loss.py:12-92``); the body is one call into
+``libemlight_hip.so`` (``eml_sinkhorn_schedule_f32`` + ``eml_sinkhorn_fwd_f32``) instead of
+four materialised (B,N,N) cost tensors and ~250 ATen launches.  Extra, optional arguments
+lift what the reference hard-codes: ``anchors`` (reference: 96, ``geomloss/utils.py:66``)
+and ``cost_matrix`` (a runtime (N,N) ground cost -- gives the GMLight variant,
+``gmloss/utils.py:63-108``, for free).  ``batchsize`` is accepted and ignored: the chord
+matrix is stored once, not ``batchsize`` times (``utils.py:80-81``).
+"""
+import numpy as np
+import torch
+from torch.nn import Module
+
+from ... import _lib
+from ..util import sphere_points
+
+
+def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False):
+    """One call into the HIP library; returns every device-side output (no autograd)."""
+    L = _lib.lib()
+    B, N = x.shape
+    dev = x.device
+    eps_s = torch.empty(64, dtype=torch.float32, device=dev)
+    n_eps = torch.empty(1, dtype=torch.int32, device=dev)
+    diam = torch.empty(1, dtype=torch.float32, device=dev)
+    stream = _lib.current_stream()
+    _lib.check(L.eml_sinkhorn_schedule_f32(
+        _lib.ptr(x), _lib.ptr(y), B * N, float(blur), float(scaling), int(p),
+        float(diameter) if diameter is not None else -1.0,
+        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(diam), stream), "eml_sinkhorn_schedule_f32")
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    gx = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gx else None
+    gy = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gy else None
+    work = torch.empty(8, B, N, dtype=torch.float32, device=dev)
+    _lib.check(L.eml_sinkhorn_fwd_f32(
+        _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
+        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(loss), _lib.ptr(gx), _lib.ptr(gy),
+        _lib.ptr(work), B, N, stream), "eml_sinkhorn_fwd_f32")
+    return {"loss": loss, "gx": gx, "gy": gy, "eps_s": eps_s, "n_eps": n_eps, "diameter": diam,
+            "duals": work[:4]}
+
+
+class _SinkhornDivergence(torch.autograd.Function):
+    """loss (B,) = S_eps(alpha@x, beta@y).  Backward = analytic gradient of the last
+    extrapolation (``sinkhorn_divergence.py:101-107``), produced by the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, y, alpha, beta, M, Mt, p, blur, scaling, diameter):
+        r = sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter,
+                         ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        ctx.save_for_backward(r["gx"], r["gy"])
+        return r["loss"]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        gx_u, gy_u = ctx.saved_tensors
+        L = _lib.lib()
+        gloss = gloss.contiguous()
+        out = [None, None]
+        for k, gu in enumerate((gx_u, gy_u)):
+            if gu is None:
+                continue
+            B, N = gu.shape
+            go = torch.empty_like(gu)
+            _lib.check(L.eml_sinkhorn_bwd_f32(_lib.ptr(gloss), _lib.ptr(gu), _lib.ptr(go), B, N,
+                                              _lib.current_stream()), "eml_sinkhorn_bwd_f32")
+            out[k] = go
+        return out[0], out[1], None, None, None, None, None, None, None, None
+
+
+class SamplesLoss(Module):
+    """Debiased Sinkhorn divergence between sampled measures on the N sphere anchors.
+
+    ``SamplesLoss(loss="sinkhorn", p=2, blur=.05, reach=None, diameter=None, scaling=.5,
+    batchsize=None)`` -- reference signature ``samples_loss.py:22``; ``forward(x, y)`` with
+    ``x, y`` of shape ``(B, N, 1)`` returns ``(B,)`` (``samples_loss.py:35-46``).
+    """
+
+    def __init__(self, loss="sinkhorn", p=2, blur=.05, reach=None, diameter=None, scaling=.5,
+                 batchsize=None, anchors=96, cost_matrix=None):
+        super().__init__()
+        if loss != "sinkhorn":
+            raise ValueError("only loss='sinkhorn' exists in EMLight's geomloss fork")
+        if reach is not None:
+            raise NotImplementedError("unbalanced OT (reach) is not on EMLight's path (rho=None)")
+        self.loss, self.p, self.blur, self.reach = loss, p, blur, reach
+        self.diameter, self.scaling = diameter, scaling
+        self.N = int(anchors) if cost_matrix is None else int(cost_matrix.shape[-1])
+        # anchors as the reference builds them: float64 Fibonacci sphere cast to f32 (utils.py:67-69)
+        self.register_buffer("anchors", torch.from_numpy(sphere_points(self.N)).float(), persistent=False)
+        if cost_matrix is not None:
+            M = torch.as_tensor(cost_matrix, dtype=torch.float32).reshape(self.N, self.N).clone()
+            self.register_buffer("M", M, persistent=False)
+            self.register_buffer("Mt", M.t().contiguous(), persistent=False)
+        else:
+            self.M = None
+            self.Mt = None
+
+    def cost_matrix(self, device):
+        """(N,N) chord matrix on ``device`` -- built once by ``eml_emd_anchor_cost_f32``."""
+        if self.M is None or self.M.device != device:
+            if self.M is not None:  # user-supplied matrix: just move it
+                self.M, self.Mt = self.M.to(device), self.Mt.to(device)
+            else:
+                a = self.anchors.to(device).contiguous()
+                M = torch.empty(self.N, self.N, dtype=torch.float32, device=device)
+                _lib.check(_lib.lib().eml_emd_anchor_cost_f32(_lib.ptr(a), _lib.ptr(M), self.N,
+                                                              _lib.current_stream()), "eml_emd_anchor_cost_f32")
+                self.M, self.Mt = M, M  # symmetric: the transpose aliases
+        return self.M, self.Mt
+
+    @staticmethod
+    def generate_weights(x):
+        if x.dim() == 3:
+            B, N, _ = x.shape
+            return torch.ones(B, N).type_as(x) / N
+        raise ValueError("Input samples 'x' and 'y' should be encoded as (B,N,D) (batch) tensors.")
+
+    def process_args(self, *args):
+        if len(args) == 6:
+            _, a, x, _, b, y = args
+            return a, x, b, y
+        if len(args) == 4:
+            return args
+        if len(args) == 2:
+            x, y = args
+            return None, x, None, y  # uniform 1/N weights are generated inside the kernel
+        raise ValueError("A SamplesLoss accepts two (x, y), four (a, x, b, y) or six (l_x, a, x, l_y, b, y) arguments.")
+
+    def forward(self, *args):
+        a, x, b, y = self.process_args(*args)
+        if x.dim() != 3 or x.shape[-1] != 1 or y.shape != x.shape or x.shape[1] != self.N:
+            raise ValueError("expected x, y of shape (B, %d, 1), got %s and %s"
+                             % (self.N, tuple(x.shape), tuple(y.shape)))
+        B = x.shape[0]
+        x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
+        y2 = _lib.require_gpu_tensor(y.reshape(B, self.N), "y")
+        a2 = None if a is None else _lib.require_gpu_tensor(a.reshape(B, self.N), "alpha")
+        b2 = None if b is None else _lib.require_gpu_tensor(b.reshape(B, self.N), "beta")
+        M, Mt = self.cost_matrix(x2.device)
+        return _SinkhornDivergence.apply(x2, y2, a2, b2, M, Mt, self.p, self.blur, self.scaling, self.diameter)
+
+    def forward_raw(self, x, y, need_gx=True, need_gy=True):
+        """Every device output of one call (loss, unit grads, schedule, duals) -- for parity tests."""
+        B = x.shape[0]
+        x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
+        y2 = _lib.require_gpu_tensor(y.reshape(B, self.N), "y")
+        M, Mt = self.cost_matrix(x2.device)
+        return sinkhorn_raw(x2, y2, None, None, M, Mt, self.p, self.blur, self.scaling, self.diameter,
+                            need_gx, need_gy)

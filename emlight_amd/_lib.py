@@ -1,0 +1,90 @@
+"""ctypes binding of libemlight_hip.so (the C ABI declared in include/emlight_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent,
+``lib()`` raises -- a GPU box must run the HIP kernels or fail loudly.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemlight_hip.so")
+
+_f32p = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+_i32p = ctypes.c_void_p
+_stream = ctypes.c_void_p
+_int = ctypes.c_int
+
+# symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
+SIGNATURES = {
+    "eml_abi_version": (_int, []),
+    "eml_last_error": (ctypes.c_char_p, []),
+    "eml_sg_rasterise_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
+    "eml_sg_rasterise_bwd_colors_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
+    "eml_emd_anchor_cost_f32": (_int, [_f32p, _f32p, _int, _stream]),
+    "eml_sinkhorn_schedule_f32": (_int, [_f32p, _f32p, ctypes.c_long, ctypes.c_double, ctypes.c_double, _int,
+                                         ctypes.c_double, _f32p, _i32p, _f32p, _stream]),
+    "eml_sinkhorn_work_floats": (ctypes.c_size_t, [_int, _int]),
+    "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p,
+                                    _f32p, _f32p, _int, _int, _stream]),
+    "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class EmlightHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EmlightHipError(
+                "libemlight_hip.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C emlight_amd/csrc`. "
+                "There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise EmlightHipError("libemlight_hip.so lacks symbol %s" % name) from e
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().eml_last_error()
+        raise EmlightHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a contiguous f32/i32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise EmlightHipError("%s must be a tensor on the MI355X (got %s); there is no CPU path"
+                              % (name, getattr(t, "device", type(t))))
+    if t.dtype != (dtype or torch.float32):
+        raise EmlightHipError("%s must be %s (got %s)" % (name, dtype or torch.float32, t.dtype))
+    return t.contiguous()

@@ -1,0 +1,379 @@
+// EMLight's "spherical mover's" loss: debiased Sinkhorn divergence over N sphere anchors.
+//
+// Replaces the whole of SamplesLoss.sinkhorn_tensorized (reference
+// RegressionNetwork/geomloss/samples_loss.py:79-92 + sinkhorn_divergence.py:72-109): there a
+// step costs 4 materialised (B,N,N) cost tensors and ~200-300 tiny ATen launches
+// (4*(n_eps+2) softmins x ~6 ops) plus a .item() host sync for the diameter.
+//
+// Here one C-ABI call enqueues the loop kernel + a tiny finishing kernel.  The four coupled
+// softmin problems      g=0 xx -> a_x   g=1 yy -> b_y   g=2 yx -> a_y   g=3 xy -> b_x
+// each own 4 wavefronts (256 threads); a sample is two 512-thread workgroups -- role 0 runs
+// the independent pair (xx, yy), role 1 the coupled pair (yx, xy) -- so 2*B workgroups spread
+// over the CUs and a thread may use up to 256 VGPRs.
+//
+// N <= 128 ("cached" kernel): thread (i, half) of a group keeps its <=64 costs
+// C_ij = .5*(.1*(p_i-q_j)^2 + M_ij) of row i in REGISTERS for the whole eps-scaling loop
+// (the cost matrices never exist in HBM; M is staged once through LDS with coalesced
+// reads).  A sweep is one fma+max pass and one fma+exp2+add pass over those registers, the
+// row reduction is a single lane-pair shuffle, and the dual vectors h = log w + f/eps
+// travel between the two groups through a double-buffered LDS array with ONE barrier per
+// sweep.  N > 128 ("stream" kernel): thread = row, costs recomputed per sweep from Mt
+// (coalesced, L2-resident).
+//
+// Roofline: algorithmic bytes per eps-step = 4*(B*N^2*4 + 2*B*N*4), i.e. the
+// reference's materialised-cost traffic; this kernel's real HBM traffic is x, y, M and the
+// outputs only, so it is latency/transcendental-bound: (n_eps+2)*4*N^2 exp2 per sample.
+#include "eml_common.h"
+
+namespace {
+
+constexpr int kGT = 256;   // threads per softmin group (4 waves)
+constexpr int kJPT = 64;   // cached costs per thread (N <= 2*kJPT)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kBig = 1e30f;
+
+__host__ __device__ __forceinline__ int round_up4(int v) { return (v + 3) & ~3; }
+
+// C_ij following geomloss/utils.py:90-94 and the /2 of samples_loss.py:82
+__device__ __forceinline__ float cost_ij(float p, float q, float m) {
+  const float d = (p * p - 2.0f * (p * q) + q * q) * 0.1f + m;
+  return d * 0.5f;
+}
+
+// LDS carve-up (floats).  NP = round_up4(N) + kJPT so unrolled reads past a row's end stay
+// in-bounds; everything is 16-B aligned.
+//   pts [2][NP]  x, y            lw2 [2][NP]  log2(e)*log-weights (alpha, beta)
+//   h2  [2][2][NP] double-buffered log2(e)*(log w + f/eps), per consuming local group
+//   pot [2][NP]  potentials (stream kernel)      M [N][ldm] (cached kernel)
+constexpr int kSmemVecs = 2 + 2 + 4 + 2;
+
+template <bool kCached>
+__global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
+    const float* __restrict__ Mt, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ eps_s, const int* __restrict__ n_eps_p,
+    float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NP = round_up4(N) + kJPT;
+  float* pts = smem;
+  float* lw2 = pts + 2 * NP;
+  float* h2 = lw2 + 2 * NP;
+  float* potl = h2 + 4 * NP;
+  float* Ml = potl + 2 * NP;
+
+  const int b = blockIdx.x >> 1;
+  const int role = blockIdx.x & 1;     // 0: (xx, yy)   1: (yx, xy)
+  const int tid = threadIdx.x;
+  const int gl = tid >> 8;             // local group 0/1
+  const int g = 2 * role + gl;         // global problem id 0..3
+  const int t = tid & (kGT - 1);
+  const bool rows_x = (g == 0 || g == 3);
+  const bool cols_x = (g == 0 || g == 2);
+  const int consumer_l = role ? (1 - gl) : gl;  // local group whose h this potential feeds
+  const int n_eps = max(1, min(*n_eps_p, EML_MAX_EPS));
+
+  // ---- stage points and log-weights; zero the h buffers (their pads are read)
+  const float unif = 1.0f / (float)N;
+  for (int i = tid; i < 2 * NP; i += 512) {
+    const int which = i / NP, k = i - which * NP;
+    float p = 0.f, l = 0.f;
+    if (k < N) {
+      p = (which == 0 ? x : y)[(size_t)b * N + k];
+      const float* wp = which == 0 ? alpha : beta;
+      const float w = wp ? wp[(size_t)b * N + k] : unif;
+      l = (w > 0.f) ? logf(w) : -100000.0f;  // sinkhorn_divergence.py:47-50
+    }
+    pts[i] = p;
+    lw2[i] = l * kLog2e;
+  }
+  for (int i = tid; i < 4 * NP; i += 512) h2[i] = 0.f;
+
+  const float* P = pts + (rows_x ? 0 : NP);
+  const float* Q = pts + (cols_x ? 0 : NP);
+  const float* lw2_rows = lw2 + (rows_x ? 0 : NP);
+  const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
+
+  // ---- cached kernel: M -> LDS (coalesced), then this thread's costs -> registers
+  float c[kJPT];
+  int i = 0, jbase = 0;
+  bool owner = false;
+  if constexpr (kCached) {
+    const int ldm = round_up4(N) + 4;
+    for (int e = tid; e < N * N; e += 512) {
+      const int r = e / N, cc = e - r * N;
+      Ml[r * ldm + cc] = M[e];
+    }
+    __syncthreads();
+    const int split = round_up4((N + 1) >> 1);
+    const int half = t & 1;
+    i = t >> 1;
+    jbase = half * split;
+    const int cnt = (i < N) ? max(0, min(split, N - jbase)) : 0;
+    owner = (half == 0) && (i < N);
+    const int ic = min(i, N - 1);
+    const float pi = P[ic];
+    const float4* mrow = reinterpret_cast<const float4*>(Ml + ic * ldm + jbase);
+    const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
+#pragma unroll
+    for (int q = 0; q < kJPT / 4; ++q) {
+      const float4 mv = mrow[q];
+      const float4 qv = qrow[q];
+      c[4 * q + 0] = (4 * q + 0 < cnt) ? cost_ij(pi, qv.x, mv.x) : kBig;
+      c[4 * q + 1] = (4 * q + 1 < cnt) ? cost_ij(pi, qv.y, mv.y) : kBig;
+      c[4 * q + 2] = (4 * q + 2 < cnt) ? cost_ij(pi, qv.z, mv.z) : kBig;
+      c[4 * q + 3] = (4 * q + 3 < cnt) ? cost_ij(pi, qv.w, mv.w) : kBig;
+    }
+  }
+  // sweep 0 reads h = log w (potentials are zero): sinkhorn_divergence.py:82-85
+  for (int k = t; k < N; k += kGT) h2[gl * NP + k] = lw2_cols[k];
+  __syncthreads();
+
+  const size_t plane = (size_t)B * N;
+  float* fin_out = work + (size_t)g * plane + (size_t)b * N;        // a_x | b_y | a_y | b_x
+  float* e_out = work + (size_t)(4 + g) * plane + (size_t)b * N;    // E_i[q] of the last softmax
+
+  float pot = 0.f;  // this row's potential (cached kernel)
+  for (int s = 0; s < n_eps + 2; ++s) {
+    const bool final_sweep = (s == n_eps + 1);
+    const float eps = eps_s[(s == 0) ? 0 : min(s - 1, n_eps - 1)];
+    const float eps_next = eps_s[min(s, n_eps - 1)];
+    const float nie2 = -kLog2e / eps;
+    const float k_next = kLog2e / eps_next;
+    const float* hsrc = h2 + (s & 1) * 2 * NP + gl * NP;
+    float* hdst = h2 + ((s + 1) & 1) * 2 * NP + consumer_l * NP;
+
+    if constexpr (kCached) {
+      const float4* hv4 = reinterpret_cast<const float4*>(hsrc + jbase);
+      float m = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < kJPT / 4; ++q) {
+        const float4 hv = hv4[q];
+        m = fmaxf(m, fmaf(c[4 * q + 0], nie2, hv.x));
+        m = fmaxf(m, fmaf(c[4 * q + 1], nie2, hv.y));
+        m = fmaxf(m, fmaf(c[4 * q + 2], nie2, hv.z));
+        m = fmaxf(m, fmaf(c[4 * q + 3], nie2, hv.w));
+      }
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      float sum = 0.f, tq = 0.f;
+      if (!final_sweep) {
+#pragma unroll
+        for (int q = 0; q < kJPT / 4; ++q) {
+          const float4 hv = hv4[q];
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
+          const float e2 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
+          const float e3 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
+          sum += (e0 + e1) + (e2 + e3);
+        }
+      } else {
+        const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
+#pragma unroll
+        for (int q = 0; q < kJPT / 4; ++q) {
+          const float4 hv = hv4[q];
+          const float4 qv = qrow[q];
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
+          const float e2 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
+          const float e3 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
+          sum += (e0 + e1) + (e2 + e3);
+          tq = fmaf(e0, qv.x, fmaf(e1, qv.y, fmaf(e2, qv.z, fmaf(e3, qv.w, tq))));
+        }
+        tq += __shfl_xor(tq, 1, 64);
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      // softmin = -eps * logsumexp (samples_loss.py:75-77), evaluated in base 2
+      const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
+      if (final_sweep) {
+        if (owner) {
+          fin_out[i] = sm;
+          e_out[i] = tq / sum;
+        }
+      } else {
+        pot = (s == 0) ? sm : 0.5f * (pot + sm);  // symmetrised update, sinkhorn_divergence.py:96-97
+        if (owner) hdst[i] = fmaf(pot, k_next, lw2_rows[i]);
+      }
+    } else {
+      for (int r = t; r < N; r += kGT) {
+        const float pi = P[r];
+        float m = -INFINITY;
+#pragma unroll 4
+        for (int j = 0; j < N; ++j)
+          m = fmaxf(m, fmaf(cost_ij(pi, Q[j], Mt[(size_t)j * N + r]), nie2, hsrc[j]));
+        float sum = 0.f, tq = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < N; ++j) {
+          const float qj = Q[j];
+          const float e =
+              __builtin_amdgcn_exp2f(fmaf(cost_ij(pi, qj, Mt[(size_t)j * N + r]), nie2, hsrc[j] - m));
+          sum += e;
+          tq = fmaf(e, qj, tq);
+        }
+        const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
+        if (final_sweep) {
+          fin_out[r] = sm;
+          e_out[r] = tq / sum;
+        } else {
+          const float pr = (s == 0) ? sm : 0.5f * (potl[gl * NP + r] + sm);
+          potl[gl * NP + r] = pr;
+          hdst[r] = fmaf(pr, k_next, lw2_rows[r]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// loss_b = <alpha, b_x - a_x> + <beta, a_y - b_y>  (sinkhorn_divergence.py:65-69) and the
+// analytic backward of the last extrapolation: the gradient reaches x only through the final
+// xx / xy softmins and only through the cost's first argument (utils.py:88), and since the
+// softmax rows sum to one,  dL_b/dx_i = alpha_i * 0.1 * (E^xx_i[x] - E^xy_i[y])  (same for y).
+__global__ __launch_bounds__(256) void sinkhorn_finish_kernel(
+    const float* __restrict__ work, const float* __restrict__ alpha, const float* __restrict__ beta,
+    float* __restrict__ loss, float* __restrict__ gx, float* __restrict__ gy, int B, int N) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t plane = (size_t)B * N, row = (size_t)b * N;
+  const float unif = 1.0f / (float)N;
+  float part = 0.f;
+  for (int k = tid; k < N; k += 256) {
+    const size_t o = row + k;
+    const float a_x = work[o], b_y = work[plane + o], a_y = work[2 * plane + o], b_x = work[3 * plane + o];
+    const float al = alpha ? alpha[o] : unif, be = beta ? beta[o] : unif;
+    part += al * (b_x - a_x) + be * (a_y - b_y);
+    if (gx) gx[o] = al * 0.1f * (work[4 * plane + o] - work[7 * plane + o]);
+    if (gy) gy[o] = be * 0.1f * (work[5 * plane + o] - work[6 * plane + o]);
+  }
+  part = eml::wave_sum(part);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) loss[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Chord matrix M_ij = ||a_i - a_j||_2 on f32 anchors (geomloss/utils.py:67-76).
+__global__ __launch_bounds__(256) void anchor_cost_kernel(const float* __restrict__ a,
+                                                          float* __restrict__ M, int N) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * N) return;
+  const int i = idx / N, j = idx - i * N;
+  const float dx = a[3 * i] - a[3 * j], dy = a[3 * i + 1] - a[3 * j + 1], dz = a[3 * i + 2] - a[3 * j + 2];
+  M[idx] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// Diameter (range of x U y) + epsilon schedule, all on the device.
+__global__ __launch_bounds__(1024) void schedule_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ y, long n,
+                                                        double blur, double scaling, int p,
+                                                        double diameter, float* __restrict__ eps_out,
+                                                        int* __restrict__ n_eps_out,
+                                                        float* __restrict__ diameter_out) {
+  __shared__ float red_min[16], red_max[16];
+  const int tid = threadIdx.x;
+  float lo = INFINITY, hi = -INFINITY;
+  if (diameter <= 0.0) {
+    for (long k = tid; k < n; k += 1024) {
+      const float a = x[k], c = y[k];
+      lo = fminf(lo, fminf(a, c));
+      hi = fmaxf(hi, fmaxf(a, c));
+    }
+    lo = eml::wave_min(lo);
+    hi = eml::wave_max(hi);
+    if ((tid & 63) == 0) {
+      red_min[tid >> 6] = lo;
+      red_max[tid >> 6] = hi;
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  double d = diameter;
+  if (diameter <= 0.0) {
+    for (int w = 0; w < 16; ++w) {
+      lo = fminf(lo, red_min[w]);
+      hi = fmaxf(hi, red_max[w]);
+    }
+    d = (double)(hi - lo);  // f32 subtraction, then .item(): sinkhorn_divergence.py:15
+  }
+  *diameter_out = (float)d;
+  // sinkhorn_divergence.py:21-25, in f64 like numpy
+  int k = 0;
+  eps_out[k++] = (float)((p == 2) ? d * d : pow(d, (double)p));
+  if (d > 0.0) {
+    const double start = p * log(d), stop = p * log(blur), step = p * log(scaling);
+    const double cntd = ceil((stop - start) / step);  // numpy.arange length
+    const int cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
+    for (int e = 0; e < cnt; ++e) eps_out[k++] = (float)exp(start + e * step);
+  }
+  eps_out[k++] = (float)((p == 2) ? blur * blur : pow(blur, (double)p));
+  *n_eps_out = k;
+  for (; k < EML_MAX_EPS; ++k) eps_out[k] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ gloss,
+                                                         const float* __restrict__ gunit,
+                                                         float* __restrict__ gout, int B, int N) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  gout[idx] = gloss[idx / N] * gunit[idx];
+}
+
+}  // namespace
+
+extern "C" int eml_emd_anchor_cost_f32(const float* anchors, float* M, int N, eml_stream_t stream) {
+  if (!anchors || !M || N < 1 || N > 16384) return eml::fail(EML_EINVAL, "eml_emd_anchor_cost_f32: bad arguments");
+  hipLaunchKernelGGL(anchor_cost_kernel, dim3((N * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, anchors, M, N);
+  return eml::check_launch("eml_emd_anchor_cost_f32");
+}
+
+extern "C" int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blur,
+                                         double scaling, int p, double diameter, float* eps_out,
+                                         int* n_eps_out, float* diameter_out, eml_stream_t stream) {
+  if (!eps_out || !n_eps_out || !diameter_out) return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: null output");
+  if (diameter <= 0.0 && (!x || !y || n < 1))
+    return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: need x, y, n>=1 when diameter is not given");
+  if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
+    return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: need blur>0, 0<scaling<1, p>=1");
+  hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, n, blur, scaling, p,
+                     diameter, eps_out, n_eps_out, diameter_out);
+  return eml::check_launch("eml_sinkhorn_schedule_f32");
+}
+
+extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)8 * B * N; }
+
+extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
+                                    const float* alpha, const float* beta, const float* eps_s,
+                                    const int* n_eps, float* loss, float* gx, float* gy,
+                                    float* work, int B, int N, eml_stream_t stream) {
+  if (!x || !y || !M || !Mt || !eps_s || !n_eps || !loss || !work)
+    return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
+  if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
+  if (B == 0) return EML_OK;
+  const int NP = round_up4(N) + kJPT;
+  size_t lds = (size_t)(kSmemVecs * NP) * sizeof(float);
+  if (N <= 2 * kJPT) {
+    lds += (size_t)(N * (round_up4(N) + 4) + kJPT) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
+                       alpha, beta, eps_s, n_eps, work, B, N);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
+                       alpha, beta, eps_s, n_eps, work, B, N);
+  }
+  int rc = eml::check_launch("eml_sinkhorn_fwd_f32(loop)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sinkhorn_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, work, alpha, beta, loss,
+                     gx, gy, B, N);
+  return eml::check_launch("eml_sinkhorn_fwd_f32(finish)");
+}
+
+extern "C" int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, int B, int N,
+                                    eml_stream_t stream) {
+  if (!gloss || !gunit || !gout || B < 0 || N < 1) return eml::fail(EML_EINVAL, "eml_sinkhorn_bwd_f32: bad arguments");
+  if (B == 0) return EML_OK;
+  const size_t total = (size_t)B * N;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     gloss, gunit, gout, B, N);
+  return eml::check_launch("eml_sinkhorn_bwd_f32");
+}

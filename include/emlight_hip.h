@@ -1,0 +1,102 @@
+/*
+ * emlight_hip.h -- C ABI of libemlight_hip.so, the MI355X (gfx950) hot path of EMLight.
+ *
+ * Drop-in boundary.  Every entry point replaces a chain of ATen
+ * ops in the reference's Python (the reference has no native code of its own); the
+ * reference file:line each one stands in for is cited on the declaration.  A reference
+ * maintainer binds these with ctypes -- plain pointers and sizes,
+ * no torch types.
+ *
+ * Conventions
+ *   - all tensors are contiguous f32 device buffers owned by the caller (PyTorch);
+ *     the library allocates nothing and keeps no global mutable state;
+ *   - every launcher only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *     no host synchronisation, no host reads of device data;
+ *   - return value: 0 on success, otherwise a negative EML_E* code or a positive
+ *     hipError_t; eml_last_error() returns a thread-local message for the last failure;
+ *   - launchers never throw and never exit().
+ */
+#ifndef EMLIGHT_HIP_H
+#define EMLIGHT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* eml_stream_t; /* hipStream_t */
+
+#define EML_OK 0
+#define EML_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define EML_ELAUNCH (-2)  /* kernel launch failed, see eml_last_error()    */
+
+#define EML_MAX_EPS 64    /* capacity of an epsilon schedule buffer (floats) */
+
+/* Library ABI version (bumped on any signature change) and last-error text. */
+int eml_abi_version(void);
+const char* eml_last_error(void);
+
+/* ---------------------------------------------------------------- SG rasteriser
+ * lights[b,c,h,w] = sum_i colors[b,3i+c] * exp((dirs[b,3i:3i+3] . xyz[:,h,w] - 1) / sizes[b,i])
+ * with xyz the W = 2H equirect view-vector grid.
+ * Replaces convert_to_panorama: RegressionNetwork/util.py:222-245 (copies:
+ * representation/util.py:205-228, GenProjector/util.py:346-369; variable latitude:
+ * RegressionNetwork/panorama.py:68-82,142-152).
+ * dirs (B,3N), sizes (B,N), colors (B,3N) -> out (B,3,H,W); W must equal 2H. */
+int eml_sg_rasterise_f32(const float* dirs, const float* sizes, const float* colors,
+                         float* out, int B, int N, int H, int W, eml_stream_t stream);
+
+/* d loss / d colors of the rasteriser (autograd of util.py:239-244 wrt `colors`):
+ * gcolors[b,3i+c] = sum_hw gout[b,c,h,w] * exp((dirs_i . xyz_hw - 1) / sizes_i). */
+int eml_sg_rasterise_bwd_colors_f32(const float* dirs, const float* sizes, const float* gout,
+                                    float* gcolors, int B, int N, int H, int W,
+                                    eml_stream_t stream);
+
+/* ---------------------------------------------------------------- Sinkhorn (spherical mover's loss)
+ * Chord-length ground cost M_ij = ||a_i - a_j||_2 over N anchors (N x 3, f32).
+ * Replaces the N^2 Python torch.norm loop of distance.__init__,
+ * RegressionNetwork/geomloss/utils.py:65-76. */
+int eml_emd_anchor_cost_f32(const float* anchors, float* M, int N, eml_stream_t stream);
+
+/* Epsilon schedule on the device (no .item() host sync):
+ *   d     = diameter > 0 ? diameter : max(x U y) - min(x U y)        (n values each)
+ *   eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p]
+ * evaluated in f64 exactly as numpy does, stored as f32.
+ * Replaces max_diameter / scaling_parameters / epsilon_schedule,
+ * RegressionNetwork/geomloss/sinkhorn_divergence.py:9-36.
+ * Outputs: eps_out[EML_MAX_EPS], *n_eps_out (device int), *diameter_out (device float). */
+int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blur,
+                              double scaling, int p, double diameter, float* eps_out,
+                              int* n_eps_out, float* diameter_out, eml_stream_t stream);
+
+/* Whole debiased Sinkhorn divergence in one call (loop kernel + finishing kernel): cost build
+ * C = .5*(.1*(x_i-y_j)^2 + M_ij) (never materialised in HBM), init sweep, n_eps symmetrised
+ * eps-scaling sweeps, last extrapolation, loss_b = <alpha,b_x-a_x> + <beta,a_y-b_y>, and the
+ * analytic gradients d loss_b/d x, d loss_b/d y of the last extrapolation.
+ * Replaces SamplesLoss.sinkhorn_tensorized: geomloss/samples_loss.py:79-92 with
+ * utils.py:85-99 (cost), samples_loss.py:75-77 (softmin), sinkhorn_divergence.py:72-109
+ * (loop), :65-69 (cost), and the autograd backward of :102-107.
+ *   x, y        (B,N)  1-D "points" (the mass at each anchor)
+ *   M, Mt       (N,N)  ground cost and its transpose (may alias when M is symmetric)
+ *   alpha, beta (B,N)  weights, or NULL for uniform 1/N
+ *   eps_s, n_eps       device schedule from eml_sinkhorn_schedule_f32
+ *   loss        (B)
+ *   gx, gy      (B,N)  d loss_b / d x_i, d loss_b / d y_j, or NULL
+ *   work        (8,B,N) caller-owned scratch, eml_sinkhorn_work_floats(B,N) floats; on return
+ *                      planes 0..3 hold the final duals a_x, b_y, a_y, b_x */
+size_t eml_sinkhorn_work_floats(int B, int N);
+int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
+                         const float* alpha, const float* beta, const float* eps_s,
+                         const int* n_eps, float* loss, float* gx, float* gy, float* work,
+                         int B, int N, eml_stream_t stream);
+
+/* Backward of the loss vector: gout[b,i] = gloss[b] * gunit[b,i]  (gunit = gx or gy above). */
+int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, int B, int N,
+                         eml_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMLIGHT_HIP_H */

@@ -1,0 +1,72 @@
+"""GPU parity: HIP SG rasteriser (through the C ABI) vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+# north_star: HDR map within 1e-2 rel; we hold 1e-4 of the map's peak + 1e-4 rel
+RTOL, ATOL_OF_MAX = 1e-4, 1e-4
+
+
+def _run(dirs, sizes, colors, hw=(128, 256)):
+    from emlight_amd.RegressionNetwork.util import convert_to_panorama
+    return convert_to_panorama(torch.from_numpy(dirs).cuda(), torch.from_numpy(sizes).cuda(),
+                               torch.from_numpy(colors).cuda(), pano_hw=hw)
+
+
+@pytest.mark.parametrize("case,hw", [("b1_n128", (128, 256)), ("b2_n96", (128, 256)), ("b3_n42", (128, 256)),
+                                     ("lat256", (256, 512))])
+def test_golden_cases(golden_raster, case, hw):
+    c = golden_raster.case(case)
+    pano = _run(c["dirs"], c["sizes"], c["colors"], hw).cpu().numpy()
+    rows = int(c["row_stride"])
+    want = c["pano_rows"]
+    np.testing.assert_allclose(pano[:, :, ::rows], want, rtol=RTOL, atol=ATOL_OF_MAX * want.max())
+    assert abs(pano.astype(np.float64).sum() - float(c["sum"])) <= 1e-4 * abs(float(c["sum"]))
+
+
+@pytest.mark.parametrize("B,n,H", [(32, 128, 128), (4, 7, 128), (2, 600, 64), (16, 256, 256)])
+def test_vs_oracle_seeded(B, n, H):
+    g = np.random.default_rng([3, B, n])
+    d = g.standard_normal((B, n, 3))
+    dirs = (d / np.linalg.norm(d, axis=2, keepdims=True)).reshape(B, 3 * n).astype(np.float32)
+    sizes = g.uniform(0.002, 0.2, (B, n)).astype(np.float32)
+    colors = g.uniform(0, 3, (B, 3 * n)).astype(np.float32)
+    want = oracle.convert_to_panorama(torch.from_numpy(dirs), torch.from_numpy(sizes), torch.from_numpy(colors),
+                                      height=H).numpy()
+    got = _run(dirs, sizes, colors, (H, 2 * H)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL_OF_MAX * want.max())
+
+
+def test_linearity_and_grad_colors():
+    """Linearity in colours (size-independent property) and d/d(colors) vs oracle autograd."""
+    B, n, H = 3, 128, 128
+    g = np.random.default_rng(17)
+    dirs = np.tile(oracle.sphere_points(n).reshape(1, 3 * n), (B, 1)).astype(np.float32)
+    sizes = np.full((B, n), 0.0025, np.float32)
+    c1 = g.uniform(0, 2, (B, 3 * n)).astype(np.float32)
+    c2 = g.uniform(0, 2, (B, 3 * n)).astype(np.float32)
+    p1, p2, p12 = _run(dirs, sizes, c1), _run(dirs, sizes, c2), _run(dirs, sizes, c1 + 2 * c2)
+    np.testing.assert_allclose(p12.cpu().numpy(), (p1 + 2 * p2).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+    from emlight_amd.RegressionNetwork.util import convert_to_panorama
+    w = torch.from_numpy(g.standard_normal((B, 3, H, 2 * H)).astype(np.float32))
+    co = torch.from_numpy(c1).requires_grad_(True)
+    (oracle.convert_to_panorama(torch.from_numpy(dirs), torch.from_numpy(sizes), co) * w).sum().backward()
+    cg = torch.from_numpy(c1).cuda().requires_grad_(True)
+    (convert_to_panorama(torch.from_numpy(dirs).cuda(), torch.from_numpy(sizes).cuda(), cg) * w.cuda()).sum().backward()
+    want = co.grad.numpy()
+    np.testing.assert_allclose(cg.grad.cpu().numpy(), want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
+
+
+def test_empty_batch_and_bad_shapes():
+    from emlight_amd.RegressionNetwork.util import convert_to_panorama
+    out = convert_to_panorama(torch.empty(0, 12, device="cuda"), torch.empty(0, 4, device="cuda"),
+                              torch.empty(0, 12, device="cuda"))
+    assert out.shape == (0, 3, 128, 256)
+    with pytest.raises(ValueError):
+        convert_to_panorama(torch.rand(1, 12, device="cuda"), torch.rand(1, 5, device="cuda"),
+                            torch.rand(1, 12, device="cuda"))

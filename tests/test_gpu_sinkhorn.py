@@ -1,0 +1,112 @@
+"""GPU parity: HIP Sinkhorn (through the C ABI) vs the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.golden.make_golden import SINKHORN_CASES
+
+pytestmark = pytest.mark.gpu
+
+LOSS_ATOL = 1e-6      # SURVEY 8d parity gate: loss <= 1e-6 abs at loss values ~1e-4
+GRAD_RTOL = 1e-4      # grad <= 1e-4 rel (of the largest component)
+
+
+def _crit(n, blur, diameter=None):
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    return SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=n)
+
+
+def test_anchor_cost_matrix_matches_oracle():
+    for n in (96, 128, 256, 50):
+        crit = _crit(n, .05)
+        M, _ = crit.cost_matrix(torch.device("cuda"))
+        np.testing.assert_allclose(M.cpu().numpy(), oracle.anchor_cost_matrix(n).numpy(), rtol=0, atol=3e-7)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in SINKHORN_CASES])
+def test_golden_cases(golden_sinkhorn, case):
+    c = golden_sinkhorn.case(case)
+    B, n = c["x"].shape
+    diam = None if c["fixed_diameter"] < 0 else float(c["fixed_diameter"])
+    crit = _crit(n, float(c["blur"]), diam)
+    x = torch.from_numpy(c["x"]).cuda().view(B, n, 1)
+    y = torch.from_numpy(c["y"]).cuda().view(B, n, 1)
+    r = crit.forward_raw(x, y)
+    n_eps = int(r["n_eps"].item())
+    assert n_eps == len(c["eps_s"])
+    np.testing.assert_allclose(r["eps_s"][:n_eps].cpu().numpy(), c["eps_s"].astype(np.float32), rtol=2e-7)
+    assert abs(float(r["diameter"].item()) - float(c["diameter"])) <= 1e-7 * max(1.0, float(c["diameter"]))
+    scale = max(1.0, float(np.abs(c["loss"]).max()) / 1e-4)
+    np.testing.assert_allclose(r["loss"].cpu().numpy(), c["loss"], rtol=0, atol=LOSS_ATOL * scale)
+    duals = r["duals"].cpu().numpy()
+    np.testing.assert_allclose(duals, c["duals"], rtol=0, atol=2e-6 * max(1.0, np.abs(c["duals"]).max()))
+    gref = c["grad_x"]
+    np.testing.assert_allclose(r["gx"].cpu().numpy(), gref, rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(gref).max())
+
+
+@pytest.mark.parametrize("B,n,blur", [(64, 128, .05), (7, 96, .025), (5, 33, .05), (3, 200, .05), (16, 256, .05)])
+def test_autograd_vs_oracle(B, n, blur):
+    """Seeded inputs at BASELINE cfg2/cfg5 shapes + ragged N; loss, d/dx and d/dy through autograd."""
+    g = torch.Generator().manual_seed(1234)
+    x_c = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    y_c = torch.softmax(3 * torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    w = torch.rand(B, generator=g) + 0.5
+    xo, yo = x_c.clone().requires_grad_(True), y_c.clone().requires_grad_(True)
+    M = oracle.anchor_cost_matrix(n)
+    lo = oracle.samples_loss(xo, yo, M, blur=blur)
+    (lo * w).sum().backward()
+    # the reference detaches y inside the cost (utils.py:88) but y still gets gradient through
+    # the yy / yx problems' first argument -- the HIP backward returns exactly that.
+    crit = _crit(n, blur)
+    xg, yg = x_c.cuda().requires_grad_(True), y_c.cuda().requires_grad_(True)
+    lg = crit(xg, yg)
+    (lg * w.cuda()).sum().backward()
+    scale = max(1.0, float(lo.abs().max()) / 1e-4)
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), lo.detach().numpy(), rtol=0, atol=LOSS_ATOL * scale)
+    for got, want in ((xg.grad, xo.grad), (yg.grad, yo.grad)):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(want).max())
+
+
+def test_weighted_four_argument_form_and_zero_weights():
+    """(alpha, x, beta, y) form incl. zero-mass anchors (log-weight -1e5, sinkhorn_divergence.py:47-50)."""
+    B, n = 3, 96
+    g = torch.Generator().manual_seed(5)
+    x = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    y = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    a = torch.rand(B, n, generator=g)
+    a[:, ::7] = 0
+    a = a / a.sum(1, keepdim=True)
+    b = torch.rand(B, n, generator=g)
+    b = b / b.sum(1, keepdim=True)
+    M = oracle.anchor_cost_matrix(n)
+    C = lambda p, q: oracle.spherical_cost(p, q, M)
+    eps_s = oracle.epsilon_schedule(2, oracle.max_diameter(x, y), .05, .5)
+    duals = oracle.sinkhorn_loop(oracle.log_weights(a), oracle.log_weights(b), C(x, x), C(y, y), C(x, y), C(y, x), eps_s)
+    want = oracle.sinkhorn_cost(a, b, *duals).numpy()
+    got = _crit(n, .05)(a.cuda(), x.cuda(), b.cuda(), y.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=LOSS_ATOL * max(1.0, np.abs(want).max() / 1e-4))
+
+
+def test_properties_at_full_size():
+    """Size-independent properties at BASELINE cfg4 per-GPU batch: S(x,x)=0, symmetry, determinism."""
+    B, n = 256, 128
+    g = torch.Generator().manual_seed(9)
+    x = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1).cuda()
+    y = torch.softmax(2 * torch.randn(B, n, generator=g), 1).view(B, n, 1).cuda()
+    crit = _crit(n, .05, diameter=1.0)
+    sxx = crit(x, x)
+    assert float(sxx.abs().max()) <= 2e-7
+    sxy, syx = crit(x, y), crit(y, x)
+    np.testing.assert_allclose(sxy.cpu().numpy(), syx.cpu().numpy(), rtol=0, atol=1e-6)
+    assert float(sxy.min()) > 0
+    assert torch.equal(crit(x, y), sxy)  # bitwise run-to-run
+
+
+def test_empty_batch_and_errors():
+    crit = _crit(96, .05)
+    out = crit(torch.empty(0, 96, 1, device="cuda"), torch.empty(0, 96, 1, device="cuda"))
+    assert out.shape == (0,)
+    with pytest.raises(ValueError):
+        crit(torch.rand(2, 64, 1, device="cuda"), torch.rand(2, 64, 1, device="cuda"))
