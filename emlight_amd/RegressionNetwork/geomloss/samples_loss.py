@@ -137,6 +137,8 @@ class SamplesLoss(Module):
         B = x.shape[0]
         x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
         y2 = _lib.require_gpu_tensor(y.reshape(B, self.N), "y")
+        if B == 0:
+            return x2.new_zeros(0) + 0.0 * (x2.sum() + y2.sum())
         a2 = None if a is None else _lib.require_gpu_tensor(a.reshape(B, self.N), "alpha")
         b2 = None if b is None else _lib.require_gpu_tensor(b.reshape(B, self.N), "beta")
         M, Mt = self.cost_matrix(x2.device)

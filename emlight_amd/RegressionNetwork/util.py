@@ -62,6 +62,8 @@ def convert_to_panorama(dirs, sizes, colors, pano_hw=(128, 256)):
     if d.shape != (B, 3 * N) or c.shape != (B, 3 * N):
         raise ValueError("expected dirs (B,3N), sizes (B,N), colors (B,3N); got %s %s %s"
                          % (tuple(d.shape), tuple(s.shape), tuple(c.shape)))
+    if B == 0:
+        return c.new_zeros(0, 3, int(H), int(W))
     return _Rasterise.apply(d, s, c, int(H), int(W))
 
 

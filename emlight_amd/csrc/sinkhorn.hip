@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
     lw2[i] = l * kLog2e;
   }
   for (int i = tid; i < 4 * NP; i += 512) h2[i] = 0.f;
+  __syncthreads();  // pts / lw2 / zeroed h2 visible to every thread before any cross-thread read
 
   const float* P = pts + (rows_x ? 0 : NP);
   const float* Q = pts + (cols_x ? 0 : NP);

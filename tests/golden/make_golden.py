@@ -27,9 +27,13 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 
-torch.Tensor.cuda = lambda self, *a, **k: self
-torch.nn.Module.cuda = lambda self, *a, **k: self
-torch.set_num_threads(8)
+
+
+def install_shims():
+    """Only when generating (never on import: the tests import SINKHORN_CASES from here)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.set_num_threads(8)
 
 
 def rng(*seed):
@@ -318,6 +322,7 @@ def gen_densenet():
 
 
 if __name__ == "__main__":
+    install_shims()
     which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet"]
     if "sinkhorn" in which:
         gen_sinkhorn()
