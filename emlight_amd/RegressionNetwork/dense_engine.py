@@ -1,0 +1,256 @@
+"""HIP engine of the DenseNet-BC feature extractor (``DenseNet.features`` + relu + avgpool).
+
+Orchestrates the gfx950 kernels of ``csrc/dense_fwd.hip`` / ``csrc/dense_bwd.hip`` through the
+C ABI.  PyTorch only owns the memory: one zero-initialised pixel-major (NHWC) buffer per
+dense block (the concatenation axis -- ``torch.cat`` of ``DenseNet.py:55`` is a pointer
+offset), the 48-channel bottleneck outputs kept for backward, and small per-layer BN
+scale/shift / statistics vectors.  With 288 GB of HBM per GPU nothing is recomputed or
+freed inside a step; buffers are allocated once per input shape and reused.
+
+Train-mode BatchNorm (the reference never calls ``.eval()`` on this network): each producer
+kernel emits f64 partial sums of what it writes, ``eml_dense_bn_prepare_f32`` folds them and
+emits the (scale, shift) the next consumer applies while loading its MFMA operand.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+def _r16(v):
+    return (v + 15) // 16 * 16
+
+
+class _Workspace:
+    """All device buffers for one (B, H, W, train) shape."""
+
+    def __init__(self, enc, B, H, W, dev, keep_all):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.B, self.H, self.W = B, H, W
+        self.blocks = []
+        h, w = H, W
+        for bi, (c0, nl) in enumerate(zip(enc.block_c0, enc.block_layers)):
+            ctot = c0 + nl * enc.growth
+            blk = {
+                "H": h, "W": w, "P": B * h * w, "C0": c0, "Ctot": ctot, "ld": _r16(ctot),
+                "X": torch.zeros(B * h * w, _r16(ctot), **f32),  # zeros: padded / not-yet-written channels stay finite
+                "Z": torch.empty(nl if keep_all else 1, B * h * w, enc.inter, **f32),
+                "mean": torch.zeros(_r16(ctot), **f32), "var": torch.ones(_r16(ctot), **f32),
+                "istd": torch.ones(_r16(ctot), **f32),
+                "layers": [],
+            }
+            for l in range(nl):
+                kp = _r16(c0 + l * enc.growth)
+                blk["layers"].append({
+                    "Cin": c0 + l * enc.growth, "Kp": kp,
+                    "scale1": torch.zeros(kp, **f32), "shift1": torch.zeros(kp, **f32),
+                    "scale2": torch.zeros(enc.inter, **f32), "shift2": torch.zeros(enc.inter, **f32),
+                    "zmean": torch.zeros(enc.inter, **f32), "zvar": torch.ones(enc.inter, **f32),
+                    "zistd": torch.ones(enc.inter, **f32),
+                    "W1p": torch.empty(kp * 48, **f32), "W2p": torch.empty(9 * 3 * 4 * 16 * 4, **f32),
+                })
+            cout = enc.trans_cout[bi]
+            kpt = _r16(ctot)
+            blk["trans"] = {
+                "Cout": cout, "Kp": kpt, "nchunks": (cout + 47) // 48,
+                "scale": torch.zeros(kpt, **f32), "shift": torch.zeros(kpt, **f32),
+                "Wp": torch.empty(((cout + 47) // 48) * kpt * 48, **f32),
+                "T": torch.empty(B * (h // 2) * (w // 2), cout, **f32),
+                "tmean": torch.zeros(cout, **f32), "tvar": torch.ones(cout, **f32), "tistd": torch.ones(cout, **f32),
+                "scaleL": torch.zeros(cout, **f32), "shiftL": torch.zeros(cout, **f32),
+            }
+            self.blocks.append(blk)
+            h, w = h // 2, w // 2
+        self.hf, self.wf = h, w
+        cf = enc.trans_cout[-1]
+        self.F = torch.zeros(B * h * w, _r16(cf), **f32)          # last_norm3 output
+        self.Y0 = torch.empty(B * H * W, enc.c_init, **f32)       # raw conv0 output (kept for backward)
+        self.mean0 = torch.zeros(enc.c_init, **f32)
+        self.var0 = torch.ones(enc.c_init, **f32)
+        self.istd0 = torch.ones(enc.c_init, **f32)
+        self.scale0 = torch.zeros(enc.c_init, **f32)
+        self.shift0 = torch.zeros(enc.c_init, **f32)
+        self.partials = torch.zeros(4 * enc.grid_max * 96, dtype=torch.float64, device=dev)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        ctx.enc = enc
+        needs_grad = any(ctx.needs_input_grad[2:])
+        ws, pooled = enc.run_forward(x, keep_all=needs_grad)
+        ctx.ws = ws
+        ctx.save_for_backward(x)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpooled):
+        (x,) = ctx.saved_tensors
+        grads = ctx.enc.run_backward(ctx.ws, x, gpooled.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class HipDenseEncoder:
+    def __init__(self, model):
+        f = model.features
+        self.model = model
+        self.growth = model.growth_rate
+        self.inter = model.bn_size * model.growth_rate
+        if self.inter != 48 or self.growth != 12:
+            raise NotImplementedError("the HIP engine is built for growth_rate=12, bn_size=4 (EMLight's DenseNet)")
+        self.c_init = f.conv0.out_channels
+        self.block_layers = list(model.block_config)
+        self.block_c0, self.trans_cout = [], []
+        c = self.c_init
+        for bi, nl in enumerate(self.block_layers):
+            self.block_c0.append(c)
+            c += nl * self.growth
+            c = getattr(f, "transition%d" % (bi + 1)).conv.out_channels
+            self.trans_cout.append(c)
+        self.avgpool = model.avgpool_size
+        self.grid_max = 1024
+        self._ws = {}
+        self._cu = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def param_list(self):
+        f = self.model.features
+        ps = [f.conv0.weight, f.norm0.weight, f.norm0.bias]
+        for bi, nl in enumerate(self.block_layers):
+            blk = getattr(f, "denseblock%d" % (bi + 1))
+            for l in range(nl):
+                L = getattr(blk, "denselayer%d" % (l + 1))
+                ps += [L.norm1.weight, L.norm1.bias, L.conv1.weight, L.norm2.weight, L.norm2.bias, L.conv2.weight]
+            T = getattr(f, "transition%d" % (bi + 1))
+            ps += [T.norm.weight, T.norm.bias, T.conv.weight]
+            LN = getattr(f, "last_norm%d" % (bi + 1))
+            ps += [LN.weight, LN.bias]
+        return ps
+
+    def __call__(self, x):
+        x = _lib.require_gpu_tensor(x, "x")
+        B, C, H, W = x.shape
+        if C != 3:
+            raise ValueError("expected (B,3,H,W) input")
+        if (H % (8 * self.avgpool)) or (W % (8 * self.avgpool)):
+            # three /2 transitions then avgpool(k): the reference silently floors; keep it exact
+            pass
+        return _EncoderFn.apply(self, x, *self.param_list())
+
+    def _grid(self, dev):
+        if self._cu is None:
+            self._cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        return min(self.grid_max, 2 * self._cu)
+
+    def workspace(self, B, H, W, dev, keep_all):
+        key = (B, H, W, dev, keep_all)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = _Workspace(self, B, H, W, dev, keep_all)
+            self._ws = {key: ws}  # one live shape at a time (buffers are GBs at training sizes)
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _prepare(self, L, st, partials, G, pstride, n_new, c_new0, count, mean, var, istd, bn, C, Cpad, training,
+                 scale, shift):
+        p = _lib.ptr
+        if bn is None:
+            args = (None, None, None, None)
+            eps, mom = 1e-5, 0.1
+        else:
+            args = (p(bn.weight), p(bn.bias), p(bn.running_mean), p(bn.running_var))
+            eps, mom = bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+        _lib.check(L.eml_dense_bn_prepare_f32(p(partials), G, pstride, n_new, c_new0, float(count), p(mean), p(var),
+                                              p(istd), *args, C, Cpad, eps, mom, int(training), p(scale), p(shift),
+                                              st), "eml_dense_bn_prepare_f32")
+
+    def run_forward(self, x, keep_all):
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        m = self.model
+        f = m.features
+        B, _, H, W = x.shape
+        dev = x.device
+        ws = self.workspace(B, H, W, dev, keep_all)
+        G = self._grid(dev)
+        Gb = min(self.grid_max, 4 * (self._cu or 256))
+        training = m.training
+        part = ws.partials
+        b0 = ws.blocks[0]
+        # ---- conv0 -> norm0 -> relu0 (DenseNet.py:88-93)
+        _lib.check(L.eml_dense_conv0_fwd_f32(p(x), p(f.conv0.weight), p(ws.Y0), self.c_init, B, H, W, self.c_init,
+                                             p(part), G, st), "eml_dense_conv0_fwd_f32")
+        self._prepare(L, st, part, G, 2 * self.c_init, self.c_init, 0, b0["P"], ws.mean0, ws.var0, ws.istd0, f.norm0,
+                      self.c_init, self.c_init, training, ws.scale0, ws.shift0)
+        _lib.check(L.eml_dense_bn_apply_f32(p(ws.Y0), self.c_init, p(b0["X"]), b0["ld"], self.c_init, b0["P"],
+                                            p(ws.scale0), p(ws.shift0), 1, p(part), Gb, st), "eml_dense_bn_apply_f32")
+        self._prepare(L, st, part, Gb, 2 * self.c_init, self.c_init, 0, b0["P"], b0["mean"], b0["var"], b0["istd"],
+                      None, 0, 0, training, None, None)
+        nb = len(ws.blocks)
+        for bi, blk in enumerate(ws.blocks):
+            mod = getattr(f, "denseblock%d" % (bi + 1))
+            P, Hb, Wb, ld = blk["P"], blk["H"], blk["W"], blk["ld"]
+            pending = False  # partial stats of the previous layer's 12 new channels wait in `part`
+            for l, lay in enumerate(blk["layers"]):
+                Lm = getattr(mod, "denselayer%d" % (l + 1))
+                cin, kp = lay["Cin"], lay["Kp"]
+                z = blk["Z"][l if keep_all else 0]
+                self._prepare(L, st, part if pending else None, G, 32, 12, cin - 12, P, blk["mean"], blk["var"],
+                              blk["istd"], Lm.norm1, cin, kp, training, lay["scale1"], lay["shift1"])
+                _lib.check(L.eml_dense_permute_w1_f32(p(Lm.conv1.weight), 48, cin, kp, p(lay["W1p"]), st),
+                           "eml_dense_permute_w1_f32")
+                _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, P, Hb, Wb, 0, kp, p(lay["scale1"]),
+                                                       p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), G, st),
+                           "eml_dense_conv1x1_fwd_f32")
+                self._prepare(L, st, part, G, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
+                              training, lay["scale2"], lay["shift2"])
+                _lib.check(L.eml_dense_permute_w2_f32(p(Lm.conv2.weight), 12, p(lay["W2p"]), st),
+                           "eml_dense_permute_w2_f32")
+                _lib.check(L.eml_dense_conv3x3_fwd_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2p"]),
+                                                       p(blk["X"]), ld, cin, B, Hb, Wb, p(part), G, st),
+                           "eml_dense_conv3x3_fwd_f32")
+                pending = True
+            # ---- transition (BN-ReLU-1x1-avgpool2, DenseNet.py:14-21) + last_norm (DenseNet.py:122)
+            tr, T = blk["trans"], getattr(f, "transition%d" % (bi + 1))
+            LN = getattr(f, "last_norm%d" % (bi + 1))
+            ctot, cout, kpt = blk["Ctot"], tr["Cout"], tr["Kp"]
+            self._prepare(L, st, part if pending else None, G, 32, 12, ctot - 12, P, blk["mean"], blk["var"],
+                          blk["istd"], T.norm, ctot, kpt, training, tr["scale"], tr["shift"])
+            _lib.check(L.eml_dense_permute_w1_f32(p(T.conv.weight), cout, ctot, kpt, p(tr["Wp"]), st),
+                       "eml_dense_permute_w1_f32")
+            Pn = B * (Hb // 2) * (Wb // 2)
+            _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, p(tr["scale"]), p(tr["shift"]),
+                                                   p(tr["Wp"]), cout, p(tr["T"]), cout, p(part), G, st),
+                       "eml_dense_conv1x1_fwd_f32(transition)")
+            for ch in range(tr["nchunks"]):
+                nv = min(48, cout - 48 * ch)
+                last = ch == tr["nchunks"] - 1
+                pv = part[ch * G * 96:]
+                self._prepare(L, st, pv, G, 96, nv, 48 * ch, Pn, tr["tmean"], tr["tvar"], tr["tistd"],
+                              LN if last else None, cout if last else 0, cout if last else 0, training,
+                              tr["scaleL"] if last else None, tr["shiftL"] if last else None)
+            if bi + 1 < nb:
+                nxt = ws.blocks[bi + 1]
+                dst, ldd = nxt["X"], nxt["ld"]
+            else:
+                dst, ldd = ws.F, ws.F.shape[1]
+            _lib.check(L.eml_dense_bn_apply_f32(p(tr["T"]), cout, p(dst), ldd, cout, Pn, p(tr["scaleL"]),
+                                                p(tr["shiftL"]), 0, p(part), Gb, st), "eml_dense_bn_apply_f32")
+            if bi + 1 < nb:
+                self._prepare(L, st, part, Gb, 2 * cout, cout, 0, Pn, nxt["mean"], nxt["var"], nxt["istd"], None, 0, 0,
+                              training, None, None)
+        # ---- relu -> avgpool(k) -> flatten in (C,h,w) order (DenseNet.py:136-137)
+        cf = self.trans_cout[-1]
+        k = self.avgpool
+        pooled = torch.empty(B, cf * (ws.hf // k) * (ws.wf // k), dtype=torch.float32, device=dev)
+        _lib.check(L.eml_dense_head_pool_fwd_f32(p(ws.F), ws.F.shape[1], cf, B, ws.hf, ws.wf, k, p(pooled), st),
+                   "eml_dense_head_pool_fwd_f32")
+        if training:
+            bns = [mm for mm in f.modules() if isinstance(mm, torch.nn.BatchNorm2d)]
+            torch._foreach_add_([mm.num_batches_tracked for mm in bns], 1)
+        return ws, pooled
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, ws, x, gpooled):
+        from .dense_engine_bwd import run_backward
+        return run_backward(self, ws, x, gpooled)

@@ -28,6 +28,20 @@ SIGNATURES = {
     "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p,
                                     _f32p, _f32p, _int, _int, _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
+    # DenseNet-BC encoder, forward
+    "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
+    "eml_dense_bn_apply_f32": (_int, [_f32p, _int, _f32p, _int, _int, ctypes.c_long, _f32p, _f32p, _int, _f32p,
+                                      _int, _stream]),
+    "eml_dense_bn_prepare_f32": (_int, [_f32p, _int, _int, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _f32p,
+                                        _f32p, _f32p, _f32p, _int, _int, ctypes.c_float, ctypes.c_float, _int,
+                                        _f32p, _f32p, _stream]),
+    "eml_dense_permute_w1_f32": (_int, [_f32p, _int, _int, _int, _f32p, _stream]),
+    "eml_dense_permute_w2_f32": (_int, [_f32p, _int, _f32p, _stream]),
+    "eml_dense_conv1x1_fwd_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _f32p, _f32p, _f32p,
+                                         _int, _f32p, _int, _f32p, _int, _stream]),
+    "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
+                                         _int, _stream]),
+    "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),
 }
 
 _lock = threading.Lock()

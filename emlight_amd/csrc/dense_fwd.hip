@@ -1,0 +1,586 @@
+// Forward kernels of the DenseNet-BC encoder (reference RegressionNetwork/DenseNet.py:14-65,
+// 88-122) for gfx950, f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32, 157 TF/s peak).
+//
+// Data layout: every dense block lives in ONE pixel-major (NHWC) buffer X[P][ld] whose
+// channel axis is the concatenation, so `torch.cat` (DenseNet.py:55) is a pointer offset: a
+// layer reads channels [0, C_in) and appends its 12 new channels at [C_in, C_in+12).
+//
+// conv1x1 (bottleneck, and the transitions): out[p][o] = sum_k relu(s_k X[p][k] + t_k) W[k][o]
+//   BN1 + ReLU are applied in registers on the way from HBM to the MFMA A operand -- the
+//   normalised activation never exists in memory.  The A operand is loaded straight from
+//   global memory as float4 (16 B/lane): MFMA's k index is only a summation index, so step t
+//   of a 16-channel group takes lane (row r, kk) 's channel 16j+4kk+t and the weights are
+//   pre-permuted to match ([Kp/16][4][48][4], one ds_read_b128 per B fragment).  No LDS
+//   staging of activations, no barrier in the main loop.
+// conv3x3 (48 -> 12): BN2 (no ReLU, DenseNet.py:38-43) is applied while a 10x34x48 halo tile
+//   is staged into LDS (zero padding applied AFTER BN, as F.conv2d pads the BN output);
+//   the 9x48x16 weight fragments stay in registers for the whole persistent loop.
+// Batch statistics for train-mode BN are emitted by every producer's epilogue as per-block
+//   f64 partial (sum, sumsq) and finished by bn_prepare -- deterministic, no atomics.
+#include "eml_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float4 bn_relu4(float4 x, float4 s, float4 t) {
+  float4 r;
+  r.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f);
+  r.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
+  r.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f);
+  r.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+  return r;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// Reduce per-lane f64 (sum, sumsq) of NCH channels-per-lane over the 4 row groups of a wave
+// and the 4 waves of a block; channel of (n, lane) is 16n + (lane & 15).
+template <int NT>
+__device__ __forceinline__ void block_stats_store(double (&s)[NT], double (&q)[NT], double* red /*LDS [4][NT*16][2]*/,
+                                                  double* __restrict__ partials /*[NT*16][2]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    s[n] += shfl_xor_d(s[n], 16);
+    s[n] += shfl_xor_d(s[n], 32);
+    q[n] += shfl_xor_d(q[n], 16);
+    q[n] += shfl_xor_d(q[n], 32);
+    if (lane < 16) {
+      red[(wave * NT * 16 + n * 16 + lane) * 2 + 0] = s[n];
+      red[(wave * NT * 16 + n * 16 + lane) * 2 + 1] = q[n];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NT * 16 * 2; e += 256)
+    partials[e] = (red[e] + red[NT * 32 + e]) + (red[2 * NT * 32 + e] + red[3 * NT * 32 + e]);
+}
+
+// ------------------------------------------------------------------------------ conv1x1
+// out[p][n0 + o] (o < n_valid <= 48) for output pixels p < P.  POOL: the A operand is the
+// 2x2 average of relu(bn(x)) (avg-pool commutes with the 1x1 conv: transition, DenseNet.py:14-21).
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
+    const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ Wp,
+    float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                 // [Kp/16][4][48][4]
+  float* sl = wl + (size_t)Kp * 48; // [Kp]
+  float* tl = sl + Kp;              // [Kp]
+  double* red = reinterpret_cast<double*>(tl + Kp);  // [4][48][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+
+  for (int e = tid; e < Kp * 12; e += 256)
+    reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(Wp)[e];
+  for (int e = tid; e < Kp; e += 256) {
+    sl[e] = scale[e];
+    tl[e] = shift[e];
+  }
+  __syncthreads();
+
+  double ssum[3] = {0, 0, 0}, ssq[3] = {0, 0, 0};
+  const int nj = Kp >> 4;
+  const int ntiles = (P + 255) >> 8;
+  const int Wo = Win >> 1, Ho = Hin >> 1;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = tile * 256 + wave * 64;
+    const float* rp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int pm = min(p0 + 16 * m + r, P - 1);
+      if constexpr (POOL) {
+        const int b = pm / (Ho * Wo), rem = pm - b * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        rp[m] = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx + 4 * kk;
+      } else {
+        rp[m] = X + (size_t)pm * ldx + 4 * kk;
+      }
+    }
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j = 0; j < nj; ++j) {
+      const float4 s4 = *reinterpret_cast<const float4*>(sl + 16 * j + 4 * kk);
+      const float4 t4 = *reinterpret_cast<const float4*>(tl + 16 * j + 4 * kk);
+      float4 a[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (POOL) {
+          const float* q = rp[m] + 16 * j;
+          const float4 v0 = bn_relu4(*reinterpret_cast<const float4*>(q), s4, t4);
+          const float4 v1 = bn_relu4(*reinterpret_cast<const float4*>(q + ldx), s4, t4);
+          const float4 v2 = bn_relu4(*reinterpret_cast<const float4*>(q + (size_t)Win * ldx), s4, t4);
+          const float4 v3 = bn_relu4(*reinterpret_cast<const float4*>(q + (size_t)Win * ldx + ldx), s4, t4);
+          a[m].x = ((v0.x + v1.x) + (v2.x + v3.x)) * 0.25f;
+          a[m].y = ((v0.y + v1.y) + (v2.y + v3.y)) * 0.25f;
+          a[m].z = ((v0.z + v1.z) + (v2.z + v3.z)) * 0.25f;
+          a[m].w = ((v0.w + v1.w) + (v2.w + v3.w)) * 0.25f;
+        } else {
+          a[m] = bn_relu4(*reinterpret_cast<const float4*>(rp[m] + 16 * j), s4, t4);
+        }
+      }
+      float4 bw[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+        bw[n] = *reinterpret_cast<const float4*>(wl + ((size_t)(j * 4 + kk) * 48 + 16 * n + r) * 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          acc[m][n] = mfma16(a[m].x, bw[n].x, acc[m][n]);
+          acc[m][n] = mfma16(a[m].y, bw[n].y, acc[m][n]);
+          acc[m][n] = mfma16(a[m].z, bw[n].z, acc[m][n]);
+          acc[m][n] = mfma16(a[m].w, bw[n].w, acc[m][n]);
+        }
+    }
+    // epilogue: C/D layout col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = 16 * n + r;
+      float ls = 0.f, lq = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int p = p0 + 16 * m + 4 * kk + g;
+          const float v = acc[m][n][g];
+          if (p < P && col < n_valid) {
+            out[(size_t)p * ldo + col] = v;
+            ls += v;
+            lq = fmaf(v, v, lq);
+          }
+        }
+      ssum[n] += (double)ls;
+      ssq[n] += (double)lq;
+    }
+  }
+  block_stats_store<3>(ssum, ssq, red, partials + (size_t)blockIdx.x * 96);
+}
+
+// ------------------------------------------------------------------------------ conv3x3
+constexpr int kTH = 8, kTW = 32;            // output tile per block
+constexpr int kHH = kTH + 2, kHW = kTW + 2; // halo tile
+constexpr int kPS = 52;                     // LDS pixel stride (48 + 4 pad, 16-B aligned)
+
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(
+    const float* __restrict__ Z, const float* __restrict__ scale2, const float* __restrict__ shift2,
+    const float* __restrict__ W2p, float* __restrict__ X, int ldx, int c_out0, int B, int H, int W,
+    double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile_l = smem;                                   // [kHH*kHW][kPS]
+  float* st_l = tile_l + kHH * kHW * kPS;                 // [2][48]
+  double* red = reinterpret_cast<double*>(st_l + 96);     // [4][16][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+
+  if (tid < 48) {
+    st_l[tid] = scale2[tid];
+    st_l[48 + tid] = shift2[tid];
+  }
+  // weight fragments: lane (kk, o=r) holds W2[o][16j+4kk+t][tap], t = 0..3
+  float4 bw[9][3];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      bw[tap][j] = *reinterpret_cast<const float4*>(W2p + ((size_t)((tap * 3 + j) * 4 + kk) * 16 + r) * 4);
+  __syncthreads();
+
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int ntiles = B * ty_n * tx_n;
+  double ssum[1] = {0}, ssq[1] = {0};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
+    // stage BN2(z) halo tile; out-of-image -> 0 (padding is applied to the BN output)
+    for (int e = tid; e < kHH * kHW * 12; e += 256) {
+      const int pix = e / 12, q = e - pix * 12;
+      const int hy = pix / kHW, hx = pix - hy * kHW;
+      const int gy = y0 + hy, gx = x0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const float4 z = *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q);
+        const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
+        const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
+        v.x = fmaf(z.x, s.x, t.x);
+        v.y = fmaf(z.y, s.y, t.y);
+        v.z = fmaf(z.z, s.z, t.z);
+        v.w = fmaf(z.w, s.w, t.w);
+      }
+      *reinterpret_cast<float4*>(tile_l + pix * kPS + 4 * q) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wave w owns output rows 2w, 2w+1; M-tile m = row (m>>1), 16 columns at 16*(m&1)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float4 a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int hy = 2 * wave + (m >> 1) + dy, hx = 16 * (m & 1) + r + dx;
+          a[m] = *reinterpret_cast<const float4*>(tile_l + (hy * kHW + hx) * kPS + 16 * j + 4 * kk);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          acc[m] = mfma16(a[m].x, bw[tap][j].x, acc[m]);
+          acc[m] = mfma16(a[m].y, bw[tap][j].y, acc[m]);
+          acc[m] = mfma16(a[m].z, bw[tap][j].z, acc[m]);
+          acc[m] = mfma16(a[m].w, bw[tap][j].w, acc[m]);
+        }
+      }
+    }
+    float ls = 0.f, lq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int gy = ty * kTH + 2 * wave + (m >> 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int gx = tx * kTW + 16 * (m & 1) + 4 * kk + g;
+        const float v = acc[m][g];
+        if (gy < H && gx < W && r < 12) {
+          X[((size_t)(b * H + gy) * W + gx) * ldx + c_out0 + r] = v;
+          ls += v;
+          lq = fmaf(v, v, lq);
+        }
+      }
+    }
+    ssum[0] += (double)ls;
+    ssq[0] += (double)lq;
+    __syncthreads();  // everyone done with the halo tile before it is restaged
+  }
+  block_stats_store<1>(ssum, ssq, red, partials + (size_t)blockIdx.x * 32);
+}
+
+// ------------------------------------------------------------------------------ conv0 (3 -> C0, 3x3, NCHW in)
+template <int C0>
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                        float* __restrict__ X, int ldx, int B, int H, int W,
+                                                        double* __restrict__ partials) {
+  __shared__ float wl[C0 * 27];
+  __shared__ double wacc[4][C0][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < C0 * 27; e += 256) wl[e] = w0[e];  // [o][c][ky][kx]
+  for (int e = tid; e < 4 * C0 * 2; e += 256) (&wacc[0][0][0])[e] = 0.0;
+  __syncthreads();
+  const size_t P = (size_t)B * H * W, plane = (size_t)H * W;
+  const size_t nt = (P + 255) / 256;
+  for (size_t tile = blockIdx.x; tile < nt; tile += gridDim.x) {
+    const size_t p = tile * 256 + tid;
+    const bool valid = p < P;
+    const size_t pc = valid ? p : P - 1;
+    const int b = (int)(pc / plane);
+    const int rem = (int)(pc - (size_t)b * plane);
+    const int yy = rem / W, xx = rem - yy * W;
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int gy = yy + ky - 1, gx = xx + kx - 1;
+          in[c * 9 + ky * 3 + kx] =
+              (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)(b * 3 + c) * H + gy) * W + gx] : 0.f;
+        }
+    // 8 output channels at a time keeps the register footprint small (27 inputs + 8 sums)
+#pragma unroll 1
+    for (int g8 = 0; g8 < C0 / 8; ++g8) {
+      float o[8];
+#pragma unroll
+      for (int oc = 0; oc < 8; ++oc) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) s = fmaf(in[k], wl[(g8 * 8 + oc) * 27 + k], s);
+        o[oc] = s;
+      }
+      if (valid) {
+        float4* dst = reinterpret_cast<float4*>(X + p * ldx + g8 * 8);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+#pragma unroll
+      for (int oc = 0; oc < 8; ++oc) {
+        const float v = valid ? o[oc] : 0.f;
+        const float s = eml::wave_sum(v), q = eml::wave_sum(v * v);
+        if (lane == 0) {
+          wacc[wave][g8 * 8 + oc][0] += (double)s;
+          wacc[wave][g8 * 8 + oc][1] += (double)q;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < C0 * 2; e += 256) {
+    const int oc = e >> 1, k = e & 1;
+    partials[(size_t)blockIdx.x * C0 * 2 + e] = (wacc[0][oc][k] + wacc[1][oc][k]) + (wacc[2][oc][k] + wacc[3][oc][k]);
+  }
+}
+
+// ------------------------------------------------------------------------------ BN apply (+ReLU) with stats of the result
+// dst[p][c] = act(scale[c]*src[p][c] + shift[c]) for c < C; emits f64 partial stats of dst.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                       int ldd, int C, size_t P, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu,
+                                                       double* __restrict__ partials /*[G][C][2]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* red = reinterpret_cast<double*>(smem);  // [4][CP][2], CP = 64*ceil(C/64)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = (C + 63) >> 6;  // <= 6
+  float s[6], t[6];
+  double acc_s[6], acc_q[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int c = lane + 64 * k;
+    s[k] = (k < nk && c < C) ? scale[c] : 0.f;
+    t[k] = (k < nk && c < C) ? shift[c] : 0.f;
+    acc_s[k] = acc_q[k] = 0.0;
+  }
+  for (size_t p = (size_t)blockIdx.x * 4 + wave; p < P; p += (size_t)gridDim.x * 4) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int c = lane + 64 * k;
+      if (k < nk && c < C) {
+        float v = fmaf(src[p * lds_ + c], s[k], t[k]);
+        if (relu) v = fmaxf(v, 0.f);
+        dst[p * ldd + c] = v;
+        acc_s[k] += (double)v;
+        acc_q[k] += (double)v * (double)v;
+      }
+    }
+  }
+  const int CP = nk * 64;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k < nk) {
+      red[(wave * CP + lane + 64 * k) * 2 + 0] = acc_s[k];
+      red[(wave * CP + lane + 64 * k) * 2 + 1] = acc_q[k];
+    }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256)
+    partials[(size_t)blockIdx.x * C * 2 + e] =
+        (red[e] + red[CP * 2 + e]) + (red[2 * CP * 2 + e] + red[3 * CP * 2 + e]);
+}
+
+// ------------------------------------------------------------------------------ BN prepare
+// (1) fold the f64 partial stats of n_new freshly produced channels [c_new0, c_new0+n_new)
+//     into the block's per-channel mean / biased var / invstd arrays;
+// (2) scale_k = gamma_k * invstd_k, shift_k = beta_k - mean_k * scale_k for k < C (zero up to Cpad);
+// (3) training: running stats update with momentum (unbiased var), as nn.BatchNorm2d does.
+// eval (training == 0): mean / var are taken from the running buffers.
+__global__ __launch_bounds__(256) void bn_prepare_kernel(
+    const double* __restrict__ partials, int G, int pstride, int n_new, int c_new0, double count,
+    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ istd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, int C, int Cpad, float eps, float momentum, int training,
+    float* __restrict__ scale, float* __restrict__ shift) {
+  const int tid = threadIdx.x;
+  if (partials) {
+    for (int c = tid; c < n_new; c += 256) {
+      double s = 0.0, q = 0.0;
+      for (int g = 0; g < G; ++g) {
+        s += partials[(size_t)g * pstride + 2 * c];
+        q += partials[(size_t)g * pstride + 2 * c + 1];
+      }
+      const double m = s / count;
+      const double v = fmax(q / count - m * m, 0.0);
+      mean[c_new0 + c] = (float)m;
+      var[c_new0 + c] = (float)v;
+      istd[c_new0 + c] = (float)(1.0 / sqrt(v + (double)eps));
+    }
+    __syncthreads();
+  }
+  if (!scale) return;
+  for (int c = tid; c < Cpad; c += 256) {
+    float sc = 0.f, sh = 0.f;
+    if (c < C) {
+      float m, is;
+      if (training) {
+        m = mean[c];
+        is = istd[c];
+        const double unbiased = (double)var[c] * (count / fmax(count - 1.0, 1.0));
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+      } else {
+        m = rmean[c];
+        is = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+      }
+      sc = gamma[c] * is;
+      sh = beta[c] - m * sc;
+    }
+    scale[c] = sc;
+    shift[c] = sh;
+  }
+}
+
+// ------------------------------------------------------------------------------ weight permutes
+// W [Cout][Cin] (1x1 conv, PyTorch layout) -> Wp[chunk][Kp/16][4][48][4] with
+// Wp[..][j][kk][o][t] = W[n0+o][16j+4kk+t], zero outside.
+__global__ void permute_w1_kernel(const float* __restrict__ W, int Cout, int Cin, int Kp, int nchunks,
+                                  float* __restrict__ Wp) {
+  const size_t total = (size_t)nchunks * Kp * 48;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 3);
+    size_t rest = e >> 2;
+    const int o = (int)(rest % 48);
+    rest /= 48;
+    const int kk = (int)(rest & 3);
+    rest >>= 2;
+    const int j = (int)(rest % (Kp >> 4));
+    const int ch = (int)(rest / (Kp >> 4));
+    const int k = 16 * j + 4 * kk + t, oc = ch * 48 + o;
+    Wp[e] = (k < Cin && oc < Cout) ? W[(size_t)oc * Cin + k] : 0.f;
+  }
+}
+// W2 [12][48][3][3] -> W2p[tap][j][kk][16][4] with W2p = W2[o][16j+4kk+t][tap], zero for o >= 12.
+__global__ void permute_w2_kernel(const float* __restrict__ W2, int Cout, float* __restrict__ W2p) {
+  const int total = 9 * 3 * 4 * 16 * 4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int t = e & 3, o = (e >> 2) & 15, kk = (e >> 6) & 3;
+    const int rest = e >> 8, j = rest % 3, tap = rest / 3;
+    const int c = 16 * j + 4 * kk + t;
+    W2p[e] = (o < Cout) ? W2[((size_t)o * 48 + c) * 9 + tap] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------ head: relu -> avgpool(k) -> (B, C, h, w) flatten
+__global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ F, int ldf, int C, int B, int H, int W,
+                                                        int k, float* __restrict__ out) {
+  const int Ho = H / k, Wo = W / k;
+  const size_t total = (size_t)B * Ho * Wo * C;
+  const float inv = 1.0f / (float)(k * k);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    size_t rest = e / C;
+    const int ox = (int)(rest % Wo);
+    rest /= Wo;
+    const int oy = (int)(rest % Ho);
+    const int b = (int)(rest / Ho);
+    float s = 0.f;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        s += fmaxf(F[((size_t)(b * H + oy * k + i) * W + ox * k + j) * ldf + c], 0.f);
+    out[(((size_t)b * C + c) * Ho + oy) * Wo + ox] = s * inv;
+  }
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int eml_dense_conv0_fwd_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
+                                       int C0, double* partials, int grid, eml_stream_t stream) {
+  if (!x || !w0 || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || ldx < C0 || (ldx & 3))
+    return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_f32: bad arguments");
+  if (C0 != 24) return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_f32: only num_init_features=24 is built (got %d)", C0);
+  hipLaunchKernelGGL(conv0_fwd_kernel<24>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w0, X, ldx, B, H, W, partials);
+  return eml::check_launch("eml_dense_conv0_fwd_f32");
+}
+
+extern "C" int eml_dense_bn_apply_f32(const float* src, int ld_src, float* dst, int ld_dst, int C, long P,
+                                      const float* scale, const float* shift, int relu, double* partials, int grid,
+                                      eml_stream_t stream) {
+  if (!src || !dst || !scale || !shift || !partials || C < 1 || C > 384 || P < 1 || grid < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_bn_apply_f32: bad arguments (C<=384)");
+  const size_t lds = (size_t)4 * ((C + 63) / 64) * 64 * 2 * sizeof(double);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, src, ld_src, dst, ld_dst, C,
+                     (size_t)P, scale, shift, relu, partials);
+  return eml::check_launch("eml_dense_bn_apply_f32");
+}
+
+extern "C" int eml_dense_bn_prepare_f32(const double* partials, int G, int pstride, int n_new, int c_new0, double count,
+                                        float* mean, float* var, float* istd, const float* gamma, const float* beta,
+                                        float* rmean, float* rvar, int C, int Cpad, float eps, float momentum,
+                                        int training, float* scale, float* shift, eml_stream_t stream) {
+  if (!mean || !var || !istd || count < 1.0) return eml::fail(EML_EINVAL, "eml_dense_bn_prepare_f32: bad arguments");
+  if (scale && (!shift || !gamma || !beta || !rmean || !rvar || C < 1 || Cpad < C))
+    return eml::fail(EML_EINVAL, "eml_dense_bn_prepare_f32: bad BN arguments");
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, G, pstride, n_new, c_new0,
+                     count, mean, var, istd, gamma, beta, rmean, rvar, C, Cpad, eps, momentum, training, scale, shift);
+  return eml::check_launch("eml_dense_bn_prepare_f32");
+}
+
+extern "C" int eml_dense_permute_w1_f32(const float* W, int Cout, int Cin, int Kp, float* Wp, eml_stream_t stream) {
+  if (!W || !Wp || Cout < 1 || Cin < 1 || Kp < Cin || (Kp & 15))
+    return eml::fail(EML_EINVAL, "eml_dense_permute_w1_f32: bad arguments");
+  const int nchunks = (Cout + 47) / 48;
+  hipLaunchKernelGGL(permute_w1_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, Cout, Cin, Kp, nchunks, Wp);
+  return eml::check_launch("eml_dense_permute_w1_f32");
+}
+
+extern "C" int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t stream) {
+  if (!W2 || !W2p || Cout < 1 || Cout > 16) return eml::fail(EML_EINVAL, "eml_dense_permute_w2_f32: bad arguments");
+  hipLaunchKernelGGL(permute_w2_kernel, dim3(27), dim3(256), 0, (hipStream_t)stream, W2, Cout, W2p);
+  return eml::check_launch("eml_dense_permute_w2_f32");
+}
+
+// conv1x1 over all ceil(Cout/48) output chunks.  pool != 0: transition (2x2 avg-pool fused in
+// the operand load; P = B*(Hin/2)*(Win/2) output pixels).  partials: [chunks][grid][48][2] f64.
+extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, int Kp,
+                                         const float* scale, const float* shift, const float* Wp, int Cout,
+                                         float* out, int ldo, double* partials, int grid, eml_stream_t stream) {
+  if (!X || !scale || !shift || !Wp || !out || !partials || P < 1 || grid < 1 || Kp < 16 || (Kp & 15) || Kp > ldx ||
+      (ldx & 3) || Cout < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: bad arguments");
+  if (pool && ((Hin & 1) || (Win & 1))) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: pool needs even H, W");
+  const size_t lds = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double);
+  if (lds > 160 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: Kp=%d does not fit LDS", Kp);
+  const int nchunks = (Cout + 47) / 48;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nv = (Cout - ch * 48 < 48) ? Cout - ch * 48 : 48;
+    const float* wp = Wp + (size_t)ch * Kp * 48;
+    double* pp = partials + (size_t)ch * grid * 96;
+    if (pool) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
+                         Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
+                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp);
+    }
+    int rc = eml::check_launch("eml_dense_conv1x1_fwd_f32");
+    if (rc) return rc;
+  }
+  return EML_OK;
+}
+
+extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* shift2, const float* W2p,
+                                         float* X, int ldx, int c_out0, int B, int H, int W, double* partials, int grid,
+                                         eml_stream_t stream) {
+  if (!Z || !scale2 || !shift2 || !W2p || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || c_out0 + 12 > ldx)
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_fwd_f32: bad arguments");
+  const size_t lds = (size_t)(kHH * kHW * kPS + 96) * sizeof(float) + 4 * 16 * 2 * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, Z, scale2, shift2, W2p, X, ldx,
+                     c_out0, B, H, W, partials);
+  return eml::check_launch("eml_dense_conv3x3_fwd_f32");
+}
+
+extern "C" int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, int W, int k, float* out,
+                                           eml_stream_t stream) {
+  if (!F || !out || C < 1 || B < 1 || k < 1 || H < k || W < k) return eml::fail(EML_EINVAL, "eml_dense_head_pool_fwd_f32: bad arguments");
+  const size_t total = (size_t)B * (H / k) * (W / k) * C;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(head_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, F, ldf, C, B, H, W, k, out);
+  return eml::check_launch("eml_dense_head_pool_fwd_f32");
+}

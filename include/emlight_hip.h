@@ -96,6 +96,60 @@ int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const f
 int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, int B, int N,
                          eml_stream_t stream);
 
+
+/* ---------------------------------------------------------------- DenseNet-BC encoder, forward
+ * All activations are pixel-major (NHWC) f32: a dense block is ONE buffer X[P][ld] whose channel
+ * axis is the concatenation (torch.cat of DenseNet.py:55 becomes a pointer offset).  Train-mode
+ * BatchNorm statistics are emitted by each producer as per-workgroup f64 partial (sum, sumsq)
+ * pairs, `grid` rows of them, and folded by eml_dense_bn_prepare_f32 -- no atomics.
+ * `grid` = number of persistent workgroups to launch (the caller sizes `partials` by it). */
+
+/* conv0: 3 -> C0 (=24) 3x3 pad 1 on the NCHW input (DenseNet.py:88-90), raw output into
+ * X[:, 0:C0] (ld = ldx); partials [grid][C0][2]. */
+int eml_dense_conv0_fwd_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
+                            int C0, double* partials, int grid, eml_stream_t stream);
+
+/* dst[p][c] = act(scale[c]*src[p][c] + shift[c]), c < C (norm0+relu0, DenseNet.py:91-92; last_norm,
+ * DenseNet.py:122); partials [grid][C][2] = stats of dst. */
+int eml_dense_bn_apply_f32(const float* src, int ld_src, float* dst, int ld_dst, int C, long P,
+                           const float* scale, const float* shift, int relu, double* partials,
+                           int grid, eml_stream_t stream);
+
+/* Fold partial stats of n_new fresh channels [c_new0, c_new0+n_new) into mean/var/istd (biased var,
+ * istd = 1/sqrt(var+eps)), then (if scale != NULL) write the BatchNorm2d affine for channels
+ * [0, C): scale = gamma*istd, shift = beta - mean*scale (zeros up to Cpad), and update the running
+ * statistics with `momentum` (unbiased var) when training; eval uses the running buffers
+ * (nn.BatchNorm2d semantics; DenseNet.py:17,29,40,91,122). */
+int eml_dense_bn_prepare_f32(const double* partials, int G, int pstride, int n_new, int c_new0,
+                             double count, float* mean, float* var, float* istd, const float* gamma,
+                             const float* beta, float* rmean, float* rvar, int C, int Cpad, float eps,
+                             float momentum, int training, float* scale, float* shift,
+                             eml_stream_t stream);
+
+/* Weight re-layouts into MFMA fragment order (done once per step):
+ * W [Cout][Cin] (1x1) -> Wp [ceil(Cout/48)][Kp/16][4][48][4];  W2 [Cout<=16][48][3][3] -> W2p [9][3][4][16][4]. */
+int eml_dense_permute_w1_f32(const float* W, int Cout, int Cin, int Kp, float* Wp, eml_stream_t stream);
+int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t stream);
+
+/* out[p][o] = sum_k relu(scale_k*X[p][k] + shift_k) * W[o][k]:  BN1 -> ReLU -> conv1 of a dense layer
+ * (DenseNet.py:30-37; Cout = 48) and, with pool != 0, a transition BN -> ReLU -> conv -> avgpool2
+ * (DenseNet.py:14-21; the pool is applied to the operand: it commutes with the 1x1 conv).
+ * P output pixels; partials [ceil(Cout/48)][grid][48][2]. */
+int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, int Kp,
+                              const float* scale, const float* shift, const float* Wp, int Cout,
+                              float* out, int ldo, double* partials, int grid, eml_stream_t stream);
+
+/* X[p][c_out0 + o] = conv3x3(scale2*Z + shift2)[p][o], o < 12: BN2 -> conv2 of a dense layer
+ * (DenseNet.py:38-43, no ReLU between them); Z is (B,H,W,48); partials [grid][16][2]. */
+int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* shift2,
+                              const float* W2p, float* X, int ldx, int c_out0, int B, int H, int W,
+                              double* partials, int grid, eml_stream_t stream);
+
+/* out (B, C, H/k, W/k) = avg_pool_k(relu(F)) for NHWC F: the head of DenseNet.forward
+ * (DenseNet.py:136-137), flattened in the reference's (C,h,w) order for `fc`. */
+int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, int W, int k,
+                                float* out, eml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
