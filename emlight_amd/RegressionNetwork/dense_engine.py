@@ -56,7 +56,8 @@ class _Workspace:
                 "Cout": cout, "Kp": kpt, "nchunks": (cout + 47) // 48,
                 "scale": torch.zeros(kpt, **f32), "shift": torch.zeros(kpt, **f32),
                 "Wp": torch.empty(((cout + 47) // 48) * kpt * 48, **f32),
-                "T": torch.empty(B * (h // 2) * (w // 2), cout, **f32),
+                "Ko": _r16(cout),
+                "T": torch.zeros(B * (h // 2) * (w // 2), _r16(cout), **f32),  # raw transition output (kept for backward)
                 "tmean": torch.zeros(cout, **f32), "tvar": torch.ones(cout, **f32), "tistd": torch.ones(cout, **f32),
                 "scaleL": torch.zeros(cout, **f32), "shiftL": torch.zeros(cout, **f32),
             }
@@ -220,7 +221,7 @@ class HipDenseEncoder:
                        "eml_dense_permute_w1_f32")
             Pn = B * (Hb // 2) * (Wb // 2)
             _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, p(tr["scale"]), p(tr["shift"]),
-                                                   p(tr["Wp"]), cout, p(tr["T"]), cout, p(part), G, st),
+                                                   p(tr["Wp"]), cout, p(tr["T"]), tr["Ko"], p(part), G, st),
                        "eml_dense_conv1x1_fwd_f32(transition)")
             for ch in range(tr["nchunks"]):
                 nv = min(48, cout - 48 * ch)
@@ -234,7 +235,7 @@ class HipDenseEncoder:
                 dst, ldd = nxt["X"], nxt["ld"]
             else:
                 dst, ldd = ws.F, ws.F.shape[1]
-            _lib.check(L.eml_dense_bn_apply_f32(p(tr["T"]), cout, p(dst), ldd, cout, Pn, p(tr["scaleL"]),
+            _lib.check(L.eml_dense_bn_apply_f32(p(tr["T"]), tr["Ko"], p(dst), ldd, cout, Pn, p(tr["scaleL"]),
                                                 p(tr["shiftL"]), 0, p(part), Gb, st), "eml_dense_bn_apply_f32")
             if bi + 1 < nb:
                 self._prepare(L, st, part, Gb, 2 * cout, cout, 0, Pn, nxt["mean"], nxt["var"], nxt["istd"], None, 0, 0,

@@ -42,6 +42,27 @@ SIGNATURES = {
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
                                          _int, _stream]),
     "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),
+    # DenseNet-BC encoder, backward
+    "eml_dense_conv3x3_bwd_data_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
+                                              _f32p, _int, _stream]),
+    "eml_dense_conv3x3_bwd_weight_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _int, _int, _int, _f32p,
+                                                _f32p, _int, _stream]),
+    "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,
+                                             _int, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
+                                                _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
+                                                _f32p, _int, _stream]),
+    "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),
+    "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
+                                              _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
+                                              _int, _f32p, _f32p, _int, _stream]),
+    "eml_dense_bn_bwd_accumulate_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p, _int, _int,
+                                               ctypes.c_long, _int, _stream]),
+    "eml_dense_bn_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _int, _int, ctypes.c_long, _f32p,
+                                          _f32p, _f32p, _int, _stream]),
+    "eml_dense_conv0_bwd_weight_f32": (_int, [_f32p, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p,
+                                              _int, _int, _int, _f32p, _f32p, _int, _stream]),
+    "eml_dense_head_pool_bwd_f32": (_int, [_f32p, _f32p, _int, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,813 @@
+// Backward kernels of the DenseNet-BC encoder for gfx950 (f32 MFMA 16x16x4).
+//
+// Per dense layer (reverse order), with G the gradient buffer that mirrors the block buffer X:
+//   conv3x3_bwd_data   dzn = conv2^T(G[:, Cin:Cin+12])           + partial (sum dzn, sum dzn*zhat)
+//   conv3x3_bwd_weight dW2 = sum_p g[p] (x) BN2(z)[p+tap]        (persistent accumulators, partials)
+//   bn_bwd_finalize    dgamma2, dbeta2, and the affine that turns dzn into dz on the fly:
+//                      dz = cA*dzn + cB*z + cC   (BatchNorm backward is affine per channel)
+//   conv1x1_bwd_weight dW1 = sum_p relu(bn1(x))[p] (x) dz[p]     (dz rebuilt in the operand load)
+//   conv1x1_bwd_data   da  = dz W1, masked by relu, written once + partial (sum, sum*xhat)
+//   bn_bwd_finalize    dgamma1, dbeta1, affine of BN1 backward
+//   bn_bwd_accumulate  G[:, :Cin] += cA*da + cB*x + cC
+// The transitions reuse the conv1x1 kernels with the 2x2 average pool folded into the operand
+// (POOL) and last_norm's backward folded into the dz affine.  All reductions are per-block
+// partials + a finishing kernel: deterministic, no atomics.
+#include "eml_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+constexpr int kTH = 8, kTW = 32, kHH = kTH + 2, kHW = kTW + 2;
+
+// =============================================================================== conv3x3 backward: data
+// dzn[q][c] = sum_{dy,dx,o} W2[o][c][dy][dx] * g[(qy-dy+1, qx-dx+1)][o]
+constexpr int kPSG = 12;  // LDS pixel stride of the g halo tile
+
+__global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
+    const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
+    const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
+    double* __restrict__ partials /*[grid][48][2]*/) {
+  __shared__ __attribute__((aligned(16))) float g_l[kHH * kHW * kPSG];
+  __shared__ double red[4 * 48 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+
+  // B fragments: lane (kk, c = 16n + r) holds W2[o = 4s + kk][c][tap]
+  float bw[9][3][3];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bw[tap][s][n] = W2[((size_t)(4 * s + kk) * 48 + 16 * n + r) * 9 + tap];
+  float zm[3], zi[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    zm[n] = zmean[16 * n + r];
+    zi[n] = zistd[16 * n + r];
+  }
+
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int ntiles = B * ty_n * tx_n;
+  double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
+    for (int e = tid; e < kHH * kHW * 6; e += 256) {
+      const int pix = e / 6, q = e - pix * 6;
+      const int hy = pix / kHW, hx = pix - hy * kHW;
+      const int gy = y0 + hy, gx = x0 + hx;
+      float2 v = make_float2(0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const float2*>(G + ((size_t)(b * H + gy) * W + gx) * ldg + c0 + 2 * q);
+      *reinterpret_cast<float2*>(g_l + pix * kPSG + 2 * q) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        float a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int hy = 2 * wave + (m >> 1) + 2 - dy, hx = 16 * (m & 1) + r + 2 - dx;
+          a[m] = g_l[(hy * kHW + hx) * kPSG + 4 * s + kk];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(a[m], bw[tap][s][n], acc[m][n]);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int gy = ty * kTH + 2 * wave + (m >> 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int gx = tx * kTW + 16 * (m & 1) + 4 * kk + g;
+          if (gy < H && gx < W) {
+            const size_t p = (size_t)(b * H + gy) * W + gx;
+            const float v = acc[m][n][g];
+            DZ[p * 48 + 16 * n + r] = v;
+            const float zh = (Z[p * 48 + 16 * n + r] - zm[n]) * zi[n];
+            l1 += v;
+            l2 = fmaf(v, zh, l2);
+          }
+        }
+      }
+      s1[n] += (double)l1;
+      s2[n] += (double)l2;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    s1[n] += shfl_xor_d(s1[n], 16);
+    s1[n] += shfl_xor_d(s1[n], 32);
+    s2[n] += shfl_xor_d(s2[n], 16);
+    s2[n] += shfl_xor_d(s2[n], 32);
+    if (lane < 16) {
+      red[(wave * 48 + 16 * n + lane) * 2 + 0] = s1[n];
+      red[(wave * 48 + 16 * n + lane) * 2 + 1] = s2[n];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 96; e += 256)
+    partials[(size_t)blockIdx.x * 96 + e] = (red[e] + red[96 + e]) + (red[192 + e] + red[288 + e]);
+}
+
+// =============================================================================== conv3x3 backward: weight
+// dW2[o][c][dy][dx] = sum_p g[p][o] * zn[p + (dy-1, dx-1)][c];  D[i=c][j=o], MFMA-k = pixel.
+// 27 (tap, 16-channel group) accumulator tiles are spread over the 4 waves (7,7,7,6).
+constexpr int kPSW = 48;
+
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(
+    const float* __restrict__ G, int ldg, int c0, const float* __restrict__ Z, const float* __restrict__ scale2,
+    const float* __restrict__ shift2, int B, int H, int W, float* __restrict__ partial /*[grid][27][16][16]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile_l = smem;                       // [kHH*kHW][48]
+  float* st_l = tile_l + kHH * kHW * kPSW;    // [2][48]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  if (tid < 48) {
+    st_l[tid] = scale2[tid];
+    st_l[48 + tid] = shift2[tid];
+  }
+  __syncthreads();
+  f32x4 acc[7];
+  int aoff[7];  // LDS offset of this wave's (tap, mc) pair relative to the pixel
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int idx = min(wave + 4 * i, 26), tap = idx / 3, mc = idx - 3 * tap;
+    aoff[i] = ((tap / 3) * kHW + (tap % 3)) * kPSW + 16 * mc + r;
+  }
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int ntiles = B * ty_n * tx_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
+    // B operand: lane (kk, o = r) needs g[pixel 4*ks + kk][o] for the 64 k-steps of the tile
+    float gb[64];
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+      const int q = 4 * ks + kk, oy = q >> 5, ox = q & 31;
+      const int gy = ty * kTH + oy, gx = tx * kTW + ox;
+      gb[ks] = (gy < H && gx < W && r < 12) ? G[((size_t)(b * H + gy) * W + gx) * ldg + c0 + r] : 0.f;
+    }
+    for (int e = tid; e < kHH * kHW * 12; e += 256) {
+      const int pix = e / 12, q = e - pix * 12;
+      const int hy = pix / kHW, hx = pix - hy * kHW;
+      const int gy = y0 + hy, gx = x0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const float4 z = *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q);
+        const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
+        const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
+        v.x = fmaf(z.x, s.x, t.x);
+        v.y = fmaf(z.y, s.y, t.y);
+        v.z = fmaf(z.z, s.z, t.z);
+        v.w = fmaf(z.w, s.w, t.w);
+      }
+      *reinterpret_cast<float4*>(tile_l + pix * kPSW + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+      const int q = 4 * ks + kk, oy = q >> 5, ox = q & 31;
+      const float* base = tile_l + (oy * kHW + ox) * kPSW;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = mfma16(base[aoff[i]], gb[ks], acc[i]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int idx = wave + 4 * i;
+    if (idx < 27) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        partial[(((size_t)blockIdx.x * 27 + idx) * 16 + 4 * kk + g) * 16 + r] = acc[i][g];
+    }
+  }
+}
+
+// dW2[o][c][tap] = sum_blocks partial[blk][tap*3 + c/16][c%16][o]
+__global__ void reduce_dw2_kernel(const float* __restrict__ partial, int R, float* __restrict__ dW2, int Cout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Cout * 48 * 9) return;
+  const int tap = e % 9, c = (e / 9) % 48, o = e / (9 * 48);
+  const int idx = tap * 3 + (c >> 4);
+  double s = 0.0;
+  for (int b = 0; b < R; ++b) s += (double)partial[(((size_t)b * 27 + idx) * 16 + (c & 15)) * 16 + o];
+  dW2[e] = (float)s;
+}
+
+// =============================================================================== BN backward: finalize
+// From the partial (S1 = sum dy, S2 = sum dy*xhat) of C channels: dgamma = S2, dbeta = S1 and the
+// per-channel affine of the input gradient  dx = cA*dy + cB*x + cC  where
+//   cA = gamma*istd,  cB = -gamma*istd^2*S2/n,  cC = -gamma*istd*S1/n + gamma*istd^2*S2/n*mean.
+// Coefficients are zero-padded to Cpad.  eval-mode BN (training == 0): dx = gamma*istd*dy.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const double* __restrict__ partials, int R, int pstride, double count, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ istd, int C, int Cpad, int training,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
+    float* __restrict__ cC) {
+  for (int c = threadIdx.x; c < Cpad; c += 256) {
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (c < C) {
+      double S1 = 0.0, S2 = 0.0;
+      for (int g = 0; g < R; ++g) {
+        S1 += partials[(size_t)g * pstride + 2 * c];
+        S2 += partials[(size_t)g * pstride + 2 * c + 1];
+      }
+      dgamma[c] = (float)S2;
+      dbeta[c] = (float)S1;
+      const double ga = gamma[c], is = istd[c], mu = mean[c];
+      a = (float)(ga * is);
+      if (training) {
+        b = (float)(-ga * is * is * S2 / count);
+        d = (float)(-ga * is * S1 / count + ga * is * is * S2 / count * mu);
+      }
+    }
+    cA[c] = a;
+    cB[c] = b;
+    cC[c] = d;
+  }
+}
+
+// =============================================================================== conv1x1 backward: weight
+// dW[k][o] = sum_p a[p][k] * dz[p][o];  a = relu(s1*x + t1) (POOL: 2x2 mean of it),
+// dz[p][o] = cA[o]*DY[p][o] + cB[o]*Zr[p][o] + cC[o].  D[i=k][j=o], MFMA-k = pixel.
+// Waves split the Kp/16 channel tiles (and, when there are fewer than 4, the pixels).
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
+    const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp, const float* __restrict__ scale1,
+    const float* __restrict__ shift1, const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr,
+    int ld_z, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n_valid,
+    float* __restrict__ partial /*[grid*PW][Kp][48]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int nmt = Kp >> 4;
+  const int MW = (nmt >= 4) ? 4 : 2, PW = 4 / MW;
+  const int mg = wave % MW, pg = wave / MW;
+
+  float s1[6], t1[6];
+  int coff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int mt = mg + MW * i;
+    const bool v = mt < nmt;
+    const int ch = v ? 16 * mt + r : 0;
+    coff[i] = ch;
+    s1[i] = v ? scale1[ch] : 0.f;
+    t1[i] = v ? shift1[ch] : 0.f;
+  }
+  float ca[3], cb[3], cc[3];
+  bool nv[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    nv[n] = 16 * n + r < n_valid;
+    ca[n] = nv[n] ? cA[16 * n + r] : 0.f;
+    cb[n] = nv[n] ? cB[16 * n + r] : 0.f;
+    cc[n] = nv[n] ? cC[16 * n + r] : 0.f;
+  }
+  f32x4 acc[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int Wo = Win >> 1, Ho = Hin >> 1;
+  const long nq = ((long)P + 3) >> 2;
+  const long qstride = (long)gridDim.x * PW;
+  for (long q = (long)blockIdx.x * PW + pg; q < nq; q += qstride) {
+    const long p = 4 * q + kk;
+    const bool pv = p < P;
+    const long pc = pv ? p : (long)P - 1;
+    float dz[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = nv[n] ? 16 * n + r : 0;
+      const float v = fmaf(ca[n], DY[pc * ld_dy + col], fmaf(cb[n], Zr[pc * ld_z + col], cc[n]));
+      dz[n] = (pv && nv[n]) ? v : 0.f;
+    }
+    const float* xp;
+    if constexpr (POOL) {
+      const int b = (int)(pc / (Ho * Wo)), rem = (int)(pc - (long)b * (Ho * Wo));
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
+    } else {
+      xp = X + (size_t)pc * ldx;
+    }
+    float a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if constexpr (POOL) {
+        const float v0 = fmaxf(fmaf(xp[coff[i]], s1[i], t1[i]), 0.f);
+        const float v1 = fmaxf(fmaf(xp[ldx + coff[i]], s1[i], t1[i]), 0.f);
+        const float v2 = fmaxf(fmaf(xp[(size_t)Win * ldx + coff[i]], s1[i], t1[i]), 0.f);
+        const float v3 = fmaxf(fmaf(xp[(size_t)Win * ldx + ldx + coff[i]], s1[i], t1[i]), 0.f);
+        a[i] = ((v0 + v1) + (v2 + v3)) * 0.25f;
+      } else {
+        a[i] = fmaxf(fmaf(xp[coff[i]], s1[i], t1[i]), 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[i][n] = mfma16(a[i], dz[n], acc[i][n]);
+  }
+  float* out = partial + ((size_t)blockIdx.x * PW + pg) * Kp * 48;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int mt = mg + MW * i;
+    if (mt < nmt) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[(size_t)(16 * mt + 4 * kk + g) * 48 + 16 * n + r] = acc[i][n][g];
+    }
+  }
+}
+
+// dW[n0+o][k] (+)= sum_rows partial[row][k][o]   (PyTorch layout [Cout][Cin])
+__global__ void reduce_dw1_kernel(const float* __restrict__ partial, int R, int Kp, int Cin, int n0, int n_valid,
+                                  float* __restrict__ dW) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_valid * Cin) return;
+  const int k = e % Cin, o = e / Cin;
+  double s = 0.0;
+  for (int b = 0; b < R; ++b) s += (double)partial[((size_t)b * Kp + k) * 48 + o];
+  dW[(size_t)(n0 + o) * Cin + k] = (float)s;
+}
+
+// =============================================================================== conv1x1 backward: data
+// da[p][k] = sum_o dz[p][o] W[o][k], masked by relu(bn1(x)) > 0, stored to DA[P_in][Kp], with
+// partial sums S1 = sum dam, S2 = sum dam * xhat per input channel (xhat = (x-mean)*istd).
+// Wd: weights in B-fragment order [Kp/16][Ko/16][4][16][4] = W[o=16jo+4kk+t][k=16nt+col].
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
+    const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
+    const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
+    const float* __restrict__ X, int ldx, const float* __restrict__ scale1, const float* __restrict__ shift1,
+    const float* __restrict__ mean, const float* __restrict__ istd, int P, int Hin, int Win, int Kp,
+    float* __restrict__ DA, double* __restrict__ partials /*[grid][Kp][2]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* sacc = reinterpret_cast<double*>(smem);  // [4 waves][Kp][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < 4 * Kp * 2; e += 256) sacc[e] = 0.0;
+  __syncthreads();
+  double* my = sacc + (size_t)wave * Kp * 2;
+  const int nnt = Kp >> 4, njo = Ko >> 4;
+  const int ntiles = (P + 255) >> 8;
+  const int Wo = Win >> 1, Ho = Hin >> 1;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = tile * 256 + wave * 64;
+    long prow[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) prow[m] = min(p0 + 16 * m + r, P - 1);
+
+    for (int nt0 = 0; nt0 < nnt; nt0 += 4) {
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int jo = 0; jo < njo; ++jo) {
+        const int ch = 16 * jo + 4 * kk;
+        const float4 a4 = *reinterpret_cast<const float4*>(cA + ch);
+        const float4 b4 = *reinterpret_cast<const float4*>(cB + ch);
+        const float4 c4 = *reinterpret_cast<const float4*>(cC + ch);
+        float4 dz[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float4 dy = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
+          const float4 zr = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+          dz[m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
+          dz[m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
+          dz[m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
+          dz[m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int nt = min(nt0 + n, nnt - 1);
+          const float4 w = *reinterpret_cast<const float4*>(Wd + ((((size_t)nt * njo + jo) * 4 + kk) * 16 + r) * 4);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            acc[m][n] = mfma16(dz[m].x, w.x, acc[m][n]);
+            acc[m][n] = mfma16(dz[m].y, w.y, acc[m][n]);
+            acc[m][n] = mfma16(dz[m].z, w.z, acc[m][n]);
+            acc[m][n] = mfma16(dz[m].w, w.w, acc[m][n]);
+          }
+        }
+      }
+      // epilogue: col = input channel k, rows = pixels
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int nt = nt0 + n;
+        if (nt < nnt) {
+          const int k = 16 * nt + r;
+          const float sk = scale1[k], tk = shift1[k], mu = mean[k], is = istd[k];
+          float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int p = p0 + 16 * m + 4 * kk + g;
+              if (p < P) {
+                const float da = acc[m][n][g];
+                if constexpr (POOL) {
+                  const int b = p / (Ho * Wo), rem = p - b * (Ho * Wo);
+                  const int oy = rem / Wo, ox = rem - oy * Wo;
+                  const size_t pin = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;
+#pragma unroll
+                  for (int sub = 0; sub < 4; ++sub) {
+                    const size_t pi = pin + (sub >> 1) * (size_t)Win + (sub & 1);
+                    const float xv = X[pi * ldx + k];
+                    const float dam = (fmaf(xv, sk, tk) > 0.f) ? 0.25f * da : 0.f;
+                    DA[pi * Kp + k] = dam;
+                    l1 += dam;
+                    l2 = fmaf(dam, (xv - mu) * is, l2);
+                  }
+                } else {
+                  const float xv = X[(size_t)p * ldx + k];
+                  const float dam = (fmaf(xv, sk, tk) > 0.f) ? da : 0.f;
+                  DA[(size_t)p * Kp + k] = dam;
+                  l1 += dam;
+                  l2 = fmaf(dam, (xv - mu) * is, l2);
+                }
+              }
+            }
+          l1 += __shfl_xor(l1, 16, 64);
+          l1 += __shfl_xor(l1, 32, 64);
+          l2 += __shfl_xor(l2, 16, 64);
+          l2 += __shfl_xor(l2, 32, 64);
+          if (lane < 16) {
+            my[2 * k] += (double)l1;
+            my[2 * k + 1] += (double)l2;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < Kp * 2; e += 256)
+    partials[(size_t)blockIdx.x * Kp * 2 + e] =
+        (sacc[e] + sacc[(size_t)Kp * 2 + e]) + (sacc[(size_t)2 * Kp * 2 + e] + sacc[(size_t)3 * Kp * 2 + e]);
+}
+
+// Wd[nt][jo][kk][col][t] = W[o = 16jo+4kk+t][k = 16nt+col]  (W is [Cout][Cin]); zero outside.
+__global__ void permute_w1_bwd_kernel(const float* __restrict__ W, int Cout, int Cin, int Kp, int Ko,
+                                      float* __restrict__ Wd) {
+  const size_t total = (size_t)Kp * Ko;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 3), col = (int)((e >> 2) & 15), kk = (int)((e >> 6) & 3);
+    const size_t rest = e >> 8;
+    const int jo = (int)(rest % (Ko >> 4)), nt = (int)(rest / (Ko >> 4));
+    const int o = 16 * jo + 4 * kk + t, k = 16 * nt + col;
+    Wd[e] = (o < Cout && k < Cin) ? W[(size_t)o * Cin + k] : 0.f;
+  }
+}
+
+// =============================================================================== BN backward: accumulate
+// G[p][k] (+)= cA[k]*DA[p][k] + cB[k]*X[p][k] + cC[k]   for k < Kp (coefficients zero-padded)
+__global__ __launch_bounds__(256) void bn_bwd_accumulate_kernel(const float* __restrict__ DA, int ld_da,
+                                                                const float* __restrict__ X, int ldx,
+                                                                const float* __restrict__ cA,
+                                                                const float* __restrict__ cB,
+                                                                const float* __restrict__ cC, float* __restrict__ Gd,
+                                                                int ldg, int Kp, size_t P, int accumulate) {
+  const int nq = Kp >> 2;
+  const size_t total = P * nq;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t p = e / nq;
+    const int q = (int)(e - p * nq);
+    const float4 a = *reinterpret_cast<const float4*>(cA + 4 * q);
+    const float4 b = *reinterpret_cast<const float4*>(cB + 4 * q);
+    const float4 c = *reinterpret_cast<const float4*>(cC + 4 * q);
+    const float4 d = *reinterpret_cast<const float4*>(DA + p * ld_da + 4 * q);
+    const float4 x = *reinterpret_cast<const float4*>(X + p * ldx + 4 * q);
+    float4* gp = reinterpret_cast<float4*>(Gd + p * ldg + 4 * q);
+    float4 g = accumulate ? *gp : make_float4(0.f, 0.f, 0.f, 0.f);
+    g.x += fmaf(a.x, d.x, fmaf(b.x, x.x, c.x));
+    g.y += fmaf(a.y, d.y, fmaf(b.y, x.y, c.y));
+    g.z += fmaf(a.z, d.z, fmaf(b.z, x.z, c.z));
+    g.w += fmaf(a.w, d.w, fmaf(b.w, x.w, c.w));
+    *gp = g;
+  }
+}
+
+// =============================================================================== BN backward: stats (elementwise BN)
+// For y = act(BN(raw)):  dym = dy * (relu ? out > 0 : 1);  S1 = sum dym, S2 = sum dym * rawhat.
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ DY, int ld_dy,
+                                                           const float* __restrict__ raw, int ld_raw,
+                                                           const float* __restrict__ out, int ld_out, int relu, int C,
+                                                           size_t P, const float* __restrict__ mean,
+                                                           const float* __restrict__ istd,
+                                                           double* __restrict__ partials /*[grid][C][2]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = (C + 63) >> 6;
+  float mu[6], is[6];
+  double a1[6], a2[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int c = lane + 64 * k;
+    mu[k] = (k < nk && c < C) ? mean[c] : 0.f;
+    is[k] = (k < nk && c < C) ? istd[c] : 0.f;
+    a1[k] = a2[k] = 0.0;
+  }
+  for (size_t p = (size_t)blockIdx.x * 4 + wave; p < P; p += (size_t)gridDim.x * 4) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int c = lane + 64 * k;
+      if (k < nk && c < C) {
+        float dy = DY[p * ld_dy + c];
+        if (relu && !(out[p * ld_out + c] > 0.f)) dy = 0.f;
+        a1[k] += (double)dy;
+        a2[k] += (double)(dy * ((raw[p * ld_raw + c] - mu[k]) * is[k]));
+      }
+    }
+  }
+  const int CP = nk * 64;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k < nk) {
+      red[(wave * CP + lane + 64 * k) * 2 + 0] = a1[k];
+      red[(wave * CP + lane + 64 * k) * 2 + 1] = a2[k];
+    }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256)
+    partials[(size_t)blockIdx.x * C * 2 + e] =
+        (red[e] + red[CP * 2 + e]) + (red[2 * CP * 2 + e] + red[3 * CP * 2 + e]);
+}
+
+// =============================================================================== conv0 backward: weight
+// dW0[o][c][ky][kx] = sum_p dY0[p][o] * x[b][c][y+ky-1][x+kx-1],
+// dY0 = cA*(G*(X1>0)) + cB*Y0 + cC (norm0 + relu0 backward folded into the operand).
+// D[i=(c,ky,kx) 27->32][j=o 24->32], MFMA-k = pixel.
+__global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
+    const float* __restrict__ x, const float* __restrict__ Gd, int ldg, const float* __restrict__ X1, int ldx,
+    const float* __restrict__ Y0, int C0, const float* __restrict__ cA, const float* __restrict__ cB,
+    const float* __restrict__ cC, int B, int H, int W, float* __restrict__ partial /*[grid*4][32][32]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ca[2], cb[2], cc[2];
+  bool ov[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    ov[n] = 16 * n + r < C0;
+    ca[n] = ov[n] ? cA[16 * n + r] : 0.f;
+    cb[n] = ov[n] ? cB[16 * n + r] : 0.f;
+    cc[n] = ov[n] ? cC[16 * n + r] : 0.f;
+  }
+  int ci[2], dyi[2], dxi[2];
+  bool iv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = 16 * i + r;
+    iv[i] = t < 27;
+    ci[i] = iv[i] ? t / 9 : 0;
+    dyi[i] = iv[i] ? (t % 9) / 3 - 1 : 0;
+    dxi[i] = iv[i] ? (t % 3) - 1 : 0;
+  }
+  const size_t P = (size_t)B * H * W, plane = (size_t)H * W;
+  const size_t nq = (P + 3) >> 2;
+  for (size_t q = (size_t)blockIdx.x * 4 + wave; q < nq; q += (size_t)gridDim.x * 4) {
+    const size_t p = 4 * q + kk;
+    const bool pv = p < P;
+    const size_t pc = pv ? p : P - 1;
+    const int b = (int)(pc / plane), rem = (int)(pc - (size_t)b * plane);
+    const int yy = rem / W, xx = rem - yy * W;
+    float a[2], d[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gy = yy + dyi[i], gx = xx + dxi[i];
+      a[i] = (pv && iv[i] && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)(b * 3 + ci[i]) * H + gy) * W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int o = ov[n] ? 16 * n + r : 0;
+      float g = Gd[pc * ldg + o];
+      if (!(X1[pc * ldx + o] > 0.f)) g = 0.f;
+      const float v = fmaf(ca[n], g, fmaf(cb[n], Y0[pc * C0 + o], cc[n]));
+      d[n] = (pv && ov[n]) ? v : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[i][n] = mfma16(a[i], d[n], acc[i][n]);
+  }
+  float* out = partial + ((size_t)blockIdx.x * 4 + wave) * 1024;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(16 * i + 4 * kk + g) * 32 + 16 * n + r] = acc[i][n][g];
+}
+
+__global__ void reduce_dw0_kernel(const float* __restrict__ partial, int R, int C0, float* __restrict__ dW0) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C0 * 27) return;
+  const int t = e % 27, o = e / 27;
+  double s = 0.0;
+  for (int b = 0; b < R; ++b) s += (double)partial[(size_t)b * 1024 + t * 32 + o];
+  dW0[e] = (float)s;
+}
+
+// =============================================================================== head backward
+// dF[p][c] = (F[p][c] > 0) ? gpooled[b][c][oy/k][ox/k] / k^2 : 0
+__global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ F,
+                                                            int ldf, int C, int B, int H, int W, int k,
+                                                            float* __restrict__ dF, int ldd) {
+  const int Ho = H / k, Wo = W / k;
+  const size_t total = (size_t)B * H * W * C;
+  const float inv = 1.0f / (float)(k * k);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const size_t p = e / C;
+    const int xx = (int)(p % W);
+    const size_t rest = p / W;
+    const int yy = (int)(rest % H), b = (int)(rest / H);
+    const int oy = yy / k, ox = xx / k;
+    float v = 0.f;
+    if (oy < Ho && ox < Wo && F[p * ldf + c] > 0.f) v = gp[(((size_t)b * C + c) * Ho + oy) * Wo + ox] * inv;
+    dF[p * ldd + c] = v;
+  }
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
+                                              const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
+                                              double* partials, int grid, eml_stream_t stream) {
+  if (!G || !W2 || !Z || !zmean || !zistd || !DZ || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || (c0 & 1) ||
+      (ldg & 1))
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: bad arguments");
+  hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
+                     zistd, DZ, B, H, W, partials);
+  return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
+}
+
+extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const float* Z, const float* scale2,
+                                                const float* shift2, int B, int H, int W, float* partial, float* dW2,
+                                                int grid, eml_stream_t stream) {
+  if (!G || !Z || !scale2 || !shift2 || !partial || !dW2 || B < 1 || H < 1 || W < 1 || grid < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_weight_f32: bad arguments");
+  const size_t lds = (size_t)(kHH * kHW * kPSW + 96) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_weight_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, G, ldg, c0, Z, scale2,
+                     shift2, B, H, W, partial);
+  int rc = eml::check_launch("eml_dense_conv3x3_bwd_weight_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_dw2_kernel, dim3((12 * 48 * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                     grid, dW2, 12);
+  return eml::check_launch("eml_dense_conv3x3_bwd_weight_f32(reduce)");
+}
+
+extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
+                                             const float* gamma, const float* mean, const float* istd, int C, int Cpad,
+                                             int training, float* dgamma, float* dbeta, float* cA, float* cB,
+                                             float* cC, eml_stream_t stream) {
+  if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || !cA || !cB || !cC || C < 1 || Cpad < C || R < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, R, pstride, count,
+                     gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC);
+  return eml::check_launch("eml_dense_bn_bwd_finalize_f32");
+}
+
+// partial: [grid*2][Kp][48] floats of scratch; dW: [Cout][Cin] (PyTorch layout), all chunks.
+extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, int Kp,
+                                                int Cin, const float* scale1, const float* shift1, const float* DY,
+                                                int ld_dy, const float* Zr, int ld_z, const float* cA, const float* cB,
+                                                const float* cC, int Cout, float* partial, float* dW, int grid,
+                                                eml_stream_t stream) {
+  if (!X || !scale1 || !shift1 || !DY || !Zr || !cA || !cB || !cC || !partial || !dW || P < 1 || grid < 1 || Kp < 32 ||
+      (Kp & 15) || Cin > Kp || Cout < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: bad arguments");
+  const int PW = (Kp >= 64) ? 1 : 2;
+  const int nchunks = (Cout + 47) / 48;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int n0 = ch * 48, nv = (Cout - n0 < 48) ? Cout - n0 : 48;
+    if (pool)
+      hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)P,
+                         Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0, nv,
+                         partial);
+    else
+      hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                         (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
+                         nv, partial);
+    int rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_dw1_kernel, dim3((nv * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                       grid * PW, Kp, Cin, n0, nv, dW);
+    rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32(reduce)");
+    if (rc) return rc;
+  }
+  return EML_OK;
+}
+
+extern "C" int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int Ko, float* Wd,
+                                            eml_stream_t stream) {
+  if (!W || !Wd || Cout < 1 || Cin < 1 || Kp < Cin || (Kp & 15) || Ko < Cout || (Ko & 15))
+    return eml::fail(EML_EINVAL, "eml_dense_permute_w1_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(permute_w1_bwd_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, Cout, Cin, Kp, Ko, Wd);
+  return eml::check_launch("eml_dense_permute_w1_bwd_f32");
+}
+
+extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, int ld_z, const float* cA,
+                                              const float* cB, const float* cC, int Ko, const float* Wd,
+                                              const float* X, int ldx, const float* scale1, const float* shift1,
+                                              const float* mean, const float* istd, long P, int Hin, int Win, int pool,
+                                              int Kp, float* DA, double* partials, int grid, eml_stream_t stream) {
+  if (!DY || !Zr || !cA || !cB || !cC || !Wd || !X || !scale1 || !shift1 || !mean || !istd || !DA || !partials ||
+      P < 1 || grid < 1 || (Kp & 15) || (Ko & 15) || Ko > ld_dy || Ko > ld_z || (ld_dy & 3) || (ld_z & 3))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: bad arguments");
+  const size_t lds = (size_t)4 * Kp * 2 * sizeof(double);
+  if (pool)
+    hipLaunchKernelGGL(conv1x1_bwd_data_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
+                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, DA, partials);
+  else
+    hipLaunchKernelGGL(conv1x1_bwd_data_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
+                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, DA, partials);
+  return eml::check_launch("eml_dense_conv1x1_bwd_data_f32");
+}
+
+extern "C" int eml_dense_bn_bwd_accumulate_f32(const float* DA, int ld_da, const float* X, int ldx, const float* cA,
+                                               const float* cB, const float* cC, float* G, int ldg, int Kp, long P,
+                                               int accumulate, eml_stream_t stream) {
+  if (!DA || !X || !cA || !cB || !cC || !G || P < 1 || (Kp & 3) || (ld_da & 3) || (ldx & 3) || (ldg & 3))
+    return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_accumulate_f32: bad arguments");
+  const size_t total = (size_t)P * (Kp >> 2);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bn_bwd_accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, DA, ld_da, X, ldx, cA, cB,
+                     cC, G, ldg, Kp, (size_t)P, accumulate);
+  return eml::check_launch("eml_dense_bn_bwd_accumulate_f32");
+}
+
+extern "C" int eml_dense_bn_bwd_stats_f32(const float* DY, int ld_dy, const float* raw, int ld_raw, const float* out,
+                                          int ld_out, int relu, int C, long P, const float* mean, const float* istd,
+                                          double* partials, int grid, eml_stream_t stream) {
+  if (!DY || !raw || !mean || !istd || !partials || (relu && !out) || C < 1 || C > 384 || P < 1 || grid < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_stats_f32: bad arguments");
+  const size_t lds = (size_t)4 * ((C + 63) / 64) * 64 * 2 * sizeof(double);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, raw, ld_raw, out,
+                     ld_out, relu, C, (size_t)P, mean, istd, partials);
+  return eml::check_launch("eml_dense_bn_bwd_stats_f32");
+}
+
+extern "C" int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, int ldg, const float* X1, int ldx,
+                                              const float* Y0, int C0, const float* cA, const float* cB,
+                                              const float* cC, int B, int H, int W, float* partial, float* dW0,
+                                              int grid, eml_stream_t stream) {
+  if (!x || !G || !X1 || !Y0 || !cA || !cB || !cC || !partial || !dW0 || C0 < 1 || C0 > 32 || B < 1 || grid < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_conv0_bwd_weight_f32: bad arguments");
+  hipLaunchKernelGGL(conv0_bwd_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, G, ldg, X1, ldx, Y0, C0,
+                     cA, cB, cC, B, H, W, partial);
+  int rc = eml::check_launch("eml_dense_conv0_bwd_weight_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_dw0_kernel, dim3((C0 * 27 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                     grid * 4, C0, dW0);
+  return eml::check_launch("eml_dense_conv0_bwd_weight_f32(reduce)");
+}
+
+extern "C" int eml_dense_head_pool_bwd_f32(const float* gpooled, const float* F, int ldf, int C, int B, int H, int W,
+                                           int k, float* dF, int ldd, eml_stream_t stream) {
+  if (!gpooled || !F || !dF || C < 1 || B < 1 || k < 1) return eml::fail(EML_EINVAL, "eml_dense_head_pool_bwd_f32: bad arguments");
+  const size_t total = (size_t)B * H * W * C;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gpooled, F, ldf, C, B, H, W, k,
+                     dF, ldd);
+  return eml::check_launch("eml_dense_head_pool_bwd_f32");
+}

@@ -150,6 +150,71 @@ int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* 
 int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, int W, int k,
                                 float* out, eml_stream_t stream);
 
+/* ---------------------------------------------------------------- DenseNet-BC encoder, backward
+ * (autograd of DenseNet.py:14-65,88-122 -- the reference has no explicit backward code).
+ * G mirrors the block buffer X and accumulates d loss / d X.  BatchNorm backward is affine per
+ * channel, dx = cA*dy + cB*x + cC, so it is folded into the operand loads of the consumers. */
+
+/* dzn = conv2^T(G[:, c0:c0+12]) -> DZ (B,H,W,48); partials [grid][48][2] = (sum dzn, sum dzn*zhat). */
+int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
+                                   const float* zmean, const float* zistd, float* DZ, int B, int H,
+                                   int W, double* partials, int grid, eml_stream_t stream);
+
+/* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: grid*27*256 floats. */
+int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const float* Z,
+                                     const float* scale2, const float* shift2, int B, int H, int W,
+                                     float* partial, float* dW2, int grid, eml_stream_t stream);
+
+/* Finish a BatchNorm backward from R rows of (S1 = sum dy, S2 = sum dy*xhat) partials: dgamma, dbeta
+ * and the affine cA, cB, cC (zero-padded to Cpad) with dx = cA*dy + cB*x + cC. */
+int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
+                                  const float* gamma, const float* mean, const float* istd, int C,
+                                  int Cpad, int training, float* dgamma, float* dbeta, float* cA,
+                                  float* cB, float* cC, eml_stream_t stream);
+
+/* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
+ * in the operand load (pool != 0: transition, 2x2 mean of the activation).
+ * partial: grid*2*Kp*48 floats of scratch. */
+int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, int Win, int pool,
+                                     int Kp, int Cin, const float* scale1, const float* shift1,
+                                     const float* DY, int ld_dy, const float* Zr, int ld_z,
+                                     const float* cA, const float* cB, const float* cC, int Cout,
+                                     float* partial, float* dW, int grid, eml_stream_t stream);
+
+/* W (Cout,Cin) -> Wd [Kp/16][Ko/16][4][16][4], the B-fragment order of the data-gradient kernel. */
+int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int Ko, float* Wd,
+                                 eml_stream_t stream);
+
+/* DA[p][k] = relu-mask(scale1*X+shift1) * sum_o dz[p][o] W[o][k]  (pool != 0: spread over the 2x2
+ * input pixels, /4); partials [grid][Kp][2] = (sum DA, sum DA*xhat) for the BN1 backward. */
+int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, int ld_z,
+                                   const float* cA, const float* cB, const float* cC, int Ko,
+                                   const float* Wd, const float* X, int ldx, const float* scale1,
+                                   const float* shift1, const float* mean, const float* istd, long P,
+                                   int Hin, int Win, int pool, int Kp, float* DA, double* partials,
+                                   int grid, eml_stream_t stream);
+
+/* G[p][k] (+)= cA[k]*DA[p][k] + cB[k]*X[p][k] + cC[k], k < Kp. */
+int eml_dense_bn_bwd_accumulate_f32(const float* DA, int ld_da, const float* X, int ldx,
+                                    const float* cA, const float* cB, const float* cC, float* G,
+                                    int ldg, int Kp, long P, int accumulate, eml_stream_t stream);
+
+/* Stats of an elementwise BN(+ReLU) backward (last_norm; norm0+relu0): partials [grid][C][2]. */
+int eml_dense_bn_bwd_stats_f32(const float* DY, int ld_dy, const float* raw, int ld_raw,
+                               const float* out, int ld_out, int relu, int C, long P,
+                               const float* mean, const float* istd, double* partials, int grid,
+                               eml_stream_t stream);
+
+/* dW0 (C0,3,3,3) with norm0+relu0's backward folded into the operand; partial: grid*4*1024 floats. */
+int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, int ldg, const float* X1, int ldx,
+                                   const float* Y0, int C0, const float* cA, const float* cB,
+                                   const float* cC, int B, int H, int W, float* partial, float* dW0,
+                                   int grid, eml_stream_t stream);
+
+/* dF = relu-mask(F) * unpool_k(gpooled) / k^2 : backward of DenseNet.py:136-137. */
+int eml_dense_head_pool_bwd_f32(const float* gpooled, const float* F, int ldf, int C, int B, int H,
+                                int W, int k, float* dF, int ldd, eml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

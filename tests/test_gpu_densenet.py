@@ -69,3 +69,42 @@ def test_forward_cfg1_240x320_128_anchors(golden_densenet):
         p = net(x)
     for k in KEYS:
         np.testing.assert_allclose(p[k].cpu().numpy(), g["cfg1/" + k], rtol=0, atol=OUT_ATOL)
+
+
+def _grad_check(net, ref):
+    """Whole-network gradient parity.  Two f32 implementations of a ReLU network cannot agree
+    element-wise: forward values differ by ~1e-5 rel, so a few pre-activations per layer with
+    |pre| < 1e-5 get the opposite ReLU mask (measured: exactly one channel of transition3.norm.bias
+    off by one element's gradient, every other channel < 5e-7).  The bounds below are therefore on
+    the relative L2 error per tensor, scaled by the network's typical gradient magnitude so that
+    analytically-zero gradients (last_norm{1,2}.bias feed only train-mode BNs) do not blow up;
+    the per-kernel tests in test_gpu_dense_kernels.py hold each kernel to f32 round-off."""
+    named_r, named_g = dict(ref.named_parameters()), dict(net.named_parameters())
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a))))
+    floor = 1e-3 * np.median([rms(p.grad.numpy()) for p in named_r.values()])
+    errs = []
+    for name, pr in named_r.items():
+        gr, gg = pr.grad.numpy(), named_g[name].grad.cpu().numpy()
+        assert np.isfinite(gg).all(), name
+        errs.append((rms(gg - gr) / max(rms(gr), floor), name))
+    errs.sort(reverse=True)
+    assert errs[0][0] < 5e-2, "largest relative L2 grad errors: %s" % errs[:8]
+    assert np.median([e for e, _ in errs]) < 5e-3, "median relative L2 grad error %g" % np.median([e for e, _ in errs])
+
+
+@pytest.mark.parametrize("crop_hw,B", [((64, 96), 2), ((32, 64), 3)])
+def test_backward_small_vs_oracle(crop_hw, B):
+    """Every parameter gradient of one train-mode step vs the oracle's autograd (CPU)."""
+    ref, net = _pair(32, crop_hw, seed=5)
+    ref.train(), net.train()
+    g = np.random.default_rng([4, B])
+    x = torch.from_numpy(g.random((B, 3) + crop_hw, dtype=np.float32))
+    w = {k: torch.from_numpy(g.standard_normal(s).astype(np.float32))
+         for k, s in (("distribution", (B, 32)), ("intensity", (B, 1)), ("rgb_ratio", (B, 3)), ("ambient", (B, 3)))}
+    po = ref(x)
+    sum((po[k] * w[k]).sum() for k in KEYS).backward()
+    pg = net(x.cuda())
+    sum((pg[k] * w[k].cuda()).sum() for k in KEYS).backward()
+    for k in KEYS:
+        np.testing.assert_allclose(pg[k].detach().cpu().numpy(), po[k].detach().numpy(), rtol=1e-5, atol=OUT_ATOL)
+    _grad_check(net, ref)
