@@ -21,7 +21,6 @@ class _BwdBuffers:
         self.GF = torch.zeros(ws.F.shape[0], ws.F.shape[1], **f32)
         maxP = ws.blocks[0]["P"]
         self.DZ = torch.empty(maxP, 48, **f32)
-        self.DA = torch.empty(max(blk["P"] * blk["ld"] for blk in ws.blocks), **f32)
         self.Wd = torch.empty(352 * 176, **f32)
         self.coef = torch.zeros(6, 384, **f32)  # cA,cB,cC for the "dz" side and for the "dx" side
         g = enc.grid_max
@@ -46,12 +45,19 @@ def run_backward(enc, ws, x, gpooled):
     params = enc.param_list()
     grads = {id(q): torch.empty_like(q) for q in params}
     gr = lambda q: p(grads[id(q)])
-    cA, cB, cC, dA, dB, dC = (bw.coef[i] for i in range(6))
+    cA, cB, cC, sB, sC = (bw.coef[i] for i in range(5))
 
-    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, a, b, c):
-        _lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, pstride, float(count), p(bn.weight), p(mean), p(istd),
-                                                   C, Cpad, 1, gr(bn.weight), gr(bn.bias), p(a), p(b), p(c), st),
-                   "eml_dense_bn_bwd_finalize_f32")
+    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=True, s_acc=None):
+        """dgamma/dbeta of `bn`; coef: write the dz affine (cA,cB,cC); s_acc: fold (cB,cC) into sB/sC."""
+        _lib.check(L.eml_dense_bn_bwd_finalize_f32(
+            p(part), R, pstride, float(count), p(bn.weight), p(mean), p(istd), C, Cpad, 1, gr(bn.weight), gr(bn.bias),
+            p(cA) if coef else None, p(cB) if coef else None, p(cC) if coef else None,
+            p(sB) if s_acc is not None else None, p(sC) if s_acc is not None else None, int(bool(s_acc)), st),
+            "eml_dense_bn_bwd_finalize_f32")
+
+    def materialize(Gbuf, blk, c0, n):
+        _lib.check(L.eml_dense_grad_materialize_f32(p(Gbuf), blk["ld"], p(blk["X"]), blk["ld"], p(sB), p(sC), c0, n,
+                                                    blk["P"], st), "eml_dense_grad_materialize_f32")
 
     # ---- head: relu -> avgpool(k) backward
     cf, k = enc.trans_cout[-1], enc.avgpool
@@ -71,7 +77,7 @@ def run_backward(enc, ws, x, gpooled):
         # ---- last_norm backward (affine folded into the transition kernels' dz operand)
         _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(tr["T"]), Ko, None, 0, 0, cout, Pn, p(tr["tmean"]),
                                                 p(tr["tistd"]), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
-        finalize(Gb, 2 * cout, Pn, LN, tr["tmean"], tr["tistd"], cout, Ko, cA, cB, cC)
+        finalize(Gb, 2 * cout, Pn, LN, tr["tmean"], tr["tistd"], cout, Ko)
         # ---- transition conv (pool folded): weight grad, data grad, BN backward -> G (write)
         _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
             p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, ctot, p(tr["scale"]), p(tr["shift"]), p(dY), ld_dy, p(tr["T"]), Ko,
@@ -80,24 +86,23 @@ def run_backward(enc, ws, x, gpooled):
                    "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
             p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.Wd), p(blk["X"]), ld, p(tr["scale"]),
-            p(tr["shift"]), p(blk["mean"]), p(blk["istd"]), Pn, Hb, Wb, 1, kpt, p(bw.DA), p(part), G, st),
+            p(tr["shift"]), p(blk["mean"]), p(blk["istd"]), Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, st),
             "eml_dense_conv1x1_bwd_data_f32")
-        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, dA, dB, dC)
-        _lib.check(L.eml_dense_bn_bwd_accumulate_f32(p(bw.DA), kpt, p(blk["X"]), ld, p(dA), p(dB), p(dC), p(Gbuf), ld,
-                                                     kpt, P, 0, st), "eml_dense_bn_bwd_accumulate_f32")
+        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=False, s_acc=False)
         # ---- dense layers, last to first
         for l in reversed(range(len(blk["layers"]))):
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
             cin, kp = lay["Cin"], lay["Kp"]
             z = blk["Z"][l]
+            materialize(Gbuf, blk, cin, 12)  # gradient of this layer's 12 output channels is complete
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gbuf), ld, cin, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
                                                         p(lay["zistd"]), p(bw.DZ), B, Hb, Wb, p(part), G, st),
                        "eml_dense_conv3x3_bwd_data_f32")
             _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gbuf), ld, cin, p(z), p(lay["scale2"]), p(lay["shift2"]),
                                                           B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G, st),
                        "eml_dense_conv3x3_bwd_weight_f32")
-            finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, cA, cB, cC)
+            finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48)
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(bw.DZ), 48, p(z), 48,
                 p(cA), p(cB), p(cC), 48, p(bw.partW), gr(Lm.conv1.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
@@ -105,18 +110,18 @@ def run_backward(enc, ws, x, gpooled):
                        "eml_dense_permute_w1_bwd_f32")
             _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
                 p(bw.DZ), 48, p(z), 48, p(cA), p(cB), p(cC), 48, p(bw.Wd), p(blk["X"]), ld, p(lay["scale1"]),
-                p(lay["shift1"]), p(blk["mean"]), p(blk["istd"]), P, Hb, Wb, 0, kp, p(bw.DA), p(part), G, st),
+                p(lay["shift1"]), p(blk["mean"]), p(blk["istd"]), P, Hb, Wb, 0, kp, p(Gbuf), ld, 1, p(part), G, st),
                 "eml_dense_conv1x1_bwd_data_f32")
-            finalize(G, 2 * kp, P, Lm.norm1, blk["mean"], blk["istd"], cin, kp, dA, dB, dC)
-            _lib.check(L.eml_dense_bn_bwd_accumulate_f32(p(bw.DA), kp, p(blk["X"]), ld, p(dA), p(dB), p(dC), p(Gbuf),
-                                                         ld, kp, P, 1, st), "eml_dense_bn_bwd_accumulate_f32")
+            finalize(G, 2 * kp, P, Lm.norm1, blk["mean"], blk["istd"], cin, kp, coef=False, s_acc=True)
+        c0b = blk["C0"]
+        materialize(Gbuf, blk, 0, c0b)  # block input channels: every layer has contributed
         dY, ld_dy = Gbuf, ld
     # ---- relu0 / norm0 / conv0
     b0 = ws.blocks[0]
     c0 = enc.c_init
     _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(ws.Y0), c0, p(b0["X"]), b0["ld"], 1, c0, b0["P"],
                                             p(ws.mean0), p(ws.istd0), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
-    finalize(Gb, 2 * c0, b0["P"], f.norm0, ws.mean0, ws.istd0, c0, _r16(c0), cA, cB, cC)
+    finalize(Gb, 2 * c0, b0["P"], f.norm0, ws.mean0, ws.istd0, c0, _r16(c0))
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")

@@ -6,9 +6,10 @@
 //   bn_bwd_finalize    dgamma2, dbeta2, and the affine that turns dzn into dz on the fly:
 //                      dz = cA*dzn + cB*z + cC   (BatchNorm backward is affine per channel)
 //   conv1x1_bwd_weight dW1 = sum_p relu(bn1(x))[p] (x) dz[p]     (dz rebuilt in the operand load)
-//   conv1x1_bwd_data   da  = dz W1, masked by relu, written once + partial (sum, sum*xhat)
-//   bn_bwd_finalize    dgamma1, dbeta1, affine of BN1 backward
-//   bn_bwd_accumulate  G[:, :Cin] += cA*da + cB*x + cC
+//   conv1x1_bwd_data   dam = relu-mask * (dz W1);  G[:, :Cin] += scale1*dam in the epilogue (the
+//                      dy-coefficient of BN1's backward needs no statistics) + partial (sum, sum*xhat)
+//   bn_bwd_finalize    dgamma1, dbeta1; the statistics-dependent affine (cB*x + cC) is only summed
+//                      per channel into sB/sC and applied ONCE per channel by grad_materialize
 // The transitions reuse the conv1x1 kernels with the 2x2 average pool folded into the operand
 // (POOL) and last_norm's backward folded into the dz affine.  All reductions are per-block
 // partials + a finishing kernel: deterministic, no atomics.
@@ -211,16 +212,6 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(
   }
 }
 
-// dW2[o][c][tap] = sum_blocks partial[blk][tap*3 + c/16][c%16][o]
-__global__ void reduce_dw2_kernel(const float* __restrict__ partial, int R, float* __restrict__ dW2, int Cout) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= Cout * 48 * 9) return;
-  const int tap = e % 9, c = (e / 9) % 48, o = e / (9 * 48);
-  const int idx = tap * 3 + (c >> 4);
-  double s = 0.0;
-  for (int b = 0; b < R; ++b) s += (double)partial[(((size_t)b * 27 + idx) * 16 + (c & 15)) * 16 + o];
-  dW2[e] = (float)s;
-}
 
 // =============================================================================== BN backward: finalize
 // From the partial (S1 = sum dy, S2 = sum dy*xhat) of C channels: dgamma = S2, dbeta = S1 and the
@@ -231,28 +222,81 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const double* __restrict__ partials, int R, int pstride, double count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ istd, int C, int Cpad, int training,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
-    float* __restrict__ cC) {
-  for (int c = threadIdx.x; c < Cpad; c += 256) {
-    float a = 0.f, b = 0.f, d = 0.f;
-    if (c < C) {
-      double S1 = 0.0, S2 = 0.0;
-      for (int g = 0; g < R; ++g) {
-        S1 += partials[(size_t)g * pstride + 2 * c];
-        S2 += partials[(size_t)g * pstride + 2 * c + 1];
-      }
+    float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate) {
+  // one wavefront per channel; lanes stride over the R partial rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave;
+  if (c >= Cpad) return;
+  float a = 0.f, b = 0.f, d = 0.f;
+  if (c < C) {
+    double S1 = 0.0, S2 = 0.0;
+    for (int g = lane; g < R; g += 64) {
+      S1 += partials[(size_t)g * pstride + 2 * c];
+      S2 += partials[(size_t)g * pstride + 2 * c + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      S1 += __shfl_xor(S1, o, 64);
+      S2 += __shfl_xor(S2, o, 64);
+    }
+    if (lane == 0) {
       dgamma[c] = (float)S2;
       dbeta[c] = (float)S1;
-      const double ga = gamma[c], is = istd[c], mu = mean[c];
-      a = (float)(ga * is);
-      if (training) {
-        b = (float)(-ga * is * is * S2 / count);
-        d = (float)(-ga * is * S1 / count + ga * is * is * S2 / count * mu);
-      }
     }
+    const double ga = gamma[c], is = istd[c], mu = mean[c];
+    a = (float)(ga * is);
+    if (training) {
+      b = (float)(-ga * is * is * S2 / count);
+      d = (float)(-ga * is * S1 / count + ga * is * is * S2 / count * mu);
+    }
+  }
+  if (lane != 0) return;
+  if (cA) {
     cA[c] = a;
     cB[c] = b;
     cC[c] = d;
   }
+  if (sB) {  // deferred x-affine of the block gradient: Gfull = G + sB*x + sC
+    sB[c] = (s_accumulate ? sB[c] : 0.f) + b;
+    sC[c] = (s_accumulate ? sC[c] : 0.f) + d;
+  }
+}
+
+// Sum R partial rows into a weight-gradient tensor (64 outputs x 4 row slices per block, f64).
+// mode 0: dW1  src k*48+o (k<dim0=Cin, o<dim1=n_valid)     -> dW[(n0+o)*Cin + k]
+// mode 1: dW2  src ((tap*3+mc)*16+ci)*16+o (o<12)            -> dW2[(o*48 + 16mc+ci)*9 + tap]
+// mode 2: dW0  src t*32+o (t<27, o<dim1=C0)                  -> dW0[o*27 + t]
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, size_t row_stride,
+                                                          int mode, int dim0, int dim1, int n0,
+                                                          float* __restrict__ out) {
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, e = blockIdx.x * 64 + (tid & 63), slice = tid >> 6;
+  size_t src = 0, dst = 0;
+  bool valid = false;
+  if (mode == 0) {
+    const int k = e / 48, o = e - 48 * k;
+    valid = k < dim0 && o < dim1;
+    src = (size_t)e;
+    dst = (size_t)(n0 + o) * dim0 + k;
+  } else if (mode == 1) {
+    const int o = e & 15, ci = (e >> 4) & 15, pair = e >> 8, tap = pair / 3, mc = pair - 3 * tap;
+    valid = pair < 27 && o < 12;
+    src = (size_t)e;
+    dst = (size_t)(o * 48 + 16 * mc + ci) * 9 + tap;
+  } else {
+    const int t = e >> 5, o = e & 31;
+    valid = t < 27 && o < dim1;
+    src = (size_t)e;
+    dst = (size_t)o * 27 + t;
+  }
+  double s = 0.0;
+  if (valid) {
+#pragma unroll 8
+    for (int r = slice; r < R; r += 4) s += (double)partial[(size_t)r * row_stride + src];
+  }
+  red[slice][tid & 63] = s;
+  __syncthreads();
+  if (slice == 0 && valid) out[dst] = (float)((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
 }
 
 // =============================================================================== conv1x1 backward: weight
@@ -350,28 +394,24 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
   }
 }
 
-// dW[n0+o][k] (+)= sum_rows partial[row][k][o]   (PyTorch layout [Cout][Cin])
-__global__ void reduce_dw1_kernel(const float* __restrict__ partial, int R, int Kp, int Cin, int n0, int n_valid,
-                                  float* __restrict__ dW) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_valid * Cin) return;
-  const int k = e % Cin, o = e / Cin;
-  double s = 0.0;
-  for (int b = 0; b < R; ++b) s += (double)partial[((size_t)b * Kp + k) * 48 + o];
-  dW[(size_t)(n0 + o) * Cin + k] = (float)s;
-}
 
 // =============================================================================== conv1x1 backward: data
-// da[p][k] = sum_o dz[p][o] W[o][k], masked by relu(bn1(x)) > 0, stored to DA[P_in][Kp], with
-// partial sums S1 = sum dam, S2 = sum dam * xhat per input channel (xhat = (x-mean)*istd).
-// Wd: weights in B-fragment order [Kp/16][Ko/16][4][16][4] = W[o=16jo+4kk+t][k=16nt+col].
+// da[p][k] = sum_o dz[p][o] W[o][k], masked by relu(bn1(x)) > 0, and -- since the dy-coefficient of
+// a BatchNorm backward, gamma*istd == scale1, needs no statistics -- accumulated straight into the
+// block gradient:  G[p][k] (+)= scale1[k] * dam[p][k].  The statistics-dependent part of BN1's
+// backward (cB*x + cC) is affine in x with per-channel coefficients, so it is only summed into
+// sB/sC by bn_bwd_finalize and applied once per channel by grad_materialize.
+// Partial sums S1 = sum dam, S2 = sum dam * xhat per input channel (xhat = (x-mean)*istd).
+// The MFMA computes D^T (rows = channels, cols = pixels) so a lane owns 4 CONSECUTIVE channels of
+// one pixel: X / G are touched with 16-B accesses.
+// Wd: weights in fragment order [Kp/16][Ko/16][4][16][4] = W[o=16jo+4kk+t][k=16nt+col].
 template <bool POOL>
 __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
     const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
     const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
     const float* __restrict__ X, int ldx, const float* __restrict__ scale1, const float* __restrict__ shift1,
     const float* __restrict__ mean, const float* __restrict__ istd, int P, int Hin, int Win, int Kp,
-    float* __restrict__ DA, double* __restrict__ partials /*[grid][Kp][2]*/) {
+    float* __restrict__ Gd, int ldg, int accumulate, double* __restrict__ partials /*[grid][Kp][2]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   double* sacc = reinterpret_cast<double*>(smem);  // [4 waves][Kp][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -386,9 +426,18 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = tile * 256 + wave * 64;
     long prow[4];
+    size_t pin[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) prow[m] = min(p0 + 16 * m + r, P - 1);
-
+    for (int m = 0; m < 4; ++m) {
+      prow[m] = min(p0 + 16 * m + r, P - 1);
+      if constexpr (POOL) {
+        const int b = (int)(prow[m] / (Ho * Wo)), rem = (int)(prow[m] - (long)b * (Ho * Wo));
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        pin[m] = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;
+      } else {
+        pin[m] = (size_t)prow[m];
+      }
+    }
     for (int nt0 = 0; nt0 < nnt; nt0 += 4) {
       f32x4 acc[4][4];
 #pragma unroll
@@ -415,58 +464,68 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
           const int nt = min(nt0 + n, nnt - 1);
           const float4 w = *reinterpret_cast<const float4*>(Wd + ((((size_t)nt * njo + jo) * 4 + kk) * 16 + r) * 4);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            acc[m][n] = mfma16(dz[m].x, w.x, acc[m][n]);
-            acc[m][n] = mfma16(dz[m].y, w.y, acc[m][n]);
-            acc[m][n] = mfma16(dz[m].z, w.z, acc[m][n]);
-            acc[m][n] = mfma16(dz[m].w, w.w, acc[m][n]);
+          for (int m = 0; m < 4; ++m) {  // A = W^T fragment, B = dz fragment  ->  D[channel][pixel]
+            acc[m][n] = mfma16(w.x, dz[m].x, acc[m][n]);
+            acc[m][n] = mfma16(w.y, dz[m].y, acc[m][n]);
+            acc[m][n] = mfma16(w.z, dz[m].z, acc[m][n]);
+            acc[m][n] = mfma16(w.w, dz[m].w, acc[m][n]);
           }
         }
       }
-      // epilogue: col = input channel k, rows = pixels
+      // epilogue: this lane owns channels k4..k4+3 (k4 = 16nt + 4kk) of pixel p0 + 16m + r
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int nt = nt0 + n;
         if (nt < nnt) {
-          const int k = 16 * nt + r;
-          const float sk = scale1[k], tk = shift1[k], mu = mean[k], is = istd[k];
-          float l1 = 0.f, l2 = 0.f;
+          const int k4 = 16 * nt + 4 * kk;
+          const float4 sk = *reinterpret_cast<const float4*>(scale1 + k4);
+          const float4 tk = *reinterpret_cast<const float4*>(shift1 + k4);
+          const float4 mu = *reinterpret_cast<const float4*>(mean + k4);
+          const float4 is = *reinterpret_cast<const float4*>(istd + k4);
+          float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+          for (int m = 0; m < 4; ++m) {
+            if (p0 + 16 * m + r < P) {
+              const float da[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+              constexpr int NSUB = POOL ? 4 : 1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int p = p0 + 16 * m + 4 * kk + g;
-              if (p < P) {
-                const float da = acc[m][n][g];
-                if constexpr (POOL) {
-                  const int b = p / (Ho * Wo), rem = p - b * (Ho * Wo);
-                  const int oy = rem / Wo, ox = rem - oy * Wo;
-                  const size_t pin = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;
-#pragma unroll
-                  for (int sub = 0; sub < 4; ++sub) {
-                    const size_t pi = pin + (sub >> 1) * (size_t)Win + (sub & 1);
-                    const float xv = X[pi * ldx + k];
-                    const float dam = (fmaf(xv, sk, tk) > 0.f) ? 0.25f * da : 0.f;
-                    DA[pi * Kp + k] = dam;
-                    l1 += dam;
-                    l2 = fmaf(dam, (xv - mu) * is, l2);
-                  }
-                } else {
-                  const float xv = X[(size_t)p * ldx + k];
-                  const float dam = (fmaf(xv, sk, tk) > 0.f) ? da : 0.f;
-                  DA[(size_t)p * Kp + k] = dam;
-                  l1 += dam;
-                  l2 = fmaf(dam, (xv - mu) * is, l2);
-                }
+              for (int sub = 0; sub < NSUB; ++sub) {
+                const size_t pi = pin[m] + (sub >> 1) * (size_t)Win + (sub & 1);
+                const float4 xv = *reinterpret_cast<const float4*>(X + pi * ldx + k4);
+                float4* gp = reinterpret_cast<float4*>(Gd + pi * ldg + k4);
+                float4 g = accumulate ? *gp : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float f = POOL ? 0.25f : 1.0f;
+                const float d0 = (fmaf(xv.x, sk.x, tk.x) > 0.f) ? f * da[0] : 0.f;
+                const float d1 = (fmaf(xv.y, sk.y, tk.y) > 0.f) ? f * da[1] : 0.f;
+                const float d2 = (fmaf(xv.z, sk.z, tk.z) > 0.f) ? f * da[2] : 0.f;
+                const float d3 = (fmaf(xv.w, sk.w, tk.w) > 0.f) ? f * da[3] : 0.f;
+                g.x = fmaf(sk.x, d0, g.x);
+                g.y = fmaf(sk.y, d1, g.y);
+                g.z = fmaf(sk.z, d2, g.z);
+                g.w = fmaf(sk.w, d3, g.w);
+                *gp = g;
+                l1[0] += d0;
+                l1[1] += d1;
+                l1[2] += d2;
+                l1[3] += d3;
+                l2[0] = fmaf(d0, (xv.x - mu.x) * is.x, l2[0]);
+                l2[1] = fmaf(d1, (xv.y - mu.y) * is.y, l2[1]);
+                l2[2] = fmaf(d2, (xv.z - mu.z) * is.z, l2[2]);
+                l2[3] = fmaf(d3, (xv.w - mu.w) * is.w, l2[3]);
               }
             }
-          l1 += __shfl_xor(l1, 16, 64);
-          l1 += __shfl_xor(l1, 32, 64);
-          l2 += __shfl_xor(l2, 16, 64);
-          l2 += __shfl_xor(l2, 32, 64);
-          if (lane < 16) {
-            my[2 * k] += (double)l1;
-            my[2 * k + 1] += (double)l2;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              l1[g] += __shfl_xor(l1[g], o, 64);
+              l2[g] += __shfl_xor(l2[g], o, 64);
+            }
+            if (r == 0) {
+              my[2 * (k4 + g)] += (double)l1[g];
+              my[2 * (k4 + g) + 1] += (double)l2[g];
+            }
           }
         }
       }
@@ -491,30 +550,23 @@ __global__ void permute_w1_bwd_kernel(const float* __restrict__ W, int Cout, int
   }
 }
 
-// =============================================================================== BN backward: accumulate
-// G[p][k] (+)= cA[k]*DA[p][k] + cB[k]*X[p][k] + cC[k]   for k < Kp (coefficients zero-padded)
-__global__ __launch_bounds__(256) void bn_bwd_accumulate_kernel(const float* __restrict__ DA, int ld_da,
-                                                                const float* __restrict__ X, int ldx,
-                                                                const float* __restrict__ cA,
-                                                                const float* __restrict__ cB,
-                                                                const float* __restrict__ cC, float* __restrict__ Gd,
-                                                                int ldg, int Kp, size_t P, int accumulate) {
-  const int nq = Kp >> 2;
-  const size_t total = P * nq;
+// =============================================================================== deferred BN1 affine
+// Gfull[p][c] = G[p][c] + sB[c]*X[p][c] + sC[c] for the n channels [c0, c0+n) whose gradient is now
+// complete (every later layer has added its scale1*dam term and its (cB, cC) into sB/sC).
+__global__ __launch_bounds__(256) void grad_materialize_kernel(float* __restrict__ Gd, int ldg,
+                                                               const float* __restrict__ X, int ldx,
+                                                               const float* __restrict__ sB,
+                                                               const float* __restrict__ sC, int c0, int n, size_t P) {
+  const int nh = n >> 1;
+  const size_t total = P * nh;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const size_t p = e / nq;
-    const int q = (int)(e - p * nq);
-    const float4 a = *reinterpret_cast<const float4*>(cA + 4 * q);
-    const float4 b = *reinterpret_cast<const float4*>(cB + 4 * q);
-    const float4 c = *reinterpret_cast<const float4*>(cC + 4 * q);
-    const float4 d = *reinterpret_cast<const float4*>(DA + p * ld_da + 4 * q);
-    const float4 x = *reinterpret_cast<const float4*>(X + p * ldx + 4 * q);
-    float4* gp = reinterpret_cast<float4*>(Gd + p * ldg + 4 * q);
-    float4 g = accumulate ? *gp : make_float4(0.f, 0.f, 0.f, 0.f);
-    g.x += fmaf(a.x, d.x, fmaf(b.x, x.x, c.x));
-    g.y += fmaf(a.y, d.y, fmaf(b.y, x.y, c.y));
-    g.z += fmaf(a.z, d.z, fmaf(b.z, x.z, c.z));
-    g.w += fmaf(a.w, d.w, fmaf(b.w, x.w, c.w));
+    const size_t p = e / nh;
+    const int c = c0 + 2 * (int)(e - p * nh);
+    const float2 x = *reinterpret_cast<const float2*>(X + p * ldx + c);
+    float2* gp = reinterpret_cast<float2*>(Gd + p * ldg + c);
+    float2 g = *gp;
+    g.x += fmaf(sB[c], x.x, sC[c]);
+    g.y += fmaf(sB[c + 1], x.y, sC[c + 1]);
     *gp = g;
   }
 }
@@ -635,15 +687,6 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
       for (int g = 0; g < 4; ++g) out[(16 * i + 4 * kk + g) * 32 + 16 * n + r] = acc[i][n][g];
 }
 
-__global__ void reduce_dw0_kernel(const float* __restrict__ partial, int R, int C0, float* __restrict__ dW0) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= C0 * 27) return;
-  const int t = e % 27, o = e / 27;
-  double s = 0.0;
-  for (int b = 0; b < R; ++b) s += (double)partial[(size_t)b * 1024 + t * 32 + o];
-  dW0[e] = (float)s;
-}
-
 // =============================================================================== head backward
 // dF[p][c] = (F[p][c] > 0) ? gpooled[b][c][oy/k][ox/k] / k^2 : 0
 __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ F,
@@ -691,19 +734,22 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
                      shift2, B, H, W, partial);
   int rc = eml::check_launch("eml_dense_conv3x3_bwd_weight_f32");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_dw2_kernel, dim3((12 * 48 * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                     grid, dW2, 12);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partial, grid,
+                     (size_t)27 * 256, 1, 0, 0, 0, dW2);
   return eml::check_launch("eml_dense_conv3x3_bwd_weight_f32(reduce)");
 }
 
 extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                              const float* gamma, const float* mean, const float* istd, int C, int Cpad,
                                              int training, float* dgamma, float* dbeta, float* cA, float* cB,
-                                             float* cC, eml_stream_t stream) {
-  if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || !cA || !cB || !cC || C < 1 || Cpad < C || R < 1)
+                                             float* cC, float* sB, float* sC, int s_accumulate,
+                                             eml_stream_t stream) {
+  if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || C < 1 || Cpad < C || R < 1 ||
+      (cA && (!cB || !cC)) || (sB && !sC))
     return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, R, pstride, count,
-                     gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cpad + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, R,
+                     pstride, count, gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC, sB, sC,
+                     s_accumulate);
   return eml::check_launch("eml_dense_bn_bwd_finalize_f32");
 }
 
@@ -730,8 +776,8 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
                          nv, partial);
     int rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_dw1_kernel, dim3((nv * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                       grid * PW, Kp, Cin, n0, nv, dW);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((Cin * 48 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+                       grid * PW, (size_t)Kp * 48, 0, Cin, nv, n0, dW);
     rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32(reduce)");
     if (rc) return rc;
   }
@@ -750,30 +796,33 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
                                               const float* cB, const float* cC, int Ko, const float* Wd,
                                               const float* X, int ldx, const float* scale1, const float* shift1,
                                               const float* mean, const float* istd, long P, int Hin, int Win, int pool,
-                                              int Kp, float* DA, double* partials, int grid, eml_stream_t stream) {
-  if (!DY || !Zr || !cA || !cB || !cC || !Wd || !X || !scale1 || !shift1 || !mean || !istd || !DA || !partials ||
-      P < 1 || grid < 1 || (Kp & 15) || (Ko & 15) || Ko > ld_dy || Ko > ld_z || (ld_dy & 3) || (ld_z & 3))
+                                              int Kp, float* G, int ldg, int accumulate, double* partials, int grid,
+                                              eml_stream_t stream) {
+  if (!DY || !Zr || !cA || !cB || !cC || !Wd || !X || !scale1 || !shift1 || !mean || !istd || !G || !partials ||
+      P < 1 || grid < 1 || (Kp & 15) || (Ko & 15) || Ko > ld_dy || Ko > ld_z || (ld_dy & 3) || (ld_z & 3) ||
+      (ldx & 3) || (ldg & 3) || Kp > ldx || Kp > ldg)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: bad arguments");
   const size_t lds = (size_t)4 * Kp * 2 * sizeof(double);
   if (pool)
     hipLaunchKernelGGL(conv1x1_bwd_data_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
-                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, DA, partials);
+                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, ldg,
+                       accumulate, partials);
   else
     hipLaunchKernelGGL(conv1x1_bwd_data_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
-                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, DA, partials);
+                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, ldg,
+                       accumulate, partials);
   return eml::check_launch("eml_dense_conv1x1_bwd_data_f32");
 }
 
-extern "C" int eml_dense_bn_bwd_accumulate_f32(const float* DA, int ld_da, const float* X, int ldx, const float* cA,
-                                               const float* cB, const float* cC, float* G, int ldg, int Kp, long P,
-                                               int accumulate, eml_stream_t stream) {
-  if (!DA || !X || !cA || !cB || !cC || !G || P < 1 || (Kp & 3) || (ld_da & 3) || (ldx & 3) || (ldg & 3))
-    return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_accumulate_f32: bad arguments");
-  const size_t total = (size_t)P * (Kp >> 2);
+extern "C" int eml_dense_grad_materialize_f32(float* G, int ldg, const float* X, int ldx, const float* sB,
+                                              const float* sC, int c0, int n, long P, eml_stream_t stream) {
+  if (!G || !X || !sB || !sC || P < 1 || n < 2 || (n & 1) || (c0 & 1) || (ldg & 1) || (ldx & 1))
+    return eml::fail(EML_EINVAL, "eml_dense_grad_materialize_f32: bad arguments");
+  const size_t total = (size_t)P * (n >> 1);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(bn_bwd_accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, DA, ld_da, X, ldx, cA, cB,
-                     cC, G, ldg, Kp, (size_t)P, accumulate);
-  return eml::check_launch("eml_dense_bn_bwd_accumulate_f32");
+  hipLaunchKernelGGL(grad_materialize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, ldg, X, ldx, sB, sC, c0,
+                     n, (size_t)P);
+  return eml::check_launch("eml_dense_grad_materialize_f32");
 }
 
 extern "C" int eml_dense_bn_bwd_stats_f32(const float* DY, int ld_dy, const float* raw, int ld_raw, const float* out,
@@ -797,8 +846,8 @@ extern "C" int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, in
                      cA, cB, cC, B, H, W, partial);
   int rc = eml::check_launch("eml_dense_conv0_bwd_weight_f32");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_dw0_kernel, dim3((C0 * 27 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                     grid * 4, C0, dW0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 32 / 64 + 1), dim3(256), 0, (hipStream_t)stream, partial, grid * 4,
+                     (size_t)1024, 2, 0, C0, 0, dW0);
   return eml::check_launch("eml_dense_conv0_bwd_weight_f32(reduce)");
 }
 

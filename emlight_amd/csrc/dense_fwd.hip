@@ -391,43 +391,56 @@ __global__ __launch_bounds__(256) void bn_prepare_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, int C, int Cpad, float eps, float momentum, int training,
     float* __restrict__ scale, float* __restrict__ shift) {
-  const int tid = threadIdx.x;
-  if (partials) {
-    for (int c = tid; c < n_new; c += 256) {
-      double s = 0.0, q = 0.0;
-      for (int g = 0; g < G; ++g) {
-        s += partials[(size_t)g * pstride + 2 * c];
-        q += partials[(size_t)g * pstride + 2 * c + 1];
-      }
-      const double m = s / count;
-      const double v = fmax(q / count - m * m, 0.0);
-      mean[c_new0 + c] = (float)m;
-      var[c_new0 + c] = (float)v;
-      istd[c_new0 + c] = (float)(1.0 / sqrt(v + (double)eps));
+  // one wavefront per channel: lanes stride over the G partial rows, f64 wave reduction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 4 + wave;
+  const int total = scale ? Cpad : n_new;
+  if (idx >= total) return;
+  const int c = scale ? idx : c_new0 + idx;
+  const bool is_new = partials && c >= c_new0 && c < c_new0 + n_new;
+  float m = 0.f, is = 0.f, v = 0.f;
+  if (is_new) {
+    double s = 0.0, q = 0.0;
+    for (int g = lane; g < G; g += 64) {
+      s += partials[(size_t)g * pstride + 2 * (c - c_new0)];
+      q += partials[(size_t)g * pstride + 2 * (c - c_new0) + 1];
     }
-    __syncthreads();
-  }
-  if (!scale) return;
-  for (int c = tid; c < Cpad; c += 256) {
-    float sc = 0.f, sh = 0.f;
-    if (c < C) {
-      float m, is;
-      if (training) {
-        m = mean[c];
-        is = istd[c];
-        const double unbiased = (double)var[c] * (count / fmax(count - 1.0, 1.0));
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
-      } else {
-        m = rmean[c];
-        is = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
-      }
-      sc = gamma[c] * is;
-      sh = beta[c] - m * sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
     }
-    scale[c] = sc;
-    shift[c] = sh;
+    const double md = s / count;
+    const double vd = fmax(q / count - md * md, 0.0);
+    m = (float)md;
+    v = (float)vd;
+    is = (float)(1.0 / sqrt(vd + (double)eps));
+    if (lane == 0) {
+      mean[c] = m;
+      var[c] = v;
+      istd[c] = is;
+    }
+  } else if (scale && c < C && training) {
+    m = mean[c];
+    v = var[c];
+    is = istd[c];
   }
+  if (!scale || lane != 0) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) {
+    if (training) {
+      const double unbiased = (double)v * (count / fmax(count - 1.0, 1.0));
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    } else {
+      m = rmean[c];
+      is = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+    }
+    sc = gamma[c] * is;
+    sh = beta[c] - m * sc;
+  }
+  scale[c] = sc;
+  shift[c] = sh;
 }
 
 // ------------------------------------------------------------------------------ weight permutes
@@ -511,7 +524,9 @@ extern "C" int eml_dense_bn_prepare_f32(const double* partials, int G, int pstri
   if (!mean || !var || !istd || count < 1.0) return eml::fail(EML_EINVAL, "eml_dense_bn_prepare_f32: bad arguments");
   if (scale && (!shift || !gamma || !beta || !rmean || !rvar || C < 1 || Cpad < C))
     return eml::fail(EML_EINVAL, "eml_dense_bn_prepare_f32: bad BN arguments");
-  hipLaunchKernelGGL(bn_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, G, pstride, n_new, c_new0,
+  const int total = scale ? Cpad : n_new;
+  if (total < 1) return EML_OK;
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, G, pstride, n_new, c_new0,
                      count, mean, var, istd, gamma, beta, rmean, rvar, C, Cpad, eps, momentum, training, scale, shift);
   return eml::check_launch("eml_dense_bn_prepare_f32");
 }

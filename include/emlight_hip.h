@@ -166,11 +166,15 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
                                      float* partial, float* dW2, int grid, eml_stream_t stream);
 
 /* Finish a BatchNorm backward from R rows of (S1 = sum dy, S2 = sum dy*xhat) partials: dgamma, dbeta
- * and the affine cA, cB, cC (zero-padded to Cpad) with dx = cA*dy + cB*x + cC. */
+ * and the affine dx = cA*dy + cB*x + cC (cA = gamma*istd, cB = -gamma*istd^2*S2/n,
+ * cC = -gamma*istd*S1/n + gamma*istd^2*S2/n*mean), zero-padded to Cpad.  cA/cB/cC may be NULL.
+ * sB/sC (may be NULL): running per-channel sums of (cB, cC) -- the deferred x-affine of a dense
+ * block's gradient (s_accumulate = 0 overwrites, 1 adds). */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
                                   int Cpad, int training, float* dgamma, float* dbeta, float* cA,
-                                  float* cB, float* cC, eml_stream_t stream);
+                                  float* cB, float* cC, float* sB, float* sC, int s_accumulate,
+                                  eml_stream_t stream);
 
 /* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).
@@ -185,19 +189,20 @@ int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, i
 int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int Ko, float* Wd,
                                  eml_stream_t stream);
 
-/* DA[p][k] = relu-mask(scale1*X+shift1) * sum_o dz[p][o] W[o][k]  (pool != 0: spread over the 2x2
- * input pixels, /4); partials [grid][Kp][2] = (sum DA, sum DA*xhat) for the BN1 backward. */
+/* dam[p][k] = relu-mask(scale1*X+shift1) * sum_o dz[p][o] W[o][k]  (pool != 0: spread over the 2x2
+ * input pixels, /4) and G[p][k] (+)= scale1[k]*dam[p][k] (accumulate = 0 overwrites);
+ * partials [grid][Kp][2] = (sum dam, sum dam*xhat) for the BN1 backward. */
 int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, int ld_z,
                                    const float* cA, const float* cB, const float* cC, int Ko,
                                    const float* Wd, const float* X, int ldx, const float* scale1,
                                    const float* shift1, const float* mean, const float* istd, long P,
-                                   int Hin, int Win, int pool, int Kp, float* DA, double* partials,
-                                   int grid, eml_stream_t stream);
+                                   int Hin, int Win, int pool, int Kp, float* G, int ldg,
+                                   int accumulate, double* partials, int grid, eml_stream_t stream);
 
-/* G[p][k] (+)= cA[k]*DA[p][k] + cB[k]*X[p][k] + cC[k], k < Kp. */
-int eml_dense_bn_bwd_accumulate_f32(const float* DA, int ld_da, const float* X, int ldx,
-                                    const float* cA, const float* cB, const float* cC, float* G,
-                                    int ldg, int Kp, long P, int accumulate, eml_stream_t stream);
+/* G[p][c] += sB[c]*X[p][c] + sC[c] for c in [c0, c0+n): applies the deferred BN1-backward affine once
+ * the gradient of those channels is complete. */
+int eml_dense_grad_materialize_f32(float* G, int ldg, const float* X, int ldx, const float* sB,
+                                   const float* sC, int c0, int n, long P, eml_stream_t stream);
 
 /* Stats of an elementwise BN(+ReLU) backward (last_norm; norm0+relu0): partials [grid][C][2]. */
 int eml_dense_bn_bwd_stats_f32(const float* DY, int ld_dy, const float* raw, int ld_raw,
