@@ -97,10 +97,20 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("EML_DEBUG_SYNC"))
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().eml_last_error()
         raise EmlightHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+    if _DEBUG_SYNC:  # debugging aid: localise an asynchronous GPU fault to the launcher that caused it
+        import sys
+        import torch
+        sys.stderr.write("[eml] %s ... " % what)
+        sys.stderr.flush()
+        torch.cuda.synchronize()
+        sys.stderr.write("ok\n")
 
 
 def ptr(t):

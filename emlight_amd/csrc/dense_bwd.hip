@@ -47,16 +47,24 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int n = 0; n < 3; ++n) bw[tap][s][n] = W2[((size_t)(4 * s + kk) * 48 + 16 * n + r) * 9 + tap];
-  float zm[3], zi[3];
+  float4 zm[3], zi[3];
 #pragma unroll
   for (int n = 0; n < 3; ++n) {
-    zm[n] = zmean[16 * n + r];
-    zi[n] = zistd[16 * n + r];
+    zm[n] = *reinterpret_cast<const float4*>(zmean + 16 * n + 4 * kk);
+    zi[n] = *reinterpret_cast<const float4*>(zistd + 16 * n + 4 * kk);
   }
 
   const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
   const int ntiles = B * ty_n * tx_n;
-  double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+  double s1[3][4], s2[3][4];
+  float l1[3][4], l2[3][4];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      s1[n][g] = s2[n][g] = 0.0;
+      l1[n][g] = l2[n][g] = 0.f;
+    }
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
@@ -92,44 +100,58 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(a[m], bw[tap][s][n], acc[m][n]);
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(bw[tap][s][n], a[m], acc[m][n]);  // D[channel][pixel]
       }
     }
+    // epilogue: lane owns channels 16n + 4kk .. +3 of pixel (row 2w + (m>>1), col 16(m&1) + r)
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      float l1 = 0.f, l2 = 0.f;
+    for (int m = 0; m < 4; ++m) {
+      const int gy = ty * kTH + 2 * wave + (m >> 1), gx = tx * kTW + 16 * (m & 1) + r;
+      if (gy < H && gx < W) {
+        const size_t p = (size_t)(b * H + gy) * W + gx;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int gy = ty * kTH + 2 * wave + (m >> 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int gx = tx * kTW + 16 * (m & 1) + 4 * kk + g;
-          if (gy < H && gx < W) {
-            const size_t p = (size_t)(b * H + gy) * W + gx;
-            const float v = acc[m][n][g];
-            DZ[p * 48 + 16 * n + r] = v;
-            const float zh = (Z[p * 48 + 16 * n + r] - zm[n]) * zi[n];
-            l1 += v;
-            l2 = fmaf(v, zh, l2);
-          }
+        for (int n = 0; n < 3; ++n) {
+          const int c4 = 16 * n + 4 * kk;
+          const float4 z = *reinterpret_cast<const float4*>(Z + p * 48 + c4);
+          const float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+          *reinterpret_cast<float4*>(DZ + p * 48 + c4) = v;
+          l1[n][0] += v.x;
+          l1[n][1] += v.y;
+          l1[n][2] += v.z;
+          l1[n][3] += v.w;
+          l2[n][0] = fmaf(v.x, (z.x - zm[n].x) * zi[n].x, l2[n][0]);
+          l2[n][1] = fmaf(v.y, (z.y - zm[n].y) * zi[n].y, l2[n][1]);
+          l2[n][2] = fmaf(v.z, (z.z - zm[n].z) * zi[n].z, l2[n][2]);
+          l2[n][3] = fmaf(v.w, (z.w - zm[n].w) * zi[n].w, l2[n][3]);
         }
       }
-      s1[n] += (double)l1;
-      s2[n] += (double)l2;
     }
+    // fold this tile's f32 sums into the f64 accumulators
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s1[n][g] += (double)l1[n][g];
+        s2[n][g] += (double)l2[n][g];
+        l1[n][g] = 0.f;
+        l2[n][g] = 0.f;
+      }
     __syncthreads();
   }
 #pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    s1[n] += shfl_xor_d(s1[n], 16);
-    s1[n] += shfl_xor_d(s1[n], 32);
-    s2[n] += shfl_xor_d(s2[n], 16);
-    s2[n] += shfl_xor_d(s2[n], 32);
-    if (lane < 16) {
-      red[(wave * 48 + 16 * n + lane) * 2 + 0] = s1[n];
-      red[(wave * 48 + 16 * n + lane) * 2 + 1] = s2[n];
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1[n][g] += shfl_xor_d(s1[n][g], o);
+        s2[n][g] += shfl_xor_d(s2[n][g], o);
+      }
+      if (r == 0) {
+        red[(wave * 48 + 16 * n + 4 * kk + g) * 2 + 0] = s1[n][g];
+        red[(wave * 48 + 16 * n + 4 * kk + g) * 2 + 1] = s2[n][g];
+      }
     }
-  }
   __syncthreads();
   for (int e = tid; e < 96; e += 256)
     partials[(size_t)blockIdx.x * 96 + e] = (red[e] + red[96 + e]) + (red[192 + e] + red[288 + e]);
@@ -301,99 +323,169 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 
 // =============================================================================== conv1x1 backward: weight
 // dW[k][o] = sum_p a[p][k] * dz[p][o];  a = relu(s1*x + t1) (POOL: 2x2 mean of it),
-// dz[p][o] = cA[o]*DY[p][o] + cB[o]*Zr[p][o] + cC[o].  D[i=k][j=o], MFMA-k = pixel.
-// Waves split the Kp/16 channel tiles (and, when there are fewer than 4, the pixels).
+// dz[p][o] = cA[o]*DY[p][o] + cB[o]*Zr[p][o] + cC[o].  D[i][j=o], MFMA-k = pixel.
+//   * dz of a 64-pixel chunk is built once per workgroup in LDS (double-buffered, one barrier per
+//     chunk) and read as B fragments by all four waves;
+//   * the A operand comes straight from global memory as float2: MFMA's row index is only a label,
+//     so lane i of a 32-channel group loads channels (2i, 2i+1) of its pixel -- 128 contiguous
+//     bytes per pixel -- and feeds them to two accumulator tiles whose row i means channel 2i+t;
+//   * the Kp/32 channel groups are dealt round-robin to the 4 waves (<= 3 each).
 template <bool POOL>
 __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp, const float* __restrict__ scale1,
     const float* __restrict__ shift1, const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr,
     int ld_z, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n_valid,
-    float* __restrict__ partial /*[grid*PW][Kp][48]*/) {
+    int n_load /* columns (multiple of 4) that may be read without leaving the DY / Zr rows */,
+    float* __restrict__ partial /*[grid][Kp][48]*/) {
+  __shared__ __attribute__((aligned(16))) float dz_l[2][64 * 48];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
-  const int nmt = Kp >> 4;
-  const int MW = (nmt >= 4) ? 4 : 2, PW = 4 / MW;
-  const int mg = wave % MW, pg = wave / MW;
+  const int ngroups = (Kp + 31) >> 5;
 
-  float s1[6], t1[6];
-  int coff[6];
+  float2 s2[3], t2[3];
+  int coff[3];
+  bool gv[3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int mt = mg + MW * i;
-    const bool v = mt < nmt;
-    const int ch = v ? 16 * mt + r : 0;
-    coff[i] = ch;
-    s1[i] = v ? scale1[ch] : 0.f;
-    t1[i] = v ? shift1[ch] : 0.f;
+  for (int i = 0; i < 3; ++i) {
+    const int cg = wave + 4 * i;
+    const int ch = 32 * cg + 2 * r;
+    gv[i] = cg < ngroups && ch < Kp;
+    coff[i] = gv[i] ? ch : 0;
+    s2[i] = gv[i] ? *reinterpret_cast<const float2*>(scale1 + ch) : make_float2(0.f, 0.f);
+    t2[i] = gv[i] ? *reinterpret_cast<const float2*>(shift1 + ch) : make_float2(0.f, 0.f);
   }
-  float ca[3], cb[3], cc[3];
-  bool nv[3];
+  // dz staging role: pixel = tid >> 2, columns 4*(q + 4j), j = 0..2
+  const int spix = tid >> 2, sq = tid & 3;
+  float4 sa[3], sb[3], sc[3];
 #pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    nv[n] = 16 * n + r < n_valid;
-    ca[n] = nv[n] ? cA[16 * n + r] : 0.f;
-    cb[n] = nv[n] ? cB[16 * n + r] : 0.f;
-    cc[n] = nv[n] ? cC[16 * n + r] : 0.f;
+  for (int j = 0; j < 3; ++j) {
+    const int col = 4 * (sq + 4 * j);
+    float a[4], b[4], c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool v = col + e < n_valid;
+      a[e] = v ? cA[col + e] : 0.f;
+      b[e] = v ? cB[col + e] : 0.f;
+      c[e] = v ? cC[col + e] : 0.f;
+    }
+    sa[j] = make_float4(a[0], a[1], a[2], a[3]);
+    sb[j] = make_float4(b[0], b[1], b[2], b[3]);
+    sc[j] = make_float4(c[0], c[1], c[2], c[3]);
   }
-  f32x4 acc[6][3];
+  f32x4 acc[3][2][3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[i][t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int Wo = Win >> 1, Ho = Hin >> 1;
-  const long nq = ((long)P + 3) >> 2;
-  const long qstride = (long)gridDim.x * PW;
-  for (long q = (long)blockIdx.x * PW + pg; q < nq; q += qstride) {
-    const long p = 4 * q + kk;
-    const bool pv = p < P;
-    const long pc = pv ? p : (long)P - 1;
-    float dz[3];
+  const int nchunks = (P + 63) >> 6;
+  const int ngw = (ngroups > wave) ? (ngroups - wave + 3) >> 2 : 0;  // channel groups of this wave (uniform)
+
+  // dz tile of a chunk: global -> registers (issued early) -> affine -> LDS (written late)
+  float4 rdy[3], rzr[3];
+  bool rpv = false;
+  auto stage_load = [&](int chunk) {
+    const int p = chunk * 64 + spix;
+    rpv = chunk < nchunks && p < P;
+    const size_t pc = rpv ? p : 0;
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      const int col = nv[n] ? 16 * n + r : 0;
-      const float v = fmaf(ca[n], DY[pc * ld_dy + col], fmaf(cb[n], Zr[pc * ld_z + col], cc[n]));
-      dz[n] = (pv && nv[n]) ? v : 0.f;
+    for (int j = 0; j < 3; ++j) {
+      const int col = 4 * (sq + 4 * j);
+      const bool cv = col < n_load;
+      rdy[j] = cv ? *reinterpret_cast<const float4*>(DY + pc * ld_dy + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rzr[j] = cv ? *reinterpret_cast<const float4*>(Zr + pc * ld_z + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float* xp;
-    if constexpr (POOL) {
-      const int b = (int)(pc / (Ho * Wo)), rem = (int)(pc - (long)b * (Ho * Wo));
-      const int oy = rem / Wo, ox = rem - oy * Wo;
-      xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
-    } else {
-      xp = X + (size_t)pc * ldx;
-    }
-    float a[6];
+  };
+  auto stage_write = [&](float* dzb) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      const int col = 4 * (sq + 4 * j);
+      float4 v;
+      v.x = rpv ? fmaf(sa[j].x, rdy[j].x, fmaf(sb[j].x, rzr[j].x, sc[j].x)) : 0.f;
+      v.y = rpv ? fmaf(sa[j].y, rdy[j].y, fmaf(sb[j].y, rzr[j].y, sc[j].y)) : 0.f;
+      v.z = rpv ? fmaf(sa[j].z, rdy[j].z, fmaf(sb[j].z, rzr[j].z, sc[j].z)) : 0.f;
+      v.w = rpv ? fmaf(sa[j].w, rdy[j].w, fmaf(sb[j].w, rzr[j].w, sc[j].w)) : 0.f;
+      *reinterpret_cast<float4*>(dzb + spix * 48 + col) = v;
+    }
+  };
+  stage_load(blockIdx.x);
+  stage_write(dz_l[0]);
+  __syncthreads();
+  int it = 0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
+    const float* dzb = dz_l[it & 1];
+    stage_load(chunk + gridDim.x);  // next chunk's loads fly during this chunk's MFMAs
+#pragma unroll 4
+    for (int q4 = 0; q4 < 16; ++q4) {
+      const int pl = 4 * q4 + kk;
+      const int p = chunk * 64 + pl;
+      const bool pv = p < P;
+      const int pc = pv ? p : P - 1;
+      const float* xp;
       if constexpr (POOL) {
-        const float v0 = fmaxf(fmaf(xp[coff[i]], s1[i], t1[i]), 0.f);
-        const float v1 = fmaxf(fmaf(xp[ldx + coff[i]], s1[i], t1[i]), 0.f);
-        const float v2 = fmaxf(fmaf(xp[(size_t)Win * ldx + coff[i]], s1[i], t1[i]), 0.f);
-        const float v3 = fmaxf(fmaf(xp[(size_t)Win * ldx + ldx + coff[i]], s1[i], t1[i]), 0.f);
-        a[i] = ((v0 + v1) + (v2 + v3)) * 0.25f;
+        const int b = pc / (Ho * Wo), rem = pc - b * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
       } else {
-        a[i] = fmaxf(fmaf(xp[coff[i]], s1[i], t1[i]), 0.f);
+        xp = X + (size_t)pc * ldx;
+      }
+      float2 a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (i < ngw) {
+          if constexpr (POOL) {
+            const float2 x0 = *reinterpret_cast<const float2*>(xp + coff[i]);
+            const float2 x1 = *reinterpret_cast<const float2*>(xp + ldx + coff[i]);
+            const float2 x2 = *reinterpret_cast<const float2*>(xp + (size_t)Win * ldx + coff[i]);
+            const float2 x3 = *reinterpret_cast<const float2*>(xp + (size_t)Win * ldx + ldx + coff[i]);
+            a[i].x = ((fmaxf(fmaf(x0.x, s2[i].x, t2[i].x), 0.f) + fmaxf(fmaf(x1.x, s2[i].x, t2[i].x), 0.f)) +
+                      (fmaxf(fmaf(x2.x, s2[i].x, t2[i].x), 0.f) + fmaxf(fmaf(x3.x, s2[i].x, t2[i].x), 0.f))) * 0.25f;
+            a[i].y = ((fmaxf(fmaf(x0.y, s2[i].y, t2[i].y), 0.f) + fmaxf(fmaf(x1.y, s2[i].y, t2[i].y), 0.f)) +
+                      (fmaxf(fmaf(x2.y, s2[i].y, t2[i].y), 0.f) + fmaxf(fmaf(x3.y, s2[i].y, t2[i].y), 0.f))) * 0.25f;
+          } else {
+            const float2 x0 = *reinterpret_cast<const float2*>(xp + coff[i]);
+            a[i].x = fmaxf(fmaf(x0.x, s2[i].x, t2[i].x), 0.f);
+            a[i].y = fmaxf(fmaf(x0.y, s2[i].y, t2[i].y), 0.f);
+          }
+          if (!pv) a[i] = make_float2(0.f, 0.f);
+        }
+      }
+      float bz[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (i < ngw) {
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            acc[i][0][n] = mfma16(a[i].x, bz[n], acc[i][0][n]);
+            acc[i][1][n] = mfma16(a[i].y, bz[n], acc[i][1][n]);
+          }
+        }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int n = 0; n < 3; ++n) acc[i][n] = mfma16(a[i], dz[n], acc[i][n]);
+    stage_write(dz_l[(it + 1) & 1]);
+    __syncthreads();
   }
-  float* out = partial + ((size_t)blockIdx.x * PW + pg) * Kp * 48;
+  float* out = partial + (size_t)blockIdx.x * Kp * 48;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int mt = mg + MW * i;
-    if (mt < nmt) {
+  for (int i = 0; i < 3; ++i) {
+    const int cg = wave + 4 * i;
 #pragma unroll
-      for (int n = 0; n < 3; ++n)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) out[(size_t)(16 * mt + 4 * kk + g) * 48 + 16 * n + r] = acc[i][n][g];
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int ch = 32 * cg + 2 * (4 * kk + g) + t;  // D row 4kk+g of tile t
+        if (cg < ngroups && ch < Kp) {
+#pragma unroll
+          for (int n = 0; n < 3; ++n) out[(size_t)ch * 48 + 16 * n + r] = acc[i][t][n][g];
+        }
+      }
   }
 }
-
 
 // =============================================================================== conv1x1 backward: data
 // da[p][k] = sum_o dz[p][o] W[o][k], masked by relu(bn1(x)) > 0, and -- since the dy-coefficient of
@@ -405,7 +497,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
 // The MFMA computes D^T (rows = channels, cols = pixels) so a lane owns 4 CONSECUTIVE channels of
 // one pixel: X / G are touched with 16-B accesses.
 // Wd: weights in fragment order [Kp/16][Ko/16][4][16][4] = W[o=16jo+4kk+t][k=16nt+col].
-template <bool POOL>
+template <bool POOL, bool RES /* Ko == 48: dz fragments stay in registers across channel chunks */>
 __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
     const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
     const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
@@ -438,27 +530,33 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
         pin[m] = (size_t)prow[m];
       }
     }
+    auto load_dz = [&](int jo, float4 (&dz)[4]) {
+      const int ch = 16 * jo + 4 * kk;
+      const float4 a4 = *reinterpret_cast<const float4*>(cA + ch);
+      const float4 b4 = *reinterpret_cast<const float4*>(cB + ch);
+      const float4 c4 = *reinterpret_cast<const float4*>(cC + ch);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 dy = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
+        const float4 zr = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+        dz[m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
+        dz[m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
+        dz[m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
+        dz[m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
+      }
+    };
+    float4 dzr[3][4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int jo = 0; jo < 3; ++jo) load_dz(jo, dzr[jo]);
+    }
     for (int nt0 = 0; nt0 < nnt; nt0 += 4) {
       f32x4 acc[4][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int jo = 0; jo < njo; ++jo) {
-        const int ch = 16 * jo + 4 * kk;
-        const float4 a4 = *reinterpret_cast<const float4*>(cA + ch);
-        const float4 b4 = *reinterpret_cast<const float4*>(cB + ch);
-        const float4 c4 = *reinterpret_cast<const float4*>(cC + ch);
-        float4 dz[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float4 dy = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
-          const float4 zr = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
-          dz[m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
-          dz[m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
-          dz[m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
-          dz[m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
-        }
+      auto mma = [&](int jo, const float4 (&dz)[4]) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const int nt = min(nt0 + n, nnt - 1);
@@ -470,6 +568,16 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
             acc[m][n] = mfma16(w.z, dz[m].z, acc[m][n]);
             acc[m][n] = mfma16(w.w, dz[m].w, acc[m][n]);
           }
+        }
+      };
+      if constexpr (RES) {
+#pragma unroll
+        for (int jo = 0; jo < 3; ++jo) mma(jo, dzr[jo]);
+      } else {
+        for (int jo = 0; jo < njo; ++jo) {
+          float4 dz[4];
+          load_dz(jo, dz);
+          mma(jo, dz);
         }
       }
       // epilogue: this lane owns channels k4..k4+3 (k4 = 16nt + 4kk) of pixel p0 + 16m + r
@@ -762,22 +870,24 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
   if (!X || !scale1 || !shift1 || !DY || !Zr || !cA || !cB || !cC || !partial || !dW || P < 1 || grid < 1 || Kp < 32 ||
       (Kp & 15) || Cin > Kp || Cout < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: bad arguments");
-  const int PW = (Kp >= 64) ? 1 : 2;
   const int nchunks = (Cout + 47) / 48;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int n0 = ch * 48, nv = (Cout - n0 < 48) ? Cout - n0 : 48;
+    int n_load = ((ld_dy < ld_z ? ld_dy : ld_z) - n0) & ~3;
+    if (n_load > 48) n_load = 48;
+    if (n_load < nv) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: DY/Zr rows narrower than Cout");
     if (pool)
       hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)P,
                          Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0, nv,
-                         partial);
+                         n_load, partial);
     else
       hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
                          (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
-                         nv, partial);
+                         nv, n_load, partial);
     int rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((Cin * 48 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
-                       grid * PW, (size_t)Kp * 48, 0, Cin, nv, n0, dW);
+                       grid, (size_t)Kp * 48, 0, Cin, nv, n0, dW);
     rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32(reduce)");
     if (rc) return rc;
   }
@@ -803,14 +913,16 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
       (ldx & 3) || (ldg & 3) || Kp > ldx || Kp > ldg)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: bad arguments");
   const size_t lds = (size_t)4 * Kp * 2 * sizeof(double);
-  if (pool)
-    hipLaunchKernelGGL(conv1x1_bwd_data_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
-                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, ldg,
-                       accumulate, partials);
-  else
-    hipLaunchKernelGGL(conv1x1_bwd_data_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, Zr,
-                       ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, ldg,
-                       accumulate, partials);
+#define EML_LAUNCH_BWD_DATA(POOLV, RESV)                                                                              \
+  hipLaunchKernelGGL((conv1x1_bwd_data_kernel<POOLV, RESV>), dim3(grid), dim3(256), lds, (hipStream_t)stream, DY,    \
+                     ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, \
+                     ldg, accumulate, partials)
+  if (pool) {
+    if (Ko == 48) EML_LAUNCH_BWD_DATA(true, true); else EML_LAUNCH_BWD_DATA(true, false);
+  } else {
+    if (Ko == 48) EML_LAUNCH_BWD_DATA(false, true); else EML_LAUNCH_BWD_DATA(false, false);
+  }
+#undef EML_LAUNCH_BWD_DATA
   return eml::check_launch("eml_dense_conv1x1_bwd_data_f32");
 }
 
