@@ -29,50 +29,75 @@ STEP_GFLOP_240x320 = 131.2      # forward + dgrad + wgrad (minus conv0 dgrad)
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 
 
-def conv1x1_flops(B, crop_hw):
-    """Algorithmic FLOPs of ALL dense-layer + transition conv1x1 forward launches of one step."""
+def conv_flops(B, crop_hw):
+    """Algorithmic FLOPs (2*Cout*Cin*k*k*Hout*Wout) of one pass over all conv1x1 launches
+    (dense bottlenecks + transitions) and over all conv3x3 launches of the encoder, for batch B."""
     h, w = crop_hw
-    c, tot = 24, 0.0
+    c, f1, f3 = 24, 0.0, 0.0
     for _ in range(3):
         for l in range(16):
-            tot += 2.0 * (c + 12 * l) * 48 * h * w
+            f1 += 2.0 * (c + 12 * l) * 48 * h * w
+            f3 += 2.0 * 48 * 12 * 9 * h * w
         c_tot = c + 192
-        tot += 2.0 * c_tot * (c_tot // 2) * (h // 2) * (w // 2)
+        f1 += 2.0 * c_tot * (c_tot // 2) * (h // 2) * (w // 2)
         c, h, w = c_tot // 2, h // 2, w // 2
-    return tot * B
+    return f1 * B, f3 * B
 
 
-def time_kernel_family(trainer, batch, steps):
-    """Average duration of the conv1x1 forward launches of one training step, by bracketing the
-    encoder's forward pass kernels with HIP events on the launch stream (no profiler)."""
+# launcher -> (kernel family, which algorithmic FLOP count one pass over its launches performs)
+FAMILIES = {
+    "eml_dense_conv1x1_fwd_f32": ("conv1x1_fwd_kernel (BN1+ReLU fused into the MFMA operand load)", 0),
+    "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS)", 0),
+    "eml_dense_conv1x1_bwd_data_f32": ("conv1x1_bwd_data_kernel (dgrad + ReLU mask + BN1-backward accumulate)", 0),
+    "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
+    "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),
+    "eml_dense_conv3x3_bwd_weight_f32": ("conv3x3_bwd_weight_kernel", 1),
+}
+
+
+def time_kernel_families(trainer, batch, steps, B, crop_hw):
+    """Per-family GPU time of one training step, measured live: every dense-engine launcher call is
+    bracketed by HIP events on the stream it launches on (torch's current stream)."""
     from emlight_amd import _lib
     L = _lib.lib()
-    orig = L.eml_dense_conv1x1_fwd_f32
-    events = []
+    events = {k: [] for k in FAMILIES}
+    orig = {k: getattr(L, k) for k in FAMILIES}
 
-    class Timed:
-        def __call__(self, *a):
+    def timed(name):
+        fn = orig[name]
+
+        def call(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = orig(*a)
+            rc = fn(*a)
             e1.record()
-            events.append((e0, e1))
+            events[name].append((e0, e1))
             return rc
-    L.eml_dense_conv1x1_fwd_f32 = Timed()
+        return call
+    for k in FAMILIES:
+        setattr(L, k, timed(k))
     try:
         for _ in range(steps):
             trainer.step(batch)
         torch.cuda.synchronize()
     finally:
-        L.eml_dense_conv1x1_fwd_f32 = orig
-    total_ms = sum(a.elapsed_time(b) for a, b in events)
-    return total_ms / steps, len(events) // steps
+        for k in FAMILIES:
+            setattr(L, k, orig[k])
+    flops = conv_flops(B, crop_hw)
+    rows = []
+    for k, (label, which) in FAMILIES.items():
+        ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
+        n = len(events[k]) // steps
+        rows.append({"kernel": label, "launches_per_step": n, "ms_per_step": round(ms, 3),
+                     "avg_launch_ms": round(ms / max(n, 1), 4),
+                     "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
 
 
-def cpu_baseline(anchors, crop_hw, blur, batch=2, steps=1):
-    """Oracle (port of the reference's PyTorch-CPU maths) training step on the host cores."""
+def _cpu_baseline_worker(anchors, crop_hw, blur, batch, threads, q):
     import oracle
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(threads)
     from emlight_amd.RegressionNetwork.data import synthetic_batch
     net = oracle.OracleDenseNet(anchors=anchors, crop_hw=crop_hw).train()
     M = oracle.anchor_cost_matrix(anchors)
@@ -85,14 +110,69 @@ def cpu_baseline(anchors, crop_hw, blur, batch=2, steps=1):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    one()  # warm-up
     t0 = time.time()
+    one()  # warm-up (also the fallback sample if the box is slow)
+    warm = time.time() - t0
+    steps, dt = 1, warm
+    if warm < 8.0:
+        steps = 2
+        t0 = time.time()
+        for _ in range(steps):
+            one()
+        dt = (time.time() - t0) / steps
+    q.put((batch / dt, steps))
+
+
+def cpu_baseline(anchors, crop_hw, blur, batch=2, budget_s=150):
+    """Oracle (port of the reference's PyTorch-CPU maths) training step on this box's host cores:
+    a BOUNDED sample (batch 2, <= 3 steps) in a child process with a wall-clock budget.  Thread count
+    is capped at 32: at batch 2 the reference's ATen CPU kernels slow down, not up, beyond that
+    (measured: 256 threads -> 292 s per step on the MI355X host)."""
+    import multiprocessing as mp
+    threads = min(os.cpu_count() or 1, 32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(anchors, crop_hw, blur, batch, threads, q))
+    pr.start()
+    pr.join(budget_s)
+    if pr.is_alive():
+        pr.terminate()
+        pr.join()
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": "oracle step of batch %d did not finish within %d s" % (batch, budget_s)}
+    try:
+        value, steps = q.get(timeout=10)
+    except Exception:
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": "oracle child process exited without a result (exit code %s)" % pr.exitcode}
+    return {"value": round(value, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d timed step(s) of batch %d, %dx%d crops, %d anchors, oracle torch-CPU f32 training step "
+                      "(fwd + Sinkhorn + bwd + Adam), %d threads of %d host cpus"
+                      % (steps, batch, crop_hw[0], crop_hw[1], anchors, threads, os.cpu_count() or 1)}
+
+
+def run_timed(step_fn, steps, warmup, world, device):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones bracketed by barrier + device sync on both
+    sides; returns the MAX over ranks of the elapsed seconds (identical on every rank)."""
+    is_cuda = str(device).startswith("cuda")
+    sync = torch.cuda.synchronize if is_cuda else (lambda: None)
+    for _ in range(warmup):
+        step_fn()
+    sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
     for _ in range(steps):
-        one()
-    dt = (time.time() - t0) / steps
-    return {"value": batch / dt, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d step(s) of batch %d, %dx%d crops, %d anchors, oracle torch-CPU f32, %d threads"
-                      % (steps, batch, crop_hw[0], crop_hw[1], anchors, os.cpu_count())}
+        step_fn()
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device if is_cuda else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
 
 
 def main():
@@ -118,22 +198,7 @@ def main():
                            engine=args.engine, world=world)
     batch = synthetic_batch(args.batch, args.anchors, crop_hw, seed=1234 + rank, device=dev)
 
-    for _ in range(args.warmup):
-        tr.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = run_timed(lambda: tr.step(batch), args.steps, args.warmup, world, dev)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -152,13 +217,15 @@ def main():
             if crop_hw == (240, 320) else None,
         }
         if args.engine == "hip":
-            fam_ms, n_launch = time_kernel_family(tr, batch, 2)
-            fl = conv1x1_flops(args.batch, crop_hw)
-            ach = fl / (fam_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "conv1x1_fwd_kernel (BN1+ReLU fused f32-MFMA 1x1 conv; %d launches/step)" % n_launch,
-                               "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "avg_launch_ms": round(fam_ms / max(n_launch, 1), 4)}
+            fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw)
+            dom = fams[0]  # the dominant kernel family of the step, by measured GPU time
+            out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
+                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
+                               "note": "achieved = algorithmic conv FLOPs of the family's launches / their summed "
+                                       "HIP-event duration; f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak"}
+            out["kernel_families"] = fams
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)
         print(json.dumps(out))

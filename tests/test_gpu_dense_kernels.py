@@ -1,0 +1,324 @@
+"""GPU: every DenseNet-engine kernel of libemlight_hip.so, one launcher at a time, against the same op
+written in plain PyTorch (f64 on the GPU) on identical inputs.  Shapes are deliberately ragged (pixel
+counts that are not multiples of the 256-pixel tiles, H/W that are not multiples of the 8x32 conv
+tile, channel counts that are not multiples of 16) so every bounds path runs.  Tolerances are f32
+round-off for the reduction length involved."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = 64  # persistent workgroups used by the tests (the engine uses 2 x #CU)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from emlight_amd import _lib
+    return _lib
+
+
+def r16(v):
+    return (v + 15) // 16 * 16
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, device=DEV) * scale
+
+
+def close(got, want, rtol=2e-5, atol=None, what=""):
+    want = want.double()
+    atol = atol if atol is not None else 2e-5 * float(want.abs().max() + 1e-30)
+    err = (got.double() - want).abs()
+    assert bool((err <= atol + rtol * want.abs()).all()), "%s: max err %.3e (scale %.3e)" % (
+        what, float(err.max()), float(want.abs().max()))
+
+
+def fold_partials(part, rows, nch):
+    """[rows][nch][2] f64 partials -> (sum, sumsq)"""
+    v = part[:rows * nch * 2].view(rows, nch, 2).sum(0)
+    return v[:, 0], v[:, 1]
+
+
+def nhwc(t):  # (B,C,H,W) -> (B*H*W, C)
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def nchw(t, B, H, W):  # (P, C) -> (B,C,H,W)
+    return t.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ forward
+def test_conv0_fwd_and_stats(lib):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    B, H, W, ld = 2, 20, 44, 32
+    x, w0 = torch.rand(B, 3, H, W, device=DEV), rnd(24, 3, 3, 3, scale=0.3)
+    Y = torch.zeros(B * H * W, ld, device=DEV)
+    part = torch.zeros(G * 48, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_conv0_fwd_f32(p(x), p(w0), p(Y), ld, B, H, W, 24, p(part), G, st), "conv0")
+    want = nhwc(F.conv2d(x.double(), w0.double(), padding=1))
+    close(Y[:, :24], want, what="conv0")
+    s, q = fold_partials(part, G, 24)
+    close(s, want.sum(0), what="conv0 sum", rtol=1e-6)
+    close(q, (want * want).sum(0), what="conv0 sumsq", rtol=1e-6)
+
+
+@pytest.mark.parametrize("relu,C", [(1, 24), (0, 171), (0, 150)])
+def test_bn_apply_and_prepare(lib, relu, C):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    P, lds, ldd = 777, r16(C), r16(C) + 16
+    src, dst = rnd(P, lds), torch.zeros(P, ldd, device=DEV)
+    sc, sh = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.3)
+    part = torch.zeros(G * C * 2, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_bn_apply_f32(p(src), lds, p(dst), ldd, C, P, p(sc), p(sh), relu, p(part), G, st), "apply")
+    want = src[:, :C].double() * sc.double() + sh.double()
+    if relu:
+        want = want.clamp_min(0)
+    close(dst[:, :C], want, what="bn_apply")
+    assert float(dst[:, C:].abs().max()) == 0.0
+    # bn_prepare folds those partials: mean / biased var / istd, scale / shift, running stats
+    mean, var, istd = (torch.zeros(ldd, device=DEV) for _ in range(3))
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.2)
+    rm, rv = rnd(C, scale=0.1), torch.rand(C, device=DEV) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    Cpad = r16(C)
+    scale, shift = torch.full((Cpad,), 9.0, device=DEV), torch.full((Cpad,), 9.0, device=DEV)
+    lib.check(L.eml_dense_bn_prepare_f32(p(part), G, 2 * C, C, 0, float(P), p(mean), p(var), p(istd), p(gamma), p(beta),
+                                         p(rm), p(rv), C, Cpad, 1e-5, 0.1, 1, p(scale), p(shift), st), "prepare")
+    m, v = want.mean(0), want.var(0, unbiased=False)
+    close(mean[:C], m, what="mean", atol=1e-6)
+    close(var[:C], v, what="var", rtol=1e-5)
+    close(istd[:C], 1 / torch.sqrt(v + 1e-5), what="istd", rtol=1e-5)
+    close(scale[:C], gamma.double() / torch.sqrt(v + 1e-5), what="scale", rtol=1e-5)
+    close(shift[:C], beta.double() - m * gamma.double() / torch.sqrt(v + 1e-5), what="shift", rtol=1e-5, atol=1e-5)
+    assert float(scale[C:].abs().max() if Cpad > C else 0) == 0.0
+    close(rm, 0.9 * rm0.double() + 0.1 * m, what="running_mean", atol=1e-6)
+    close(rv, 0.9 * rv0.double() + 0.1 * want.var(0, unbiased=True), what="running_var", rtol=1e-5)
+    # eval mode: affine from the running buffers, statistics untouched
+    lib.check(L.eml_dense_bn_prepare_f32(None, 0, 0, 0, 0, float(P), p(mean), p(var), p(istd), p(gamma), p(beta), p(rm),
+                                         p(rv), C, Cpad, 1e-5, 0.1, 0, p(scale), p(shift), st), "prepare eval")
+    close(scale[:C], gamma.double() / torch.sqrt(rv.double() + 1e-5), what="eval scale", rtol=1e-5)
+
+
+@pytest.mark.parametrize("pool,Cin,Cout,B,H,W", [(0, 24, 48, 2, 20, 44), (0, 330, 48, 1, 12, 20), (0, 150, 48, 3, 6, 10),
+                                                 (1, 216, 108, 2, 12, 20), (1, 342, 171, 1, 8, 12),
+                                                 (1, 300, 150, 2, 6, 10)])
+def test_conv1x1_fwd(lib, pool, Cin, Cout, B, H, W):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Kp, ld = r16(Cin), r16(Cin) + 16
+    Pin = B * H * W
+    P = Pin // 4 if pool else Pin
+    X = rnd(Pin, ld)
+    sc, sh = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+    sc[:Cin], sh[:Cin] = torch.rand(Cin, device=DEV) + 0.5, rnd(Cin, scale=0.3)
+    Wt = rnd(Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    nch = (Cout + 47) // 48
+    Wp = torch.empty(nch * Kp * 48, device=DEV)
+    lib.check(L.eml_dense_permute_w1_f32(p(Wt), Cout, Cin, Kp, p(Wp), st), "permute")
+    ldo = r16(Cout)
+    out = torch.zeros(P, ldo, device=DEV)
+    part = torch.zeros(nch * G * 96, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_conv1x1_fwd_f32(p(X), ld, P, H, W, pool, Kp, p(sc), p(sh), p(Wp), Cout, p(out), ldo, p(part),
+                                          G, st), "conv1x1")
+    a = (X[:, :Cin].double() * sc[:Cin].double() + sh[:Cin].double()).clamp_min(0)
+    if pool:
+        a = nhwc(F.avg_pool2d(nchw(a, B, H, W), 2, 2))
+    want = a @ Wt.double().t()
+    close(out[:, :Cout], want, what="conv1x1 out")
+    assert float(out[:, Cout:].abs().max() if ldo > Cout else 0) == 0.0
+    for ch in range(nch):
+        nv = min(48, Cout - 48 * ch)
+        s, q = fold_partials(part[ch * G * 96:], G, 48)
+        close(s[:nv], want[:, 48 * ch:48 * ch + nv].sum(0), what="stats sum", rtol=1e-6, atol=1e-4)
+        close(q[:nv], (want[:, 48 * ch:48 * ch + nv] ** 2).sum(0), what="stats sq", rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,c_out0,ld", [(2, 20, 44, 24, 64), (1, 8, 32, 150, 176), (3, 7, 9, 108, 128)])
+def test_conv3x3_fwd(lib, B, H, W, c_out0, ld):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    P = B * H * W
+    Z = rnd(P, 48)
+    s2, t2 = torch.rand(48, device=DEV) + 0.5, rnd(48, scale=0.3)
+    W2 = rnd(12, 48, 3, 3, scale=0.05)
+    W2p = torch.empty(9 * 3 * 4 * 16 * 4, device=DEV)
+    lib.check(L.eml_dense_permute_w2_f32(p(W2), 12, p(W2p), st), "permute2")
+    X = torch.full((P, ld), 5.0, device=DEV)
+    part = torch.zeros(G * 32, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_conv3x3_fwd_f32(p(Z), p(s2), p(t2), p(W2p), p(X), ld, c_out0, B, H, W, p(part), G, st), "c3")
+    zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W)
+    want = nhwc(F.conv2d(zn, W2.double(), padding=1))  # zero padding applies to the BN output
+    close(X[:, c_out0:c_out0 + 12], want, what="conv3x3 out")
+    assert bool((X[:, :c_out0] == 5.0).all()) and bool((X[:, c_out0 + 12:] == 5.0).all())
+    s, q = fold_partials(part, G, 16)
+    close(s[:12], want.sum(0), what="sum", rtol=1e-6, atol=1e-4)
+    close(q[:12], (want ** 2).sum(0), what="sq", rtol=1e-5)
+
+
+def test_head_pool_fwd_bwd(lib):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    B, H, W, C, k, ld = 2, 8, 12, 171, 4, 176
+    Fm = rnd(B * H * W, ld)
+    out = torch.empty(B, C * (H // k) * (W // k), device=DEV)
+    lib.check(L.eml_dense_head_pool_fwd_f32(p(Fm), ld, C, B, H, W, k, p(out), st), "head")
+    f = nchw(Fm[:, :C].double(), B, H, W).requires_grad_(True)
+    want = F.avg_pool2d(torch.relu(f), k).reshape(B, -1)
+    close(out, want, what="head pool")
+    gp = rnd(B, C * (H // k) * (W // k))
+    dF = torch.zeros(B * H * W, ld, device=DEV)
+    lib.check(L.eml_dense_head_pool_bwd_f32(p(gp), p(Fm), ld, C, B, H, W, k, p(dF), ld, st), "head bwd")
+    (want * gp.double()).sum().backward()
+    close(dF[:, :C], nhwc(f.grad), what="head pool bwd")
+
+
+# ------------------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("B,H,W,c0,ld", [(2, 20, 44, 24, 64), (1, 8, 32, 162, 176), (3, 7, 9, 108, 128)])
+def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    P = B * H * W
+    Gd, Z = rnd(P, ld), rnd(P, 48)
+    W2 = rnd(12, 48, 3, 3, scale=0.05)
+    s2, t2 = torch.rand(48, device=DEV) + 0.5, rnd(48, scale=0.3)
+    zmean, zistd = rnd(48, scale=0.1), torch.rand(48, device=DEV) + 0.5
+    DZ = torch.empty(P, 48, device=DEV)
+    part = torch.zeros(G * 96, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, c0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
+                                               st), "c3 bwd data")
+    zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
+    w = W2.double().requires_grad_(True)
+    g = nchw(Gd[:, c0:c0 + 12].double(), B, H, W)
+    (F.conv2d(zn, w, padding=1) * g).sum().backward()
+    dzn = nhwc(zn.grad)
+    close(DZ, dzn, what="dzn")
+    s1, s2p = fold_partials(part, G, 48)
+    zh = (Z.double() - zmean.double()) * zistd.double()
+    close(s1, dzn.sum(0), what="S1", rtol=1e-6, atol=1e-4)
+    close(s2p, (dzn * zh).sum(0), what="S2", rtol=1e-6, atol=1e-4)
+    partW = torch.empty(G * 27 * 256, device=DEV)
+    dW2 = torch.empty(12, 48, 3, 3, device=DEV)
+    lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gd), ld, c0, p(Z), p(s2), p(t2), B, H, W, p(partW), p(dW2), G, st),
+              "c3 bwd weight")
+    close(dW2, w.grad, what="dW2", rtol=1e-4)
+
+
+def test_bn_bwd_finalize(lib):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    C, Cpad, R, n = 150, 160, 37, 1234.0
+    part = torch.randn(R * 2 * C, dtype=torch.float64, device=DEV)
+    gamma, mean, istd = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.2), torch.rand(C, device=DEV) + 0.5
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    cA, cB, cC = (torch.full((Cpad,), 3.0, device=DEV) for _ in range(3))
+    sB, sC = torch.ones(Cpad, device=DEV), torch.ones(Cpad, device=DEV)
+    lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg), p(db),
+                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, st), "finalize")
+    S = part.view(R, C, 2).sum(0)
+    S1, S2 = S[:, 0], S[:, 1]
+    ga, is_, mu = gamma.double(), istd.double(), mean.double()
+    close(db, S1, what="dbeta")
+    close(dg, S2, what="dgamma")
+    close(cA[:C], ga * is_, what="cA")
+    close(cB[:C], -ga * is_ * is_ * S2 / n, what="cB")
+    close(cC[:C], -ga * is_ * S1 / n + ga * is_ * is_ * S2 / n * mu, what="cC", atol=1e-6)
+    close(sB[:C], 1 + (-ga * is_ * is_ * S2 / n), what="sB accumulate")
+    assert float(cA[C:].abs().max()) == 0.0 and float((sB[C:] - 1).abs().max()) == 0.0
+
+
+def _dz(DY, Zr, cA, cB, cC, Cout):
+    return cA[:Cout].double() * DY[:, :Cout].double() + cB[:Cout].double() * Zr[:, :Cout].double() + cC[:Cout].double()
+
+
+@pytest.mark.parametrize("pool,Cin,Cout,B,H,W", [(0, 24, 48, 2, 20, 44), (0, 330, 48, 1, 12, 20), (0, 36, 48, 3, 6, 10),
+                                                 (1, 216, 108, 2, 12, 20), (1, 342, 171, 1, 8, 12),
+                                                 (1, 300, 150, 2, 6, 10)])
+def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Kp, Ko = r16(Cin), r16(Cout)
+    ld = Kp + 16
+    Pin = B * H * W
+    P = Pin // 4 if pool else Pin
+    X = rnd(Pin, ld)
+    s1, t1 = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+    s1[:Cin], t1[:Cin] = torch.rand(Cin, device=DEV) + 0.5, rnd(Cin, scale=0.3)
+    mean, istd = rnd(ld, scale=0.1), torch.rand(ld, device=DEV) + 0.5
+    ld_dy = Ko + 16
+    DY, Zr = rnd(P, ld_dy), rnd(P, Ko)
+    cA, cB, cC = (torch.zeros(Ko, device=DEV) for _ in range(3))
+    cA[:Cout], cB[:Cout], cC[:Cout] = rnd(Cout), rnd(Cout, scale=0.1), rnd(Cout, scale=0.1)
+    Wt = rnd(Cout, Cin, scale=1.0 / np.sqrt(Cout))
+    dz = _dz(DY, Zr, cA, cB, cC, Cout)
+    pre = X[:, :Cin].double() * s1[:Cin].double() + t1[:Cin].double()
+    a = pre.clamp_min(0)
+    if pool:
+        a = nhwc(F.avg_pool2d(nchw(a, B, H, W), 2, 2))
+    # ---- weight gradient
+    partW = torch.empty(G * Kp * 48, device=DEV)
+    dW = torch.empty(Cout, Cin, device=DEV)
+    lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                 p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, st), "wgrad")
+    close(dW, dz.t() @ a, what="dW", rtol=1e-4)
+    # ---- data gradient, accumulate and overwrite modes, + BN1-backward partial sums
+    Wd = torch.empty(Kp * Ko, device=DEV)
+    lib.check(L.eml_dense_permute_w1_bwd_f32(p(Wt), Cout, Cin, Kp, Ko, p(Wd), st), "permute bwd")
+    da = dz @ Wt.double()
+    if pool:
+        da = da.view(B, H // 2, 1, W // 2, 1, Cin).expand(B, H // 2, 2, W // 2, 2, Cin).reshape(Pin, Cin) * 0.25
+    dam = torch.where(pre > 0, da, torch.zeros_like(da))
+    xh = (X[:, :Cin].double() - mean[:Cin].double()) * istd[:Cin].double()
+    for accumulate in (1, 0):
+        G0 = rnd(Pin, ld)
+        Gd = G0.clone()
+        part = torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV)
+        lib.check(L.eml_dense_conv1x1_bwd_data_f32(p(DY), ld_dy, p(Zr), Ko, p(cA), p(cB), p(cC), Ko, p(Wd), p(X), ld,
+                                                   p(s1), p(t1), p(mean), p(istd), P, H, W, pool, Kp, p(Gd), ld,
+                                                   accumulate, p(part), G, st), "dgrad")
+        want = s1[:Cin].double() * dam + (G0[:, :Cin].double() if accumulate else 0)
+        close(Gd[:, :Cin], want, what="G (accumulate=%d)" % accumulate, rtol=1e-4)
+        assert torch.equal(Gd[:, Kp:], G0[:, Kp:])
+        S1, S2 = fold_partials(part, G, Kp)
+        close(S1[:Cin], dam.sum(0), what="S1", rtol=1e-5, atol=1e-4)
+        close(S2[:Cin], (dam * xh).sum(0), what="S2", rtol=1e-5, atol=1e-4)
+
+
+def test_grad_materialize_and_bn_bwd_stats(lib):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    P, ld, c0, n = 999, 64, 24, 12
+    Gd, X = rnd(P, ld), rnd(P, ld)
+    sB, sC = rnd(ld, scale=0.1), rnd(ld, scale=0.1)
+    G0 = Gd.clone()
+    lib.check(L.eml_dense_grad_materialize_f32(p(Gd), ld, p(X), ld, p(sB), p(sC), c0, n, P, st), "materialize")
+    want = G0.double()
+    want[:, c0:c0 + n] += sB[c0:c0 + n].double() * X[:, c0:c0 + n].double() + sC[c0:c0 + n].double()
+    close(Gd, want, what="materialize")
+    for relu, C in ((1, 24), (0, 171)):
+        ldc = r16(C)
+        DY, raw, out = rnd(P, ldc + 16), rnd(P, ldc), rnd(P, ldc)
+        mean, istd = rnd(C, scale=0.1), torch.rand(C, device=DEV) + 0.5
+        part = torch.zeros(G * C * 2, dtype=torch.float64, device=DEV)
+        lib.check(L.eml_dense_bn_bwd_stats_f32(p(DY), ldc + 16, p(raw), ldc, p(out), ldc, relu, C, P, p(mean), p(istd),
+                                               p(part), G, st), "bn bwd stats")
+        dy = DY[:, :C].double()
+        if relu:
+            dy = torch.where(out[:, :C] > 0, dy, torch.zeros_like(dy))
+        S1, S2 = fold_partials(part, G, C)
+        close(S1, dy.sum(0), what="S1", atol=1e-4)
+        close(S2, (dy * (raw[:, :C].double() - mean.double()) * istd.double()).sum(0), what="S2", atol=1e-4)
+
+
+def test_conv0_bwd_weight(lib):
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    B, H, W, ld = 2, 20, 44, 32
+    P = B * H * W
+    x = torch.rand(B, 3, H, W, device=DEV)
+    Gd, X1, Y0 = rnd(P, ld), rnd(P, ld), rnd(P, 24)
+    cA, cB, cC = (torch.zeros(32, device=DEV) for _ in range(3))
+    cA[:24], cB[:24], cC[:24] = rnd(24), rnd(24, scale=0.1), rnd(24, scale=0.1)
+    partW = torch.empty(G * 4 * 1024, device=DEV)
+    dW0 = torch.empty(24, 3, 3, 3, device=DEV)
+    lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(Gd), ld, p(X1), ld, p(Y0), 24, p(cA), p(cB), p(cC), B, H, W,
+                                               p(partW), p(dW0), G, st), "conv0 bwd")
+    g = torch.where(X1[:, :24] > 0, Gd[:, :24].double(), torch.zeros(P, 24, device=DEV, dtype=torch.float64))
+    dY0 = cA[:24].double() * g + cB[:24].double() * Y0.double() + cC[:24].double()
+    w = torch.zeros(24, 3, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, padding=1) * nchw(dY0, B, H, W)).sum().backward()
+    close(dW0, w.grad, what="dW0", rtol=1e-4)
