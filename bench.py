@@ -95,6 +95,33 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
     return rows
 
 
+def time_sinkhorn(B, anchors, blur, dev, reps=20):
+    """BASELINE's second metric: Sinkhorn ms per eps-step (1 iter = 4 softmin sweeps + averaging,
+    sinkhorn_divergence.py:87-97) of the HIP loss at the bench batch, by HIP events."""
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    g = torch.Generator().manual_seed(7)
+    x = torch.softmax(torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
+    y = torch.softmax(3 * torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
+    crit = SamplesLoss("sinkhorn", p=2, blur=blur, anchors=anchors)
+    r = crit.forward_raw(x, y)
+    n_eps = int(r["n_eps"].item())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        crit.forward_raw(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg_bytes = 4.0 * (B * anchors * anchors * 4 + 2 * B * anchors * 4)  # per eps-step, SURVEY 8d
+    per_step = ms / (n_eps + 2)
+    return {"ms_per_loss_call": round(ms, 4), "n_eps": n_eps, "sweeps": n_eps + 2,
+            "ms_per_eps_step": round(per_step, 5), "algorithmic_GBps": round(alg_bytes / (per_step * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak_8TBps": round(alg_bytes / (per_step * 1e-3) / 8e12, 4),
+            "note": "loss call = schedule + loop + finish kernels (forward and unit gradients); "
+                    "algorithmic bytes = the reference's materialised-cost traffic"}
+
+
 def _cpu_baseline_worker(anchors, crop_hw, blur, batch, threads, q):
     import oracle
     torch.set_num_threads(threads)
@@ -226,6 +253,7 @@ def main():
                                "note": "achieved = algorithmic conv FLOPs of the family's launches / their summed "
                                        "HIP-event duration; f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak"}
             out["kernel_families"] = fams
+            out["sinkhorn"] = time_sinkhorn(args.batch, args.anchors, args.blur, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)
         print(json.dumps(out))
