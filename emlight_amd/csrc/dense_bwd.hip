@@ -15,6 +15,8 @@
 // partials + a finishing kernel: deterministic, no atomics.
 #include "eml_common.h"
 
+#include <type_traits>
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -411,64 +413,80 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
       *reinterpret_cast<float4*>(dzb + spix * 48 + col) = v;
     }
   };
-  stage_load(blockIdx.x);
-  stage_write(dz_l[0]);
-  __syncthreads();
-  int it = 0;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
-    const float* dzb = dz_l[it & 1];
-    stage_load(chunk + gridDim.x);  // next chunk's loads fly during this chunk's MFMAs
-#pragma unroll 4
-    for (int q4 = 0; q4 < 16; ++q4) {
-      const int pl = 4 * q4 + kk;
-      const int p = chunk * 64 + pl;
-      const bool pv = p < P;
-      const int pc = pv ? p : P - 1;
-      const float* xp;
-      if constexpr (POOL) {
-        const int b = pc / (Ho * Wo), rem = pc - b * (Ho * Wo);
-        const int oy = rem / Wo, ox = rem - oy * Wo;
-        xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
-      } else {
-        xp = X + (size_t)pc * ldx;
-      }
-      float2 a[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        if (i < ngw) {
-          if constexpr (POOL) {
-            const float2 x0 = *reinterpret_cast<const float2*>(xp + coff[i]);
-            const float2 x1 = *reinterpret_cast<const float2*>(xp + ldx + coff[i]);
-            const float2 x2 = *reinterpret_cast<const float2*>(xp + (size_t)Win * ldx + coff[i]);
-            const float2 x3 = *reinterpret_cast<const float2*>(xp + (size_t)Win * ldx + ldx + coff[i]);
-            a[i].x = ((fmaxf(fmaf(x0.x, s2[i].x, t2[i].x), 0.f) + fmaxf(fmaf(x1.x, s2[i].x, t2[i].x), 0.f)) +
-                      (fmaxf(fmaf(x2.x, s2[i].x, t2[i].x), 0.f) + fmaxf(fmaf(x3.x, s2[i].x, t2[i].x), 0.f))) * 0.25f;
-            a[i].y = ((fmaxf(fmaf(x0.y, s2[i].y, t2[i].y), 0.f) + fmaxf(fmaf(x1.y, s2[i].y, t2[i].y), 0.f)) +
-                      (fmaxf(fmaf(x2.y, s2[i].y, t2[i].y), 0.f) + fmaxf(fmaf(x3.y, s2[i].y, t2[i].y), 0.f))) * 0.25f;
-          } else {
-            const float2 x0 = *reinterpret_cast<const float2*>(xp + coff[i]);
-            a[i].x = fmaxf(fmaf(x0.x, s2[i].x, t2[i].x), 0.f);
-            a[i].y = fmaxf(fmaf(x0.y, s2[i].y, t2[i].y), 0.f);
-          }
-          if (!pv) a[i] = make_float2(0.f, 0.f);
-        }
-      }
-      float bz[3];
-#pragma unroll
-      for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        if (i < ngw) {
-#pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            acc[i][0][n] = mfma16(a[i].x, bz[n], acc[i][0][n]);
-            acc[i][1][n] = mfma16(a[i].y, bz[n], acc[i][1][n]);
-          }
-        }
-      }
-    }
-    stage_write(dz_l[(it + 1) & 1]);
+  // The chunk loop, specialised on the (wave-uniform) number of channel groups so that the operand
+  // loads of UQ pixel-quads are issued back to back with no control flow between them.
+  auto chunk_loop = [&](auto ngw_c) {
+    constexpr int NGW = decltype(ngw_c)::value;
+    constexpr int UQ = POOL ? 2 : 4;      // pixel quads per batch
+    constexpr int NS = POOL ? 4 : 1;      // input pixels per output pixel
+    stage_load(blockIdx.x);
+    stage_write(dz_l[0]);
     __syncthreads();
+    int it = 0;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
+      const float* dzb = dz_l[it & 1];
+      stage_load(chunk + gridDim.x);  // next chunk's loads fly during this chunk's MFMAs
+      if constexpr (NGW > 0) {
+        for (int q0 = 0; q0 < 16; q0 += UQ) {
+          float2 xr[UQ][NGW][NS];
+          bool pvs[UQ];
+#pragma unroll
+          for (int u = 0; u < UQ; ++u) {
+            const int p = chunk * 64 + 4 * (q0 + u) + kk;
+            pvs[u] = p < P;
+            const int pc = pvs[u] ? p : P - 1;
+            const float* xp;
+            if constexpr (POOL) {
+              const int b = pc / (Ho * Wo), rem = pc - b * (Ho * Wo);
+              const int oy = rem / Wo, ox = rem - oy * Wo;
+              xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
+            } else {
+              xp = X + (size_t)pc * ldx;
+            }
+#pragma unroll
+            for (int i = 0; i < NGW; ++i)
+#pragma unroll
+              for (int sub = 0; sub < NS; ++sub)
+                xr[u][i][sub] =
+                    *reinterpret_cast<const float2*>(xp + ((sub >> 1) * (size_t)Win + (sub & 1)) * ldx + coff[i]);
+          }
+#pragma unroll
+          for (int u = 0; u < UQ; ++u) {
+            const int pl = 4 * (q0 + u) + kk;
+            float bz[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
+#pragma unroll
+            for (int i = 0; i < NGW; ++i) {
+              float ax = 0.f, ay = 0.f;
+#pragma unroll
+              for (int sub = 0; sub < NS; ++sub) {
+                ax += fmaxf(fmaf(xr[u][i][sub].x, s2[i].x, t2[i].x), 0.f);
+                ay += fmaxf(fmaf(xr[u][i][sub].y, s2[i].y, t2[i].y), 0.f);
+              }
+              if constexpr (POOL) {
+                ax *= 0.25f;
+                ay *= 0.25f;
+              }
+              if (!pvs[u]) ax = ay = 0.f;
+#pragma unroll
+              for (int n = 0; n < 3; ++n) {
+                acc[i][0][n] = mfma16(ax, bz[n], acc[i][0][n]);
+                acc[i][1][n] = mfma16(ay, bz[n], acc[i][1][n]);
+              }
+            }
+          }
+        }
+      }
+      stage_write(dz_l[(it + 1) & 1]);
+      __syncthreads();
+    }
+  };
+  switch (ngw) {  // wave-uniform
+    case 0: chunk_loop(std::integral_constant<int, 0>{}); break;
+    case 1: chunk_loop(std::integral_constant<int, 1>{}); break;
+    case 2: chunk_loop(std::integral_constant<int, 2>{}); break;
+    default: chunk_loop(std::integral_constant<int, 3>{}); break;
   }
   float* out = partial + (size_t)blockIdx.x * Kp * 48;
 #pragma unroll
