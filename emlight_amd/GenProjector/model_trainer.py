@@ -1,0 +1,71 @@
+"""``Trainer`` of the projector (reference ``GenProjector/model_trainer.py``): one G step + one D step.
+
+The reference wraps the model in a single-process multi-thread ``DataParallelWithCallback``; here each GPU is
+its own process: G and D are wrapped in DistributedDataParallel (gradient all-reduce over RCCL/xGMI, G's
+473 MB in 25 MB buckets overlapped with backward) and SPADE's param-free BatchNorm becomes ``nn.SyncBatchNorm``
+(an all-reduce of 2C+1 floats per norm layer), which is what the vendored ``sync_batchnorm`` package did."""
+import torch
+import torch.distributed as dist
+
+from .pix2pix_model import Pix2PixModel
+
+
+class Trainer:
+    def __init__(self, opt, device="cuda", world=1):
+        self.opt = opt
+        self.model = Pix2PixModel(opt).to(device)
+        self.world = world
+        if world > 1:
+            if str(device).startswith("cuda"):
+                self.model.netG = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model.netG)
+            ids = [torch.device(device).index] if str(device).startswith("cuda") else None
+            self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
+            self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)
+            # the model calls self.netG / self.netD: route those through the DDP wrappers
+            object.__setattr__(self.model, "_fwdG", self._ddpG)
+            object.__setattr__(self.model, "_fwdD", self._ddpD)
+            self.model.generate_fake = lambda inp, crop: self._ddpG(inp, crop)
+            netD_plain = self.model.netD
+            self.model.__dict__["_netD_call"] = self._ddpD
+            self.model.discriminate = self._discriminate_ddp
+        self.optimizer_G, self.optimizer_D = self.model.create_optimizers(opt)
+        self.old_lr = opt.lr
+        self.g_losses, self.d_losses, self.generated = {}, {}, None
+
+    def _discriminate_ddp(self, inp, fake, real):
+        both = torch.cat([torch.cat([inp, fake], dim=1), torch.cat([inp, real], dim=1)], dim=0)
+        out = self._ddpD(both)
+        return ([[t[:t.size(0) // 2] for t in p] for p in out], [[t[t.size(0) // 2:] for t in p] for p in out])
+
+    def run_generator_one_step(self, data):
+        self.optimizer_G.zero_grad()
+        g_losses, generated = self.model(data, mode="generator")
+        sum(g_losses.values()).mean().backward()
+        self.optimizer_G.step()
+        self.g_losses, self.generated = g_losses, generated
+
+    def run_discriminator_one_step(self, data):
+        self.optimizer_D.zero_grad()
+        d_losses = self.model(data, mode="discriminator")
+        sum(d_losses.values()).mean().backward()
+        self.optimizer_D.step()
+        self.d_losses = d_losses
+
+    def step(self, data):
+        """One training iteration as ``GenProjector/train.py:33-37``."""
+        self.run_generator_one_step(data)
+        self.run_discriminator_one_step(data)
+
+    def get_latest_losses(self):
+        return {**self.g_losses, **self.d_losses}
+
+    def update_learning_rate(self, epoch, niter=50, niter_decay=0):
+        """Linear decay after ``niter`` epochs with TTUR (``model_trainer.py:68-88``)."""
+        new_lr = self.old_lr - self.opt.lr / niter_decay if (epoch > niter and niter_decay > 0) else self.old_lr
+        if new_lr != self.old_lr:
+            g, d = (new_lr, new_lr) if self.opt.no_TTUR else (new_lr / 2, new_lr * 2)
+            for pg in self.optimizer_G.param_groups:
+                pg["lr"] = g
+            for pg in self.optimizer_D.param_groups:
+                pg["lr"] = d
+            self.old_lr = new_lr

@@ -1,0 +1,283 @@
+"""SPADE generator, conv encoder, multiscale PatchGAN discriminator and GAN losses of the projector.
+
+Clean restatements of ``GenProjector/models/networks/{generator,architecture,normalization,discriminator,
+loss}.py`` with the same module names (hence the same ``state_dict`` keys: reference ``*_net_G.pth`` /
+``*_net_D.pth`` load) and forward signatures.  ``opt`` is any namespace with the reference's option names;
+``default_options()`` gives the reference defaults (``options/base_options.py``, ``train_options.py``).
+"""
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import spectral_norm
+
+from .spherenet import SphereConv2D
+
+
+def default_options(**kw):
+    opt = Namespace(ngf=64, ndf=64, crop_size=256, aspect_ratio=2.0, num_upsampling_layers="normal",
+                    norm_G="spectralspadesyncbatch3x3", norm_D="spectralinstance", norm_E="spectralinstance",
+                    label_nc=3, output_nc=3, semantic_nc=3, num_D=2, n_layers_D=4, netD_subarch="n_layer",
+                    no_ganFeat_loss=False, no_vgg_loss=True, gan_mode="hinge", lr=2e-4, beta1=0.0, beta2=0.9,
+                    no_TTUR=False, init_type="xavier", init_variance=0.02, isTrain=True)
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    return opt
+
+
+def init_weights(net, init_type="xavier", gain=0.02):
+    """``BaseNetwork.init_weights`` (``base_network.py:32-59``): xavier_normal(gain) on conv/linear weights."""
+    def f(m):
+        name = m.__class__.__name__
+        if name.find("BatchNorm2d") != -1:
+            if getattr(m, "weight", None) is not None:
+                nn.init.normal_(m.weight.data, 1.0, gain)
+            if getattr(m, "bias", None) is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+        elif hasattr(m, "weight") and (name.find("Conv") != -1 or name.find("Linear") != -1):
+            if init_type == "normal":
+                nn.init.normal_(m.weight.data, 0.0, gain)
+            elif init_type == "xavier":
+                nn.init.xavier_normal_(m.weight.data, gain=gain)
+            elif init_type == "kaiming":
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+            elif init_type == "orthogonal":
+                nn.init.orthogonal_(m.weight.data, gain=gain)
+            elif init_type != "none":
+                raise NotImplementedError(init_type)
+            if getattr(m, "bias", None) is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+    net.apply(f)
+    return net
+
+
+def nonspade_norm(norm_type):
+    """``get_nonspade_norm_layer`` (``normalization.py:20-62``) for 'spectral' + {none, instance, batch}."""
+    def wrap(layer):
+        sub = norm_type
+        if sub.startswith("spectral"):
+            layer = spectral_norm(layer)
+            sub = sub[len("spectral"):]
+        if sub in ("none", ""):
+            return layer
+        if getattr(layer, "bias", None) is not None:
+            delattr(layer, "bias")
+            layer.register_parameter("bias", None)
+        ch = getattr(layer, "out_channels", None) or layer.weight.size(0)
+        if sub == "instance":
+            norm = nn.InstanceNorm2d(ch, affine=False)
+        elif sub in ("batch", "sync_batch"):
+            norm = nn.BatchNorm2d(ch, affine=True)
+        else:
+            raise ValueError("normalization layer %s is not recognized" % sub)
+        return nn.Sequential(layer, norm)
+    return wrap
+
+
+class SPADE(nn.Module):
+    """``out = norm(x) * (1 + gamma(seg)) + beta(seg)`` (``normalization.py:68-115``).  The param-free norm is
+    a BatchNorm2d(affine=False); under DDP it is converted to ``nn.SyncBatchNorm`` (RCCL all-reduce of the
+    statistics) -- the job of the reference's vendored ``sync_batchnorm`` package."""
+
+    def __init__(self, config_text, norm_nc, label_nc):
+        super().__init__()
+        assert config_text.startswith("spade")
+        kind = config_text[len("spade"):-3]
+        if kind == "instance":
+            self.param_free_norm = nn.InstanceNorm2d(norm_nc, affine=False)
+        elif kind in ("syncbatch", "batch"):
+            self.param_free_norm = nn.BatchNorm2d(norm_nc, affine=False)
+        else:
+            raise ValueError("%s is not a recognized param-free norm type in SPADE" % kind)
+        nhidden = 128
+        self.mlp_shared = nn.Sequential(SphereConv2D(label_nc, nhidden), nn.ReLU())
+        self.mlp_gamma = SphereConv2D(nhidden, norm_nc)
+        self.mlp_beta = SphereConv2D(nhidden, norm_nc)
+
+    def forward(self, x, segmap):
+        normalized = self.param_free_norm(x)
+        segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
+        actv = self.mlp_shared(segmap)
+        return normalized * (1 + self.mlp_gamma(actv)) + self.mlp_beta(actv)
+
+
+class SPADEResnetBlock(nn.Module):
+    """``architecture.py:20-62``."""
+
+    def __init__(self, fin, fout, opt):
+        super().__init__()
+        self.learned_shortcut = fin != fout
+        fmiddle = min(fin, fout)
+        self.conv_0 = SphereConv2D(fin, fmiddle)
+        self.conv_1 = SphereConv2D(fmiddle, fout)
+        if self.learned_shortcut:
+            self.conv_s = SphereConv2D(fin, fout)
+        if "spectral" in opt.norm_G:
+            self.conv_0, self.conv_1 = spectral_norm(self.conv_0), spectral_norm(self.conv_1)
+            if self.learned_shortcut:
+                self.conv_s = spectral_norm(self.conv_s)
+        cfg = opt.norm_G.replace("spectral", "")
+        self.norm_0 = SPADE(cfg, fin, opt.semantic_nc)
+        self.norm_1 = SPADE(cfg, fmiddle, opt.semantic_nc)
+        if self.learned_shortcut:
+            self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
+
+    def forward(self, x, seg):
+        x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
+        dx = self.conv_0(F.leaky_relu(self.norm_0(x, seg), 2e-1))
+        dx = self.conv_1(F.leaky_relu(self.norm_1(dx, seg), 2e-1))
+        return x_s + dx
+
+
+class ConvEncoder(nn.Module):
+    """crop -> 128x128 bilinear -> 5 stride-2 convs (+InstanceNorm) -> fc -> 32*ngf vector (``generator.py:90-125``)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        ndf = opt.ngf
+        norm = nonspade_norm(opt.norm_E)
+        self.layer1 = norm(nn.Conv2d(3, ndf, 3, stride=2, padding=1))
+        self.layer2 = norm(nn.Conv2d(ndf, ndf * 2, 3, stride=2, padding=1))
+        self.layer3 = norm(nn.Conv2d(ndf * 2, ndf * 4, 3, stride=2, padding=1))
+        self.layer4 = norm(nn.Conv2d(ndf * 4, ndf * 8, 3, stride=2, padding=1))
+        self.layer5 = norm(nn.Conv2d(ndf * 8, ndf * 8, 3, stride=2, padding=1))
+        self.fc = nn.Linear(ndf * 8 * 4 * 4, 16 * ndf * 2 * 1)
+        self.actvn = nn.LeakyReLU(0.2, False)
+
+    def forward(self, x):
+        x = F.interpolate(x, size=(128, 128), mode="bilinear")
+        x = self.layer1(x)
+        for layer in (self.layer2, self.layer3, self.layer4, self.layer5):
+            x = layer(self.actvn(x))
+        return self.fc(self.actvn(x).view(x.size(0), -1))
+
+
+class SPADEGenerator(nn.Module):
+    """``forward(input, crop)``: the Gaussian map ``input`` (B,3,128,256) guides 7 SPADE blocks that upsample the
+    encoded ``crop`` from (sh, sw) = (4, 8) to 128x256; output ``(tanh + 1) * 25`` (``generator.py:17-88``)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nf = opt.ngf
+        self.sw, self.sh = self.compute_latent_vector_size(opt)
+        self.head_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_1 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.up_0 = SPADEResnetBlock(16 * nf, 8 * nf, opt)
+        self.up_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt)
+        self.up_2 = SPADEResnetBlock(4 * nf, 2 * nf, opt)
+        self.up_3 = SPADEResnetBlock(2 * nf, 1 * nf, opt)
+        self.up = nn.Upsample(scale_factor=2)
+        self.sphere_conv1 = SphereConv2D(nf, 3, stride=1)
+        self.netE = ConvEncoder(opt)
+
+    @staticmethod
+    def compute_latent_vector_size(opt):
+        n_up = {"normal": 5, "more": 6, "most": 7}[opt.num_upsampling_layers]
+        sw = opt.crop_size // (2 ** n_up)
+        return sw, round(sw / opt.aspect_ratio)
+
+    def forward(self, input, crop):
+        guide = input
+        x = self.netE(crop).view(-1, 16 * self.opt.ngf, 1, 2)
+        x = F.interpolate(x, size=(self.sh, self.sw))
+        x = self.head_0(x, guide)
+        x = self.up(x)
+        x = self.G_middle_0(x, guide)
+        x = self.G_middle_1(x, guide)
+        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+            x = blk(self.up(x), guide)
+        x = self.sphere_conv1(F.leaky_relu(x, 2e-1))
+        return (torch.tanh(x) + 1) * 25
+
+
+class NLayerDiscriminator(nn.Module):
+    """``discriminator.py:68-125``: SphereConv stages model0..model{n}, returns every stage's output."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nf = opt.ndf
+        norm = nonspade_norm(opt.norm_D)
+        seq = [[SphereConv2D(opt.label_nc + opt.output_nc, nf, stride=2), nn.LeakyReLU(0.2, False)]]
+        for n in range(1, opt.n_layers_D):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            stride = 1 if n == opt.n_layers_D - 1 else 2
+            seq += [[norm(SphereConv2D(nf_prev, nf, stride=stride)), nn.LeakyReLU(0.2, False)]]
+        seq += [[SphereConv2D(nf, 3, stride=1)]]
+        for n, s in enumerate(seq):
+            self.add_module("model" + str(n), nn.Sequential(*s))
+
+    def forward(self, input):
+        results = [input]
+        for sub in self.children():
+            results.append(sub(results[-1]))
+        return results[1:] if not self.opt.no_ganFeat_loss else results[-1]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """``discriminator.py:16-65``: ``num_D`` PatchGANs on an avg-pooled pyramid -> list[list[Tensor]]."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        for i in range(opt.num_D):
+            self.add_module("discriminator_%d" % i, NLayerDiscriminator(opt))
+
+    @staticmethod
+    def downsample(x):
+        return F.avg_pool2d(x, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, input):
+        result = []
+        for _, D in self.named_children():
+            out = D(input)
+            result.append(out if not self.opt.no_ganFeat_loss else [out])
+            input = self.downsample(input)
+        return result
+
+
+class GANLoss(nn.Module):
+    """``loss.py:16-99`` (hinge default; ls / original / w kept)."""
+
+    def __init__(self, gan_mode="hinge"):
+        super().__init__()
+        if gan_mode not in ("ls", "original", "w", "hinge"):
+            raise ValueError("Unexpected gan_mode {}".format(gan_mode))
+        self.gan_mode = gan_mode
+
+    def loss(self, x, target_is_real, for_discriminator=True):
+        if self.gan_mode == "original":
+            return F.binary_cross_entropy_with_logits(x, torch.full_like(x, 1.0 if target_is_real else 0.0))
+        if self.gan_mode == "ls":
+            return F.mse_loss(x, torch.full_like(x, 1.0 if target_is_real else 0.0))
+        if self.gan_mode == "hinge":
+            if for_discriminator:
+                v = (x - 1) if target_is_real else (-x - 1)
+                return -torch.mean(torch.min(v, torch.zeros_like(v)))
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            return -torch.mean(x)
+        return -x.mean() if target_is_real else x.mean()
+
+    def forward(self, x, target_is_real, for_discriminator=True):
+        if isinstance(x, list):
+            total = 0
+            for pred in x:
+                if isinstance(pred, list):
+                    pred = pred[-1]
+                lt = self.loss(pred, target_is_real, for_discriminator)
+                bs = 1 if lt.dim() == 0 else lt.size(0)
+                total = total + torch.mean(lt.view(bs, -1), dim=1)
+            return total / len(x)
+        return self.loss(x, target_is_real, for_discriminator)
+
+
+def define_G(opt):
+    return init_weights(SPADEGenerator(opt), opt.init_type, opt.init_variance)
+
+
+def define_D(opt):
+    return init_weights(MultiscaleDiscriminator(opt), opt.init_type, opt.init_variance)

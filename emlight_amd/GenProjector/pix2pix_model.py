@@ -1,0 +1,87 @@
+"""``Pix2PixModel`` -- generator / discriminator losses of the projector (reference ``models/pix2pix_model.py``).
+
+``forward(data, mode)`` with ``mode in {'generator', 'discriminator', 'inference'}`` and the data dict keys
+``input`` (Gaussian map, B,3,128,256), ``crop`` (B,3,128,128), ``warped`` (real HDR panorama), ``map`` (light mask).
+Loss terms as ``pix2pix_model.py:92-141``: hinge GAN, mask-weighted feature matching (x50 off the lights),
+cosine x5, VGG x5.  The VGG term needs torchvision's pretrained VGG19 weights, which cannot be obtained
+offline (parity unpinned); it is included only when ``opt.no_vgg_loss`` is False and a
+``vgg_features`` callable is supplied.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import networks
+
+
+class Pix2PixModel(torch.nn.Module):
+    def __init__(self, opt, vgg_features=None):
+        super().__init__()
+        self.opt = opt
+        self.netG = networks.define_G(opt)
+        self.netD = networks.define_D(opt) if opt.isTrain else None
+        self.vgg_features = vgg_features
+        if opt.isTrain:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode)
+            self.criterionFeat = torch.nn.L1Loss()
+            if not opt.no_vgg_loss and vgg_features is None:
+                raise RuntimeError("VGG perceptual loss requested but no pretrained VGG19 is available offline "
+                                   "(pass vgg_features=..., or set opt.no_vgg_loss=True)")
+
+    def forward(self, data, mode):
+        dev = next(self.netG.parameters()).device
+        inp, crop, real, mask = (data[k].to(dev) for k in ("input", "crop", "warped", "map"))
+        if mode == "generator":
+            return self.compute_generator_loss(inp, crop, real, mask)
+        if mode == "discriminator":
+            return self.compute_discriminator_loss(inp, crop, real)
+        if mode == "inference":
+            with torch.no_grad():
+                return self.generate_fake(inp, crop)
+        raise ValueError("|mode| is invalid")
+
+    def create_optimizers(self, opt):
+        G_lr, D_lr = (opt.lr, opt.lr) if opt.no_TTUR else (opt.lr / 2, opt.lr * 2)
+        return (torch.optim.Adam(self.netG.parameters(), lr=G_lr, betas=(opt.beta1, opt.beta2)),
+                torch.optim.Adam(self.netD.parameters(), lr=D_lr, betas=(opt.beta1, opt.beta2)))
+
+    def generate_fake(self, inp, crop):
+        return self.netG(inp, crop)
+
+    def discriminate(self, inp, fake, real):
+        both = torch.cat([torch.cat([inp, fake], dim=1), torch.cat([inp, real], dim=1)], dim=0)
+        out = self.netD(both)
+        fake_p = [[t[:t.size(0) // 2] for t in p] for p in out]
+        real_p = [[t[t.size(0) // 2:] for t in p] for p in out]
+        return fake_p, real_p
+
+    def compute_generator_loss(self, inp, crop, real, mask):
+        losses = {}
+        fake = self.generate_fake(inp, crop)
+        pred_fake, pred_real = self.discriminate(inp, fake, real)
+        losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False)
+        if not self.opt.no_ganFeat_loss:
+            num_D = len(pred_fake)
+            feat = fake.new_zeros(1)
+            for i in range(num_D):
+                for j in range(len(pred_fake[i]) - 1):
+                    h, w = pred_fake[i][j].shape[2:]
+                    mask = F.interpolate(mask, size=(h, w))  # the reference re-interpolates the running mask
+                    wf = pred_fake[i][j] * mask + pred_fake[i][j] * (1 - mask) * 50
+                    wr = pred_real[i][j] * mask + pred_real[i][j] * (1 - mask) * 50
+                    feat = feat + self.criterionFeat(wf, wr.detach()) / num_D
+            losses["GAN_Feat"] = feat
+        if not self.opt.no_vgg_loss:
+            weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+            xf, yf = self.vgg_features(fake), self.vgg_features(real)
+            losses["VGG"] = sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(weights, xf, yf)) * 5
+        cos = torch.nn.CosineSimilarity(dim=1, eps=1e-20)
+        losses["COS"] = (1 - cos(fake, real)).mean() * 5
+        return losses, fake
+
+    def compute_discriminator_loss(self, inp, crop, real):
+        with torch.no_grad():
+            fake = self.generate_fake(inp, crop).detach()
+        fake.requires_grad_()
+        pred_fake, pred_real = self.discriminate(inp, fake, real)
+        return {"D_Fake": self.criterionGAN(pred_fake, False, for_discriminator=True),
+                "D_real": self.criterionGAN(pred_real, True, for_discriminator=True)}

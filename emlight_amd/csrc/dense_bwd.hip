@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
 // The MFMA computes D^T (rows = channels, cols = pixels) so a lane owns 4 CONSECUTIVE channels of
 // one pixel: X / G are touched with 16-B accesses.
 // Wd: weights in fragment order [Kp/16][Ko/16][4][16][4] = W[o=16jo+4kk+t][k=16nt+col].
-template <bool POOL, bool RES /* Ko == 48: dz fragments stay in registers across channel chunks */>
+template <bool POOL, bool RES /* Ko == 48: dz fragments stay in registers across channel chunks */, int NCH = 4>
 __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
     const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
     const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
@@ -568,15 +568,15 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
 #pragma unroll
       for (int jo = 0; jo < 3; ++jo) load_dz(jo, dzr[jo]);
     }
-    for (int nt0 = 0; nt0 < nnt; nt0 += 4) {
-      f32x4 acc[4][4];
+    for (int nt0 = 0; nt0 < nnt; nt0 += NCH) {
+      f32x4 acc[4][NCH];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NCH; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto mma = [&](int jo, const float4 (&dz)[4]) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NCH; ++n) {
           const int nt = min(nt0 + n, nnt - 1);
           const float4 w = *reinterpret_cast<const float4*>(Wd + ((((size_t)nt * njo + jo) * 4 + kk) * 16 + r) * 4);
 #pragma unroll
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
       }
       // epilogue: this lane owns channels k4..k4+3 (k4 = 16nt + 4kk) of pixel p0 + 16m + r
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NCH; ++n) {
         const int nt = nt0 + n;
         if (nt < nnt) {
           const int k4 = 16 * nt + 4 * kk;
@@ -931,14 +931,16 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
       (ldx & 3) || (ldg & 3) || Kp > ldx || Kp > ldg)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: bad arguments");
   const size_t lds = (size_t)4 * Kp * 2 * sizeof(double);
-#define EML_LAUNCH_BWD_DATA(POOLV, RESV)                                                                              \
-  hipLaunchKernelGGL((conv1x1_bwd_data_kernel<POOLV, RESV>), dim3(grid), dim3(256), lds, (hipStream_t)stream, DY,    \
+#define EML_LAUNCH_BWD_DATA(POOLV, RESV, NCHV)                                                                        \
+  hipLaunchKernelGGL((conv1x1_bwd_data_kernel<POOLV, RESV, NCHV>), dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, \
                      ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, \
                      ldg, accumulate, partials)
+  // dense layers (Ko == 48): 2 channel tiles per chunk -> fewer accumulators, 3 waves/SIMD; measured
+  // 10-20 % faster than 4 (the kernel is HBM-bound: more waves = more bytes in flight)
   if (pool) {
-    if (Ko == 48) EML_LAUNCH_BWD_DATA(true, true); else EML_LAUNCH_BWD_DATA(true, false);
+    if (Ko == 48) EML_LAUNCH_BWD_DATA(true, true, 4); else EML_LAUNCH_BWD_DATA(true, false, 4);
   } else {
-    if (Ko == 48) EML_LAUNCH_BWD_DATA(false, true); else EML_LAUNCH_BWD_DATA(false, false);
+    if (Ko == 48) EML_LAUNCH_BWD_DATA(false, true, 2); else EML_LAUNCH_BWD_DATA(false, false, 4);
   }
 #undef EML_LAUNCH_BWD_DATA
   return eml::check_launch("eml_dense_conv1x1_bwd_data_f32");

@@ -24,12 +24,13 @@ from .sinkhorn import (sphere_points, anchor_cost_matrix, spherical_cost,
                        sinkhorn_loop, sinkhorn_cost, samples_loss,
                        samples_loss_grad_analytic)
 from .rasteriser import pano_grid, convert_to_panorama
-from .densenet import OracleDenseNet, deterministic_state_dict, regression_loss
+from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss,
+                       deterministic_projector_state_dict)
 
 __all__ = [
     "sphere_points", "anchor_cost_matrix", "spherical_cost", "epsilon_schedule",
     "max_diameter", "log_weights", "softmin", "sinkhorn_loop", "sinkhorn_cost",
     "samples_loss", "samples_loss_grad_analytic", "pano_grid",
     "convert_to_panorama", "OracleDenseNet", "deterministic_state_dict",
-    "regression_loss",
+    "regression_loss", "deterministic_projector_state_dict",
 ]

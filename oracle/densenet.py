@@ -155,3 +155,29 @@ def regression_loss(pred, gt, emd_fn, anchors):
         "ambient_loss": F.mse_loss(pred["ambient"], gt["ambient"]) * 1.0,
     }
     return sum(terms.values()), terms
+
+
+def deterministic_projector_state_dict(reference_state_dict, seed=0):
+    """Key-addressed deterministic weights for the GenProjector networks (spectral-norm aware):
+    conv / linear weights ~ N(0, 1/fan_in), power-iteration vectors unit-norm, small biases."""
+    out = {}
+    for key, ref in reference_state_dict.items():
+        rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+        shape = tuple(ref.shape)
+        if key.endswith("num_batches_tracked"):
+            out[key] = torch.zeros((), dtype=torch.long)
+            continue
+        if key.endswith("running_mean"):
+            v = rng.uniform(-0.1, 0.1, shape)
+        elif key.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith("weight_u") or key.endswith("weight_v"):
+            v = rng.standard_normal(shape)
+            v = v / np.linalg.norm(v)
+        elif key.endswith("weight") or key.endswith("weight_orig"):
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            v = rng.normal(0.0, math.sqrt(1.0 / fan_in), shape)
+        else:
+            v = rng.uniform(-0.05, 0.05, shape)
+        out[key] = torch.from_numpy(np.asarray(v, dtype=np.float32))
+    return out

@@ -321,12 +321,90 @@ def gen_densenet():
     np.savez_compressed(os.path.join(HERE, "densenet.npz"), **out)
 
 
+# --------------------------------------------------------------------------- GenProjector
+def projector_inputs(B, seed):
+    g = rng(seed, B)
+    inp = (g.random((B, 3, 128, 256)) ** 4 * 20).astype(np.float32)        # sparse-ish HDR Gaussian map
+    crop = g.random((B, 3, 128, 128), dtype=np.float32)
+    warped = (inp * g.uniform(0.5, 1.5, (B, 1, 128, 256))).astype(np.float32)
+    mask = (g.random((B, 1, 128, 256)) > 0.7).astype(np.float32)
+    return inp, crop, warped, mask
+
+
+def gen_projector():
+    """SPADE generator + multiscale PatchGAN of the REAL reference at ngf = ndf = 8 (the full-width G is 118 M
+    parameters and 23 s per CPU forward), deterministic weights, train-mode forward + loss terms.
+    VGG term excluded: pretrained VGG19 cannot be obtained offline (parity unpinned)."""
+    from argparse import Namespace
+    stub_io_modules()
+    gp = os.path.join(REF, "GenProjector")
+    sys.path.insert(0, gp)
+    for m in list(sys.modules):
+        if m == "util" or m.startswith("models"):
+            del sys.modules[m]
+    from models.networks.generator import SPADEGenerator
+    from models.networks.discriminator import MultiscaleDiscriminator
+    from models.networks.loss import GANLoss
+    from models.pix2pix_model import Pix2PixModel
+    from oracle.densenet import deterministic_projector_state_dict
+    opt = Namespace(ngf=8, ndf=8, crop_size=256, aspect_ratio=2.0, num_upsampling_layers="normal",
+                    norm_G="spectralspadesyncbatch3x3", norm_D="spectralinstance", norm_E="spectralinstance",
+                    label_nc=3, output_nc=3, semantic_nc=3, num_D=2, n_layers_D=4, netD_subarch="n_layer",
+                    no_ganFeat_loss=False, no_vgg_loss=True, gan_mode="hinge", gpu_ids=[], isTrain=True)
+    torch.manual_seed(0)
+    G, D = SPADEGenerator(opt), MultiscaleDiscriminator(opt)
+    G.load_state_dict(deterministic_projector_state_dict(G.state_dict(), seed=11))
+    D.load_state_dict(deterministic_projector_state_dict(D.state_dict(), seed=12))
+    G.train(), D.train()
+    inp, crop, warped, mask = (torch.from_numpy(a) for a in projector_inputs(2, 21))
+    model = Pix2PixModel.__new__(Pix2PixModel)
+    torch.nn.Module.__init__(model)
+    model.opt, model.netG, model.netD = opt, G, D
+    model.FloatTensor = torch.FloatTensor
+    model.criterionGAN = GANLoss("hinge", tensor=torch.FloatTensor, opt=opt)
+    model.criterionFeat = torch.nn.L1Loss()
+    model.criterionVGG = lambda a, b: torch.zeros(())
+    out = {}
+    g_losses, fake = model.compute_generator_loss(inp, crop, warped, mask)
+    total = sum(v.mean() for k, v in g_losses.items() if k != "VGG")
+    total.backward()
+    idx = np.linspace(0, fake.numel() - 1, 512).astype(np.int64)
+    out["fake_sample"], out["fake_idx"] = fake.detach().reshape(-1)[idx].numpy(), idx
+    out["fake_mean"] = np.float64(fake.detach().double().mean())
+    for k in ("GAN", "GAN_Feat", "COS"):
+        out["g_loss/" + k] = np.float64(g_losses[k].detach().mean())
+    for key in ("sphere_conv1.weight", "head_0.conv_0.weight_orig", "up_3.norm_0.mlp_gamma.weight", "netE.fc.weight",
+                "up_1.conv_s.weight_orig"):
+        gsm = dict(G.named_parameters())[key].grad
+        gi = np.linspace(0, gsm.numel() - 1, 32).astype(np.int64)
+        out["g_grad/" + key], out["g_grad_idx/" + key] = gsm.reshape(-1)[gi].numpy(), gi
+        out["g_grad_l2/" + key] = np.float64(gsm.double().norm())
+    # discriminator side, with fresh identical networks (spectral-norm power iterations are stateful)
+    G2, D2 = SPADEGenerator(opt), MultiscaleDiscriminator(opt)
+    G2.load_state_dict(deterministic_projector_state_dict(G2.state_dict(), seed=11))
+    D2.load_state_dict(deterministic_projector_state_dict(D2.state_dict(), seed=12))
+    model.netG, model.netD = G2.train(), D2.train()
+    d_losses = model.compute_discriminator_loss(inp, crop, warped)
+    for k in ("D_Fake", "D_real"):
+        out["d_loss/" + k] = np.float64(d_losses[k].detach().mean())
+    with torch.no_grad():
+        feats = D2(torch.cat([inp, warped], 1))
+    out["d_shapes"] = np.array([[list(t.shape) for t in p] for p in feats], dtype=np.int64)
+    out["d_last0"] = feats[0][-1].numpy()[:, :, ::2, ::4]
+    out["d_last1"] = feats[1][-1].numpy()
+    print("projector: fake mean %.4f, losses" % out["fake_mean"], {k: float(v.mean()) for k, v in g_losses.items()},
+          {k: float(v) for k, v in d_losses.items()})
+    np.savez_compressed(os.path.join(HERE, "projector.npz"), **out)
+
+
 if __name__ == "__main__":
     install_shims()
-    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet"]
+    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector"]
     if "sinkhorn" in which:
         gen_sinkhorn()
     if "rasteriser" in which:
         gen_rasteriser()
     if "densenet" in which:
         gen_densenet()
+    if "projector" in which:
+        gen_projector()

@@ -1,0 +1,94 @@
+"""CPU: the GenProjector mirror (SPADE generator, multiscale PatchGAN, loss terms) against vectors produced
+by the REAL reference networks at ngf = ndf = 8 (tests/golden/make_golden.py::gen_projector).  These modules run
+on stock PyTorch ops on any device, so this pins SURVEY section 8 row a15 numerically; the VGG term is excluded
+(pretrained VGG19 unobtainable offline)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.conftest import Golden
+from tests.golden.make_golden import projector_inputs
+
+torch.set_num_threads(8)
+
+
+@pytest.fixture(scope="module")
+def g():
+    return Golden("projector")
+
+
+def _model(seedG=11, seedD=12):
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    opt = networks.default_options(ngf=8, ndf=8)
+    m = Pix2PixModel(opt)
+    m.netG.load_state_dict(oracle.deterministic_projector_state_dict(m.netG.state_dict(), seed=seedG))
+    m.netD.load_state_dict(oracle.deterministic_projector_state_dict(m.netD.state_dict(), seed=seedD))
+    return m.train()
+
+
+def test_sampling_grid_properties():
+    from emlight_amd.GenProjector.spherenet import sphere_sampling_grid
+    grid = sphere_sampling_grid(16, 32, 1)
+    assert grid.shape == (1, 48, 96, 2)
+    centre = grid[0, 1::3, 1::3]  # centre tap of every pixel is the pixel itself: v*2/size - 1
+    np.testing.assert_allclose(centre[..., 0].numpy(), np.tile(np.arange(32) * 2 / 32 - 1, (16, 1)), atol=1e-6)
+    np.testing.assert_allclose(centre[..., 1].numpy(), np.tile((np.arange(16) * 2 / 16 - 1)[:, None], (1, 32)), atol=1e-6)
+    assert sphere_sampling_grid(16, 32, 2).shape == (1, 24, 48, 2)
+
+
+def test_generator_step_matches_reference(g):
+    m = _model()
+    inp, crop, warped, mask = (torch.from_numpy(a) for a in projector_inputs(2, 21))
+    losses, fake = m({"input": inp, "crop": crop, "warped": warped, "map": mask}, "generator")
+    assert fake.shape == (2, 3, 128, 256) and float(fake.min()) >= 0 and float(fake.max()) <= 50
+    np.testing.assert_allclose(fake.detach().reshape(-1)[torch.from_numpy(g["fake_idx"])].numpy(), g["fake_sample"],
+                               rtol=1e-4, atol=2e-4)
+    assert abs(float(fake.detach().double().mean()) - float(g["fake_mean"])) < 1e-4
+    for k in ("GAN", "GAN_Feat", "COS"):
+        np.testing.assert_allclose(float(losses[k].detach().mean()), float(g["g_loss/" + k]), rtol=2e-4, atol=1e-5)
+    sum(v.mean() for v in losses.values()).backward()
+    named = dict(m.netG.named_parameters())
+    for key in [k[len("g_grad/"):] for k in g.z.files if k.startswith("g_grad/")]:
+        got = named[key].grad.reshape(-1)[torch.from_numpy(g["g_grad_idx/" + key])].numpy()
+        l2 = float(g["g_grad_l2/" + key])
+        np.testing.assert_allclose(got, g["g_grad/" + key], rtol=2e-3, atol=2e-4 * l2 / np.sqrt(named[key].numel()) + 1e-8)
+
+
+def test_discriminator_step_matches_reference(g):
+    m = _model()
+    inp, crop, warped, mask = (torch.from_numpy(a) for a in projector_inputs(2, 21))
+    d = m({"input": inp, "crop": crop, "warped": warped, "map": mask}, "discriminator")
+    for k in ("D_Fake", "D_real"):
+        np.testing.assert_allclose(float(d[k].detach()), float(g["d_loss/" + k]), rtol=2e-4, atol=1e-5)
+    with torch.no_grad():
+        feats = m.netD(torch.cat([inp, warped], 1))
+    shapes = np.array([[list(t.shape) for t in p] for p in feats], dtype=np.int64)
+    np.testing.assert_array_equal(shapes, g["d_shapes"])
+    np.testing.assert_allclose(feats[0][-1].numpy()[:, :, ::2, ::4], g["d_last0"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(feats[1][-1].numpy(), g["d_last1"], rtol=1e-4, atol=1e-4)
+
+
+def test_trainer_runs_one_iteration_and_reference_keys():
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    opt = networks.default_options(ngf=4, ndf=4)
+    tr = Trainer(opt, device="cpu")
+    keys = set(tr.model.netG.state_dict())
+    for k in ("head_0.conv_0.weight_orig", "head_0.conv_0.weight_u", "head_0.norm_0.mlp_shared.0.weight",
+              "head_0.norm_0.param_free_norm.running_mean", "up_0.conv_s.weight_orig", "netE.layer1.0.weight_orig",
+              "netE.fc.bias", "sphere_conv1.weight", "G_middle_1.norm_1.mlp_beta.bias"):
+        assert k in keys, k
+    dk = set(tr.model.netD.state_dict())
+    assert "discriminator_0.model0.0.weight" in dk and "discriminator_1.model3.0.0.weight_orig" in dk
+    gsrc = torch.Generator().manual_seed(0)
+    data = {"input": torch.rand(1, 3, 128, 256, generator=gsrc) * 5, "crop": torch.rand(1, 3, 128, 128, generator=gsrc),
+            "warped": torch.rand(1, 3, 128, 256, generator=gsrc) * 5,
+            "map": (torch.rand(1, 1, 128, 256, generator=gsrc) > 0.5).float()}
+    w0 = tr.model.netG.sphere_conv1.weight.detach().clone()
+    tr.step(data)
+    losses = tr.get_latest_losses()
+    assert set(losses) == {"GAN", "GAN_Feat", "COS", "D_Fake", "D_real"}
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    assert not torch.equal(w0, tr.model.netG.sphere_conv1.weight.detach())
