@@ -95,6 +95,23 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
     return rows
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes
+    of this same command; FETCH_SIZE under-reports wide reads 2x on gfx950), or None if not collected."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    name = kernel_label.split(" ")[0]
+    if not os.path.exists(path):
+        return None
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith(name):
+            d = int(r["dispatches"])
+            tot += d * (2.0 * float(r["mean_FETCH_SIZE"]) + float(r["mean_WRITE_SIZE"])) * 1024.0
+            n += d
+    return round(tot / n) if n else None
+
+
 def time_sinkhorn(B, anchors, blur, dev, reps=20):
     """BASELINE's second metric: Sinkhorn ms per eps-step (1 iter = 4 softmin sweeps + averaging,
     sinkhorn_divergence.py:87-97) of the HIP loss at the bench batch, by HIP events."""
@@ -227,6 +244,9 @@ def main():
 
     dt = run_timed(lambda: tr.step(batch), args.steps, args.warmup, world, dev)
 
+    # live per-kernel timing: EVERY rank runs the instrumented steps (they contain DDP's all-reduce)
+    fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) if args.engine == "hip" else None
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -243,20 +263,22 @@ def main():
             "step_frac_of_f32_mfma_peak": round(STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
             if crop_hw == (240, 320) else None,
         }
-        if args.engine == "hip":
-            fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw)
-            dom = fams[0]  # the dominant kernel family of the step, by measured GPU time
+        if fams:
+            dom = fams[0]  # the dominant kernel family of the step, by measured GPU time (rank 0)
             out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                               "traffic": pmc_traffic(dom["kernel"]),
                                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
                                "note": "achieved = algorithmic conv FLOPs of the family's launches / their summed "
-                                       "HIP-event duration; f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak"}
+                                       "HIP-event duration; f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; traffic = HBM "
+                                       "bytes per launch from the committed rocprofv3 --pmc passes (profiles/), "
+                                       "(2*FETCH_SIZE + WRITE_SIZE) KiB"}
             out["kernel_families"] = fams
             out["sinkhorn"] = time_sinkhorn(args.batch, args.anchors, args.blur, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -32,8 +32,11 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        local %= torch.cuda.device_count()  # more ranks than GPUs (tests on a 1-GPU box): share devices
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # 'nccl' is RCCL on ROCm; EML_DIST_BACKEND=gloo lets two ranks share one GPU in tests
+        backend = os.environ.get("EML_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -58,7 +61,7 @@ class RegressionTrainer:
             # 37.3 MB of f32 gradients cross xGMI, in one bucket overlapped with backward.
             self.ddp = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
-                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas)
 
     def step(self, batch):
