@@ -20,9 +20,10 @@ class _BwdBuffers:
         self.G = [torch.zeros(blk["P"], blk["ld"], **f32) for blk in ws.blocks]
         self.GF = torch.zeros(ws.F.shape[0], ws.F.shape[1], **f32)
         maxP = ws.blocks[0]["P"]
-        self.DZ = torch.empty(maxP, 48, **f32)
-        self.Wd = torch.empty(352 * 176, **f32)
-        self.coef = torch.zeros(6, 384, **f32)  # cA,cB,cC for the "dz" side and for the "dx" side
+        self.DZ = torch.empty(2, maxP, 48, **f32)   # one per layer of a pair
+        self.Wd = torch.empty(2, 352 * 176, **f32)
+        self.coef = torch.zeros(8, 384, **f32)  # two (cA,cB,cC) sets for dz, then sB, sC
+        self.part2 = torch.zeros(2, enc.grid_max * 352 * 2, dtype=torch.float64, device=dev)
         g = enc.grid_max
         self.partW = torch.empty(max(g * 2 * 352 * 48 // 2, g * 27 * 256, g * 4 * 1024), **f32)
 
@@ -45,15 +46,23 @@ def run_backward(enc, ws, x, gpooled):
     params = enc.param_list()
     grads = {id(q): torch.empty_like(q) for q in params}
     gr = lambda q: p(grads[id(q)])
-    cA, cB, cC, sB, sC = (bw.coef[i] for i in range(5))
+    import ctypes
+    coefs = [tuple(bw.coef[3 * k + i] for i in range(3)) for k in range(2)]
+    cA, cB, cC = coefs[0]
+    sB, sC = bw.coef[6], bw.coef[7]
 
-    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=True, s_acc=None):
-        """dgamma/dbeta of `bn`; coef: write the dz affine (cA,cB,cC); s_acc: fold (cB,cC) into sB/sC."""
+    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=0, s_acc=None, src=None, c_lo=0, c_hi=None):
+        """dgamma/dbeta of `bn` for channels [c_lo, c_hi); coef: write the dz affine into coefficient set
+        `coef` (None: skip); s_acc: fold (cB,cC) into sB/sC (True: add, False: overwrite)."""
+        a, b, c = coefs[coef] if coef is not None else (None, None, None)
         _lib.check(L.eml_dense_bn_bwd_finalize_f32(
-            p(part), R, pstride, float(count), p(bn.weight), p(mean), p(istd), C, Cpad, 1, gr(bn.weight), gr(bn.bias),
-            p(cA) if coef else None, p(cB) if coef else None, p(cC) if coef else None,
-            p(sB) if s_acc is not None else None, p(sC) if s_acc is not None else None, int(bool(s_acc)), st),
-            "eml_dense_bn_bwd_finalize_f32")
+            p(part if src is None else src), R, pstride, float(count), p(bn.weight), p(mean), p(istd), C, Cpad, 1,
+            gr(bn.weight), gr(bn.bias), p(a), p(b), p(c),
+            p(sB) if s_acc is not None else None, p(sC) if s_acc is not None else None, int(bool(s_acc)),
+            c_lo, Cpad if c_hi is None else c_hi, st), "eml_dense_bn_bwd_finalize_f32")
+
+    def parr(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
     def materialize(Gbuf, blk, c0, n):
         _lib.check(L.eml_dense_grad_materialize_f32(p(Gbuf), blk["ld"], p(blk["X"]), blk["ld"], p(sB), p(sC), c0, n,
@@ -77,7 +86,7 @@ def run_backward(enc, ws, x, gpooled):
         # ---- last_norm backward (affine folded into the transition kernels' dz operand)
         _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(tr["T"]), Ko, None, 0, 0, cout, Pn, p(tr["tmean"]),
                                                 p(tr["tistd"]), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
-        finalize(Gb, 2 * cout, Pn, LN, tr["tmean"], tr["tistd"], cout, Ko)
+        finalize(Gb, 2 * cout, Pn, LN, tr["tmean"], tr["tistd"], cout, Ko, coef=0)
         # ---- transition conv (pool folded): weight grad, data grad, BN backward -> G (write)
         _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
             p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, ctot, p(tr["scale"]), p(tr["shift"]), p(dY), ld_dy, p(tr["T"]), Ko,
@@ -88,31 +97,65 @@ def run_backward(enc, ws, x, gpooled):
             p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.Wd), p(blk["X"]), ld, p(tr["scale"]),
             p(tr["shift"]), p(blk["mean"]), p(blk["istd"]), Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, st),
             "eml_dense_conv1x1_bwd_data_f32")
-        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=False, s_acc=False)
-        # ---- dense layers, last to first
-        for l in reversed(range(len(blk["layers"]))):
+        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False)
+        # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
+        #      "dense layers: 1 or 2 layers per pass")
+        def conv2_backward(l, slot):
+            """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad."""
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
-            cin, kp = lay["Cin"], lay["Kp"]
-            z = blk["Z"][l]
+            cin, kp, z, dz = lay["Cin"], lay["Kp"], blk["Z"][l], bw.DZ[slot]
             materialize(Gbuf, blk, cin, 12)  # gradient of this layer's 12 output channels is complete
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gbuf), ld, cin, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
-                                                        p(lay["zistd"]), p(bw.DZ), B, Hb, Wb, p(part), G, st),
+                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G, st),
                        "eml_dense_conv3x3_bwd_data_f32")
             _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gbuf), ld, cin, p(z), p(lay["scale2"]), p(lay["shift2"]),
                                                           B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G, st),
                        "eml_dense_conv3x3_bwd_weight_f32")
-            finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48)
+            finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
+            a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
-                p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(bw.DZ), 48, p(z), 48,
-                p(cA), p(cB), p(cC), 48, p(bw.partW), gr(Lm.conv1.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
-            _lib.check(L.eml_dense_permute_w1_bwd_f32(p(Lm.conv1.weight), 48, cin, kp, 48, p(bw.Wd), st),
+                p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
+                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
+            _lib.check(L.eml_dense_permute_w1_bwd_f32(p(Lm.conv1.weight), 48, cin, kp, 48, p(bw.Wd[slot]), st),
                        "eml_dense_permute_w1_bwd_f32")
-            _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
-                p(bw.DZ), 48, p(z), 48, p(cA), p(cB), p(cC), 48, p(bw.Wd), p(blk["X"]), ld, p(lay["scale1"]),
-                p(lay["shift1"]), p(blk["mean"]), p(blk["istd"]), P, Hb, Wb, 0, kp, p(Gbuf), ld, 1, p(part), G, st),
-                "eml_dense_conv1x1_bwd_data_f32")
-            finalize(G, 2 * kp, P, Lm.norm1, blk["mean"], blk["istd"], cin, kp, coef=False, s_acc=True)
+            return Lm
+
+        def dgrad(layers, slots, k_lo, k_hi):
+            """G[:, k_lo:k_hi] += sum over `layers` of scale1*dam; BN1 partial sums -> bw.part2[slot]."""
+            lays = [blk["layers"][l] for l in layers]
+            _lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
+                len(layers), parr([bw.DZ[s_] for s_ in slots]), parr([blk["Z"][l] for l in layers]),
+                parr([coefs[s_][0] for s_ in slots]), parr([coefs[s_][1] for s_ in slots]),
+                parr([coefs[s_][2] for s_ in slots]), parr([bw.Wd[s_] for s_ in slots]),
+                parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
+                parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
+                p(blk["X"]), ld, p(blk["mean"]), p(blk["istd"]), P, k_lo, k_hi, p(Gbuf), ld, G, st),
+                "eml_dense_conv1x1_bwd_data_multi_f32")
+
+        def bn1_finalize(l, Lm, slot, c_lo, c_hi):
+            lay = blk["layers"][l]
+            finalize(G, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,
+                     s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi)
+
+        l = len(blk["layers"]) - 1
+        while l >= 0:
+            if l >= 1:
+                la, lb = l, l - 1
+                cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
+                Lma = conv2_backward(la, 0)
+                dgrad([la], [0], cin_b, cin_a)                 # narrow pass: layer lb's output channels only
+                bn1_finalize(la, Lma, 0, cin_b, cin_a)
+                Lmb = conv2_backward(lb, 1)
+                dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once
+                bn1_finalize(la, Lma, 0, 0, cin_b)
+                bn1_finalize(lb, Lmb, 1, 0, blk["layers"][lb]["Kp"])
+                l -= 2
+            else:
+                Lm0 = conv2_backward(l, 0)
+                dgrad([l], [0], 0, blk["layers"][l]["Cin"])
+                bn1_finalize(l, Lm0, 0, 0, blk["layers"][l]["Kp"])
+                l -= 1
         c0b = blk["C0"]
         materialize(Gbuf, blk, 0, c0b)  # block input channels: every layer has contributed
         dY, ld_dy = Gbuf, ld
@@ -121,7 +164,7 @@ def run_backward(enc, ws, x, gpooled):
     c0 = enc.c_init
     _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(ws.Y0), c0, p(b0["X"]), b0["ld"], 1, c0, b0["P"],
                                             p(ws.mean0), p(ws.istd0), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
-    finalize(Gb, 2 * c0, b0["P"], f.norm0, ws.mean0, ws.istd0, c0, _r16(c0))
+    finalize(Gb, 2 * c0, b0["P"], f.norm0, ws.mean0, ws.istd0, c0, _r16(c0), coef=0)
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")

@@ -48,7 +48,8 @@ SIGNATURES = {
     "eml_dense_conv3x3_bwd_weight_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _int, _int, _int, _f32p,
                                                 _f32p, _int, _stream]),
     "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,
-                                             _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _stream]),
+                                             _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
+                                             _stream]),
     "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
                                                 _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
                                                 _f32p, _int, _stream]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
                                               _int, _f32p, _int, _int, _f32p, _int, _stream]),
+    "eml_dense_conv1x1_bwd_data_multi_f32": (_int, [_int] + [ctypes.c_void_p] * 10 + [_f32p, _int, _f32p, _f32p,
+                                                    ctypes.c_long, _int, _int, _f32p, _int, _int, _stream]),
     "eml_dense_grad_materialize_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _int, _int, ctypes.c_long,
                                               _stream]),
     "eml_dense_bn_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _int, _int, ctypes.c_long, _f32p,

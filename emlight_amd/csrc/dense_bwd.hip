@@ -246,11 +246,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const double* __restrict__ partials, int R, int pstride, double count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ istd, int C, int Cpad, int training,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
-    float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate) {
-  // one wavefront per channel; lanes stride over the R partial rows
+    float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate, int c_lo, int c_hi) {
+  // one wavefront per channel; lanes stride over the R partial rows; only channels [c_lo, c_hi) are touched
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 4 + wave;
-  if (c >= Cpad) return;
+  const int c = c_lo + blockIdx.x * 4 + wave;
+  if (c >= Cpad || c >= c_hi) return;
   float a = 0.f, b = 0.f, d = 0.f;
   if (c < C) {
     double S1 = 0.0, S2 = 0.0;
@@ -663,6 +663,192 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
         (sacc[e] + sacc[(size_t)Kp * 2 + e]) + (sacc[(size_t)2 * Kp * 2 + e] + sacc[(size_t)3 * Kp * 2 + e]);
 }
 
+// ------------------------------------------------------------------------------- dense layers: 1 or 2 layers per pass
+// The dense-layer backward is HBM-bound on the O(L^2) traffic of X[:, :Cin] and G[:, :Cin].  Two
+// consecutive layers (l, l-1) touch the same channels [0, Cin_{l-1}), so their dgrad is done in ONE
+// pass that reads X once and read-modify-writes G once:  G += scale1_l*dam_l + scale1_{l-1}*dam_{l-1}.
+// Layer l-1's dz needs the finished gradient of its 12 output channels, which needs layer l's
+// contribution to exactly those channels first: that is a NARROW pass of this same kernel (NL = 1,
+// channel range [Cin_{l-1}, Cin_l)).  Channels outside [k_lo, k_hi) are computed (whole 16-channel
+// MFMA tiles) but contribute 0 to G and to the statistics.
+struct BwdLayer {
+  const float* DZ;
+  const float* Zr;
+  const float* cA;
+  const float* cB;
+  const float* cC;      // dz = cA*DZ + cB*Zr + cC  (48 channels)
+  const float* Wd;      // [Kp/16][3][4][16][4]
+  const float* scale1;
+  const float* shift1;  // BN1 affine of this layer (Kp, zero-padded)
+  double* partials;     // [grid][Kp][2]
+  int Kp;
+};
+
+template <int NL, int MT /* 16-pixel tiles per wave */>
+__global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer L0, BwdLayer L1,
+                                                                        const float* __restrict__ X, int ldx,
+                                                                        const float* __restrict__ mean,
+                                                                        const float* __restrict__ istd, int P,
+                                                                        int k_lo, int k_hi, float* __restrict__ Gd,
+                                                                        int ldg, int KpMax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* sacc = reinterpret_cast<double*>(smem);  // [NL][4 waves][KpMax][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < NL * 4 * KpMax * 2; e += 256) sacc[e] = 0.0;
+  __syncthreads();
+  const BwdLayer Ls[2] = {L0, L1};
+  constexpr int TP = 64 * MT;  // pixels per workgroup tile
+  const int ntiles = (P + TP - 1) / TP;
+  const int nt_lo = k_lo >> 4, nt_hi = (k_hi + 15) >> 4;
+  constexpr int NCH = 2;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = tile * TP + wave * 16 * MT;
+    long prow[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      pv[m] = p0 + 16 * m + r < P;
+      prow[m] = min(p0 + 16 * m + r, P - 1);
+    }
+    // dz fragments of every layer stay in registers for the whole tile
+    float4 dz[NL][3][MT];
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+#pragma unroll
+      for (int jo = 0; jo < 3; ++jo) {
+        const int ch = 16 * jo + 4 * kk;
+        const float4 a4 = *reinterpret_cast<const float4*>(Ls[j].cA + ch);
+        const float4 b4 = *reinterpret_cast<const float4*>(Ls[j].cB + ch);
+        const float4 c4 = *reinterpret_cast<const float4*>(Ls[j].cC + ch);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4 dy = *reinterpret_cast<const float4*>(Ls[j].DZ + prow[m] * 48 + ch);
+          const float4 zr = *reinterpret_cast<const float4*>(Ls[j].Zr + prow[m] * 48 + ch);
+          dz[j][jo][m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
+          dz[j][jo][m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
+          dz[j][jo][m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
+          dz[j][jo][m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
+        }
+      }
+    for (int nt0 = nt_lo; nt0 < nt_hi; nt0 += NCH) {
+      float4 gs[MT][NCH], xv[MT][NCH];
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        const int k4 = 16 * min(nt0 + n, nt_hi - 1) + 4 * kk;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          gs[m][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+          xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int nnt = Ls[j].Kp >> 4;
+        if (nt0 >= nnt) continue;  // this layer has no channels here (block-uniform)
+        f32x4 acc[MT][NCH];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NCH; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jo = 0; jo < 3; ++jo)
+#pragma unroll
+          for (int n = 0; n < NCH; ++n) {
+            const int nt = min(nt0 + n, nnt - 1);
+            const float4 w = *reinterpret_cast<const float4*>(Ls[j].Wd + ((((size_t)nt * 3 + jo) * 4 + kk) * 16 + r) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][n] = mfma16(w.x, dz[j][jo][m].x, acc[m][n]);
+              acc[m][n] = mfma16(w.y, dz[j][jo][m].y, acc[m][n]);
+              acc[m][n] = mfma16(w.z, dz[j][jo][m].z, acc[m][n]);
+              acc[m][n] = mfma16(w.w, dz[j][jo][m].w, acc[m][n]);
+            }
+          }
+        double* my = sacc + ((size_t)(j * 4 + wave) * KpMax) * 2;
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+          const int nt = nt0 + n;
+          if (nt < nnt && nt < nt_hi) {
+            const int k4 = 16 * nt + 4 * kk;
+            const float4 sk = *reinterpret_cast<const float4*>(Ls[j].scale1 + k4);
+            const float4 tk = *reinterpret_cast<const float4*>(Ls[j].shift1 + k4);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + k4);
+            const float4 is = *reinterpret_cast<const float4*>(istd + k4);
+            const bool in0 = k4 + 0 >= k_lo && k4 + 0 < k_hi, in1 = k4 + 1 >= k_lo && k4 + 1 < k_hi;
+            const bool in2 = k4 + 2 >= k_lo && k4 + 2 < k_hi, in3 = k4 + 3 >= k_lo && k4 + 3 < k_hi;
+            float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              if (pv[m]) {
+                const float4 x = xv[m][n];
+                const float d0 = (in0 && fmaf(x.x, sk.x, tk.x) > 0.f) ? acc[m][n][0] : 0.f;
+                const float d1 = (in1 && fmaf(x.y, sk.y, tk.y) > 0.f) ? acc[m][n][1] : 0.f;
+                const float d2 = (in2 && fmaf(x.z, sk.z, tk.z) > 0.f) ? acc[m][n][2] : 0.f;
+                const float d3 = (in3 && fmaf(x.w, sk.w, tk.w) > 0.f) ? acc[m][n][3] : 0.f;
+                gs[m][n].x = fmaf(sk.x, d0, gs[m][n].x);
+                gs[m][n].y = fmaf(sk.y, d1, gs[m][n].y);
+                gs[m][n].z = fmaf(sk.z, d2, gs[m][n].z);
+                gs[m][n].w = fmaf(sk.w, d3, gs[m][n].w);
+                l1[0] += d0;
+                l1[1] += d1;
+                l1[2] += d2;
+                l1[3] += d3;
+                l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
+                l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
+                l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
+                l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
+              }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+              for (int o = 1; o < 16; o <<= 1) {
+                l1[g] += __shfl_xor(l1[g], o, 64);
+                l2[g] += __shfl_xor(l2[g], o, 64);
+              }
+              if (r == 0) {
+                my[2 * (k4 + g)] += (double)l1[g];
+                my[2 * (k4 + g) + 1] += (double)l2[g];
+              }
+            }
+          }
+        }
+      }
+      // one read-modify-write of G for all layers of the pass
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        const int nt = nt0 + n;
+        if (nt < nt_hi) {
+          const int k4 = 16 * nt + 4 * kk;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            if (pv[m]) {
+              float4* gp = reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4);
+              float4 g = *gp;
+              g.x += gs[m][n].x;
+              g.y += gs[m][n].y;
+              g.z += gs[m][n].z;
+              g.w += gs[m][n].w;
+              *gp = g;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int Kp = Ls[j].Kp;
+    const double* base = sacc + (size_t)j * 4 * KpMax * 2;
+    for (int e = tid; e < Kp * 2; e += 256)
+      Ls[j].partials[(size_t)blockIdx.x * Kp * 2 + e] = (base[e] + base[(size_t)KpMax * 2 + e]) +
+                                                        (base[(size_t)2 * KpMax * 2 + e] + base[(size_t)3 * KpMax * 2 + e]);
+  }
+}
+
 // Wd[nt][jo][kk][col][t] = W[o = 16jo+4kk+t][k = 16nt+col]  (W is [Cout][Cin]); zero outside.
 __global__ void permute_w1_bwd_kernel(const float* __restrict__ W, int Cout, int Cin, int Kp, int Ko,
                                       float* __restrict__ Wd) {
@@ -868,14 +1054,15 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
 extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                              const float* gamma, const float* mean, const float* istd, int C, int Cpad,
                                              int training, float* dgamma, float* dbeta, float* cA, float* cB,
-                                             float* cC, float* sB, float* sC, int s_accumulate,
-                                             eml_stream_t stream) {
+                                             float* cC, float* sB, float* sC, int s_accumulate, int c_lo,
+                                             int c_hi, eml_stream_t stream) {
   if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || C < 1 || Cpad < C || R < 1 ||
-      (cA && (!cB || !cC)) || (sB && !sC))
+      (cA && (!cB || !cC)) || (sB && !sC) || c_lo < 0 || c_hi <= c_lo)
     return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cpad + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, R,
-                     pstride, count, gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC, sB, sC,
-                     s_accumulate);
+  if (c_hi > Cpad) c_hi = Cpad;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c_hi - c_lo + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials,
+                     R, pstride, count, gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC, sB, sC,
+                     s_accumulate, c_lo, c_hi);
   return eml::check_launch("eml_dense_bn_bwd_finalize_f32");
 }
 
@@ -944,6 +1131,39 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
   }
 #undef EML_LAUNCH_BWD_DATA
   return eml::check_launch("eml_dense_conv1x1_bwd_data_f32");
+}
+
+// Dense-layer data gradient for 1 or 2 consecutive layers in one pass over channels [k_lo, k_hi).
+// Arrays of length n_layers (1 or 2): DZ/Zr (P,48), cA/cB/cC (48), Wd, scale1/shift1 (Kp_j), partials
+// ([grid][Kp_j][2]), Kp.  G[p][k] += sum_j scale1_j[k]*dam_j[p][k] for k in range.
+extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
+                                                    const float* const* cA, const float* const* cB,
+                                                    const float* const* cC, const float* const* Wd,
+                                                    const float* const* scale1, const float* const* shift1,
+                                                    double* const* partials, const int* Kp, const float* X, int ldx,
+                                                    const float* mean, const float* istd, long P, int k_lo, int k_hi,
+                                                    float* G, int ldg, int grid, eml_stream_t stream) {
+  if (n_layers < 1 || n_layers > 2 || !DZ || !Zr || !cA || !cB || !cC || !Wd || !scale1 || !shift1 || !partials ||
+      !Kp || !X || !mean || !istd || !G || P < 1 || grid < 1 || k_lo < 0 || k_hi <= k_lo || (ldx & 3) || (ldg & 3))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad arguments");
+  BwdLayer L[2];
+  int kmax = 0;
+  for (int j = 0; j < 2; ++j) {
+    const int s = j < n_layers ? j : 0;
+    L[j] = BwdLayer{DZ[s], Zr[s], cA[s], cB[s], cC[s], Wd[s], scale1[s], shift1[s], partials[s], Kp[s]};
+    if (!DZ[s] || !Zr[s] || !Wd[s] || !partials[s] || (Kp[s] & 15) || Kp[s] > ldx || Kp[s] > ldg)
+      return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad layer %d", s);
+    if (Kp[s] > kmax) kmax = Kp[s];
+  }
+  if (((k_hi + 15) & ~15) > kmax) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: range beyond Kp");
+  const size_t lds = (size_t)n_layers * 4 * kmax * 2 * sizeof(double);
+  if (n_layers == 1)
+    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<1, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, L[0],
+                       L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);
+  else  // two layers: 32 pixels per wave keeps both layers' dz fragments resident at 2 waves/SIMD
+    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<2, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, L[0],
+                       L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);
+  return eml::check_launch("eml_dense_conv1x1_bwd_data_multi_f32");
 }
 
 extern "C" int eml_dense_grad_materialize_f32(float* G, int ldg, const float* X, int ldx, const float* sB,

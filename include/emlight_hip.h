@@ -169,12 +169,12 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
  * and the affine dx = cA*dy + cB*x + cC (cA = gamma*istd, cB = -gamma*istd^2*S2/n,
  * cC = -gamma*istd*S1/n + gamma*istd^2*S2/n*mean), zero-padded to Cpad.  cA/cB/cC may be NULL.
  * sB/sC (may be NULL): running per-channel sums of (cB, cC) -- the deferred x-affine of a dense
- * block's gradient (s_accumulate = 0 overwrites, 1 adds). */
+ * block's gradient (s_accumulate = 0 overwrites, 1 adds).  Only channels [c_lo, c_hi) are processed. */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
                                   int Cpad, int training, float* dgamma, float* dbeta, float* cA,
                                   float* cB, float* cC, float* sB, float* sC, int s_accumulate,
-                                  eml_stream_t stream);
+                                  int c_lo, int c_hi, eml_stream_t stream);
 
 /* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).
@@ -198,6 +198,18 @@ int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, 
                                    const float* shift1, const float* mean, const float* istd, long P,
                                    int Hin, int Win, int pool, int Kp, float* G, int ldg,
                                    int accumulate, double* partials, int grid, eml_stream_t stream);
+
+/* The same data gradient for 1 or 2 CONSECUTIVE dense layers in one pass over the channel range
+ * [k_lo, k_hi): G[p][k] += sum_j scale1_j[k]*dam_j[p][k] -- X is read once and G read-modify-written once
+ * for both layers (the backward of a dense block is HBM-bound on exactly that traffic).  Per-layer
+ * arrays of length n_layers (1 or 2); DZ/Zr are (P,48); partials_j is [grid][Kp_j][2]. */
+int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
+                                         const float* const* cA, const float* const* cB,
+                                         const float* const* cC, const float* const* Wd,
+                                         const float* const* scale1, const float* const* shift1,
+                                         double* const* partials, const int* Kp, const float* X, int ldx,
+                                         const float* mean, const float* istd, long P, int k_lo,
+                                         int k_hi, float* G, int ldg, int grid, eml_stream_t stream);
 
 /* G[p][c] += sB[c]*X[p][c] + sC[c] for c in [c0, c0+n): applies the deferred BN1-backward affine once
  * the gradient of those channels is complete. */

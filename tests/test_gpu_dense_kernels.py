@@ -211,7 +211,7 @@ def test_bn_bwd_finalize(lib):
     cA, cB, cC = (torch.full((Cpad,), 3.0, device=DEV) for _ in range(3))
     sB, sC = torch.ones(Cpad, device=DEV), torch.ones(Cpad, device=DEV)
     lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg), p(db),
-                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, st), "finalize")
+                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, 0, Cpad, st), "finalize")
     S = part.view(R, C, 2).sum(0)
     S1, S2 = S[:, 0], S[:, 1]
     ga, is_, mu = gamma.double(), istd.double(), mean.double()
@@ -222,6 +222,14 @@ def test_bn_bwd_finalize(lib):
     close(cC[:C], -ga * is_ * S1 / n + ga * is_ * is_ * S2 / n * mu, what="cC", atol=1e-6)
     close(sB[:C], 1 + (-ga * is_ * is_ * S2 / n), what="sB accumulate")
     assert float(cA[C:].abs().max()) == 0.0 and float((sB[C:] - 1).abs().max()) == 0.0
+    # channel-range form: only [40, 52) is touched
+    cA2, sB2 = torch.full((Cpad,), 3.0, device=DEV), torch.ones(Cpad, device=DEV)
+    dg2 = torch.full((C,), 7.0, device=DEV)
+    lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg2), p(db),
+                                              p(cA2), p(cB), p(cC), p(sB2), p(sC), 1, 40, 52, st), "finalize range")
+    close(dg2[40:52], S2[40:52], what="dgamma range")
+    assert bool((dg2[:40] == 7.0).all()) and bool((dg2[52:] == 7.0).all())
+    assert bool((cA2[:40] == 3.0).all()) and bool((sB2[52:] == 1.0).all())
 
 
 def _dz(DY, Zr, cA, cB, cC, Cout):
@@ -322,3 +330,56 @@ def test_conv0_bwd_weight(lib):
     w = torch.zeros(24, 3, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
     (F.conv2d(x.double(), w, padding=1) * nchw(dY0, B, H, W)).sum().backward()
     close(dW0, w.grad, what="dW0", rtol=1e-4)
+
+
+@pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 20, 44), (330, 1, 12, 20), (162, 3, 6, 10)])
+def test_conv1x1_bwd_data_two_layers_per_pass(lib, Cin_a, B, H, W):
+    """Layers (a, b = a-1) of a dense block: the narrow pass of layer a over b's 12 output channels, then
+    the fused pass of both layers over [0, Cin_b) -- against the two single-layer results."""
+    import ctypes
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Cin_b = Cin_a - 12
+    Kpa, Kpb = r16(Cin_a), r16(Cin_b)
+    ld = Kpa + 16
+    P = B * H * W
+    X = rnd(P, ld)
+    mean, istd = rnd(ld, scale=0.1), torch.rand(ld, device=DEV) + 0.5
+
+    def layer(Cin, Kp):
+        s1, t1 = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+        s1[:Cin], t1[:Cin] = torch.rand(Cin, device=DEV) + 0.5, rnd(Cin, scale=0.3)
+        d = dict(DZ=rnd(P, 48), Zr=rnd(P, 48), cA=rnd(48), cB=rnd(48, scale=0.1), cC=rnd(48, scale=0.1), s1=s1, t1=t1,
+                 W=rnd(48, Cin, scale=0.15), Wd=torch.empty(Kp * 48, device=DEV),
+                 part=torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV), Kp=Kp, Cin=Cin)
+        lib.check(L.eml_dense_permute_w1_bwd_f32(p(d["W"]), 48, Cin, Kp, 48, p(d["Wd"]), st), "permute")
+        dz = d["cA"].double() * d["DZ"].double() + d["cB"].double() * d["Zr"].double() + d["cC"].double()
+        pre = X[:, :Cin].double() * s1[:Cin].double() + t1[:Cin].double()
+        d["dam"] = torch.where(pre > 0, dz @ d["W"].double(), torch.zeros(P, Cin, device=DEV, dtype=torch.float64))
+        return d
+    A, Bl = layer(Cin_a, Kpa), layer(Cin_b, Kpb)
+    xh = (X.double() - mean.double()) * istd.double()
+
+    def run(layers, k_lo, k_hi, Gd):
+        arr = lambda key: (ctypes.c_void_p * len(layers))(*[y[key].data_ptr() for y in layers])
+        lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
+            len(layers), arr("DZ"), arr("Zr"), arr("cA"), arr("cB"), arr("cC"), arr("Wd"), arr("s1"), arr("t1"),
+            arr("part"), (ctypes.c_int * len(layers))(*[y["Kp"] for y in layers]), p(X), ld, p(mean), p(istd), P, k_lo,
+            k_hi, p(Gd), ld, G, st), "multi")
+
+    G0 = rnd(P, ld)
+    Gd = G0.clone()
+    run([A], Cin_b, Cin_a, Gd)                    # narrow: only channels [Cin_b, Cin_a) of layer a
+    want = G0.double()
+    want[:, Cin_b:Cin_a] += A["s1"][Cin_b:Cin_a].double() * A["dam"][:, Cin_b:Cin_a]
+    close(Gd, want, what="narrow G", rtol=1e-4)
+    S1, S2 = fold_partials(A["part"], G, Kpa)
+    close(S1[Cin_b:Cin_a], A["dam"][:, Cin_b:Cin_a].sum(0), what="narrow S1", rtol=1e-5, atol=1e-4)
+    close(S2[Cin_b:Cin_a], (A["dam"] * xh[:, :Cin_a])[:, Cin_b:Cin_a].sum(0), what="narrow S2", rtol=1e-5, atol=1e-4)
+    assert float(S1[:Cin_b].abs().max()) == 0.0
+    run([A, Bl], 0, Cin_b, Gd)                    # fused: both layers over [0, Cin_b)
+    want[:, :Cin_b] += A["s1"][:Cin_b].double() * A["dam"][:, :Cin_b] + Bl["s1"][:Cin_b].double() * Bl["dam"]
+    close(Gd, want, what="fused G", rtol=1e-4)
+    for y, Kp in ((A, Kpa), (Bl, Kpb)):
+        S1, S2 = fold_partials(y["part"], G, Kp)
+        close(S1[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="fused S1", rtol=1e-5, atol=1e-4)
+        close(S2[:Cin_b], (y["dam"][:, :Cin_b] * xh[:, :Cin_b]).sum(0), what="fused S2", rtol=1e-5, atol=1e-4)

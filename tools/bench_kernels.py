@@ -15,7 +15,7 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 st = _lib.current_stream()
-G = 512
+G = int(os.environ.get("EML_G", "512"))
 for (Hb, Wb, Cin, ld) in [(240, 320, 48, 224), (240, 320, 120, 224), (240, 320, 204, 224), (120, 160, 204, 304), (60, 80, 246, 352)]:
     P = B * Hb * Wb
     Kp = (Cin + 15) // 16 * 16
