@@ -48,7 +48,9 @@ def conv_flops(B, crop_hw):
 FAMILIES = {
     "eml_dense_conv1x1_fwd_f32": ("conv1x1_fwd_kernel (BN1+ReLU fused into the MFMA operand load)", 0),
     "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS)", 0),
-    "eml_dense_conv1x1_bwd_data_f32": ("conv1x1_bwd_data_kernel (dgrad + ReLU mask + BN1-backward accumulate)", 0),
+    "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 1-2 dense layers per pass + ReLU "
+                                             "mask + BN1-backward accumulate)", 0),
+    "eml_dense_conv1x1_bwd_data_f32": ("conv1x1_bwd_data_kernel<POOL> (transition dgrad)", 2),
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
     "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),
     "eml_dense_conv3x3_bwd_weight_f32": ("conv3x3_bwd_weight_kernel", 1),
@@ -83,7 +85,14 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
     finally:
         for k in FAMILIES:
             setattr(L, k, orig[k])
-    flops = conv_flops(B, crop_hw)
+    f1, f3 = conv_flops(B, crop_hw)
+    h, w = crop_hw
+    ftr, c = 0.0, 24
+    for _ in range(3):  # transitions only (they are part of f1 as well)
+        ct = c + 192
+        ftr += 2.0 * ct * (ct // 2) * (h // 2) * (w // 2) * B
+        c, h, w = ct // 2, h // 2, w // 2
+    flops = (f1, f3, ftr)
     rows = []
     for k, (label, which) in FAMILIES.items():
         ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps

@@ -733,13 +733,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
         }
       }
     for (int nt0 = nt_lo; nt0 < nt_hi; nt0 += NCH) {
+      // X and the old G of this chunk are requested now and consumed after the MFMAs (latency hidden)
       float4 gs[MT][NCH], xv[MT][NCH];
 #pragma unroll
       for (int n = 0; n < NCH; ++n) {
         const int k4 = 16 * min(nt0 + n, nt_hi - 1) + 4 * kk;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          gs[m][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+          gs[m][n] = *reinterpret_cast<const float4*>(Gd + prow[m] * ldg + k4);
           xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4);
         }
       }
@@ -824,15 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
           const int k4 = 16 * nt + 4 * kk;
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            if (pv[m]) {
-              float4* gp = reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4);
-              float4 g = *gp;
-              g.x += gs[m][n].x;
-              g.y += gs[m][n].y;
-              g.z += gs[m][n].z;
-              g.w += gs[m][n].w;
-              *gp = g;
-            }
+            if (pv[m]) *reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4) = gs[m][n];  // gs = old G + updates
           }
         }
       }
