@@ -26,17 +26,14 @@ def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=T
     n_eps = torch.empty(1, dtype=torch.int32, device=dev)
     diam = torch.empty(1, dtype=torch.float32, device=dev)
     stream = _lib.current_stream()
-    _lib.check(L.eml_sinkhorn_schedule_f32(
-        _lib.ptr(x), _lib.ptr(y), B * N, float(blur), float(scaling), int(p),
-        float(diameter) if diameter is not None else -1.0,
-        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(diam), stream), "eml_sinkhorn_schedule_f32")
     loss = torch.empty(B, dtype=torch.float32, device=dev)
     gx = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gx else None
     gy = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gy else None
     work = torch.empty(8, B, N, dtype=torch.float32, device=dev)
     _lib.check(L.eml_sinkhorn_fwd_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
-        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(loss), _lib.ptr(gx), _lib.ptr(gy),
+        float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
+        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(diam), _lib.ptr(loss), _lib.ptr(gx), _lib.ptr(gy),
         _lib.ptr(work), B, N, stream), "eml_sinkhorn_fwd_f32")
     return {"loss": loss, "gx": gx, "gy": gy, "eps_s": eps_s, "n_eps": n_eps, "diameter": diam,
             "duals": work[:4]}

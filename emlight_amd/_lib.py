@@ -25,8 +25,9 @@ SIGNATURES = {
     "eml_sinkhorn_schedule_f32": (_int, [_f32p, _f32p, ctypes.c_long, ctypes.c_double, ctypes.c_double, _int,
                                          ctypes.c_double, _f32p, _i32p, _f32p, _stream]),
     "eml_sinkhorn_work_floats": (ctypes.c_size_t, [_int, _int]),
-    "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p,
-                                    _f32p, _f32p, _int, _int, _stream]),
+    "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_double, ctypes.c_double, _int,
+                                    ctypes.c_double, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
+                                    _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
     # DenseNet-BC encoder, forward
     "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),

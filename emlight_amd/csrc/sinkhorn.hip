@@ -5,17 +5,18 @@
 // step costs 4 materialised (B,N,N) cost tensors and ~200-300 tiny ATen launches
 // (4*(n_eps+2) softmins x ~6 ops) plus a .item() host sync for the diameter.
 //
-// Here one C-ABI call enqueues the loop kernel + a tiny finishing kernel.  The four coupled
+// Here one C-ABI call enqueues the loop kernel (which also derives the diameter and the epsilon
+// schedule on the device, redundantly per workgroup) + a tiny finishing kernel.  The four coupled
 // softmin problems      g=0 xx -> a_x   g=1 yy -> b_y   g=2 yx -> a_y   g=3 xy -> b_x
-// each own 4 wavefronts (256 threads); a sample is two 512-thread workgroups -- role 0 runs
+// each own 8 wavefronts (512 threads); a sample is two 1024-thread workgroups -- role 0 runs
 // the independent pair (xx, yy), role 1 the coupled pair (yx, xy) -- so 2*B workgroups spread
-// over the CUs and a thread may use up to 256 VGPRs.
+// over the CUs at 4 waves per SIMD.
 //
-// N <= 128 ("cached" kernel): thread (i, half) of a group keeps its <=64 costs
-// C_ij = .5*(.1*(p_i-q_j)^2 + M_ij) of row i in REGISTERS for the whole eps-scaling loop
+// N <= 128 ("cached" kernel): four lanes share row i; thread (i, quarter) keeps its <=32 costs
+// C_ij = .5*(.1*(p_i-q_j)^2 + M_ij) in REGISTERS for the whole eps-scaling loop
 // (the cost matrices never exist in HBM; M is staged once through LDS with coalesced
 // reads).  A sweep is one fma+max pass and one fma+exp2+add pass over those registers, the
-// row reduction is a single lane-pair shuffle, and the dual vectors h = log w + f/eps
+// row reduction is two lane shuffles, and the dual vectors h = log w + f/eps
 // travel between the two groups through a double-buffered LDS array with ONE barrier per
 // sweep.  N > 128 ("stream" kernel): thread = row, costs recomputed per sweep from Mt
 // (coalesced, L2-resident).
@@ -27,8 +28,8 @@
 
 namespace {
 
-constexpr int kGT = 256;   // threads per softmin group (4 waves)
-constexpr int kJPT = 64;   // cached costs per thread (N <= 2*kJPT)
+constexpr int kJPT = 64;   // LDS padding unit (unrolled reads past a row's end stay in-bounds)
+constexpr int kCJ = 32;    // cached kernel: costs per thread; 4 lanes share a row (N <= 4*kCJ = 128)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kBig = 1e30f;
@@ -48,12 +49,83 @@ __device__ __forceinline__ float cost_ij(float p, float q, float m) {
 //   pot [2][NP]  potentials (stream kernel)      M [N][ldm] (cached kernel)
 constexpr int kSmemVecs = 2 + 2 + 4 + 2;
 
+// threads per softmin group: cached kernel 512 (128 rows x 4 lanes), stream kernel 256 (row per thread)
 template <bool kCached>
-__global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
+__global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
     const float* __restrict__ Mt, const float* __restrict__ alpha, const float* __restrict__ beta,
-    const float* __restrict__ eps_s, const int* __restrict__ n_eps_p,
+    double blur, double scaling, int p_exp, double diameter, float* __restrict__ eps_out,
+    int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
+  // ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
+  // d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
+  // eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p] in f64 like numpy
+  constexpr int kGT = kCached ? 512 : 256;  // threads per softmin group
+  constexpr int kWG = 2 * kGT;              // two groups per workgroup
+  __shared__ float eps_l[EML_MAX_EPS];
+  __shared__ float red_lo[16], red_hi[16];
+  __shared__ int n_eps_l;
+  {
+    const int tid0 = threadIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    if (diameter <= 0.0) {
+      const long n_all = (long)B * N, n4 = n_all >> 2;   // hipMalloc'd buffers: 16-B aligned
+      const float4* x4 = reinterpret_cast<const float4*>(x);
+      const float4* y4 = reinterpret_cast<const float4*>(y);
+      for (long k = tid0; k < n4; k += kWG) {
+        const float4 a = x4[k], c2 = y4[k];
+        lo = fminf(fminf(fminf(lo, fminf(a.x, a.y)), fminf(a.z, a.w)), fminf(fminf(c2.x, c2.y), fminf(c2.z, c2.w)));
+        hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)), fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w)));
+      }
+      for (long k = 4 * n4 + tid0; k < n_all; k += kWG) {
+        lo = fminf(lo, fminf(x[k], y[k]));
+        hi = fmaxf(hi, fmaxf(x[k], y[k]));
+      }
+      lo = eml::wave_min(lo);
+      hi = eml::wave_max(hi);
+      if ((tid0 & 63) == 0) {
+        red_lo[tid0 >> 6] = lo;
+        red_hi[tid0 >> 6] = hi;
+      }
+    }
+    __syncthreads();
+    double d = diameter;
+    if (diameter <= 0.0) {
+      lo = red_lo[0];
+      hi = red_hi[0];
+#pragma unroll
+      for (int w = 1; w < kWG / 64; ++w) {
+        lo = fminf(lo, red_lo[w]);
+        hi = fmaxf(hi, red_hi[w]);
+      }
+      d = (double)(hi - lo);  // f32 subtraction, then .item()
+    }
+    int cnt = 0;
+    double start = 0.0, step = 0.0;
+    if (d > 0.0) {
+      start = p_exp * log(d);
+      step = p_exp * log(scaling);
+      const double cntd = ceil((p_exp * log(blur) - start) / step);  // numpy.arange length
+      cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
+    }
+    if (tid0 < cnt + 2) {  // one schedule entry per thread, in parallel
+      double e;
+      if (tid0 == 0) e = (p_exp == 2) ? d * d : pow(d, (double)p_exp);
+      else if (tid0 == cnt + 1) e = (p_exp == 2) ? blur * blur : pow(blur, (double)p_exp);
+      else e = exp(start + (tid0 - 1) * step);
+      eps_l[tid0] = (float)e;
+      if (blockIdx.x == 0 && eps_out) eps_out[tid0] = (float)e;
+    }
+    if (tid0 == 0) {
+      n_eps_l = cnt + 2;
+      if (blockIdx.x == 0) {
+        if (n_eps_out) *n_eps_out = cnt + 2;
+        if (diameter_out) *diameter_out = (float)d;
+      }
+    }
+    __syncthreads();
+  }
+  const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NP = round_up4(N) + kJPT;
   float* pts = smem;
@@ -65,17 +137,17 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
   const int b = blockIdx.x >> 1;
   const int role = blockIdx.x & 1;     // 0: (xx, yy)   1: (yx, xy)
   const int tid = threadIdx.x;
-  const int gl = tid >> 8;             // local group 0/1
+  const int gl = tid / kGT;            // local group 0/1
   const int g = 2 * role + gl;         // global problem id 0..3
   const int t = tid & (kGT - 1);
   const bool rows_x = (g == 0 || g == 3);
   const bool cols_x = (g == 0 || g == 2);
   const int consumer_l = role ? (1 - gl) : gl;  // local group whose h this potential feeds
-  const int n_eps = max(1, min(*n_eps_p, EML_MAX_EPS));
+  const int n_eps = n_eps_l;
 
   // ---- stage points and log-weights; zero the h buffers (their pads are read)
   const float unif = 1.0f / (float)N;
-  for (int i = tid; i < 2 * NP; i += 512) {
+  for (int i = tid; i < 2 * NP; i += kWG) {
     const int which = i / NP, k = i - which * NP;
     float p = 0.f, l = 0.f;
     if (k < N) {
@@ -87,7 +159,7 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
     pts[i] = p;
     lw2[i] = l * kLog2e;
   }
-  for (int i = tid; i < 4 * NP; i += 512) h2[i] = 0.f;
+  for (int i = tid; i < 4 * NP; i += kWG) h2[i] = 0.f;
   __syncthreads();  // pts / lw2 / zeroed h2 visible to every thread before any cross-thread read
 
   const float* P = pts + (rows_x ? 0 : NP);
@@ -96,28 +168,28 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
   const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
 
   // ---- cached kernel: M -> LDS (coalesced), then this thread's costs -> registers
-  float c[kJPT];
+  float c[kCJ];
   int i = 0, jbase = 0;
   bool owner = false;
   if constexpr (kCached) {
     const int ldm = round_up4(N) + 4;
-    for (int e = tid; e < N * N; e += 512) {
+    for (int e = tid; e < N * N; e += kWG) {
       const int r = e / N, cc = e - r * N;
       Ml[r * ldm + cc] = M[e];
     }
     __syncthreads();
-    const int split = round_up4((N + 1) >> 1);
-    const int half = t & 1;
-    i = t >> 1;
-    jbase = half * split;
+    const int split = round_up4((N + 3) >> 2);   // columns per lane: 4 lanes share row i
+    const int quarter = t & 3;
+    i = t >> 2;
+    jbase = quarter * split;
     const int cnt = (i < N) ? max(0, min(split, N - jbase)) : 0;
-    owner = (half == 0) && (i < N);
+    owner = (quarter == 0) && (i < N);
     const int ic = min(i, N - 1);
     const float pi = P[ic];
     const float4* mrow = reinterpret_cast<const float4*>(Ml + ic * ldm + jbase);
     const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
 #pragma unroll
-    for (int q = 0; q < kJPT / 4; ++q) {
+    for (int q = 0; q < kCJ / 4; ++q) {
       const float4 mv = mrow[q];
       const float4 qv = qrow[q];
       c[4 * q + 0] = (4 * q + 0 < cnt) ? cost_ij(pi, qv.x, mv.x) : kBig;
@@ -146,31 +218,36 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
 
     if constexpr (kCached) {
       const float4* hv4 = reinterpret_cast<const float4*>(hsrc + jbase);
-      float m = -INFINITY;
+      // four independent max / sum chains: with 2 waves per SIMD the sweep is latency-bound, not
+      // throughput-bound, so instruction-level parallelism inside the wave is what shortens it
+      float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
-      for (int q = 0; q < kJPT / 4; ++q) {
+      for (int q = 0; q < kCJ / 4; ++q) {
         const float4 hv = hv4[q];
-        m = fmaxf(m, fmaf(c[4 * q + 0], nie2, hv.x));
-        m = fmaxf(m, fmaf(c[4 * q + 1], nie2, hv.y));
-        m = fmaxf(m, fmaf(c[4 * q + 2], nie2, hv.z));
-        m = fmaxf(m, fmaf(c[4 * q + 3], nie2, hv.w));
+        m0 = fmaxf(m0, fmaf(c[4 * q + 0], nie2, hv.x));
+        m1 = fmaxf(m1, fmaf(c[4 * q + 1], nie2, hv.y));
+        m2 = fmaxf(m2, fmaf(c[4 * q + 2], nie2, hv.z));
+        m3 = fmaxf(m3, fmaf(c[4 * q + 3], nie2, hv.w));
       }
+      float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
       m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
       float sum = 0.f, tq = 0.f;
       if (!final_sweep) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int q = 0; q < kJPT / 4; ++q) {
+        for (int q = 0; q < kCJ / 4; ++q) {
           const float4 hv = hv4[q];
-          const float e0 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
-          const float e1 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
-          const float e2 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
-          const float e3 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
-          sum += (e0 + e1) + (e2 + e3);
+          s0 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
+          s1 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
+          s2 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
+          s3 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
         }
+        sum = (s0 + s1) + (s2 + s3);
       } else {
         const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
 #pragma unroll
-        for (int q = 0; q < kJPT / 4; ++q) {
+        for (int q = 0; q < kCJ / 4; ++q) {
           const float4 hv = hv4[q];
           const float4 qv = qrow[q];
           const float e0 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
@@ -181,8 +258,10 @@ __global__ __launch_bounds__(512) void sinkhorn_loop_kernel(
           tq = fmaf(e0, qv.x, fmaf(e1, qv.y, fmaf(e2, qv.z, fmaf(e3, qv.w, tq))));
         }
         tq += __shfl_xor(tq, 1, 64);
+        tq += __shfl_xor(tq, 2, 64);
       }
       sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
       // softmin = -eps * logsumexp (samples_loss.py:75-77), evaluated in base 2
       const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
       if (final_sweep) {
@@ -341,26 +420,28 @@ extern "C" int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n,
 extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)8 * B * N; }
 
 extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
-                                    const float* alpha, const float* beta, const float* eps_s,
-                                    const int* n_eps, float* loss, float* gx, float* gy,
-                                    float* work, int B, int N, eml_stream_t stream) {
-  if (!x || !y || !M || !Mt || !eps_s || !n_eps || !loss || !work)
-    return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
+                                    const float* alpha, const float* beta, double blur, double scaling, int p,
+                                    double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
+                                    float* loss, float* gx, float* gy, float* work, int B, int N,
+                                    eml_stream_t stream) {
+  if (!x || !y || !M || !Mt || !loss || !work) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
   if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
+  if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
+    return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need blur>0, 0<scaling<1, p>=1");
   if (B == 0) return EML_OK;
   const int NP = round_up4(N) + kJPT;
   size_t lds = (size_t)(kSmemVecs * NP) * sizeof(float);
-  if (N <= 2 * kJPT) {
+  if (N <= 4 * kCJ) {
     lds += (size_t)(N * (round_up4(N) + 4) + kJPT) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, eps_s, n_eps, work, B, N);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
+                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, eps_s, n_eps, work, B, N);
+                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   }
   int rc = eml::check_launch("eml_sinkhorn_fwd_f32(loop)");
   if (rc) return rc;

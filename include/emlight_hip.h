@@ -71,26 +71,29 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
                               double scaling, int p, double diameter, float* eps_out,
                               int* n_eps_out, float* diameter_out, eml_stream_t stream);
 
-/* Whole debiased Sinkhorn divergence in one call (loop kernel + finishing kernel): cost build
- * C = .5*(.1*(x_i-y_j)^2 + M_ij) (never materialised in HBM), init sweep, n_eps symmetrised
- * eps-scaling sweeps, last extrapolation, loss_b = <alpha,b_x-a_x> + <beta,a_y-b_y>, and the
- * analytic gradients d loss_b/d x, d loss_b/d y of the last extrapolation.
+/* Whole debiased Sinkhorn divergence in one call (loop kernel + finishing kernel): the diameter and the
+ * epsilon schedule (as eml_sinkhorn_schedule_f32, computed inside the loop kernel), cost build
+ * C = .5*(.1*(x_i-y_j)^2 + M_ij) (never materialised in HBM), init sweep, n_eps symmetrised eps-scaling
+ * sweeps, last extrapolation, loss_b = <alpha,b_x-a_x> + <beta,a_y-b_y>, and the analytic gradients
+ * d loss_b/d x, d loss_b/d y of the last extrapolation.
  * Replaces SamplesLoss.sinkhorn_tensorized: geomloss/samples_loss.py:79-92 with
- * utils.py:85-99 (cost), samples_loss.py:75-77 (softmin), sinkhorn_divergence.py:72-109
- * (loop), :65-69 (cost), and the autograd backward of :102-107.
+ * sinkhorn_divergence.py:9-36 (schedule), utils.py:85-99 (cost), samples_loss.py:75-77 (softmin),
+ * sinkhorn_divergence.py:72-109 (loop), :65-69 (cost), and the autograd backward of :102-107.
  *   x, y        (B,N)  1-D "points" (the mass at each anchor)
  *   M, Mt       (N,N)  ground cost and its transpose (may alias when M is symmetric)
  *   alpha, beta (B,N)  weights, or NULL for uniform 1/N
- *   eps_s, n_eps       device schedule from eml_sinkhorn_schedule_f32
+ *   blur, scaling, p, diameter   as SamplesLoss(...); diameter <= 0: range of x U y over the batch
+ *   eps_out[EML_MAX_EPS], n_eps_out, diameter_out   device outputs of the schedule, or NULL
  *   loss        (B)
  *   gx, gy      (B,N)  d loss_b / d x_i, d loss_b / d y_j, or NULL
  *   work        (8,B,N) caller-owned scratch, eml_sinkhorn_work_floats(B,N) floats; on return
  *                      planes 0..3 hold the final duals a_x, b_y, a_y, b_x */
 size_t eml_sinkhorn_work_floats(int B, int N);
 int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
-                         const float* alpha, const float* beta, const float* eps_s,
-                         const int* n_eps, float* loss, float* gx, float* gy, float* work,
-                         int B, int N, eml_stream_t stream);
+                         const float* alpha, const float* beta, double blur, double scaling, int p,
+                         double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
+                         float* loss, float* gx, float* gy, float* work, int B, int N,
+                         eml_stream_t stream);
 
 /* Backward of the loss vector: gout[b,i] = gloss[b] * gunit[b,i]  (gunit = gx or gy above). */
 int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, int B, int N,

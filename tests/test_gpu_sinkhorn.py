@@ -110,3 +110,22 @@ def test_empty_batch_and_errors():
     assert out.shape == (0,)
     with pytest.raises(ValueError):
         crit(torch.rand(2, 64, 1, device="cuda"), torch.rand(2, 64, 1, device="cuda"))
+
+
+def test_standalone_schedule_launcher_matches_numpy():
+    """eml_sinkhorn_schedule_f32 (the schedule as its own launch) vs sinkhorn_divergence.py:21-25 in numpy."""
+    from emlight_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    g = torch.Generator().manual_seed(3)
+    for scale, blur, diam in ((1.0, .05, None), (3.0, .025, None), (1.0, .05, 1.0), (1e-3, .05, None)):
+        x = (torch.randn(5, 96, generator=g) * scale).cuda()
+        y = (torch.randn(5, 96, generator=g) * scale).cuda()
+        eps = torch.zeros(64, device="cuda")
+        n_eps = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d = torch.zeros(1, device="cuda")
+        _lib.check(L.eml_sinkhorn_schedule_f32(p(x), p(y), x.numel(), blur, .5, 2, -1.0 if diam is None else diam, p(eps),
+                                               p(n_eps), p(d), _lib.current_stream()), "schedule")
+        want_d = diam if diam is not None else oracle.max_diameter(x.cpu().view(-1, 96, 1), y.cpu().view(-1, 96, 1))
+        want = oracle.epsilon_schedule(2, want_d, blur, .5)
+        assert int(n_eps.item()) == len(want)
+        np.testing.assert_allclose(eps[:len(want)].cpu().numpy(), np.asarray(want, np.float32), rtol=2e-7)
