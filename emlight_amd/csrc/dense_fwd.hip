@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
 
+#pragma unroll 8
   for (int e = tid; e < Kp * 12; e += 256)
     reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(Wp)[e];
   for (int e = tid; e < Kp; e += 256) {
@@ -205,22 +206,41 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
     const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
-    // stage BN2(z) halo tile; out-of-image -> 0 (padding is applied to the BN output)
-    for (int e = tid; e < kHH * kHW * 12; e += 256) {
-      const int pix = e / 12, q = e - pix * 12;
-      const int hy = pix / kHW, hx = pix - hy * kHW;
-      const int gy = y0 + hy, gx = x0 + hx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        const float4 z = *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q);
-        const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
-        const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
-        v.x = fmaf(z.x, s.x, t.x);
-        v.y = fmaf(z.y, s.y, t.y);
-        v.z = fmaf(z.z, s.z, t.z);
-        v.w = fmaf(z.w, s.w, t.w);
+    // stage BN2(z) halo tile; out-of-image -> 0 (padding is applied to the BN output).  All 16 loads of a
+    // thread are issued before the first is consumed: a rolled loop serialises 16 HBM round trips per tile
+    // (ISA: global_load / s_waitcnt vmcnt(0) / ds_write per iteration), which was most of a tile's time.
+    {
+      constexpr int NST = (kHH * kHW * 12 + 255) / 256;
+      float4 zt[NST];
+      unsigned inmask = 0;
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {
+        const int e = tid + 256 * it;
+        const int pix = e / 12, q = e - pix * 12;
+        const int hy = pix / kHW, hx = pix - hy * kHW;
+        const int gy = y0 + hy, gx = x0 + hx;
+        const bool in = e < kHH * kHW * 12 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        zt[it] = in ? *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        inmask |= (in ? 1u : 0u) << it;
       }
-      *reinterpret_cast<float4*>(tile_l + pix * kPS + 4 * q) = v;
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {
+        const int e = tid + 256 * it;
+        const int pix = e / 12, q = e - pix * 12;
+        if (e < kHH * kHW * 12) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((inmask >> it) & 1u) {
+            const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
+            const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
+            v.x = fmaf(zt[it].x, s.x, t.x);
+            v.y = fmaf(zt[it].y, s.y, t.y);
+            v.z = fmaf(zt[it].z, s.z, t.z);
+            v.w = fmaf(zt[it].w, s.w, t.w);
+          }
+          *reinterpret_cast<float4*>(tile_l + pix * kPS + 4 * q) = v;
+        }
+      }
     }
     __syncthreads();
 

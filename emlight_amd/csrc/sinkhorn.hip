@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   bool owner = false;
   if constexpr (kCached) {
     const int ldm = round_up4(N) + 4;
-    for (int e = tid; e < N * N; e += kWG) {
+#pragma unroll 8
+    for (int e = tid; e < N * N; e += kWG) {  // unrolled: 8 loads in flight per thread
       const int r = e / N, cc = e - r * N;
       Ml[r * ldm + cc] = M[e];
     }
