@@ -661,11 +661,8 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              l1[g] += __shfl_xor(l1[g], o, 64);
-              l2[g] += __shfl_xor(l2[g], o, 64);
-            }
+            l1[g] = eml::row16_sum(l1[g]);
+            l2[g] = eml::row16_sum(l2[g]);
             if (r == 0) {
               my[2 * (k4 + g)] += (double)l1[g];
               my[2 * (k4 + g) + 1] += (double)l2[g];
@@ -819,11 +816,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-#pragma unroll
-              for (int o = 1; o < 16; o <<= 1) {
-                l1[g] += __shfl_xor(l1[g], o, 64);
-                l2[g] += __shfl_xor(l2[g], o, 64);
-              }
+              l1[g] = eml::row16_sum(l1[g]);  // over the 16 pixels (lanes r) of this lane row: DPP, no LDS
+              l2[g] = eml::row16_sum(l2[g]);
               if (r == 0) {
                 my[2 * (k4 + g)] += (double)l1[g];
                 my[2 * (k4 + g) + 1] += (double)l2[g];

@@ -49,4 +49,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- DPP cross-lane moves (VALU, no LDS round trip).  hipcc lowers __shfl_xor to ds_bpermute_b32 + an
+// lgkmcnt(0) wait per step; inside an MFMA epilogue that serialises thousands of cycles (ISA of the
+// conv1x1 dgrad: 32 dependent bpermutes per 16-channel tile).  Control words: quad_perm [1,0,3,2] = 0xB1,
+// quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140 (a DPP "row" = 16 lanes).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }
+// sum over the 16 lanes of a row (lanes with equal lane>>4); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
 }  // namespace eml

@@ -231,8 +231,8 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
         m3 = fmaxf(m3, fmaf(c[4 * q + 3], nie2, hv.w));
       }
       float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-      m = fmaxf(m, __shfl_xor(m, 1, 64));
-      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      m = fmaxf(m, eml::lane_xor1(m));  // the 4 lanes of a row are a DPP quad
+      m = fmaxf(m, eml::lane_xor2(m));
       float sum = 0.f, tq = 0.f;
       if (!final_sweep) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -258,11 +258,11 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
           sum += (e0 + e1) + (e2 + e3);
           tq = fmaf(e0, qv.x, fmaf(e1, qv.y, fmaf(e2, qv.z, fmaf(e3, qv.w, tq))));
         }
-        tq += __shfl_xor(tq, 1, 64);
-        tq += __shfl_xor(tq, 2, 64);
+        tq += eml::lane_xor1(tq);
+        tq += eml::lane_xor2(tq);
       }
-      sum += __shfl_xor(sum, 1, 64);
-      sum += __shfl_xor(sum, 2, 64);
+      sum += eml::lane_xor1(sum);
+      sum += eml::lane_xor2(sum);
       // softmin = -eps * logsumexp (samples_loss.py:75-77), evaluated in base 2
       const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
       if (final_sweep) {
