@@ -8,7 +8,7 @@ on 240x320 crops.  N>1: one process per GPU (torchrun), the batch dimension shar
 all-reduce over RCCL/xGMI (DDP); per-GPU work is fixed -> weak scaling.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the dense-layer
-conv1x1 forward/backward family: f32 MFMA-bound), measured live with HIP events on the
+conv1x1 backward family: HBM-bound on the block buffer's O(L^2) re-reads), measured live with HIP events on the
 launch stream; `cpu_baseline` is the oracle (torch-CPU restatement, parity-pinned to the
 reference) timed on this box's host cores at a bounded batch.
 """
@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_240x320 = 43.775      # algorithmic conv FLOPs per image, forward
 STEP_GFLOP_240x320 = 131.2      # forward + dgrad + wgrad (minus conv0 dgrad)
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 stacks
 
 
 def conv_flops(B, crop_hw):
@@ -42,6 +43,31 @@ def conv_flops(B, crop_hw):
         f1 += 2.0 * c_tot * (c_tot // 2) * (h // 2) * (w // 2)
         c, h, w = c_tot // 2, h // 2, w // 2
     return f1 * B, f3 * B
+
+
+def family_bytes(B, crop_hw):
+    """Algorithmic HBM bytes per training step of every kernel family (DESIGN.md section 3 states the
+    per-pixel figures): each operand a launch must read or write once, f32, nothing for halos or re-reads."""
+    h, w = crop_hw
+    c = 24
+    by = {k: 0.0 for k in FAMILIES}
+    for _ in range(3):
+        P = float(B * h * w)
+        for l in range(16):
+            k = c + 12 * l
+            by["eml_dense_conv1x1_fwd_f32"] += (k + 48) * 4 * P          # X[:, :k] in, Z out
+            by["eml_dense_conv1x1_bwd_weight_f32"] += (k + 96) * 4 * P   # X[:, :k], DZ, Z in
+            by["eml_dense_conv3x3_fwd_f32"] += (48 + 12) * 4 * P         # Z in, 12 new channels out
+            by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 48 + 48) * 4 * P   # dY, Z (BN2 statistics) in, DZ out
+            by["eml_dense_conv3x3_bwd_weight_f32"] += (12 + 48) * 4 * P  # dY, Z in
+            if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
+                by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((3 * 12 + 96) + (3 * k + 192)) * 4 * P
+        ct = c + 192
+        by["eml_dense_conv1x1_fwd_f32"] += (ct + ct // 8) * 4 * P        # transition: X in, pooled out
+        by["eml_dense_conv1x1_bwd_weight_f32"] += (ct + ct // 8) * 4 * P
+        by["eml_dense_conv1x1_bwd_data_f32"] += (2 * ct + ct // 8) * 4 * P   # dY(pooled), X in, G out
+        c, h, w = ct // 2, h // 2, w // 2
+    return by
 
 
 # launcher -> (kernel family, which algorithmic FLOP count one pass over its launches performs)
@@ -93,13 +119,16 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
         ftr += 2.0 * ct * (ct // 2) * (h // 2) * (w // 2) * B
         c, h, w = ct // 2, h // 2, w // 2
     flops = (f1, f3, ftr)
+    nbytes = family_bytes(B, crop_hw)
     rows = []
     for k, (label, which) in FAMILIES.items():
         ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
         n = len(events[k]) // steps
         rows.append({"kernel": label, "launches_per_step": n, "ms_per_step": round(ms, 3),
                      "avg_launch_ms": round(ms / max(n, 1), 4),
-                     "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None})
+                     "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                     "algorithmic_GB_per_step": round(nbytes[k] / 1e9, 2),
+                     "algorithmic_GBps": round(nbytes[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
 
@@ -274,15 +303,25 @@ def main():
         }
         if fams:
             dom = fams[0]  # the dominant kernel family of the step, by measured GPU time (rank 0)
-            out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
-                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+            # the roof that binds is the one the kernel sits closer to: f32 activations make the dense-layer
+            # passes HBM-bound (O(L^2) re-reads of the concatenated block buffer), not MFMA-bound
+            f_hbm = dom["algorithmic_GBps"] / HBM_PEAK_GBPS
+            f_mfma = dom["tflops"] / F32_MFMA_PEAK_TFLOPS
+            hbm = f_hbm >= f_mfma
+            out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm" if hbm else "mfma",
+                               "achieved": dom["algorithmic_GBps"] if hbm else dom["tflops"],
+                               "peak": HBM_PEAK_GBPS if hbm else F32_MFMA_PEAK_TFLOPS,
+                               "unit": "GB/s" if hbm else "TFLOP/s",
+                               "frac": round(max(f_hbm, f_mfma), 4),
                                "traffic": pmc_traffic(dom["kernel"]),
+                               "algorithmic_bytes_per_launch": round(dom["algorithmic_GB_per_step"] * 1e9 /
+                                                                     max(dom["launches_per_step"], 1)),
+                               "other_roof_frac": round(min(f_hbm, f_mfma), 4),
                                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
-                               "note": "achieved = algorithmic conv FLOPs of the family's launches / their summed "
-                                       "HIP-event duration; f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; traffic = HBM "
-                                       "bytes per launch from the committed rocprofv3 --pmc passes (profiles/), "
-                                       "(2*FETCH_SIZE + WRITE_SIZE) KiB"}
+                               "note": "achieved = algorithmic bytes (or conv FLOPs) of the family's launches / their "
+                                       "summed HIP-event duration; peaks: HBM3E 8 TB/s, f32 MFMA "
+                                       "(v_mfma_f32_16x16x4_f32) 157.3 TFLOP/s; traffic = HBM bytes per launch from the "
+                                       "committed rocprofv3 --pmc passes (profiles/), (2*FETCH_SIZE + WRITE_SIZE) KiB"}
             out["kernel_families"] = fams
             out["sinkhorn"] = time_sinkhorn(args.batch, args.anchors, args.blur, dev)
         if not args.no_cpu_baseline and world == 1:

@@ -172,16 +172,22 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
 // ------------------------------------------------------------------------------ conv3x3
 constexpr int kTH = 8, kTW = 32;            // output tile per block
 constexpr int kHH = kTH + 2, kHW = kTW + 2; // halo tile
-constexpr int kPS = 52;                     // LDS pixel stride (48 + 4 pad, 16-B aligned)
+constexpr int kPS = 56;                     // LDS pixel stride: 56 dwords makes the ds_read_b128 lane groups conflict-free (48 and 52 are 2-way)
 
-__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(
+// 512 threads = 8 waves, ONE output row of the 8x32 tile per wave, one workgroup per CU.  The halo tile is
+// double-buffered in LDS (2 x 70.7 KB): the global loads of tile t+1 are issued into registers before the
+// MFMAs of tile t and committed (BN2 applied) to the other buffer after them, so a tile costs one barrier and
+// the HBM round trip hides behind 54 MFMAs/wave x 2 waves/SIMD.  (The single-buffered 256-thread version
+// alternated "all waves wait for HBM" / "all waves compute": 39 % of the f32 MFMA peak, 1.9 TB/s.)
+constexpr int kC3Threads = 512;
+
+__global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
     const float* __restrict__ Z, const float* __restrict__ scale2, const float* __restrict__ shift2,
     const float* __restrict__ W2p, float* __restrict__ X, int ldx, int c_out0, int B, int H, int W,
     double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile_l = smem;                                   // [kHH*kHW][kPS]
-  float* st_l = tile_l + kHH * kHW * kPS;                 // [2][48]
-  double* red = reinterpret_cast<double*>(st_l + 96);     // [4][16][2]
+  float* st_l = smem + 2 * kHH * kHW * kPS;               // [2][48]
+  double* red = reinterpret_cast<double*>(st_l + 96);     // [8][16][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
 
@@ -200,78 +206,104 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(
 
   const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
   const int ntiles = B * ty_n * tx_n;
-  double ssum[1] = {0}, ssq[1] = {0};
+  double ssum = 0.0, ssq = 0.0;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // staging map: threads 0..407 = (halo column hx = tid/12, 16-byte slice q = tid%12), one halo ROW per pass:
+  // the index math is tile-invariant and every LDS / global offset of pass `it` is base + it*const.
+  // Loads are UNCONDITIONAL (coordinates clamped into the image, threads >= 408 re-read column 33) and the
+  // in-image mask is applied at commit: exec-masked loads sit in their own basic blocks and the compiler then
+  // makes MFMAs wait on them.
+  const int s_hx = min(tid / 12, kHW - 1), s_q = tid % 12;
+  const float4 sc = *reinterpret_cast<const float4*>(scale2 + 4 * s_q);
+  const float4 sh = *reinterpret_cast<const float4*>(shift2 + 4 * s_q);
+  const int s_dst = s_hx * kPS + 4 * s_q;
+  float4 zt[kHH];
+  // state of the tile being staged
+  const float* s_src = Z;
+  int s_y0 = 0;
+  bool s_col = false;
+  auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
-    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
-    // stage BN2(z) halo tile; out-of-image -> 0 (padding is applied to the BN output).  All 16 loads of a
-    // thread are issued before the first is consumed: a rolled loop serialises 16 HBM round trips per tile
-    // (ISA: global_load / s_waitcnt vmcnt(0) / ds_write per iteration), which was most of a tile's time.
-    {
-      constexpr int NST = (kHH * kHW * 12 + 255) / 256;
-      float4 zt[NST];
-      unsigned inmask = 0;
-#pragma unroll
-      for (int it = 0; it < NST; ++it) {
-        const int e = tid + 256 * it;
-        const int pix = e / 12, q = e - pix * 12;
-        const int hy = pix / kHW, hx = pix - hy * kHW;
-        const int gy = y0 + hy, gx = x0 + hx;
-        const bool in = e < kHH * kHW * 12 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        zt[it] = in ? *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-        inmask |= (in ? 1u : 0u) << it;
-      }
-#pragma unroll
-      for (int it = 0; it < NST; ++it) {
-        const int e = tid + 256 * it;
-        const int pix = e / 12, q = e - pix * 12;
-        if (e < kHH * kHW * 12) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((inmask >> it) & 1u) {
-            const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
-            const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
-            v.x = fmaf(zt[it].x, s.x, t.x);
-            v.y = fmaf(zt[it].y, s.y, t.y);
-            v.z = fmaf(zt[it].z, s.z, t.z);
-            v.w = fmaf(zt[it].w, s.w, t.w);
-          }
-          *reinterpret_cast<float4*>(tile_l + pix * kPS + 4 * q) = v;
-        }
-      }
-    }
-    __syncthreads();
+    const int gx = tx * kTW - 1 + s_hx;
+    s_y0 = ty * kTH - 1;
+    s_col = gx >= 0 && gx < W;
+    s_src = Z + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * 48 + 4 * s_q;
+  };
+  auto stage_load = [&](int it) {
+    zt[it] = *reinterpret_cast<const float4*>(s_src + (size_t)min(max(s_y0 + it, 0), H - 1) * W * 48);
+  };
+  // BN2 + zero padding of the BN OUTPUT (out-of-image halo pixels are 0, not shift2)
+  auto stage_commit = [&](int it, float* tile_l) {
+    const bool ok = s_col && s_y0 + it >= 0 && s_y0 + it < H;
+    float4 v;
+    v.x = ok ? fmaf(zt[it].x, sc.x, sh.x) : 0.f;
+    v.y = ok ? fmaf(zt[it].y, sc.y, sh.y) : 0.f;
+    v.z = ok ? fmaf(zt[it].z, sc.z, sh.z) : 0.f;
+    v.w = ok ? fmaf(zt[it].w, sc.w, sh.w) : 0.f;
+    *reinterpret_cast<float4*>(tile_l + s_dst + it * kHW * kPS) = v;  // threads >= 408 duplicate column 33: same value
+  };
 
-    f32x4 acc[4];
+  int tile = blockIdx.x, cur = 0;
+  if (tile < ntiles) {
+    stage_begin(tile);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // wave w owns output rows 2w, 2w+1; M-tile m = row (m>>1), 16 columns at 16*(m&1)
+    for (int it = 0; it < kHH; ++it) stage_load(it);
+#pragma unroll
+    for (int it = 0; it < kHH; ++it) stage_commit(it, smem);
+  }
+  // vmcnt(0): the weight-fragment loads above are complete on EVERY path into the loop.  Without it the
+  // compiler's waitcnt pass keeps bw[] "possibly pending" and guards the first MFMAs of each tile with
+  // s_waitcnt vmcnt(3..0) -- which at run time waits for the prefetch loads issued just before them.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    // The next tile is staged INSIDE this tile's MFMA stream: its 10 row loads ride on the first 10 of the 27
+    // (tap, 16-channel) groups, its 10 LDS commits on the last 10 -- the two waves of a SIMD run in lockstep
+    // between barriers, so any staging done outside the MFMA stream leaves the matrix pipe idle.  On the last
+    // tile the block re-stages the same tile (harmless) to keep the stream branch-free.
+    const int nxt = tile + gridDim.x;
+    stage_begin(nxt < ntiles ? nxt : tile);
+    const float* tile_l = smem + cur * (kHH * kHW * kPS);
+    float* tile_n = smem + (cur ^ 1) * (kHH * kHW * kPS);
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wave w owns output row w; M-tile m = 16 columns at 16*m
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float4 a[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int hy = 2 * wave + (m >> 1) + dy, hx = 16 * (m & 1) + r + dx;
-          a[m] = *reinterpret_cast<const float4*>(tile_l + (hy * kHW + hx) * kPS + 16 * j + 4 * kk);
+        const int gi = tap * 3 + j;
+        if (gi < kHH) {
+          stage_load(gi);
+          __builtin_amdgcn_sched_barrier(0);  // keep the load HERE: the scheduler otherwise sinks it to its use
         }
+        float4 a[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a[m] = *reinterpret_cast<const float4*>(tile_l + ((wave + dy) * kHW + 16 * m + r + dx) * kPS + 16 * j + 4 * kk);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[m] = mfma16(f4c(a[m], t), f4c(bw[tap][j], t), acc[m]);
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(f4c(a[m], t), f4c(bw[tap][j], t), acc[m]);
+        if (gi >= 27 - kHH) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_commit(gi - (27 - kHH), tile_n);
+        }
       }
     }
     float ls = 0.f, lq = 0.f;
+    const int gy = ty * kTH + wave;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int gy = ty * kTH + 2 * wave + (m >> 1);
+    for (int m = 0; m < 2; ++m) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int gx = tx * kTW + 16 * (m & 1) + 4 * kk + g;
+        const int gx = tx * kTW + 16 * m + 4 * kk + g;
         const float v = acc[m][g];
         if (gy < H && gx < W && r < 12) {
           X[((size_t)(b * H + gy) * W + gx) * ldx + c_out0 + r] = v;
@@ -280,11 +312,27 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(
         }
       }
     }
-    ssum[0] += (double)ls;
-    ssq[0] += (double)lq;
-    __syncthreads();  // everyone done with the halo tile before it is restaged
+    ssum += (double)ls;
+    ssq += (double)lq;
+    __syncthreads();  // buffer cur^1 is complete; everyone is done reading buffer cur
+    cur ^= 1;
   }
-  block_stats_store<1>(ssum, ssq, red, partials + (size_t)blockIdx.x * 32);
+  // channel statistics of the 12 new channels: lanes with equal r (kk = 0..3), then the 8 waves
+  ssum += shfl_xor_d(ssum, 16);
+  ssum += shfl_xor_d(ssum, 32);
+  ssq += shfl_xor_d(ssq, 16);
+  ssq += shfl_xor_d(ssq, 32);
+  if (lane < 16) {
+    red[(wave * 16 + lane) * 2 + 0] = ssum;
+    red[(wave * 16 + lane) * 2 + 1] = ssq;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double t = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) t += red[w8 * 32 + tid];
+    partials[(size_t)blockIdx.x * 32 + tid] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------ conv0 (3 -> C0, 3x3, NCHW in)
@@ -601,10 +649,10 @@ extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, co
                                          eml_stream_t stream) {
   if (!Z || !scale2 || !shift2 || !W2p || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || c_out0 + 12 > ldx)
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_fwd_f32: bad arguments");
-  const size_t lds = (size_t)(kHH * kHW * kPS + 96) * sizeof(float) + 4 * 16 * 2 * sizeof(double);
+  const size_t lds = (size_t)(2 * kHH * kHW * kPS + 96) * sizeof(float) + 8 * 16 * 2 * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, Z, scale2, shift2, W2p, X, ldx,
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(grid), dim3(kC3Threads), lds, (hipStream_t)stream, Z, scale2, shift2, W2p, X, ldx,
                      c_out0, B, H, W, partials);
   return eml::check_launch("eml_dense_conv3x3_fwd_f32");
 }

@@ -3,6 +3,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from emlight_amd import _lib
+if os.environ.get('EML_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['EML_LIB_PATH']   # experiment builds (tools/exp_build.sh)
 L, p = _lib.lib(), _lib.ptr
 dev = "cuda"
 B = 64
