@@ -34,18 +34,26 @@ constexpr int kTH = 8, kTW = 32, kHH = kTH + 2, kHW = kTW + 2;
 
 // =============================================================================== conv3x3 backward: data
 // dzn[q][c] = sum_{dy,dx,o} W2[o][c][dy][dx] * g[(qy-dy+1, qx-dx+1)][o]
-constexpr int kPSG = 12;  // LDS pixel stride of the g halo tile
+// 512 threads = 8 waves, one output row of the 8x32 tile per wave (2 pixel tiles x 3 channel tiles of
+// accumulators), one workgroup per CU with 2 waves per SIMD.  Everything a tile needs from HBM is requested
+// inside the MFMA stream of the tile before it: the next g halo tile (registers -> second LDS buffer) and this
+// tile's z rows for the BN2 statistics, so a tile costs one barrier and no exposed HBM round trip.  The kernel
+// is HBM-bound (g 48 B + z 192 B in, dzn 192 B out per pixel against 81 MFMAs per 16 pixels).
+constexpr int kPSG = 14;  // LDS pixel stride of the g halo tile: 14 dwords makes the ds_read_b32 lane groups conflict-free
+constexpr int kBD = 512;
+constexpr int kGRows = 2;                                   // halo rows staged per pass
+constexpr int kGPass = kHH / kGRows;                        // 5 passes of float2 loads per thread
 
-__global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
+__global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
     double* __restrict__ partials /*[grid][48][2]*/) {
-  __shared__ __attribute__((aligned(16))) float g_l[kHH * kHW * kPSG];
-  __shared__ double red[4 * 48 * 2];
+  __shared__ __attribute__((aligned(16))) float g_l[2][kHH * kHW * kPSG];
+  __shared__ double red[8 * 48 * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
 
-  // B fragments: lane (kk, c = 16n + r) holds W2[o = 4s + kk][c][tap]
+  // A fragments (D^T form): lane (kk, c = 16n + r) holds W2[o = 4s + kk][c][tap]
   float bw[9][3][3];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -53,43 +61,75 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int n = 0; n < 3; ++n) bw[tap][s][n] = W2[((size_t)(4 * s + kk) * 48 + 16 * n + r) * 9 + tap];
-  float4 zm[3], zi[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    zm[n] = *reinterpret_cast<const float4*>(zmean + 16 * n + 4 * kk);
-    zi[n] = *reinterpret_cast<const float4*>(zistd + 16 * n + 4 * kk);
-  }
 
   const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
   const int ntiles = B * ty_n * tx_n;
-  double s1[3][4], s2[3][4];
-  float l1[3][4], l2[3][4];
+  double s1[3][4], s2[3][4];  // sum dzn, sum dzn*z  (xhat is applied to the f64 totals at the end)
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      s1[n][g] = s2[n][g] = 0.0;
-      l1[n][g] = l2[n][g] = 0.f;
-    }
+    for (int g = 0; g < 4; ++g) s1[n][g] = s2[n][g] = 0.0;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // staging map: 408 threads = 2 halo rows x 34 columns x 6 float2; threads >= 408 duplicate the last item.
+  const int st = min(tid, kGRows * kHW * 6 - 1);
+  const int s_row = st / (kHW * 6), s_rem = st - s_row * (kHW * 6);
+  const int s_hx = s_rem / 6, s_q = s_rem - 6 * s_hx;
+  const int s_dst = (s_row * kHW + s_hx) * kPSG + 2 * s_q;
+  float2 gt[kGPass];
+  const float* s_src = G;
+  int s_y0 = 0;
+  bool s_col = false;
+  auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
-    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
-    for (int e = tid; e < kHH * kHW * 6; e += 256) {  // (batching these 8 loads costs occupancy: slower)
-      const int pix = e / 6, q = e - pix * 6;
-      const int hy = pix / kHW, hx = pix - hy * kHW;
-      const int gy = y0 + hy, gx = x0 + hx;
-      float2 v = make_float2(0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *reinterpret_cast<const float2*>(G + ((size_t)(b * H + gy) * W + gx) * ldg + c0 + 2 * q);
-      *reinterpret_cast<float2*>(g_l + pix * kPSG + 2 * q) = v;
-    }
-    __syncthreads();
+    const int gx = tx * kTW - 1 + s_hx;
+    s_y0 = ty * kTH - 1 + s_row;
+    s_col = gx >= 0 && gx < W;
+    s_src = G + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * ldg + c0 + 2 * s_q;
+  };
+  auto stage_load = [&](int it) {  // unconditional (clamped): exec-masked loads make the compiler stall MFMAs on them
+    gt[it] = *reinterpret_cast<const float2*>(s_src + (size_t)min(max(s_y0 + kGRows * it, 0), H - 1) * W * ldg);
+  };
+  auto stage_commit = [&](int it, float* dst) {
+    const bool ok = s_col && s_y0 + kGRows * it >= 0 && s_y0 + kGRows * it < H;
+    float2 v;
+    v.x = ok ? gt[it].x : 0.f;
+    v.y = ok ? gt[it].y : 0.f;
+    *reinterpret_cast<float2*>(dst + s_dst + it * kGRows * kHW * kPSG) = v;
+  };
 
-    f32x4 acc[4][3];
+  int tile = blockIdx.x, cur = 0;
+  if (tile < ntiles) {
+    stage_begin(tile);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int it = 0; it < kGPass; ++it) stage_load(it);
+#pragma unroll
+    for (int it = 0; it < kGPass; ++it) stage_commit(it, g_l[0]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): bw[] is complete on every path into the loop (see conv3x3_fwd)
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    stage_begin(nxt < ntiles ? nxt : tile);
+    const float* gc = g_l[cur];
+    float* gn = g_l[cur ^ 1];
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int gy = ty * kTH + wave;
+    // this lane's two output pixels (row gy, columns 16m + r); clamped copies for the unconditional z loads
+    size_t prow[2];
+    bool pv[2];
+    float4 zr[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int gx = tx * kTW + 16 * m + r;
+      pv[m] = gy < H && gx < W;
+      prow[m] = ((size_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * 48;
+    }
+
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -97,52 +137,65 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
       const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        float a[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int hy = 2 * wave + (m >> 1) + 2 - dy, hx = 16 * (m & 1) + r + 2 - dx;
-          a[m] = g_l[(hy * kHW + hx) * kPSG + 4 * s + kk];
+        const int gi = tap * 3 + s;
+        if (gi < kGPass) {
+          stage_load(gi);
+          __builtin_amdgcn_sched_barrier(0);  // keep the request here; the scheduler would sink it to its use
+        } else if (gi < kGPass + 6) {
+          const int zi = gi - kGPass;
+          zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        float a[2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
+          a[m] = gc[((wave + 2 - dy) * kHW + 16 * m + r + 2 - dx) * kPSG + 4 * s + kk];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(bw[tap][s][n], a[m], acc[m][n]);  // D[channel][pixel]
-      }
-    }
-    // epilogue: lane owns channels 16n + 4kk .. +3 of pixel (row 2w + (m>>1), col 16(m&1) + r)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int gy = ty * kTH + 2 * wave + (m >> 1), gx = tx * kTW + 16 * (m & 1) + r;
-      if (gy < H && gx < W) {
-        const size_t p = (size_t)(b * H + gy) * W + gx;
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-          const int c4 = 16 * n + 4 * kk;
-          const float4 z = *reinterpret_cast<const float4*>(Z + p * 48 + c4);
-          const float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-          *reinterpret_cast<float4*>(DZ + p * 48 + c4) = v;
-          l1[n][0] += v.x;
-          l1[n][1] += v.y;
-          l1[n][2] += v.z;
-          l1[n][3] += v.w;
-          l2[n][0] = fmaf(v.x, (z.x - zm[n].x) * zi[n].x, l2[n][0]);
-          l2[n][1] = fmaf(v.y, (z.y - zm[n].y) * zi[n].y, l2[n][1]);
-          l2[n][2] = fmaf(v.z, (z.z - zm[n].z) * zi[n].z, l2[n][2]);
-          l2[n][3] = fmaf(v.w, (z.w - zm[n].w) * zi[n].w, l2[n][3]);
+        if (gi >= 27 - kGPass) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_commit(gi - (27 - kGPass), gn);
         }
       }
     }
-    // fold this tile's f32 sums into the f64 accumulators
+    // epilogue: lane owns channels 16n + 4kk .. +3 of its two pixels.  Statistics first (they wait for the z
+    // loads), stores after a scheduling fence: vmcnt counts in order, so a z wait placed after the stores
+    // would wait for the stores too.  The z registers are consumed unconditionally (masked value): a load whose
+    // only use is exec-masked stays "pending" for the compiler and costs a vmcnt(0) at the top of the next tile.
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < 3; ++n) {
+      float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float4 z = zr[m][n];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v = pv[m] ? acc[m][n][g] : 0.f;
+          l1[g] += v;
+          l2[g] = fmaf(v, f4c(z, g), l2[g]);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        s1[n][g] += (double)l1[n][g];
-        s2[n][g] += (double)l2[n][g];
-        l1[n][g] = 0.f;
-        l2[n][g] = 0.f;
+        s1[n][g] += (double)l1[g];
+        s2[n][g] += (double)l2[g];
       }
-    __syncthreads();
+    }
+    // vmcnt(0) HERE (only the z loads are outstanding, and they were requested a whole MFMA stream ago): the
+    // compiler sinks the statistics below the exec-masked stores, and its own wait there would cover the stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      if (pv[m]) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+          *reinterpret_cast<float4*>(DZ + prow[m] + 16 * n + 4 * kk) =
+              make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+      }
+    eml::lds_barrier();  // buffer cur^1 is complete; everyone is done reading buffer cur (LDS only: no wait for the stores)
+    cur ^= 1;
   }
 #pragma unroll
   for (int n = 0; n < 3; ++n)
@@ -159,100 +212,136 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(
       }
     }
   __syncthreads();
-  for (int e = tid; e < 96; e += 256)
-    partials[(size_t)blockIdx.x * 96 + e] = (red[e] + red[96 + e]) + (red[192 + e] + red[288 + e]);
+  if (tid < 48) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) {
+      t1 += red[(w8 * 48 + tid) * 2 + 0];
+      t2 += red[(w8 * 48 + tid) * 2 + 1];
+    }
+    // sum dzn*zhat = istd * (sum dzn*z - mean * sum dzn), in f64
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 0] = t1;
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 1] = (double)zistd[tid] * (t2 - (double)zmean[tid] * t1);
+  }
 }
 
 // =============================================================================== conv3x3 backward: weight
 // dW2[o][c][dy][dx] = sum_p g[p][o] * zn[p + (dy-1, dx-1)][c];  D[i=c][j=o], MFMA-k = pixel.
-// 27 (tap, 16-channel group) accumulator tiles are spread over the 4 waves (7,7,7,6).
-constexpr int kPSW = 48;
+// 512 threads = 8 waves: waves 0-3 contract the upper 4 rows of the 8x32 tile, waves 4-7 the lower 4; within a
+// half the 27 (tap, 16-channel group) accumulator tiles are spread over the 4 waves (7,7,7,6).  Each half writes
+// its own partial row.  The BN2(z) halo tile is double-buffered in LDS and, like the g operand registers, is
+// refilled for the NEXT tile from inside this tile's MFMA stream (see conv3x3_fwd_kernel); g[ks] is reloaded in
+// place right after its last use.
+constexpr int kPSW = 48;   // 48 dwords: the two pixels of a ds_read_b32 lane group fall on disjoint bank halves
+constexpr int kBW = 512;
 
-__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(
+__global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ Z, const float* __restrict__ scale2,
-    const float* __restrict__ shift2, int B, int H, int W, float* __restrict__ partial /*[grid][27][16][16]*/) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile_l = smem;                       // [kHH*kHW][48]
-  float* st_l = tile_l + kHH * kHW * kPSW;    // [2][48]
+    const float* __restrict__ shift2, int B, int H, int W, float* __restrict__ partial /*[2*grid][27][16][16]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][kHH*kHW][48]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
-  if (tid < 48) {
-    st_l[tid] = scale2[tid];
-    st_l[48 + tid] = shift2[tid];
-  }
-  __syncthreads();
+  const int half = wave >> 2, w4 = wave & 3;
   f32x4 acc[7];
-  int aoff[7];  // LDS offset of this wave's (tap, mc) pair relative to the pixel
+  int aoff[7];  // LDS offset of this wave's (tap, mc) pair relative to the pixel, plus the lane's own pixel
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int idx = min(wave + 4 * i, 26), tap = idx / 3, mc = idx - 3 * tap;
-    aoff[i] = ((tap / 3) * kHW + (tap % 3)) * kPSW + 16 * mc + r;
+    const int idx = min(w4 + 4 * i, 26), tap = idx / 3, mc = idx - 3 * tap;
+    aoff[i] = ((tap / 3 + 4 * half) * kHW + (tap % 3) + kk) * kPSW + 16 * mc + r;
   }
   const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
   const int ntiles = B * ty_n * tx_n;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+
+  // z staging map (as conv3x3_fwd): thread = (halo column, 16-byte slice), one halo row per pass
+  const int s_hx = min(tid / 12, kHW - 1), s_q = tid % 12;
+  const float4 sc = *reinterpret_cast<const float4*>(scale2 + 4 * s_q);
+  const float4 sh = *reinterpret_cast<const float4*>(shift2 + 4 * s_q);
+  const int s_dst = s_hx * kPSW + 4 * s_q;
+  float4 zt[kHH];
+  const float* s_src = Z;
+  int s_y0 = 0;
+  bool s_col = false;
+  // g operand of the tile being prefetched: lane (kk, o = r) needs g[pixel 128*half + 4*ks + kk][o]
+  float gb[32];
+  const float* g_src = G;
+  int g_y0 = 0, g_x0 = 0;
+  auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
-    const int y0 = ty * kTH - 1, x0 = tx * kTW - 1;
-    // B operand: lane (kk, o = r) needs g[pixel 4*ks + kk][o] for the 64 k-steps of the tile
-    float gb[64];
+    const int gx = tx * kTW - 1 + s_hx;
+    s_y0 = ty * kTH - 1;
+    s_col = gx >= 0 && gx < W;
+    s_src = Z + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * 48 + 4 * s_q;
+    g_y0 = ty * kTH + 4 * half;
+    g_x0 = tx * kTW + kk;
+    g_src = G + (size_t)b * H * W * ldg + c0 + min(r, 11);
+  };
+  auto stage_load = [&](int it) {
+    zt[it] = *reinterpret_cast<const float4*>(s_src + (size_t)min(max(s_y0 + it, 0), H - 1) * W * 48);
+  };
+  auto stage_commit = [&](int it, float* tile_l) {
+    const bool ok = s_col && s_y0 + it >= 0 && s_y0 + it < H;
+    float4 v;
+    v.x = ok ? fmaf(zt[it].x, sc.x, sh.x) : 0.f;
+    v.y = ok ? fmaf(zt[it].y, sc.y, sh.y) : 0.f;
+    v.z = ok ? fmaf(zt[it].z, sc.z, sh.z) : 0.f;
+    v.w = ok ? fmaf(zt[it].w, sc.w, sh.w) : 0.f;
+    *reinterpret_cast<float4*>(tile_l + s_dst + it * kHW * kPSW) = v;  // threads >= 408 duplicate column 33
+  };
+  auto g_load = [&](int ks) {  // unconditional, clamped; masked at use
+    const int gy = min(g_y0 + (ks >> 3), H - 1), gx = min(g_x0 + 4 * (ks & 7), W - 1);
+    gb[ks] = g_src[((size_t)gy * W + gx) * ldg];
+  };
+
+  int tile = blockIdx.x, cur = 0;
+  if (tile < ntiles) {
+    stage_begin(tile);
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) {
-      const int q = 4 * ks + kk, oy = q >> 5, ox = q & 31;
-      const int gy = ty * kTH + oy, gx = tx * kTW + ox;
-      gb[ks] = (gy < H && gx < W && r < 12) ? G[((size_t)(b * H + gy) * W + gx) * ldg + c0 + r] : 0.f;
-    }
-    {  // batched staging: 16 loads in flight, then BN2 + LDS writes
-      constexpr int NST = (kHH * kHW * 12 + 255) / 256;
-      float4 zt[NST];
-      unsigned inmask = 0;
+    for (int it = 0; it < kHH; ++it) stage_load(it);
 #pragma unroll
-      for (int it = 0; it < NST; ++it) {
-        const int e = tid + 256 * it;
-        const int pix = e / 12, q = e - pix * 12;
-        const int hy = pix / kHW, hx = pix - hy * kHW;
-        const int gy = y0 + hy, gx = x0 + hx;
-        const bool in = e < kHH * kHW * 12 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        zt[it] = in ? *reinterpret_cast<const float4*>(Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-        inmask |= (in ? 1u : 0u) << it;
+    for (int ks = 0; ks < 32; ++ks) g_load(ks);
+#pragma unroll
+    for (int it = 0; it < kHH; ++it) stage_commit(it, smem);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    // validity of THIS tile's g pixels (the registers hold clamped loads)
+    const int cy0 = g_y0, cx0 = g_x0;
+    const int nxt = tile + gridDim.x;
+    stage_begin(nxt < ntiles ? nxt : tile);
+    const float* tile_l = smem + cur * (kHH * kHW * kPSW);
+    float* tile_n = smem + (cur ^ 1) * (kHH * kHW * kPSW);
+    float av[2][7];  // A fragments are read one k-step ahead of their MFMAs (the fences below pin this order)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) av[0][i] = tile_l[aoff[i]];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks < kHH) stage_load(ks);
+      if (ks + 1 < 32) {
+        const float* base = tile_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool gok = r < 12 && cy0 + (ks >> 3) < H && cx0 + 4 * (ks & 7) < W;
+      const float gv = gok ? gb[ks] : 0.f;
 #pragma unroll
-      for (int it = 0; it < NST; ++it) {
-        const int e = tid + 256 * it;
-        const int pix = e / 12, q = e - pix * 12;
-        if (e < kHH * kHW * 12) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((inmask >> it) & 1u) {
-            const float4 s = *reinterpret_cast<const float4*>(st_l + 4 * q);
-            const float4 t = *reinterpret_cast<const float4*>(st_l + 48 + 4 * q);
-            v.x = fmaf(zt[it].x, s.x, t.x);
-            v.y = fmaf(zt[it].y, s.y, t.y);
-            v.z = fmaf(zt[it].z, s.z, t.z);
-            v.w = fmaf(zt[it].w, s.w, t.w);
-          }
-          *reinterpret_cast<float4*>(tile_l + pix * kPSW + 4 * q) = v;
-        }
-      }
+      for (int i = 0; i < 7; ++i) acc[i] = mfma16(av[ks & 1][i], gv, acc[i]);
+      g_load(ks);  // next tile's value, in place
+      if (ks >= 32 - kHH) stage_commit(ks - (32 - kHH), tile_n);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 64; ++ks) {
-      const int q = 4 * ks + kk, oy = q >> 5, ox = q & 31;
-      const float* base = tile_l + (oy * kHW + ox) * kPSW;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = mfma16(base[aoff[i]], gb[ks], acc[i]);
-    }
-    __syncthreads();
+    eml::lds_barrier();
+    cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int idx = wave + 4 * i;
+    const int idx = w4 + 4 * i;
     if (idx < 27) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        partial[(((size_t)blockIdx.x * 27 + idx) * 16 + 4 * kk + g) * 16 + r] = acc[i][g];
+        partial[((((size_t)blockIdx.x * 2 + half) * 27 + idx) * 16 + 4 * kk + g) * 16 + r] = acc[i][g];
     }
   }
 }
@@ -1031,7 +1120,7 @@ extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, c
   if (!G || !W2 || !Z || !zmean || !zistd || !DZ || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || (c0 & 1) ||
       (ldg & 1))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: bad arguments");
-  hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
+  hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
                      zistd, DZ, B, H, W, partials);
   return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
 }
@@ -1041,14 +1130,14 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
                                                 int grid, eml_stream_t stream) {
   if (!G || !Z || !scale2 || !shift2 || !partial || !dW2 || B < 1 || H < 1 || W < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_weight_f32: bad arguments");
-  const size_t lds = (size_t)(kHH * kHW * kPSW + 96) * sizeof(float);
+  const size_t lds = (size_t)(2 * kHH * kHW * kPSW) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_weight_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, G, ldg, c0, Z, scale2,
+  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(grid), dim3(kBW), lds, (hipStream_t)stream, G, ldg, c0, Z, scale2,
                      shift2, B, H, W, partial);
   int rc = eml::check_launch("eml_dense_conv3x3_bwd_weight_f32");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partial, grid,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partial, 2 * grid,
                      (size_t)27 * 256, 1, 0, 0, 0, dW2);
   return eml::check_launch("eml_dense_conv3x3_bwd_weight_f32(reduce)");
 }

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
 
   const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
   const int ntiles = B * ty_n * tx_n;
-  double ssum = 0.0, ssq = 0.0;
+  const bool aligned16 = ((c_out0 | ldx) & 3) == 0;  // block-uniform
+  double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
 
   // staging map: threads 0..407 = (halo column hx = tid/12, 16-byte slice q = tid%12), one halo ROW per pass:
   // the index math is tile-invariant and every LDS / global offset of pass `it` is base + it*const.
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // wave w owns output row w; M-tile m = 16 columns at 16*m
+    // wave w owns output row w; pixel tile m = 16 columns at 16*m.  D^T form (weights as the A operand): lane
+    // (r, kk) ends up with output channels 4kk..4kk+3 of pixel 16m + r -> one 16-byte store per pixel tile.
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
@@ -290,41 +292,55 @@ __global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[m] = mfma16(f4c(a[m], t), f4c(bw[tap][j], t), acc[m]);
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(f4c(bw[tap][j], t), f4c(a[m], t), acc[m]);
         if (gi >= 27 - kHH) {
           __builtin_amdgcn_sched_barrier(0);
           stage_commit(gi - (27 - kHH), tile_n);
         }
       }
     }
-    float ls = 0.f, lq = 0.f;
     const int gy = ty * kTH + wave;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      const int gx = tx * kTW + 16 * m + r;
+      const bool ok = gy < H && gx < W && kk < 3;  // channels 12..15 are MFMA padding
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int gx = tx * kTW + 16 * m + 4 * kk + g;
-        const float v = acc[m][g];
-        if (gy < H && gx < W && r < 12) {
-          X[((size_t)(b * H + gy) * W + gx) * ldx + c_out0 + r] = v;
-          ls += v;
-          lq = fmaf(v, v, lq);
+        const float v = ok ? acc[m][g] : 0.f;
+        ls[g] += v;
+        lq[g] = fmaf(v, v, lq[g]);
+      }
+      if (ok) {
+        float* dst = X + ((size_t)(b * H + gy) * W + gx) * ldx + c_out0 + 4 * kk;
+        if (aligned16) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        } else {  // third dense block: c_out0 = 150 + 12 l is only 8-byte aligned
+          *reinterpret_cast<float2*>(dst) = make_float2(acc[m][0], acc[m][1]);
+          *reinterpret_cast<float2*>(dst + 2) = make_float2(acc[m][2], acc[m][3]);
         }
       }
     }
-    ssum += (double)ls;
-    ssq += (double)lq;
-    __syncthreads();  // buffer cur^1 is complete; everyone is done reading buffer cur
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ssum[g] += (double)ls[g];
+      ssq[g] += (double)lq[g];
+    }
+    eml::lds_barrier();  // buffer cur^1 is complete; everyone is done reading buffer cur (LDS only: no wait for the stores)
     cur ^= 1;
   }
-  // channel statistics of the 12 new channels: lanes with equal r (kk = 0..3), then the 8 waves
-  ssum += shfl_xor_d(ssum, 16);
-  ssum += shfl_xor_d(ssum, 32);
-  ssq += shfl_xor_d(ssq, 16);
-  ssq += shfl_xor_d(ssq, 32);
-  if (lane < 16) {
-    red[(wave * 16 + lane) * 2 + 0] = ssum;
-    red[(wave * 16 + lane) * 2 + 1] = ssq;
+  // channel statistics of the 12 new channels: channel 4kk+g over the 16 pixel lanes r, then the 8 waves
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      ssum[g] += shfl_xor_d(ssum[g], o);
+      ssq[g] += shfl_xor_d(ssq[g], o);
+    }
+    if (r == 0) {
+      red[(wave * 16 + 4 * kk + g) * 2 + 0] = ssum[g];
+      red[(wave * 16 + 4 * kk + g) * 2 + 1] = ssq[g];
+    }
   }
   __syncthreads();
   if (tid < 32) {
@@ -647,7 +663,7 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
 extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* shift2, const float* W2p,
                                          float* X, int ldx, int c_out0, int B, int H, int W, double* partials, int grid,
                                          eml_stream_t stream) {
-  if (!Z || !scale2 || !shift2 || !W2p || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || c_out0 + 12 > ldx)
+  if (!Z || !scale2 || !shift2 || !W2p || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || c_out0 + 12 > ldx || (c_out0 & 1) || (ldx & 1))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_fwd_f32: bad arguments");
   const size_t lds = (size_t)(2 * kHH * kHW * kPS + 96) * sizeof(float) + 8 * 16 * 2 * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fwd_kernel),

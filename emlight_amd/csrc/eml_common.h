@@ -68,4 +68,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences GLOBAL memory at workgroup
+// scope, which the compiler implements as s_waitcnt vmcnt(0) before s_barrier: every barrier then waits for
+// all of the wave's outstanding global loads AND stores (a tile's epilogue stores, a prefetch in flight).
+// The persistent tile loops only hand LDS tiles between waves, so they use this one.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace eml

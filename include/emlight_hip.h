@@ -163,7 +163,7 @@ int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float*
                                    const float* zmean, const float* zistd, float* DZ, int B, int H,
                                    int W, double* partials, int grid, eml_stream_t stream);
 
-/* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: grid*27*256 floats. */
+/* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: 2*grid*27*256 floats (two pixel halves per block). */
 int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const float* Z,
                                      const float* scale2, const float* shift2, int B, int H, int W,
                                      float* partial, float* dW2, int grid, eml_stream_t stream);

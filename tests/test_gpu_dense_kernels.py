@@ -195,7 +195,7 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
     zh = (Z.double() - zmean.double()) * zistd.double()
     close(s1, dzn.sum(0), what="S1", rtol=1e-6, atol=1e-4)
     close(s2p, (dzn * zh).sum(0), what="S2", rtol=1e-6, atol=1e-4)
-    partW = torch.empty(G * 27 * 256, device=DEV)
+    partW = torch.empty(2 * G * 27 * 256, device=DEV)
     dW2 = torch.empty(12, 48, 3, 3, device=DEV)
     lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gd), ld, c0, p(Z), p(s2), p(t2), B, H, W, p(partW), p(dW2), G, st),
               "c3 bwd weight")
