@@ -527,42 +527,53 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
   // loads of UQ pixel-quads are issued back to back with no control flow between them.
   auto chunk_loop = [&](auto ngw_c) {
     constexpr int NGW = decltype(ngw_c)::value;
-    constexpr int UQ = POOL ? 2 : 4;      // pixel quads per batch
+    constexpr int UQ = POOL ? 1 : 4;      // pixel quads per batch
     constexpr int NS = POOL ? 4 : 1;      // input pixels per output pixel
+    constexpr int NB = 16 / UQ;           // operand batches per 64-pixel chunk (even)
+    // x operand of one batch: UNCONDITIONAL loads from clamped pixels (validity is applied when the value is
+    // used); they are requested ONE BATCH AHEAD of their MFMAs, across chunk boundaries -- issued right before
+    // use they exposed an HBM round trip per batch (ISA: global_load; s_waitcnt vmcnt; v_mfma).
+    float2 xr[2][UQ][NGW > 0 ? NGW : 1][NS];
+    auto load_batch = [&](int chunk, int q0, float2 (&dst)[UQ][NGW > 0 ? NGW : 1][NS]) {
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        const int pc = min(chunk * 64 + 4 * (q0 + u) + kk, P - 1);
+        const float* xp;
+        if constexpr (POOL) {
+          const int b = pc / (Ho * Wo), rem = pc - b * (Ho * Wo);
+          const int oy = rem / Wo, ox = rem - oy * Wo;
+          xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
+        } else {
+          xp = X + (size_t)pc * ldx;
+        }
+#pragma unroll
+        for (int i = 0; i < NGW; ++i)
+#pragma unroll
+          for (int sub = 0; sub < NS; ++sub)
+            dst[u][i][sub] = *reinterpret_cast<const float2*>(xp + ((sub >> 1) * (size_t)Win + (sub & 1)) * ldx + coff[i]);
+      }
+    };
     stage_load(blockIdx.x);
     stage_write(dz_l[0]);
+    if constexpr (NGW > 0) load_batch(min((int)blockIdx.x, nchunks - 1), 0, xr[0]);
     __syncthreads();
     int it = 0;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
       const float* dzb = dz_l[it & 1];
       stage_load(chunk + gridDim.x);  // next chunk's loads fly during this chunk's MFMAs
       if constexpr (NGW > 0) {
-        for (int q0 = 0; q0 < 16; q0 += UQ) {
-          float2 xr[UQ][NGW][NS];
-          bool pvs[UQ];
 #pragma unroll
-          for (int u = 0; u < UQ; ++u) {
-            const int p = chunk * 64 + 4 * (q0 + u) + kk;
-            pvs[u] = p < P;
-            const int pc = pvs[u] ? p : P - 1;
-            const float* xp;
-            if constexpr (POOL) {
-              const int b = pc / (Ho * Wo), rem = pc - b * (Ho * Wo);
-              const int oy = rem / Wo, ox = rem - oy * Wo;
-              xp = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx;
-            } else {
-              xp = X + (size_t)pc * ldx;
-            }
-#pragma unroll
-            for (int i = 0; i < NGW; ++i)
-#pragma unroll
-              for (int sub = 0; sub < NS; ++sub)
-                xr[u][i][sub] =
-                    *reinterpret_cast<const float2*>(xp + ((sub >> 1) * (size_t)Win + (sub & 1)) * ldx + coff[i]);
-          }
+        for (int bi = 0; bi < NB; ++bi) {
+          const int q0 = bi * UQ;
+          if (bi + 1 < NB)
+            load_batch(chunk, q0 + UQ, xr[(bi + 1) & 1]);
+          else
+            load_batch(min(chunk + (int)gridDim.x, nchunks - 1), 0, xr[0]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < UQ; ++u) {
             const int pl = 4 * (q0 + u) + kk;
+            const bool pvu = chunk * 64 + pl < P;
             float bz[3];
 #pragma unroll
             for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
@@ -571,14 +582,14 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
               float ax = 0.f, ay = 0.f;
 #pragma unroll
               for (int sub = 0; sub < NS; ++sub) {
-                ax += fmaxf(fmaf(xr[u][i][sub].x, s2[i].x, t2[i].x), 0.f);
-                ay += fmaxf(fmaf(xr[u][i][sub].y, s2[i].y, t2[i].y), 0.f);
+                ax += fmaxf(fmaf(xr[bi & 1][u][i][sub].x, s2[i].x, t2[i].x), 0.f);
+                ay += fmaxf(fmaf(xr[bi & 1][u][i][sub].y, s2[i].y, t2[i].y), 0.f);
               }
               if constexpr (POOL) {
                 ax *= 0.25f;
                 ay *= 0.25f;
               }
-              if (!pvs[u]) ax = ay = 0.f;
+              if (!pvu) ax = ay = 0.f;
 #pragma unroll
               for (int n = 0; n < 3; ++n) {
                 acc[i][0][n] = mfma16(ax, bz[n], acc[i][0][n]);
@@ -586,6 +597,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
               }
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       stage_write(dz_l[(it + 1) & 1]);
