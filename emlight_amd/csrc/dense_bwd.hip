@@ -808,16 +808,42 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
                                                                         int k_lo, int k_hi, float* __restrict__ Gd,
                                                                         int ldg, int KpMax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  double* sacc = reinterpret_cast<double*>(smem);  // [NL][4 waves][KpMax][2]
+  double* sacc = reinterpret_cast<double*>(smem);                         // [NL][4 waves][KpMax][2]
+  float* vec_l = reinterpret_cast<float*>(sacc + (size_t)NL * 4 * KpMax * 2);  // [2 + 2*NL][KpMax]: mean, istd, (scale1, shift1) per layer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
-  for (int e = tid; e < NL * 4 * KpMax * 2; e += 256) sacc[e] = 0.0;
-  __syncthreads();
   const BwdLayer Ls[2] = {L0, L1};
+  for (int e = tid; e < NL * 4 * KpMax * 2; e += 256) sacc[e] = 0.0;
+  for (int e = tid; e < KpMax; e += 256) {
+    vec_l[e] = mean[e];
+    vec_l[KpMax + e] = istd[e];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      vec_l[(2 + 2 * j) * KpMax + e] = e < Ls[j].Kp ? Ls[j].scale1[e] : 0.f;
+      vec_l[(3 + 2 * j) * KpMax + e] = e < Ls[j].Kp ? Ls[j].shift1[e] : 0.f;
+    }
+  }
+  __syncthreads();
   constexpr int TP = 64 * MT;  // pixels per workgroup tile
   const int ntiles = (P + TP - 1) / TP;
   const int nt_lo = k_lo >> 4, nt_hi = (k_hi + 15) >> 4;
   constexpr int NCH = 2;
+
+  // Weight fragments of step (chunk, layer) are requested one step ahead of their MFMAs (they come from L2: issued
+  // just in time, every step began with an exposed round trip).  Two register sets alternate.
+  float4 wq[2][3][NCH];
+  auto load_w = [&](int j, int nt0, float4 (&dst)[3][NCH]) {
+    const int nnt = Ls[j].Kp >> 4;
+#pragma unroll
+    for (int jo = 0; jo < 3; ++jo)
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        const int nt = min(nt0 + n, nnt - 1);
+        dst[jo][n] = *reinterpret_cast<const float4*>(Ls[j].Wd + ((((size_t)nt * 3 + jo) * 4 + kk) * 16 + r) * 4);
+      }
+  };
+  load_w(0, nt_lo, wq[0]);
+  int wsel = 0;  // register set holding the weights of the step about to run (compile-time after unrolling for NL = 2)
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = tile * TP + wave * 16 * MT;
@@ -860,10 +886,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
           xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4);
         }
       }
+      const int nt_next = nt0 + NCH < nt_hi ? nt0 + NCH : nt_lo;  // the next tile starts at nt_lo again
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int nnt = Ls[j].Kp >> 4;
-        if (nt0 >= nnt) continue;  // this layer has no channels here (block-uniform)
+        // request the NEXT step's weights, then run this step
+        const int cur = NL == 2 ? j : wsel;
+        if (j + 1 < NL)
+          load_w(j + 1, nt0, wq[cur ^ 1]);
+        else
+          load_w(0, nt_next, wq[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[MT][NCH];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -872,48 +905,45 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
 #pragma unroll
         for (int jo = 0; jo < 3; ++jo)
 #pragma unroll
-          for (int n = 0; n < NCH; ++n) {
-            const int nt = min(nt0 + n, nnt - 1);
-            const float4 w = *reinterpret_cast<const float4*>(Ls[j].Wd + ((((size_t)nt * 3 + jo) * 4 + kk) * 16 + r) * 4);
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int n = 0; n < NCH; ++n)
 #pragma unroll
-              for (int m = 0; m < MT; ++m) acc[m][n] = mfma16(f4c(w, t), f4c(dz[j][jo][m], t), acc[m][n]);
-          }
+              for (int m = 0; m < MT; ++m) acc[m][n] = mfma16(f4c(wq[cur][jo][n], t), f4c(dz[j][jo][m], t), acc[m][n]);
+        if (NL == 1) wsel ^= 1;
         double* my = sacc + ((size_t)(j * 4 + wave) * KpMax) * 2;
 #pragma unroll
         for (int n = 0; n < NCH; ++n) {
           const int nt = nt0 + n;
-          if (nt < nnt && nt < nt_hi) {
+          if (nt < nnt && nt < nt_hi) {  // block-uniform
             const int k4 = 16 * nt + 4 * kk;
-            const float4 sk = *reinterpret_cast<const float4*>(Ls[j].scale1 + k4);
-            const float4 tk = *reinterpret_cast<const float4*>(Ls[j].shift1 + k4);
-            const float4 mu = *reinterpret_cast<const float4*>(mean + k4);
-            const float4 is = *reinterpret_cast<const float4*>(istd + k4);
+            const float4 mu = *reinterpret_cast<const float4*>(vec_l + k4);
+            const float4 is = *reinterpret_cast<const float4*>(vec_l + KpMax + k4);
+            const float4 sk = *reinterpret_cast<const float4*>(vec_l + (2 + 2 * j) * KpMax + k4);
+            const float4 tk = *reinterpret_cast<const float4*>(vec_l + (3 + 2 * j) * KpMax + k4);
             const bool in0 = k4 + 0 >= k_lo && k4 + 0 < k_hi, in1 = k4 + 1 >= k_lo && k4 + 1 < k_hi;
             const bool in2 = k4 + 2 >= k_lo && k4 + 2 < k_hi, in3 = k4 + 3 >= k_lo && k4 + 3 < k_hi;
             float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-              if (pv[m]) {
-                const float4 x = xv[m][n];
-                const float d0 = (in0 && fmaf(x.x, sk.x, tk.x) > 0.f) ? acc[m][n][0] : 0.f;
-                const float d1 = (in1 && fmaf(x.y, sk.y, tk.y) > 0.f) ? acc[m][n][1] : 0.f;
-                const float d2 = (in2 && fmaf(x.z, sk.z, tk.z) > 0.f) ? acc[m][n][2] : 0.f;
-                const float d3 = (in3 && fmaf(x.w, sk.w, tk.w) > 0.f) ? acc[m][n][3] : 0.f;
-                gs[m][n].x = fmaf(sk.x, d0, gs[m][n].x);
-                gs[m][n].y = fmaf(sk.y, d1, gs[m][n].y);
-                gs[m][n].z = fmaf(sk.z, d2, gs[m][n].z);
-                gs[m][n].w = fmaf(sk.w, d3, gs[m][n].w);
-                l1[0] += d0;
-                l1[1] += d1;
-                l1[2] += d2;
-                l1[3] += d3;
-                l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
-                l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
-                l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
-                l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
-              }
+              // unconditional use of the loaded x / g (masked values): see conv3x3_bwd_data_kernel
+              const float4 x = xv[m][n];
+              const float d0 = (pv[m] && in0 && fmaf(x.x, sk.x, tk.x) > 0.f) ? acc[m][n][0] : 0.f;
+              const float d1 = (pv[m] && in1 && fmaf(x.y, sk.y, tk.y) > 0.f) ? acc[m][n][1] : 0.f;
+              const float d2 = (pv[m] && in2 && fmaf(x.z, sk.z, tk.z) > 0.f) ? acc[m][n][2] : 0.f;
+              const float d3 = (pv[m] && in3 && fmaf(x.w, sk.w, tk.w) > 0.f) ? acc[m][n][3] : 0.f;
+              gs[m][n].x = fmaf(sk.x, d0, gs[m][n].x);
+              gs[m][n].y = fmaf(sk.y, d1, gs[m][n].y);
+              gs[m][n].z = fmaf(sk.z, d2, gs[m][n].z);
+              gs[m][n].w = fmaf(sk.w, d3, gs[m][n].w);
+              l1[0] += d0;
+              l1[1] += d1;
+              l1[2] += d2;
+              l1[3] += d3;
+              l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
+              l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
+              l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
+              l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1259,7 +1289,12 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
     if (Kp[s] > kmax) kmax = Kp[s];
   }
   if (((k_hi + 15) & ~15) > kmax) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: range beyond Kp");
-  const size_t lds = (size_t)n_layers * 4 * kmax * 2 * sizeof(double);
+  const size_t lds = (size_t)n_layers * 4 * kmax * 2 * sizeof(double) + (size_t)(2 + 2 * n_layers) * kmax * sizeof(float);
+  if (lds > 80 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Kp=%d does not fit LDS", kmax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<1, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<2, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (n_layers == 1)
     hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<1, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, L[0],
                        L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);

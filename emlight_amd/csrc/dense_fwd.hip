@@ -89,24 +89,47 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
   }
   __syncthreads();
 
-  double ssum[3] = {0, 0, 0}, ssq[3] = {0, 0, 0};
+  // D^T form (weights as the MFMA A operand): lane (r, kk) owns output channels 16n + 4kk .. +3 of pixel
+  // p0 + 16m + r -> 16-byte stores; per-lane statistics of those 12 channels.
+  double ssum[3][4], ssq[3][4];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ssum[n][g] = ssq[n][g] = 0.0;
   const int nj = Kp >> 4;
   const int ntiles = (P + 255) >> 8;
   const int Wo = Win >> 1, Ho = Hin >> 1;
+  const bool vec_ok = (ldo & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  auto row_ptr = [&](int tile, int m) -> const float* {
+    const int pm = min(tile * 256 + wave * 64 + 16 * m + r, P - 1);
+    if constexpr (POOL) {
+      const int b = pm / (Ho * Wo), rem = pm - b * (Ho * Wo);
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      return X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx + 4 * kk;
+    } else {
+      return X + (size_t)pm * ldx + 4 * kk;
+    }
+  };
+  // Dense layers (!POOL): the raw x of K-step j+1 -- or of the next tile's first K-step -- is requested before the
+  // MFMAs of K-step j (unconditional loads, clamped rows).  Issued inside its own K-step, every 16-channel step
+  // exposed an HBM round trip (ISA: global_load; s_waitcnt vmcnt; v_mfma).
+  float4 xn[4];
+  int tile = blockIdx.x;
+  if constexpr (!POOL) {
+    if (tile < ntiles) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(row_ptr(tile, m));
+    }
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
     const int p0 = tile * 256 + wave * 64;
     const float* rp[4];
+    const float* rpn[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int pm = min(p0 + 16 * m + r, P - 1);
-      if constexpr (POOL) {
-        const int b = pm / (Ho * Wo), rem = pm - b * (Ho * Wo);
-        const int oy = rem / Wo, ox = rem - oy * Wo;
-        rp[m] = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx + 4 * kk;
-      } else {
-        rp[m] = X + (size_t)pm * ldx + 4 * kk;
-      }
+      rp[m] = row_ptr(tile, m);
+      if constexpr (!POOL) rpn[m] = row_ptr(min(tile + (int)gridDim.x, ntiles - 1), m);
     }
     f32x4 acc[4][3];
 #pragma unroll
@@ -114,13 +137,13 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int j = 0; j < nj; ++j) {
+    auto kstep = [&](int j) {
       const float4 s4 = *reinterpret_cast<const float4*>(sl + 16 * j + 4 * kk);
       const float4 t4 = *reinterpret_cast<const float4*>(tl + 16 * j + 4 * kk);
       float4 a[4];
+      if constexpr (POOL) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if constexpr (POOL) {
+        for (int m = 0; m < 4; ++m) {
           const float* q = rp[m] + 16 * j;
           const float4 v0 = bn_relu4(*reinterpret_cast<const float4*>(q), s4, t4);
           const float4 v1 = bn_relu4(*reinterpret_cast<const float4*>(q + ldx), s4, t4);
@@ -130,9 +153,17 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
           a[m].y = ((v0.y + v1.y) + (v2.y + v3.y)) * 0.25f;
           a[m].z = ((v0.z + v1.z) + (v2.z + v3.z)) * 0.25f;
           a[m].w = ((v0.w + v1.w) + (v2.w + v3.w)) * 0.25f;
-        } else {
-          a[m] = bn_relu4(*reinterpret_cast<const float4*>(rp[m] + 16 * j), s4, t4);
         }
+      } else {
+        float4 xc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xc[m] = xn[m];
+        const bool last = j + 1 == nj;  // wave-uniform
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(last ? rpn[m] : rp[m] + 16 * (j + 1));
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
       }
       float4 bw[3];
 #pragma unroll
@@ -143,30 +174,65 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(f4c(a[m], t), f4c(bw[n], t), acc[m][n]);
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(f4c(bw[n], t), f4c(a[m], t), acc[m][n]);
+    };
+    if constexpr (POOL) {
+      for (int j = 0; j < nj; ++j) kstep(j);
+    } else {
+#pragma unroll 2
+      for (int j = 0; j < nj; ++j) kstep(j);
     }
-    // epilogue: C/D layout col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel)
+    // epilogue: D rows = channels 16n + 4kk + g, column = pixel 16m + r
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
-      const int col = 16 * n + r;
-      float ls = 0.f, lq = 0.f;
+      const int c4 = 16 * n + 4 * kk;
+      float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m) {
+        const int p = p0 + 16 * m + r;
+        const bool pv = p < P;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int p = p0 + 16 * m + 4 * kk + g;
-          const float v = acc[m][n][g];
-          if (p < P && col < n_valid) {
-            out[(size_t)p * ldo + col] = v;
-            ls += v;
-            lq = fmaf(v, v, lq);
+          const float v = (pv && c4 + g < n_valid) ? acc[m][n][g] : 0.f;
+          ls[g] += v;
+          lq[g] = fmaf(v, v, lq[g]);
+        }
+        if (pv) {
+          float* dst = out + (size_t)p * ldo + c4;
+          if (vec_ok && c4 + 4 <= n_valid) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              if (c4 + g < n_valid) dst[g] = acc[m][n][g];
           }
         }
-      ssum[n] += (double)ls;
-      ssq[n] += (double)lq;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ssum[n][g] += (double)ls[g];
+        ssq[n][g] += (double)lq[g];
+      }
     }
   }
-  block_stats_store<3>(ssum, ssq, red, partials + (size_t)blockIdx.x * 96);
+  // channel statistics: over the 16 pixel lanes r, then the 4 waves
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        ssum[n][g] += shfl_xor_d(ssum[n][g], o);
+        ssq[n][g] += shfl_xor_d(ssq[n][g], o);
+      }
+      if (r == 0) {
+        red[(wave * 48 + 16 * n + 4 * kk + g) * 2 + 0] = ssum[n][g];
+        red[(wave * 48 + 16 * n + 4 * kk + g) * 2 + 1] = ssq[n][g];
+      }
+    }
+  __syncthreads();
+  for (int e = tid; e < 96; e += 256)
+    partials[(size_t)blockIdx.x * 96 + e] = (red[e] + red[96 + e]) + (red[192 + e] + red[288 + e]);
 }
 
 // ------------------------------------------------------------------------------ conv3x3
