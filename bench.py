@@ -58,7 +58,7 @@ def family_bytes(B, crop_hw):
             by["eml_dense_conv1x1_fwd_f32"] += (k + 48) * 4 * P          # X[:, :k] in, Z out
             by["eml_dense_conv1x1_bwd_weight_f32"] += (k + 96) * 4 * P   # X[:, :k], DZ, Z in
             by["eml_dense_conv3x3_fwd_f32"] += (48 + 12) * 4 * P         # Z in, 12 new channels out
-            by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 48 + 48) * 4 * P   # dY, Z (BN2 statistics) in, DZ out
+            by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 12 + 48 + 48 + 12) * 4 * P  # G, X (deferred affine), Z in; DZ, GF out
             by["eml_dense_conv3x3_bwd_weight_f32"] += (12 + 48) * 4 * P  # dY, Z in
             if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
                 by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((3 * 12 + 96) + (3 * k + 192)) * 4 * P

@@ -21,6 +21,7 @@ class _BwdBuffers:
         self.GF = torch.zeros(ws.F.shape[0], ws.F.shape[1], **f32)
         maxP = ws.blocks[0]["P"]
         self.DZ = torch.empty(2, maxP, 48, **f32)   # one per layer of a pair
+        self.GF12 = torch.empty(maxP, 12, **f32)    # finished gradient of a layer's 12 output channels (compact)
         self.Wd = torch.empty(2, 352 * 176, **f32)
         self.coef = torch.zeros(8, 384, **f32)  # two (cA,cB,cC) sets for dz, then sB, sC
         self.part2 = torch.zeros(2, enc.grid_max * 352 * 2, dtype=torch.float64, device=dev)
@@ -105,11 +106,13 @@ def run_backward(enc, ws, x, gpooled):
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
             cin, kp, z, dz = lay["Cin"], lay["Kp"], blk["Z"][l], bw.DZ[slot]
-            materialize(Gbuf, blk, cin, 12)  # gradient of this layer's 12 output channels is complete
+            # the gradient of this layer's 12 output channels is complete: its deferred BN1 affine (sB, sC) is
+            # applied inside the conv3x3 dgrad's tile staging, which also leaves the finished gradient in GF12
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gbuf), ld, cin, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
-                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G, st),
+                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G, p(blk["X"]), ld,
+                                                        p(sB), p(sC), p(bw.GF12), st),
                        "eml_dense_conv3x3_bwd_data_f32")
-            _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gbuf), ld, cin, p(z), p(lay["scale2"]), p(lay["shift2"]),
+            _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12), 12, 0, p(z), p(lay["scale2"]), p(lay["shift2"]),
                                                           B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G, st),
                        "eml_dense_conv3x3_bwd_weight_f32")
             finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)

@@ -44,10 +44,15 @@ constexpr int kBD = 512;
 constexpr int kGRows = 2;                                   // halo rows staged per pass
 constexpr int kGPass = kHH / kGRows;                        // 5 passes of float2 loads per thread
 
+// FUSE: g = G + sB*X + sC (the deferred BN1 affine of the block gradient, see grad_materialize_kernel) is applied
+// while the halo tile is staged, and the finished 12-channel gradient of the tile's own pixels is written to the
+// compact GF (P,12) for conv3x3_bwd_weight -- instead of a separate read-modify-write pass over G.
+template <bool FUSE>
 __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
-    double* __restrict__ partials /*[grid][48][2]*/) {
+    double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx,
+    const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF) {
   __shared__ __attribute__((aligned(16))) float g_l[2][kHH * kHW * kPSG];
   __shared__ double red[8 * 48 * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,27 +80,52 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   const int s_row = st / (kHW * 6), s_rem = st - s_row * (kHW * 6);
   const int s_hx = s_rem / 6, s_q = s_rem - 6 * s_hx;
   const int s_dst = (s_row * kHW + s_hx) * kPSG + 2 * s_q;
-  float2 gt[kGPass];
+  float2 gt[kGPass], xt[FUSE ? kGPass : 1];
+  float2 fb = make_float2(0.f, 0.f), fc = make_float2(0.f, 0.f);
+  if constexpr (FUSE) {
+    fb = *reinterpret_cast<const float2*>(sB + c0 + 2 * s_q);
+    fc = *reinterpret_cast<const float2*>(sC + c0 + 2 * s_q);
+  }
   const float* s_src = G;
+  const float* s_srcx = Xb;
+  float* s_gf = GF;
   int s_y0 = 0;
-  bool s_col = false;
+  bool s_col = false, s_own = false;
   auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
     const int gx = tx * kTW - 1 + s_hx;
     s_y0 = ty * kTH - 1 + s_row;
     s_col = gx >= 0 && gx < W;
-    s_src = G + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * ldg + c0 + 2 * s_q;
+    const size_t col = (size_t)b * H * W + min(max(gx, 0), W - 1);
+    s_src = G + col * ldg + c0 + 2 * s_q;
+    if constexpr (FUSE) {
+      s_srcx = Xb + col * ldx + c0 + 2 * s_q;
+      s_gf = GF + col * 12 + 2 * s_q;
+      s_own = s_col && tid < kGRows * kHW * 6 && s_hx >= 1 && s_hx <= kTW;  // a column of the tile itself (not halo)
+    }
   };
   auto stage_load = [&](int it) {  // unconditional (clamped): exec-masked loads make the compiler stall MFMAs on them
-    gt[it] = *reinterpret_cast<const float2*>(s_src + (size_t)min(max(s_y0 + kGRows * it, 0), H - 1) * W * ldg);
+    const size_t row = (size_t)min(max(s_y0 + kGRows * it, 0), H - 1) * W;
+    gt[it] = *reinterpret_cast<const float2*>(s_src + row * ldg);
+    if constexpr (FUSE) xt[it] = *reinterpret_cast<const float2*>(s_srcx + row * ldx);
   };
   auto stage_commit = [&](int it, float* dst) {
-    const bool ok = s_col && s_y0 + kGRows * it >= 0 && s_y0 + kGRows * it < H;
+    const int gy = s_y0 + kGRows * it;
+    const bool ok = s_col && gy >= 0 && gy < H;
     float2 v;
-    v.x = ok ? gt[it].x : 0.f;
-    v.y = ok ? gt[it].y : 0.f;
+    if constexpr (FUSE) {
+      v.x = ok ? fmaf(fb.x, xt[it].x, gt[it].x) + fc.x : 0.f;
+      v.y = ok ? fmaf(fb.y, xt[it].y, gt[it].y) + fc.y : 0.f;
+    } else {
+      v.x = ok ? gt[it].x : 0.f;
+      v.y = ok ? gt[it].y : 0.f;
+    }
     *reinterpret_cast<float2*>(dst + s_dst + it * kGRows * kHW * kPSG) = v;
+    if constexpr (FUSE) {
+      const int hy = s_row + kGRows * it;  // halo row 0..9; rows 1..8 are the tile's own
+      if (s_own && ok && hy >= 1 && hy <= kTH) *reinterpret_cast<float2*>(s_gf + (size_t)gy * W * 12) = v;
+    }
   };
 
   int tile = blockIdx.x, cur = 0;
@@ -1158,12 +1188,20 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
 // =============================================================================== C ABI
 extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                               const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
-                                              double* partials, int grid, eml_stream_t stream) {
+                                              double* partials, int grid, const float* X, int ldx, const float* sB,
+                                              const float* sC, float* GF, eml_stream_t stream) {
   if (!G || !W2 || !Z || !zmean || !zistd || !DZ || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || (c0 & 1) ||
       (ldg & 1))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: bad arguments");
-  hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
-                     zistd, DZ, B, H, W, partials);
+  if (X) {
+    if (!sB || !sC || !GF || (ldx & 1))
+      return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: fused affine needs X, sB, sC, GF");
+    hipLaunchKernelGGL(conv3x3_bwd_data_kernel<true>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
+                       zmean, zistd, DZ, B, H, W, partials, X, ldx, sB, sC, GF);
+  } else {
+    hipLaunchKernelGGL(conv3x3_bwd_data_kernel<false>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
+                       zmean, zistd, DZ, B, H, W, partials, nullptr, 0, nullptr, nullptr, nullptr);
+  }
   return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
 }
 

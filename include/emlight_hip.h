@@ -158,10 +158,14 @@ int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, in
  * G mirrors the block buffer X and accumulates d loss / d X.  BatchNorm backward is affine per
  * channel, dx = cA*dy + cB*x + cC, so it is folded into the operand loads of the consumers. */
 
-/* dzn = conv2^T(G[:, c0:c0+12]) -> DZ (B,H,W,48); partials [grid][48][2] = (sum dzn, sum dzn*zhat). */
+/* dzn = conv2^T(g) -> DZ (B,H,W,48); partials [grid][48][2] = (sum dzn, sum dzn*zhat).
+ * X == NULL: g = G[:, c0:c0+12].  X != NULL: the deferred BN1 affine is applied on the fly,
+ * g = G[:, c] + sB[c]*X[:, c] + sC[c] (what eml_dense_grad_materialize_f32 would write), and g is also
+ * stored compactly to GF (B*H*W, 12) for eml_dense_conv3x3_bwd_weight_f32(GF, 12, 0, ...). */
 int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                    const float* zmean, const float* zistd, float* DZ, int B, int H,
-                                   int W, double* partials, int grid, eml_stream_t stream);
+                                   int W, double* partials, int grid, const float* X, int ldx,
+                                   const float* sB, const float* sC, float* GF, eml_stream_t stream);
 
 /* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: 2*grid*27*256 floats (two pixel halves per block). */
 int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const float* Z,

@@ -183,8 +183,20 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
     zmean, zistd = rnd(48, scale=0.1), torch.rand(48, device=DEV) + 0.5
     DZ = torch.empty(P, 48, device=DEV)
     part = torch.zeros(G * 96, dtype=torch.float64, device=DEV)
+    # fused deferred affine: g = G + sB*X + sC on the layer's 12 channels, also written compactly to GF
+    X = rnd(P, ld)
+    sB, sC = rnd(ld, scale=0.3), rnd(ld, scale=0.3)
+    GF = torch.full((P, 12), 7.0, device=DEV)
     lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, c0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
-                                               st), "c3 bwd data")
+                                               p(X), ld, p(sB), p(sC), p(GF), st), "c3 bwd data (fused affine)")
+    gfull = Gd[:, c0:c0 + 12].double() + sB[c0:c0 + 12].double() * X[:, c0:c0 + 12].double() + sC[c0:c0 + 12].double()
+    close(GF, gfull, what="GF", rtol=1e-6, atol=1e-6)
+    zn0 = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
+    (F.conv2d(zn0, W2.double(), padding=1) * nchw(gfull, B, H, W)).sum().backward()
+    close(DZ, nhwc(zn0.grad), what="dzn (fused affine)")
+    # plain form (X == NULL)
+    lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, c0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
+                                               None, 0, None, None, None, st), "c3 bwd data")
     zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
     w = W2.double().requires_grad_(True)
     g = nchw(Gd[:, c0:c0 + 12].double(), B, H, W)
@@ -200,6 +212,10 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
     lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gd), ld, c0, p(Z), p(s2), p(t2), B, H, W, p(partW), p(dW2), G, st),
               "c3 bwd weight")
     close(dW2, w.grad, what="dW2", rtol=1e-4)
+    Gc = Gd[:, c0:c0 + 12].contiguous()  # the compact (P,12) form the engine passes
+    lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(Gc), 12, 0, p(Z), p(s2), p(t2), B, H, W, p(partW), p(dW2), G, st),
+              "c3 bwd weight (compact g)")
+    close(dW2, w.grad, what="dW2 (compact g)", rtol=1e-4)
 
 
 def test_bn_bwd_finalize(lib):

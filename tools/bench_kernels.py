@@ -32,6 +32,7 @@ for (Hb, Wb, Cin, ld) in [(240, 320, 48, 224), (240, 320, 120, 224), (240, 320, 
     W1p = torch.empty(Kp * 48, device=dev); W2p = torch.empty(6912, device=dev); Wd = torch.empty(Kp * 48, device=dev)
     L.eml_dense_permute_w1_f32(p(W1), 48, Cin, Kp, p(W1p), st); L.eml_dense_permute_w2_f32(p(W2), 12, p(W2p), st)
     L.eml_dense_permute_w1_bwd_f32(p(W1), 48, Cin, Kp, 48, p(Wd), st)
+    GF = torch.empty(P, 12, device=dev)
     part = torch.zeros(4 * 1024 * 96, dtype=torch.float64, device=dev)
     partW = torch.empty(1024 * 352 * 48, device=dev)
     dW1 = torch.empty(48, Cin, device=dev); dW2 = torch.empty(12, 48, 3, 3, device=dev)
@@ -39,7 +40,7 @@ for (Hb, Wb, Cin, ld) in [(240, 320, 48, 224), (240, 320, 120, 224), (240, 320, 
     fns = {
         "c1x1_fwd": (lambda: L.eml_dense_conv1x1_fwd_f32(p(X), ld, P, Hb, Wb, 0, Kp, p(s1), p(t1), p(W1p), 48, p(Z), 48, p(part), G, st), fl1),
         "c3x3_fwd": (lambda: L.eml_dense_conv3x3_fwd_f32(p(Z), p(s2), p(t2), p(W2p), p(X), ld, Cin, B, Hb, Wb, p(part), G, st), fl2),
-        "c3x3_bwd_data": (lambda: L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, Cin, p(W2), p(Z), p(mean), p(istd), p(DZ), B, Hb, Wb, p(part), G, st), fl2),
+        "c3x3_bwd_data": (lambda: L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, Cin, p(W2), p(Z), p(mean), p(istd), p(DZ), B, Hb, Wb, p(part), G, p(X), ld, p(mean), p(istd), p(GF), st), fl2),
         "c3x3_bwd_wgt": (lambda: L.eml_dense_conv3x3_bwd_weight_f32(p(Gd), ld, Cin, p(Z), p(s2), p(t2), B, Hb, Wb, p(partW), p(dW2), G, st), fl2),
         "c1x1_bwd_wgt": (lambda: L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, Hb, Wb, 0, Kp, Cin, p(s1), p(t1), p(DZ), 48, p(Z), 48, p(cA), p(cB), p(cC), 48, p(partW), p(dW1), G, st), fl1),
         "c1x1_bwd_data": (lambda: L.eml_dense_conv1x1_bwd_data_f32(p(DZ), 48, p(Z), 48, p(cA), p(cB), p(cC), 48, p(Wd), p(X), ld, p(s1), p(t1), p(mean), p(istd), P, Hb, Wb, 0, Kp, p(Gd), ld, 1, p(part), G, st), fl1),
