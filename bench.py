@@ -63,8 +63,9 @@ def family_bytes(B, crop_hw):
             if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
                 by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((3 * 12 + 96) + (3 * k + 192)) * 4 * P
         ct = c + 192
-        by["eml_dense_conv1x1_fwd_f32"] += (ct + ct // 8) * 4 * P        # transition: X in, pooled out
-        by["eml_dense_conv1x1_bwd_weight_f32"] += (ct + ct // 8) * 4 * P
+        by["eml_dense_pool_act_f32"] += (ct + ct // 4) * 4 * P           # transition: X in, pooled activation A out
+        by["eml_dense_conv1x1_fwd_f32"] += (ct // 4 + ct // 8) * 4 * P   # transition conv on A: A in, pooled out
+        by["eml_dense_conv1x1_bwd_weight_f32"] += (ct // 4 + ct // 8) * 4 * P
         by["eml_dense_conv1x1_bwd_data_f32"] += (2 * ct + ct // 8) * 4 * P   # dY(pooled), X in, G out
         c, h, w = ct // 2, h // 2, w // 2
     return by
@@ -77,6 +78,7 @@ FAMILIES = {
     "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 1-2 dense layers per pass + ReLU "
                                              "mask + BN1-backward accumulate)", 0),
     "eml_dense_conv1x1_bwd_data_f32": ("conv1x1_bwd_data_kernel<POOL> (transition dgrad)", 2),
+    "eml_dense_pool_act_f32": ("pool_act_kernel (transition operand: 2x2 mean of relu(bn(x)))", 3),
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
     "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),
     "eml_dense_conv3x3_bwd_weight_f32": ("conv3x3_bwd_weight_kernel", 1),
@@ -118,7 +120,7 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
         ct = c + 192
         ftr += 2.0 * ct * (ct // 2) * (h // 2) * (w // 2) * B
         c, h, w = ct // 2, h // 2, w // 2
-    flops = (f1, f3, ftr)
+    flops = (f1, f3, ftr, 0.0)
     nbytes = family_bytes(B, crop_hw)
     rows = []
     for k, (label, which) in FAMILIES.items():
@@ -126,7 +128,7 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
         n = len(events[k]) // steps
         rows.append({"kernel": label, "launches_per_step": n, "ms_per_step": round(ms, 3),
                      "avg_launch_ms": round(ms / max(n, 1), 4),
-                     "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                     "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 and flops[which] else None,
                      "algorithmic_GB_per_step": round(nbytes[k] / 1e9, 2),
                      "algorithmic_GBps": round(nbytes[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     rows.sort(key=lambda r: -r["ms_per_step"])
@@ -306,7 +308,7 @@ def main():
             # the roof that binds is the one the kernel sits closer to: f32 activations make the dense-layer
             # passes HBM-bound (O(L^2) re-reads of the concatenated block buffer), not MFMA-bound
             f_hbm = dom["algorithmic_GBps"] / HBM_PEAK_GBPS
-            f_mfma = dom["tflops"] / F32_MFMA_PEAK_TFLOPS
+            f_mfma = (dom["tflops"] or 0.0) / F32_MFMA_PEAK_TFLOPS
             hbm = f_hbm >= f_mfma
             out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm" if hbm else "mfma",
                                "achieved": dom["algorithmic_GBps"] if hbm else dom["tflops"],

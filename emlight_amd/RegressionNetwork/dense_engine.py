@@ -58,6 +58,9 @@ class _Workspace:
                 "Wp": torch.empty(((cout + 47) // 48) * kpt * 48, **f32),
                 "Ko": _r16(cout),
                 "T": torch.zeros(B * (h // 2) * (w // 2), _r16(cout), **f32),  # raw transition output (kept for backward)
+                # pooled activation mean2x2(relu(bn(X))): operand of the transition conv and of its weight gradient
+                "A": torch.empty(B * (h // 2) * (w // 2), kpt, **f32),
+                "one": torch.ones(kpt, **f32), "zero": torch.zeros(kpt, **f32),
                 "tmean": torch.zeros(cout, **f32), "tvar": torch.ones(cout, **f32), "tistd": torch.ones(cout, **f32),
                 "scaleL": torch.zeros(cout, **f32), "shiftL": torch.zeros(cout, **f32),
             }
@@ -220,9 +223,12 @@ class HipDenseEncoder:
             _lib.check(L.eml_dense_permute_w1_f32(p(T.conv.weight), cout, ctot, kpt, p(tr["Wp"]), st),
                        "eml_dense_permute_w1_f32")
             Pn = B * (Hb // 2) * (Wb // 2)
-            _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, p(tr["scale"]), p(tr["shift"]),
-                                                   p(tr["Wp"]), cout, p(tr["T"]), tr["Ko"], p(part), G, st),
-                       "eml_dense_conv1x1_fwd_f32(transition)")
+            # pool first (it commutes with the 1x1 conv): the conv's output chunks then read A, a quarter of X
+            _lib.check(L.eml_dense_pool_act_f32(p(blk["X"]), ld, B, Hb, Wb, kpt, p(tr["scale"]), p(tr["shift"]),
+                                                p(tr["A"]), kpt, st), "eml_dense_pool_act_f32")
+            _lib.check(L.eml_dense_conv1x1_fwd_f32(p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, p(tr["one"]),
+                                                   p(tr["zero"]), p(tr["Wp"]), cout, p(tr["T"]), tr["Ko"], p(part), G,
+                                                   st), "eml_dense_conv1x1_fwd_f32(transition)")
             for ch in range(tr["nchunks"]):
                 nv = min(48, cout - 48 * ch)
                 last = ch == tr["nchunks"] - 1

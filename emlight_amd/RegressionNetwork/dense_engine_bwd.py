@@ -89,9 +89,10 @@ def run_backward(enc, ws, x, gpooled):
                                                 p(tr["tistd"]), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
         finalize(Gb, 2 * cout, Pn, LN, tr["tmean"], tr["tistd"], cout, Ko, coef=0)
         # ---- transition conv (pool folded): weight grad, data grad, BN backward -> G (write)
+        # weight grad on the pooled activation A kept by the forward (unit BN: relu(1*A + 0) == A)
         _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
-            p(blk["X"]), ld, Pn, Hb, Wb, 1, kpt, ctot, p(tr["scale"]), p(tr["shift"]), p(dY), ld_dy, p(tr["T"]), Ko,
-            p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
+            p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, ctot, p(tr["one"]), p(tr["zero"]), p(dY), ld_dy, p(tr["T"]),
+            Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
         _lib.check(L.eml_dense_permute_w1_bwd_f32(p(T.conv.weight), cout, ctot, kpt, Ko, p(bw.Wd), st),
                    "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(

@@ -42,6 +42,7 @@ SIGNATURES = {
                                          _int, _f32p, _int, _f32p, _int, _stream]),
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
                                          _int, _stream]),
+    "eml_dense_pool_act_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _int, _stream]),
     "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),
     # DenseNet-BC encoder, backward
     "eml_dense_conv3x3_bwd_data_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,

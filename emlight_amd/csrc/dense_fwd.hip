@@ -642,6 +642,36 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------ transition: pooled activation
+// A[p'][c] = mean over the 2x2 window of relu(scale[c]*x + shift[c])  (avg-pool commutes with the 1x1 conv,
+// DenseNet.py:14-21).  The transition's conv (3-4 output chunks) and its weight gradient then read A -- a quarter
+// of the block buffer -- instead of re-reading and re-pooling the whole block buffer once per chunk.
+__global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__ X, int ldx, int B, int Hin, int Win,
+                                                       int Kp, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ A, int lda) {
+  const int Ho = Hin >> 1, Wo = Win >> 1, nq = Kp >> 2;
+  const size_t total = (size_t)B * Ho * Wo * nq;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t pp = e / nq;
+    const int q = (int)(e - pp * nq);
+    const int b = (int)(pp / ((size_t)Ho * Wo)), rem = (int)(pp - (size_t)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* src = X + ((size_t)(b * Hin + 2 * oy) * Win + 2 * ox) * ldx + 4 * q;
+    const float4 s4 = *reinterpret_cast<const float4*>(scale + 4 * q);
+    const float4 t4 = *reinterpret_cast<const float4*>(shift + 4 * q);
+    const float4 v0 = bn_relu4(*reinterpret_cast<const float4*>(src), s4, t4);
+    const float4 v1 = bn_relu4(*reinterpret_cast<const float4*>(src + ldx), s4, t4);
+    const float4 v2 = bn_relu4(*reinterpret_cast<const float4*>(src + (size_t)Win * ldx), s4, t4);
+    const float4 v3 = bn_relu4(*reinterpret_cast<const float4*>(src + (size_t)Win * ldx + ldx), s4, t4);
+    float4 a;  // same association as the fused-pool operand load of conv1x1_fwd_kernel<true>
+    a.x = ((v0.x + v1.x) + (v2.x + v3.x)) * 0.25f;
+    a.y = ((v0.y + v1.y) + (v2.y + v3.y)) * 0.25f;
+    a.z = ((v0.z + v1.z) + (v2.z + v3.z)) * 0.25f;
+    a.w = ((v0.w + v1.w) + (v2.w + v3.w)) * 0.25f;
+    *reinterpret_cast<float4*>(A + pp * lda + 4 * q) = a;
+  }
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -737,6 +767,18 @@ extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, co
   hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(grid), dim3(kC3Threads), lds, (hipStream_t)stream, Z, scale2, shift2, W2p, X, ldx,
                      c_out0, B, H, W, partials);
   return eml::check_launch("eml_dense_conv3x3_fwd_f32");
+}
+
+extern "C" int eml_dense_pool_act_f32(const float* X, int ldx, int B, int Hin, int Win, int Kp, const float* scale,
+                                      const float* shift, float* A, int lda, eml_stream_t stream) {
+  if (!X || !scale || !shift || !A || B < 1 || Hin < 2 || Win < 2 || (Hin & 1) || (Win & 1) || Kp < 4 || (Kp & 3) ||
+      Kp > ldx || Kp > lda || (ldx & 3) || (lda & 3))
+    return eml::fail(EML_EINVAL, "eml_dense_pool_act_f32: bad arguments");
+  const size_t total = (size_t)B * (Hin / 2) * (Win / 2) * (Kp / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pool_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, B, Hin, Win, Kp, scale, shift,
+                     A, lda);
+  return eml::check_launch("eml_dense_pool_act_f32");
 }
 
 extern "C" int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, int W, int k, float* out,

@@ -148,6 +148,13 @@ int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* 
                               const float* W2p, float* X, int ldx, int c_out0, int B, int H, int W,
                               double* partials, int grid, eml_stream_t stream);
 
+/* Transition operand: A[p'][c] = 2x2 mean of relu(scale[c]*X + shift[c]), p' over (B, Hin/2, Win/2), c < Kp
+ * (Kp % 4 == 0; padded channels have scale = shift = 0).  The transition's 1x1 conv and its weight gradient
+ * run on A with pool = 0 and a unit BN (scale 1, shift 0) -- replaces torch's avg_pool2d after the conv in
+ * DenseNet.py:14-21 (the pool commutes with the 1x1 conv). */
+int eml_dense_pool_act_f32(const float* X, int ldx, int B, int Hin, int Win, int Kp, const float* scale,
+                           const float* shift, float* A, int lda, eml_stream_t stream);
+
 /* out (B, C, H/k, W/k) = avg_pool_k(relu(F)) for NHWC F: the head of DenseNet.forward
  * (DenseNet.py:136-137), flattened in the reference's (C,h,w) order for `fc`. */
 int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, int W, int k,

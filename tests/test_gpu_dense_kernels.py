@@ -172,6 +172,22 @@ def test_head_pool_fwd_bwd(lib):
     close(dF[:, :C], nhwc(f.grad), what="head pool bwd")
 
 
+@pytest.mark.parametrize("B,H,W,C,ld", [(2, 6, 10, 216, 224), (1, 4, 4, 20, 32)])
+def test_pool_act(lib, B, H, W, C, ld):
+    """A = mean2x2(relu(scale*x + shift)): the transition's operand (DenseNet.py:14-21, pool commuted before the conv)."""
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Kp = (C + 15) // 16 * 16
+    X = rnd(B * H * W, ld)
+    sc, sh = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+    sc[:C], sh[:C] = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.3)
+    A = torch.full((B * (H // 2) * (W // 2), Kp), 9.0, device=DEV)
+    lib.check(L.eml_dense_pool_act_f32(p(X), ld, B, H, W, Kp, p(sc), p(sh), p(A), Kp, st), "pool_act")
+    act = torch.relu(nchw(X[:, :Kp].double(), B, H, W) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    want = nhwc(F.avg_pool2d(act, 2))
+    close(A, want, what="pooled activation", rtol=1e-6, atol=1e-6)
+    assert float(A[:, C:].abs().max()) == 0.0 if Kp > C else True
+
+
 # ------------------------------------------------------------------------------------------ backward
 @pytest.mark.parametrize("B,H,W,c0,ld", [(2, 20, 44, 24, 64), (1, 8, 32, 162, 176), (3, 7, 9, 108, 128)])
 def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
