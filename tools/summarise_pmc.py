@@ -11,7 +11,7 @@ names = sorted(out)
 counters = sorted({c for n in names for c in out[n]})
 print("kernel,dispatches," + ",".join("mean_" + c for c in counters))
 for n in names:
-    if not n.startswith(("conv", "bn_", "grad_", "sinkhorn", "sg_", "head_", "reduce", "permute")):
+    if not n.startswith(("conv", "bn_", "grad_", "sinkhorn", "sg_", "head_", "reduce", "permute", "pool_")):
         continue
     nd = max(len(v) for v in out[n].values())
     print(n + "," + str(nd) + "," + ",".join("%.1f" % (sum(out[n][c]) / len(out[n][c])) if out[n][c] else "" for c in counters))
