@@ -259,6 +259,52 @@ def run_timed(step_fn, steps, warmup, world, device):
     return dt
 
 
+G_FWD_GFLOP, D_PAIR_GFLOP = 154.1, 4.71   # SPADE generator forward / discriminator forward on a fake+real pair
+
+
+def main_projector(args):
+    """SURVEY 8d metric (ii): GenProjector training images/sec, one G step + one D step (GenProjector/train.py:33-37)
+    at BASELINE configs[2] (B=32 per GPU, 128x256 panoramas) unless --batch says otherwise.  SphereConv2D runs as HIP
+    gather kernels (im2col_sphere / col2im_sphere) around rocBLAS GEMMs, the rest of row a15 on stock PyTorch-ROCm
+    ops; the roofline object prices the WHOLE step against the f32 MFMA peak (the GEMMs dominate).
+    --engine aten selects the reference's grid_sample + conv2d for an A/B run."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # fast find: the first step must not spend minutes tuning
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    from emlight_amd.GenProjector.networks import default_options
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    from emlight_amd.GenProjector.data import projector_batch
+    rank, local, world = init_distributed()
+    dev = "cuda:%d" % local
+    B = args.batch if args.batch != 64 else 32
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    SphereConv2D.default_engine = args.engine
+    tr = Trainer(default_options(), device=dev, world=world)
+    data = projector_batch(B, dev, ln=args.anchors, seed=1234 + rank)
+    dt = run_timed(lambda: tr.step(data), args.steps, args.warmup, world, dev)
+    if rank == 0:
+        value = B * world * args.steps / dt
+        # G step: G fwd + bwd (3x) and D fwd/bwd-data on the pair (2x); D step: G fwd (no grad) + D fwd/bwd (3x)
+        gflop = 3 * G_FWD_GFLOP + 2 * D_PAIR_GFLOP + G_FWD_GFLOP + 3 * D_PAIR_GFLOP
+        tf = gflop * value / world / 1e3
+        print(json.dumps({
+            "metric": "training images/sec (projector step: SPADE generator + PatchGAN discriminator, G step + D step)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "sphereconv_engine": args.engine,
+                       "per_gpu_batch": B, "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
+                       "parallelism": "dp%d" % world if world > 1 else "single"},
+            "roofline": {"kernel": "whole step (SphereConv2D = HIP im2col/col2im gathers + rocBLAS f32 GEMMs; norms and "
+                                   "activations on stock ops)",
+                         "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D "
+                                 "step) + 5*%.2f (D) GFLOP, VGG / feature-matching terms excluded" % (G_FWD_GFLOP, D_PAIR_GFLOP)},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,7 +316,12 @@ def main():
     ap.add_argument("--blur", type=float, default=.05)
     ap.add_argument("--engine", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--workload", default="regression", choices=["regression", "projector"],
+                    help="regression = BASELINE's headline (default); projector = SURVEY 8d metric (ii), the "
+                         "GenProjector G+D step of BASELINE configs[2] on stock ops (row a15)")
     args = ap.parse_args()
+    if args.workload == "projector":
+        return main_projector(args)
 
     from emlight_amd.RegressionNetwork.engine import RegressionTrainer, init_distributed
     from emlight_amd.RegressionNetwork.data import synthetic_batch

@@ -47,13 +47,127 @@ def sphere_sampling_grid(h, w, stride=1):
     return torch.from_numpy(np.ascontiguousarray(grid)).float()
 
 
+class SphereGeometry:
+    """Per (H, W, stride, device): the bilinear tap table of the sampling grid and its CSR transpose
+    (``eml_sphere_tap_table_f32``; the transpose is what turns grid_sample's atomicAdd backward into a gather)."""
+
+    def __init__(self, h, w, stride, device):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        grid = sphere_sampling_grid(h, w, stride).to(device).contiguous()
+        self.h, self.w = h, w
+        self.ho, self.wo = grid.shape[1] // 3, grid.shape[2] // 3
+        n = self.ho * self.wo * 9
+        self.idx = torch.empty(n, 4, dtype=torch.int32, device=device)
+        self.wgt = torch.empty(n, 4, dtype=torch.float32, device=device)
+        _lib.check(L.eml_sphere_tap_table_f32(p(grid), h, w, self.ho, self.wo, p(self.idx), p(self.wgt), st),
+                   "eml_sphere_tap_table_f32")
+        dst = self.idx.view(-1).long()
+        keep = dst >= 0
+        src = torch.arange(n, device=device).repeat_interleave(4)[keep]
+        dst, wk = dst[keep], self.wgt.view(-1)[keep]
+        order = torch.argsort(dst, stable=True)
+        self.csr_src = src[order].to(torch.int32).contiguous()
+        self.csr_w = wk[order].contiguous()
+        self.csr_ptr = torch.zeros(h * w + 1, dtype=torch.int32, device=device)
+        self.csr_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=h * w), 0).to(torch.int32)
+
+
+_GEOMETRY = {}
+
+
+def sphere_geometry(h, w, stride, device):
+    key = (h, w, stride, str(device))
+    if key not in _GEOMETRY:
+        _GEOMETRY[key] = SphereGeometry(h, w, stride, device)
+    return _GEOMETRY[key]
+
+
+class _SphereConvFn(torch.autograd.Function):
+    """``conv2d(grid_sample(x, grid), weight, bias, stride=3)`` (``sphere_cnn.py:121-124``) as
+    im2col_sphere (HIP) -> GEMM (rocBLAS) forward, GEMMs + col2im_sphere (HIP, deterministic gather) backward.
+    Activations are pixel-major: inputs in ``torch.channels_last`` are used in place, the output is returned as a
+    channels-last (B, O, H', W') tensor, so a chain of SphereConvs never transposes."""
+
+    @staticmethod
+    def _im2col(xr, geo, B, C):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        po = geo.ho * geo.wo
+        a9 = torch.empty(B * po, 9 * C, dtype=torch.float32, device=xr.device)
+        _lib.check(L.eml_sphere_im2col_f32(p(xr), p(geo.idx), p(geo.wgt), p(a9), B, geo.h * geo.w, po, C, st),
+                   "eml_sphere_im2col_f32")
+        return a9
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        from .. import _lib
+        _lib.require_gpu_tensor(x, "SphereConv2D input")
+        B, C, H, W = x.shape
+        geo = sphere_geometry(H, W, stride, x.device)
+        xr = x.float().permute(0, 2, 3, 1).contiguous()           # (B,H,W,C); a view when x is channels-last
+        O = weight.shape[0]
+        w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
+        a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
+        y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
+        ctx.save_for_backward(xr, weight)
+        ctx.geo, ctx.has_bias, ctx.shape = geo, bias is not None, (B, C, H, W, O)
+        return y.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        xr, weight = ctx.saved_tensors
+        geo = ctx.geo
+        B, C, H, W, O = ctx.shape
+        po = geo.ho * geo.wo
+        gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
+        gx = gw = gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gyr.sum(0)
+        if ctx.needs_input_grad[1]:
+            a9 = _SphereConvFn._im2col(xr, geo, B, C)               # recomputed, not kept: 9x the input
+            gw = (gyr.t() @ a9).view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+            del a9
+        if ctx.needs_input_grad[0]:
+            w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
+            da9 = gyr @ w2                                           # (B*Po, 9C)
+            gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
+            if B:
+                _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
+                                                   H * W, po, C, st), "eml_sphere_col2im_f32")
+            gx = gxr.permute(0, 3, 1, 2)
+        return gx, gw, gb, None
+
+
+class sphere_engine:
+    """``with sphere_engine("aten"): ...`` -- run SphereConv2D modules without an explicit ``engine=`` on the
+    reference's stock ops (CPU host-logic tests, A/B measurements).  The default is "hip"."""
+
+    def __init__(self, name):
+        assert name in ("hip", "aten")
+        self.name = name
+
+    def __enter__(self):
+        self.prev, SphereConv2D.default_engine = SphereConv2D.default_engine, self.name
+
+    def __exit__(self, *exc):
+        SphereConv2D.default_engine = self.prev
+
+
 class SphereConv2D(nn.Module):
     """3x3 spherical convolution, same parameters (``weight`` (out,in,3,3), ``bias``) and init as the
-    reference (``sphere_cnn.py:87-109``)."""
+    reference (``sphere_cnn.py:87-109``).  ``engine="hip"`` (default): the MI355X path above, no CPU fallback.
+    ``engine="aten"``: the reference's two stock ops (grid_sample + conv2d), kept as the torch-f32 reference the
+    HIP path is tested against and for the CPU-only host-logic tests."""
 
-    def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
+    default_engine = "hip"
+
+    def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear", engine=None):
         super().__init__()
         self.in_c, self.out_c, self.stride, self.mode = in_c, out_c, stride, mode
+        self.engine = engine
         self.weight = Parameter(torch.empty(out_c, in_c, 3, 3))
         if bias:
             self.bias = Parameter(torch.empty(out_c))
@@ -76,6 +190,11 @@ class SphereConv2D(nn.Module):
         return g
 
     def forward(self, x):
+        engine = self.engine or SphereConv2D.default_engine
+        if engine == "hip":
+            if self.mode != "bilinear":
+                raise NotImplementedError("the HIP SphereConv2D implements the reference's bilinear mode")
+            return _SphereConvFn.apply(x, self.weight, self.bias, self.stride)
         grid = self.grid_for(x).expand(x.shape[0], -1, -1, -1)
         # torch >= 1.3 default align_corners=False, zero padding: what the reference runs with today
         x = nn.functional.grid_sample(x, grid, mode=self.mode, align_corners=False)

@@ -29,6 +29,10 @@ SIGNATURES = {
                                     ctypes.c_double, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                     _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
+    # GenProjector SphereConv2D
+    "eml_sphere_tap_table_f32": (_int, [_f32p, _int, _int, _int, _int, _i32p, _f32p, _stream]),
+    "eml_sphere_im2col_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
+    "eml_sphere_col2im_f32": (_int, [_f32p, _i32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
     # DenseNet-BC encoder, forward
     "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
     "eml_dense_bn_apply_f32": (_int, [_f32p, _int, _f32p, _int, _int, ctypes.c_long, _f32p, _f32p, _int, _f32p,

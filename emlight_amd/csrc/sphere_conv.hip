@@ -1,0 +1,165 @@
+// SphereConv2D support kernels for the GenProjector (reference models/networks/spherenet/sphere_cnn.py:111-124):
+//     x -> grid_sample(x, fixed tangent-plane grid) -> (B, C, 3H', 3W') -> conv2d(stride 3)
+// is restated as  A9 = im2col_sphere(x)  (B*H'*W' rows, 9*C columns, pixel-major / channels-last),
+// Y = A9 * W2^T (library GEMM), and in the backward  dA9 = dY * W2,  dW2 = dY^T * A9,  dx = col2im_sphere(dA9).
+//
+// Why: on stock ops 75 % of the projector step is ATen's grid_sampler (65 % its backward, an atomicAdd scatter
+// over the 9x blown-up tensor, profiles/r01_projector_stock_kernel_stats.csv).  The sampling pattern depends only
+// on (H, W, stride), so its transpose is a fixed sparse matrix: the backward here is a deterministic CSR gather
+// (no atomics), and the forward gather writes the GEMM operand directly in the layout the GEMM wants (no
+// NCHW<->NHWC transposes).
+//
+//   tap table : for every (output pixel, tap) the 4 bilinear corners (input pixel index or -1) and weights,
+//               computed ONCE per geometry with exactly grid_sample's arithmetic (align_corners = False, zero padding)
+//   im2col    : A9[(b*Po + p)*9 + tap][c] = sum_k wgt[p,tap,k] * X[b][idx[p,tap,k]][c]
+//   col2im    : dX[b][q][c] = sum_{e in row q of the CSR transpose} w_e * dA9[(b*Po*9 + src_e)][c]
+// All three are HBM-streaming kernels (lanes along the contiguous channel axis, 16-byte accesses when C % 4 == 0).
+#include "eml_common.h"
+
+namespace {
+
+// ATen grid_sampler_unnormalize, align_corners = false (GridSampler.cuh): ((coord + 1) * size - 1) / 2
+__device__ __forceinline__ float unnormalize(float coord, int size) { return ((coord + 1.f) * size - 1.f) / 2.f; }
+
+__global__ __launch_bounds__(256) void sphere_tap_table_kernel(const float* __restrict__ grid, int H, int W, int Ho, int Wo,
+                                                               int* __restrict__ idx, float* __restrict__ wgt) {
+  const int total = Ho * Wo * 9;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int p = e / 9, tap = e - 9 * p;
+    const int r = p / Wo, c = p - r * Wo;
+    const int a = tap / 3, b = tap - 3 * a;
+    const float* g = grid + ((size_t)(3 * r + a) * (3 * Wo) + (3 * c + b)) * 2;
+    const float ix = unnormalize(g[0], W), iy = unnormalize(g[1], H);
+    // corners and weights exactly as grid_sampler_2d (bilinear): nw, ne, sw, se
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float xe = fx + 1.f, ye = fy + 1.f;
+    const float w4[4] = {(xe - ix) * (ye - iy), (ix - fx) * (ye - iy), (xe - ix) * (iy - fy), (ix - fx) * (iy - fy)};
+    const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = xs[k] >= 0 && xs[k] < W && ys[k] >= 0 && ys[k] < H;
+      idx[(size_t)e * 4 + k] = in ? ys[k] * W + xs[k] : -1;
+      wgt[(size_t)e * 4 + k] = in ? w4[k] : 0.f;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sphere_im2col_kernel(const float* __restrict__ X, const int* __restrict__ idx,
+                                                            const float* __restrict__ wgt, float* __restrict__ A9,
+                                                            int B, int HW, int Po, int C) {
+  const int cv = C / VEC;
+  const size_t rows = (size_t)B * Po * 9, total = rows * cv;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t row = e / cv;
+    const int c = (int)(e - row * cv) * VEC;
+    const size_t bp = row / 9;                      // b*Po + p
+    const int tap = (int)(row - bp * 9);
+    const int b = (int)(bp / Po), p = (int)(bp - (size_t)b * Po);
+    const size_t t4 = ((size_t)p * 9 + tap) * 4;
+    const int4 id = *reinterpret_cast<const int4*>(idx + t4);
+    const float4 w = *reinterpret_cast<const float4*>(wgt + t4);
+    const float* xb = X + (size_t)b * HW * C + c;
+    if constexpr (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ids[4] = {id.x, id.y, id.z, id.w};
+      const float ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // same accumulation order as grid_sampler_2d: nw, ne, sw, se (skipped when out of bounds)
+        if (ids[k] >= 0) {
+          const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ids[k] * C);
+          acc.x += v.x * ws[k];
+          acc.y += v.y * ws[k];
+          acc.z += v.z * ws[k];
+          acc.w += v.w * ws[k];
+        }
+      }
+      *reinterpret_cast<float4*>(A9 + row * C + c) = acc;
+    } else {
+      float acc = 0.f;
+      const int ids[4] = {id.x, id.y, id.z, id.w};
+      const float ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ids[k] >= 0) acc += xb[(size_t)ids[k] * C] * ws[k];
+      A9[row * C + c] = acc;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sphere_col2im_kernel(const float* __restrict__ dA9, const int* __restrict__ ptr,
+                                                            const int* __restrict__ src, const float* __restrict__ w,
+                                                            float* __restrict__ dX, int B, int HW, int Po, int C) {
+  const int cv = C / VEC;
+  const size_t total = (size_t)B * HW * cv;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t bq = e / cv;                       // b*HW + q
+    const int c = (int)(e - bq * cv) * VEC;
+    const int b = (int)(bq / HW), q = (int)(bq - (size_t)b * HW);
+    const float* ab = dA9 + (size_t)b * Po * 9 * C + c;
+    const int k0 = ptr[q], k1 = ptr[q + 1];
+    if constexpr (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = k0; k < k1; ++k) {
+        const float wk = w[k];
+        const float4 v = *reinterpret_cast<const float4*>(ab + (size_t)src[k] * C);
+        acc.x = fmaf(wk, v.x, acc.x);
+        acc.y = fmaf(wk, v.y, acc.y);
+        acc.z = fmaf(wk, v.z, acc.z);
+        acc.w = fmaf(wk, v.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(dX + bq * C + c) = acc;
+    } else {
+      float acc = 0.f;
+      for (int k = k0; k < k1; ++k) acc = fmaf(w[k], ab[(size_t)src[k] * C], acc);
+      dX[bq * C + c] = acc;
+    }
+  }
+}
+
+inline int stream_grid(size_t total) {
+  const size_t g = (total + 255) / 256;
+  return (int)(g < 16384 ? (g ? g : 1) : 16384);
+}
+
+}  // namespace
+
+extern "C" int eml_sphere_tap_table_f32(const float* grid, int H, int W, int Ho, int Wo, int* idx, float* wgt,
+                                        eml_stream_t stream) {
+  if (!grid || !idx || !wgt || H < 1 || W < 1 || Ho < 1 || Wo < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_tap_table_f32: bad arguments");
+  hipLaunchKernelGGL(sphere_tap_table_kernel, dim3(stream_grid((size_t)Ho * Wo * 9)), dim3(256), 0, (hipStream_t)stream,
+                     grid, H, W, Ho, Wo, idx, wgt);
+  return eml::check_launch("eml_sphere_tap_table_f32");
+}
+
+extern "C" int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, float* A9, int B, int HW, int Po,
+                                     int C, eml_stream_t stream) {
+  if (!X || !idx || !wgt || !A9 || B < 0 || HW < 1 || Po < 1 || C < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_im2col_f32: bad arguments");
+  if (B == 0) return EML_OK;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(sphere_im2col_kernel<4>, dim3(stream_grid((size_t)B * Po * 9 * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, X, idx, wgt, A9, B, HW, Po, C);
+  else
+    hipLaunchKernelGGL(sphere_im2col_kernel<1>, dim3(stream_grid((size_t)B * Po * 9 * C)), dim3(256), 0,
+                       (hipStream_t)stream, X, idx, wgt, A9, B, HW, Po, C);
+  return eml::check_launch("eml_sphere_im2col_f32");
+}
+
+extern "C" int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, const float* w, float* dX, int B,
+                                     int HW, int Po, int C, eml_stream_t stream) {
+  if (!dA9 || !ptr || !src || !w || !dX || B < 0 || HW < 1 || Po < 1 || C < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_col2im_f32: bad arguments");
+  if (B == 0) return EML_OK;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(sphere_col2im_kernel<4>, dim3(stream_grid((size_t)B * HW * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dA9, ptr, src, w, dX, B, HW, Po, C);
+  else
+    hipLaunchKernelGGL(sphere_col2im_kernel<1>, dim3(stream_grid((size_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream,
+                       dA9, ptr, src, w, dX, B, HW, Po, C);
+  return eml::check_launch("eml_sphere_col2im_f32");
+}

@@ -246,6 +246,28 @@ int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, int ldg, cons
 int eml_dense_head_pool_bwd_f32(const float* gpooled, const float* F, int ldf, int C, int B, int H,
                                 int W, int k, float* dF, int ldd, eml_stream_t stream);
 
+/* ---------------------------------------------------------------- GenProjector: SphereConv2D
+ * models/networks/spherenet/sphere_cnn.py:111-124: y = conv2d(grid_sample(x, grid), weight, bias, stride=3) with a
+ * fixed (1, 3Ho, 3Wo, 2) tangent-plane grid (:31-84) -- restated as A9 = im2col_sphere(x), Y = A9 * W2^T (library
+ * GEMM on the caller's side), dx = col2im_sphere(dY * W2).  Pixel-major (channels-last) f32 throughout:
+ * X (B, H*W, C), A9 (B*Ho*Wo*9, C) with row (b*Po + p)*9 + tap, tap = 3a + b as in the grid. */
+
+/* The 4 bilinear corners of every (output pixel, tap): idx (Po*9, 4) = input pixel y*W + x or -1 (zero
+ * padding), wgt (Po*9, 4), computed with torch.nn.functional.grid_sample's arithmetic (bilinear,
+ * align_corners = False -- what sphere_cnn.py:122 runs with on torch >= 1.3).  grid: (3Ho, 3Wo, 2) as (x, y) in [-1, 1]. */
+int eml_sphere_tap_table_f32(const float* grid, int H, int W, int Ho, int Wo, int* idx, float* wgt,
+                             eml_stream_t stream);
+
+/* A9[(b*Po + p)*9 + tap][c] = sum_k wgt[p,tap,k] * X[b][idx[p,tap,k]][c]   (replaces F.grid_sample, :122). */
+int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, float* A9, int B, int HW,
+                          int Po, int C, eml_stream_t stream);
+
+/* Transpose of the above as a deterministic gather (replaces grid_sampler_2d_backward's atomicAdd scatter):
+ * dX[b][q][c] = sum_{k in [ptr[q], ptr[q+1])} w[k] * dA9[(b*Po*9 + src[k])][c], the CSR transpose of the tap
+ * table (src = p*9 + tap), built once per geometry by the caller. */
+int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, const float* w, float* dX,
+                          int B, int HW, int Po, int C, eml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

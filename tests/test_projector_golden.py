@@ -13,6 +13,15 @@ from tests.golden.make_golden import projector_inputs
 torch.set_num_threads(8)
 
 
+@pytest.fixture(autouse=True)
+def _stock_ops_on_cpu():
+    """These CPU tests pin the host mirror numerically; SphereConv2D's product engine is HIP-only (no CPU path), so
+    they select the reference's stock ops explicitly."""
+    from emlight_amd.GenProjector.spherenet import sphere_engine
+    with sphere_engine("aten"):
+        yield
+
+
 @pytest.fixture(scope="module")
 def g():
     return Golden("projector")
