@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
-from .spherenet import SphereConv2D
+from .spherenet import SphereConv2D, sphere_conv_siblings
 
 
 def default_options(**kw):
@@ -100,7 +100,8 @@ class SPADE(nn.Module):
         normalized = self.param_free_norm(x)
         segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
         actv = self.mlp_shared(segmap)
-        return normalized * (1 + self.mlp_gamma(actv)) + self.mlp_beta(actv)
+        gamma, beta = sphere_conv_siblings(actv, [self.mlp_gamma, self.mlp_beta])  # same input: one gather, one GEMM
+        return normalized * (1 + gamma) + beta
 
 
 class SPADEResnetBlock(nn.Module):

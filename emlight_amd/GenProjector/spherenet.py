@@ -110,7 +110,9 @@ class _SphereConvFn(torch.autograd.Function):
         w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
         a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
         y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
-        ctx.save_for_backward(xr, weight)
+        # the weight gradient needs A9 again: keep it (9x the input, sized for 288 GB of HBM) or rebuild it from x
+        ctx.keep = SphereConv2D.keep_operand and weight.requires_grad
+        ctx.save_for_backward(a9 if ctx.keep else xr, weight)
         ctx.geo, ctx.has_bias, ctx.shape = geo, bias is not None, (B, C, H, W, O)
         return y.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
 
@@ -127,7 +129,7 @@ class _SphereConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gyr.sum(0)
         if ctx.needs_input_grad[1]:
-            a9 = _SphereConvFn._im2col(xr, geo, B, C)               # recomputed, not kept: 9x the input
+            a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
             gw = (gyr.t() @ a9).view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
             del a9
         if ctx.needs_input_grad[0]:
@@ -139,6 +141,19 @@ class _SphereConvFn(torch.autograd.Function):
                                                    H * W, po, C, st), "eml_sphere_col2im_f32")
             gx = gxr.permute(0, 3, 1, 2)
         return gx, gw, gb, None
+
+
+def sphere_conv_siblings(x, convs):
+    """Several SphereConv2D modules applied to the SAME input (SPADE's gamma / beta heads, ``normalization.py:108-109``):
+    one im2col and one GEMM over the concatenated output channels.  Falls back to separate calls for stock ops."""
+    engines = {c.engine or SphereConv2D.default_engine for c in convs}
+    same = len({(c.stride, c.bias is None) for c in convs}) == 1
+    if engines != {"hip"} or not same:
+        return [c(x) for c in convs]
+    w = torch.cat([c.weight for c in convs], 0)
+    b = None if convs[0].bias is None else torch.cat([c.bias for c in convs], 0)
+    y = _SphereConvFn.apply(x, w, b, convs[0].stride)
+    return list(torch.split(y, [c.weight.shape[0] for c in convs], dim=1))
 
 
 class sphere_engine:
@@ -163,6 +178,7 @@ class SphereConv2D(nn.Module):
     HIP path is tested against and for the CPU-only host-logic tests."""
 
     default_engine = "hip"
+    keep_operand = True   # keep the im2col operand of a training forward for the weight gradient (else recompute)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear", engine=None):
         super().__init__()

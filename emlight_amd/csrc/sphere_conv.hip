@@ -14,6 +14,8 @@
 //   im2col    : A9[(b*Po + p)*9 + tap][c] = sum_k wgt[p,tap,k] * X[b][idx[p,tap,k]][c]
 //   col2im    : dX[b][q][c] = sum_{e in row q of the CSR transpose} w_e * dA9[(b*Po*9 + src_e)][c]
 // All three are HBM-streaming kernels (lanes along the contiguous channel axis, 16-byte accesses when C % 4 == 0).
+#include <algorithm>
+
 #include "eml_common.h"
 
 namespace {
@@ -45,77 +47,77 @@ __global__ __launch_bounds__(256) void sphere_tap_table_kernel(const float* __re
   }
 }
 
-template <int VEC>
+// Thread layout of the two gather kernels: TPR (a power of two) consecutive threads share one row and stride over
+// its channels, blockIdx.y is the batch sample -- all index arithmetic is 32-bit with divisions by constants only
+// (a flat 64-bit index with three runtime divisions per element made the first version VALU-bound at 2.1 TB/s).
+template <int VEC, int TPR>
 __global__ __launch_bounds__(256) void sphere_im2col_kernel(const float* __restrict__ X, const int* __restrict__ idx,
                                                             const float* __restrict__ wgt, float* __restrict__ A9,
-                                                            int B, int HW, int Po, int C) {
-  const int cv = C / VEC;
-  const size_t rows = (size_t)B * Po * 9, total = rows * cv;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const size_t row = e / cv;
-    const int c = (int)(e - row * cv) * VEC;
-    const size_t bp = row / 9;                      // b*Po + p
-    const int tap = (int)(row - bp * 9);
-    const int b = (int)(bp / Po), p = (int)(bp - (size_t)b * Po);
-    const size_t t4 = ((size_t)p * 9 + tap) * 4;
-    const int4 id = *reinterpret_cast<const int4*>(idx + t4);
-    const float4 w = *reinterpret_cast<const float4*>(wgt + t4);
-    const float* xb = X + (size_t)b * HW * C + c;
-    if constexpr (VEC == 4) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int ids[4] = {id.x, id.y, id.z, id.w};
-      const float ws[4] = {w.x, w.y, w.z, w.w};
+                                                            int HW, int Po, int C) {
+  constexpr int RPB = 256 / TPR;  // rows per block per pass
+  const int cv = C / VEC, nrows = Po * 9;
+  const int rl = threadIdx.x / TPR, cl = threadIdx.x % TPR;
+  const float* xb = X + (size_t)blockIdx.y * HW * C;
+  float* ab = A9 + (size_t)blockIdx.y * nrows * C;
+  for (int row = blockIdx.x * RPB + rl; row < nrows; row += gridDim.x * RPB) {
+    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)row * 4);   // row = p*9 + tap: the table's own order
+    const float4 w = *reinterpret_cast<const float4*>(wgt + (size_t)row * 4);
+    const int ids[4] = {id.x, id.y, id.z, id.w};
+    const float ws[4] = {w.x, w.y, w.z, w.w};
+    for (int c = cl; c < cv; c += TPR) {
+      if constexpr (VEC == 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // same accumulation order as grid_sampler_2d: nw, ne, sw, se (skipped when out of bounds)
-        if (ids[k] >= 0) {
-          const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ids[k] * C);
-          acc.x += v.x * ws[k];
-          acc.y += v.y * ws[k];
-          acc.z += v.z * ws[k];
-          acc.w += v.w * ws[k];
+        for (int k = 0; k < 4; ++k) {
+          // same accumulation order as grid_sampler_2d: nw, ne, sw, se (skipped when out of bounds)
+          if (ids[k] >= 0) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ids[k] * C + 4 * c);
+            acc.x += v.x * ws[k];
+            acc.y += v.y * ws[k];
+            acc.z += v.z * ws[k];
+            acc.w += v.w * ws[k];
+          }
         }
-      }
-      *reinterpret_cast<float4*>(A9 + row * C + c) = acc;
-    } else {
-      float acc = 0.f;
-      const int ids[4] = {id.x, id.y, id.z, id.w};
-      const float ws[4] = {w.x, w.y, w.z, w.w};
+        *reinterpret_cast<float4*>(ab + (size_t)row * C + 4 * c) = acc;
+      } else {
+        float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (ids[k] >= 0) acc += xb[(size_t)ids[k] * C] * ws[k];
-      A9[row * C + c] = acc;
+        for (int k = 0; k < 4; ++k)
+          if (ids[k] >= 0) acc += xb[(size_t)ids[k] * C + c] * ws[k];
+        ab[(size_t)row * C + c] = acc;
+      }
     }
   }
 }
 
-template <int VEC>
+template <int VEC, int TPR>
 __global__ __launch_bounds__(256) void sphere_col2im_kernel(const float* __restrict__ dA9, const int* __restrict__ ptr,
                                                             const int* __restrict__ src, const float* __restrict__ w,
-                                                            float* __restrict__ dX, int B, int HW, int Po, int C) {
+                                                            float* __restrict__ dX, int HW, int Po, int C) {
+  constexpr int RPB = 256 / TPR;
   const int cv = C / VEC;
-  const size_t total = (size_t)B * HW * cv;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const size_t bq = e / cv;                       // b*HW + q
-    const int c = (int)(e - bq * cv) * VEC;
-    const int b = (int)(bq / HW), q = (int)(bq - (size_t)b * HW);
-    const float* ab = dA9 + (size_t)b * Po * 9 * C + c;
+  const int rl = threadIdx.x / TPR, cl = threadIdx.x % TPR;
+  const float* ab = dA9 + (size_t)blockIdx.y * Po * 9 * C;
+  float* xb = dX + (size_t)blockIdx.y * HW * C;
+  for (int q = blockIdx.x * RPB + rl; q < HW; q += gridDim.x * RPB) {
     const int k0 = ptr[q], k1 = ptr[q + 1];
-    if constexpr (VEC == 4) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = k0; k < k1; ++k) {
-        const float wk = w[k];
-        const float4 v = *reinterpret_cast<const float4*>(ab + (size_t)src[k] * C);
-        acc.x = fmaf(wk, v.x, acc.x);
-        acc.y = fmaf(wk, v.y, acc.y);
-        acc.z = fmaf(wk, v.z, acc.z);
-        acc.w = fmaf(wk, v.w, acc.w);
+    for (int c = cl; c < cv; c += TPR) {
+      if constexpr (VEC == 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = k0; k < k1; ++k) {
+          const float wk = w[k];
+          const float4 v = *reinterpret_cast<const float4*>(ab + (size_t)src[k] * C + 4 * c);
+          acc.x = fmaf(wk, v.x, acc.x);
+          acc.y = fmaf(wk, v.y, acc.y);
+          acc.z = fmaf(wk, v.z, acc.z);
+          acc.w = fmaf(wk, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(xb + (size_t)q * C + 4 * c) = acc;
+      } else {
+        float acc = 0.f;
+        for (int k = k0; k < k1; ++k) acc = fmaf(w[k], ab[(size_t)src[k] * C + c], acc);
+        xb[(size_t)q * C + c] = acc;
       }
-      *reinterpret_cast<float4*>(dX + bq * C + c) = acc;
-    } else {
-      float acc = 0.f;
-      for (int k = k0; k < k1; ++k) acc = fmaf(w[k], ab[(size_t)src[k] * C], acc);
-      dX[bq * C + c] = acc;
     }
   }
 }
@@ -136,30 +138,39 @@ extern "C" int eml_sphere_tap_table_f32(const float* grid, int H, int W, int Ho,
   return eml::check_launch("eml_sphere_tap_table_f32");
 }
 
+#define EML_SPHERE_LAUNCH(KERNEL, rows, ...)                                                                     \
+  do {                                                                                                          \
+    const int cv = (C % 4 == 0) ? C / 4 : C;                                                                    \
+    const int tpr = cv <= 4 ? 4 : cv <= 16 ? 16 : cv <= 64 ? 64 : 256;                                           \
+    const int gx = (int)std::min<size_t>(((size_t)(rows) + (256 / tpr) - 1) / (256 / tpr), (size_t)8192);          \
+    const dim3 grid(gx, B);                                                                                     \
+    if (C % 4 == 0) {                                                                                           \
+      if (tpr == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);    \
+      else if (tpr == 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (tpr == 64) hipLaunchKernelGGL((KERNEL<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+    } else {                                                                                                    \
+      if (tpr == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);    \
+      else if (tpr == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (tpr == 64) hipLaunchKernelGGL((KERNEL<1, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+    }                                                                                                           \
+  } while (0)
+
 extern "C" int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, float* A9, int B, int HW, int Po,
                                      int C, eml_stream_t stream) {
-  if (!X || !idx || !wgt || !A9 || B < 0 || HW < 1 || Po < 1 || C < 1)
+  if (!X || !idx || !wgt || !A9 || B < 0 || HW < 1 || Po < 1 || C < 1 || B > 65535)
     return eml::fail(EML_EINVAL, "eml_sphere_im2col_f32: bad arguments");
   if (B == 0) return EML_OK;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL(sphere_im2col_kernel<4>, dim3(stream_grid((size_t)B * Po * 9 * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, X, idx, wgt, A9, B, HW, Po, C);
-  else
-    hipLaunchKernelGGL(sphere_im2col_kernel<1>, dim3(stream_grid((size_t)B * Po * 9 * C)), dim3(256), 0,
-                       (hipStream_t)stream, X, idx, wgt, A9, B, HW, Po, C);
+  EML_SPHERE_LAUNCH(sphere_im2col_kernel, (size_t)Po * 9, X, idx, wgt, A9, HW, Po, C);
   return eml::check_launch("eml_sphere_im2col_f32");
 }
 
 extern "C" int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, const float* w, float* dX, int B,
                                      int HW, int Po, int C, eml_stream_t stream) {
-  if (!dA9 || !ptr || !src || !w || !dX || B < 0 || HW < 1 || Po < 1 || C < 1)
+  if (!dA9 || !ptr || !src || !w || !dX || B < 0 || HW < 1 || Po < 1 || C < 1 || B > 65535)
     return eml::fail(EML_EINVAL, "eml_sphere_col2im_f32: bad arguments");
   if (B == 0) return EML_OK;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL(sphere_col2im_kernel<4>, dim3(stream_grid((size_t)B * HW * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, dA9, ptr, src, w, dX, B, HW, Po, C);
-  else
-    hipLaunchKernelGGL(sphere_col2im_kernel<1>, dim3(stream_grid((size_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream,
-                       dA9, ptr, src, w, dX, B, HW, Po, C);
+  EML_SPHERE_LAUNCH(sphere_col2im_kernel, (size_t)HW, dA9, ptr, src, w, dX, HW, Po, C);
   return eml::check_launch("eml_sphere_col2im_f32");
 }
