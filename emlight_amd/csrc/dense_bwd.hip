@@ -906,14 +906,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
       }
     for (int nt0 = nt_lo; nt0 < nt_hi; nt0 += NCH) {
       // X and the old G of this chunk are requested now and consumed after the MFMAs (latency hidden)
+      // (lanes whose 4 channels lie entirely outside [k_lo, k_hi) re-read the range's first quad -- an L1 hit --
+      // instead of pulling unused channels from HBM, and do not write back)
       float4 gs[MT][NCH], xv[MT][NCH];
 #pragma unroll
       for (int n = 0; n < NCH; ++n) {
         const int k4 = 16 * min(nt0 + n, nt_hi - 1) + 4 * kk;
+        const int k4l = (k4 + 3 >= k_lo && k4 < k_hi) ? k4 : (k_lo & ~3);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          gs[m][n] = *reinterpret_cast<const float4*>(Gd + prow[m] * ldg + k4);
-          xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4);
+          gs[m][n] = *reinterpret_cast<const float4*>(Gd + prow[m] * ldg + k4l);
+          xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4l);
         }
       }
       const int nt_next = nt0 + NCH < nt_hi ? nt0 + NCH : nt_lo;  // the next tile starts at nt_lo again
@@ -993,9 +996,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
         const int nt = nt0 + n;
         if (nt < nt_hi) {
           const int k4 = 16 * nt + 4 * kk;
+          const bool act = k4 + 3 >= k_lo && k4 < k_hi;
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            if (pv[m]) *reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4) = gs[m][n];  // gs = old G + updates
+            if (pv[m] && act) *reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4) = gs[m][n];  // gs = old G + updates
           }
         }
       }
