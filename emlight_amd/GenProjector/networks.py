@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
-from .spherenet import SphereConv2D, sphere_conv_siblings
+from .spherenet import SphereConv2D, spade_modulate
 
 
 def default_options(**kw):
@@ -96,12 +96,12 @@ class SPADE(nn.Module):
         self.mlp_gamma = SphereConv2D(nhidden, norm_nc)
         self.mlp_beta = SphereConv2D(nhidden, norm_nc)
 
-    def forward(self, x, segmap):
+    def forward(self, x, segmap, slope=1.0):
+        """``slope`` != 1 folds the LeakyReLU that follows this norm in SPADEResnetBlock (architecture.py:56-57) in."""
         normalized = self.param_free_norm(x)
         segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
         actv = self.mlp_shared(segmap)
-        gamma, beta = sphere_conv_siblings(actv, [self.mlp_gamma, self.mlp_beta])  # same input: one gather, one GEMM
-        return normalized * (1 + gamma) + beta
+        return spade_modulate(normalized, actv, self.mlp_gamma, self.mlp_beta, slope)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -127,8 +127,8 @@ class SPADEResnetBlock(nn.Module):
 
     def forward(self, x, seg):
         x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = self.conv_0(F.leaky_relu(self.norm_0(x, seg), 2e-1))
-        dx = self.conv_1(F.leaky_relu(self.norm_1(dx, seg), 2e-1))
+        dx = self.conv_0(self.norm_0(x, seg, slope=2e-1))   # leaky_relu(norm(.), 0.2), fused into the modulation
+        dx = self.conv_1(self.norm_1(dx, seg, slope=2e-1))
         return x_s + dx
 
 

@@ -47,6 +47,17 @@ def sphere_sampling_grid(h, w, stride=1):
     return torch.from_numpy(np.ascontiguousarray(grid)).float()
 
 
+def _require_gpu_f32(t, name):
+    """No CPU path: the HIP engine takes f32 tensors on the GPU.  (Layout is handled by the callers: unlike
+    ``_lib.require_gpu_tensor`` this does not force an NCHW-contiguous copy of a channels-last tensor.)"""
+    from .. import _lib
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.EmlightHipError("%s must be a tensor on the MI355X (got %s); there is no CPU path"
+                                   % (name, getattr(t, "device", type(t))))
+    if t.dtype != torch.float32:
+        raise _lib.EmlightHipError("%s must be float32 (got %s)" % (name, t.dtype))
+
+
 class SphereGeometry:
     """Per (H, W, stride, device): the bilinear tap table of the sampling grid and its CSR transpose
     (``eml_sphere_tap_table_f32``; the transpose is what turns grid_sample's atomicAdd backward into a gather)."""
@@ -102,10 +113,10 @@ class _SphereConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
         from .. import _lib
-        _lib.require_gpu_tensor(x, "SphereConv2D input")
+        _require_gpu_f32(x, "SphereConv2D input")
         B, C, H, W = x.shape
         geo = sphere_geometry(H, W, stride, x.device)
-        xr = x.float().permute(0, 2, 3, 1).contiguous()           # (B,H,W,C); a view when x is channels-last
+        xr = x.permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C); a view when x is channels-last
         O = weight.shape[0]
         w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
         a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
@@ -154,6 +165,63 @@ def sphere_conv_siblings(x, convs):
     b = None if convs[0].bias is None else torch.cat([c.bias for c in convs], 0)
     y = _SphereConvFn.apply(x, w, b, convs[0].stride)
     return list(torch.split(y, [c.weight.shape[0] for c in convs], dim=1))
+
+
+def _rows_view(t):
+    """(B,C,H,W) tensor in channels-last memory -> (its (B*H*W, C) row-major alias, row stride)."""
+    b, c, h, w = t.shape
+    if t.stride(1) != 1 or t.stride(3) % 4 or t.stride(2) != w * t.stride(3) or (b > 1 and t.stride(0) != h * t.stride(2)):
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t, t.stride(3)
+
+
+class _SpadeModulateFn(torch.autograd.Function):
+    """``leaky_relu(normalized * (1 + gamma) + beta, slope)`` (``normalization.py:113-115`` + ``architecture.py:56-57``)
+    with gamma | beta taken from the two channel halves of one tensor ``gb`` (B, 2C, H, W): one HIP pass forward,
+    one backward (``eml_spade_modulate_*``)."""
+
+    @staticmethod
+    def forward(ctx, xn, gb, slope):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        _require_gpu_f32(xn, "SPADE normalized input")
+        B, C, H, W = xn.shape
+        xn, ldx = _rows_view(xn)
+        gb, ldg = _rows_view(gb)
+        y = torch.empty_like(xn, memory_format=torch.channels_last)
+        _lib.check(L.eml_spade_modulate_fwd_f32(p(xn), ldx, p(gb), ldg, p(y), C, B * H * W, C, float(slope), st),
+                   "eml_spade_modulate_fwd_f32")
+        ctx.save_for_backward(xn, gb)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        xn, gb = ctx.saved_tensors
+        B, C, H, W = xn.shape
+        gy, ldy = _rows_view(gy)
+        dxn = torch.empty_like(xn, memory_format=torch.channels_last)
+        dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=xn.device, memory_format=torch.channels_last)
+        _lib.check(L.eml_spade_modulate_bwd_f32(p(gy), ldy, p(xn), xn.stride(3), p(gb), gb.stride(3), p(dxn), C, p(dgb),
+                                                2 * C, B * H * W, C, ctx.slope, st), "eml_spade_modulate_bwd_f32")
+        return dxn, dgb, None
+
+
+def spade_modulate(normalized, actv, conv_gamma, conv_beta, slope=1.0):
+    """SPADE's ``normalized * (1 + gamma(actv)) + beta(actv)`` followed by ``leaky_relu(., slope)`` (slope 1 = none).
+    HIP engine: gamma | beta from ONE SphereConv (one gather, one GEMM over the concatenated heads) feeding the fused
+    modulation kernel; stock-op engine: the reference's formula."""
+    engines = {c.engine or SphereConv2D.default_engine for c in (conv_gamma, conv_beta)}
+    if engines == {"hip"} and normalized.shape[1] % 4 == 0:
+        w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
+        b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
+        gb = _SphereConvFn.apply(actv, w, b, 1)
+        return _SpadeModulateFn.apply(normalized, gb, slope)
+    gamma, beta = sphere_conv_siblings(actv, [conv_gamma, conv_beta])
+    out = normalized * (1 + gamma) + beta
+    return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
 
 
 class sphere_engine:

@@ -33,6 +33,10 @@ SIGNATURES = {
     "eml_sphere_tap_table_f32": (_int, [_f32p, _int, _int, _int, _int, _i32p, _f32p, _stream]),
     "eml_sphere_im2col_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
     "eml_sphere_col2im_f32": (_int, [_f32p, _i32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
+    "eml_spade_modulate_fwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, ctypes.c_long, _int, ctypes.c_float,
+                                          _stream]),
+    "eml_spade_modulate_bwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, ctypes.c_long,
+                                          _int, ctypes.c_float, _stream]),
     # DenseNet-BC encoder, forward
     "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
     "eml_dense_bn_apply_f32": (_int, [_f32p, _int, _f32p, _int, _int, ctypes.c_long, _f32p, _f32p, _int, _f32p,

@@ -268,6 +268,16 @@ int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, floa
 int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, const float* w, float* dX,
                           int B, int HW, int Po, int C, eml_stream_t stream);
 
+/* SPADE modulation (normalization.py:113-115 + the LeakyReLU of architecture.py:56-57) on pixel-major rows:
+ * y[r][c] = leaky_relu(xn[r][c] * (1 + gb[r][c]) + gb[r][C + c], slope), slope = 1 for the plain modulation.
+ * gb (rows, >= 2C) holds gamma | beta side by side, as the fused gamma/beta SphereConv writes them.  C % 4 == 0,
+ * every ld a multiple of 4.  Backward: d = gy * leaky_relu'(t); dxn = d * (1 + gamma); dgb = (d * xn | d). */
+int eml_spade_modulate_fwd_f32(const float* xn, int ld_x, const float* gb, int ld_gb, float* y, int ld_y,
+                               long rows, int C, float slope, eml_stream_t stream);
+int eml_spade_modulate_bwd_f32(const float* gy, int ld_gy, const float* xn, int ld_x, const float* gb,
+                               int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
+                               float slope, eml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,3 +117,32 @@ def test_projector_matches_reference_golden_on_hip_sphereconv():
     d = m2.cuda().train()(data, "discriminator")
     for k in ("D_Fake", "D_real"):
         np.testing.assert_allclose(float(d[k].detach()), float(g["d_loss/" + k]), rtol=5e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("slope", [1.0, 0.2])
+def test_spade_modulate_hip_vs_stock_ops(slope):
+    """Fused gamma|beta SphereConv + modulation (+ LeakyReLU) against normalization.py:113-115 / architecture.py:56-57
+    written with stock ops: output and the gradients w.r.t. normalized, actv and the four head parameters."""
+    import torch.nn.functional as F
+    from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_modulate
+    torch.manual_seed(3)
+    B, C, H, W, nh = 2, 16, 8, 16, 12
+    ref_g, ref_b = SphereConv2D(nh, C, engine="aten").cuda(), SphereConv2D(nh, C, engine="aten").cuda()
+    hip_g, hip_b = SphereConv2D(nh, C, engine="hip").cuda(), SphereConv2D(nh, C, engine="hip").cuda()
+    for m in (ref_g, ref_b):
+        with torch.no_grad():
+            m.bias.uniform_(-0.3, 0.3)
+    hip_g.load_state_dict(ref_g.state_dict())
+    hip_b.load_state_dict(ref_b.state_dict())
+    xn0, a0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, nh, H, W, device="cuda")
+    outs = []
+    for g_, b_ in ((ref_g, ref_b), (hip_g, hip_b)):
+        xn, actv = xn0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        y = spade_modulate(xn, actv, g_, b_, slope)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        outs.append([y.detach(), xn.grad, actv.grad, g_.weight.grad, g_.bias.grad, b_.weight.grad, b_.bias.grad])
+    want = F.leaky_relu(xn0 * (1 + ref_g(a0)) + ref_b(a0), slope) if slope != 1.0 else xn0 * (1 + ref_g(a0)) + ref_b(a0)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    for name, r, h in zip(["y", "d_normalized", "d_actv", "dWg", "dbg", "dWb", "dbb"], outs[0], outs[1]):
+        s = float(r.abs().max())
+        np.testing.assert_allclose(h.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=3e-5 * s, err_msg=name)
