@@ -78,7 +78,12 @@ __global__ __launch_bounds__(256) void sphere_im2col_kernel(const float* __restr
             acc.w += v.w * ws[k];
           }
         }
-        *reinterpret_cast<float4*>(ab + (size_t)row * C + 4 * c) = acc;
+        // streaming store: A9 is 9x the input and is next read by the GEMM long after it has left L2
+        float* dst = ab + (size_t)row * C + 4 * c;
+        __builtin_nontemporal_store(acc.x, dst);
+        __builtin_nontemporal_store(acc.y, dst + 1);
+        __builtin_nontemporal_store(acc.z, dst + 2);
+        __builtin_nontemporal_store(acc.w, dst + 3);
       } else {
         float acc = 0.f;
 #pragma unroll
@@ -138,23 +143,37 @@ extern "C" int eml_sphere_tap_table_f32(const float* grid, int H, int W, int Ho,
   return eml::check_launch("eml_sphere_tap_table_f32");
 }
 
-#define EML_SPHERE_LAUNCH(KERNEL, rows, ...)                                                                     \
-  do {                                                                                                          \
-    const int cv = (C % 4 == 0) ? C / 4 : C;                                                                    \
-    const int tpr = cv <= 4 ? 4 : cv <= 16 ? 16 : cv <= 64 ? 64 : 256;                                           \
-    const int gx = (int)std::min<size_t>(((size_t)(rows) + (256 / tpr) - 1) / (256 / tpr), (size_t)8192);          \
-    const dim3 grid(gx, B);                                                                                     \
-    if (C % 4 == 0) {                                                                                           \
-      if (tpr == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);    \
-      else if (tpr == 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (tpr == 64) hipLaunchKernelGGL((KERNEL<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
-    } else {                                                                                                    \
-      if (tpr == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);    \
-      else if (tpr == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (tpr == 64) hipLaunchKernelGGL((KERNEL<1, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
-    }                                                                                                           \
+// threads per row = the smallest power of two >= C / VEC (capped at 256): no idle lanes in the channel loop
+#define EML_SPHERE_CASE(KERNEL, V, T, ...) \
+  case T: hipLaunchKernelGGL((KERNEL<V, T>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;
+#define EML_SPHERE_LAUNCH(KERNEL, rows, ...)                                                             \
+  do {                                                                                                  \
+    const int cv = (C % 4 == 0) ? C / 4 : C;                                                            \
+    int tpr = 4;                                                                                        \
+    while (tpr < cv && tpr < 256) tpr <<= 1;                                                            \
+    const int gx = (int)std::min<size_t>(((size_t)(rows) + (256 / tpr) - 1) / (256 / tpr), (size_t)8192); \
+    const dim3 grid(gx, B);                                                                             \
+    if (C % 4 == 0) {                                                                                   \
+      switch (tpr) {                                                                                    \
+        EML_SPHERE_CASE(KERNEL, 4, 4, __VA_ARGS__)                                                      \
+        EML_SPHERE_CASE(KERNEL, 4, 8, __VA_ARGS__)                                                      \
+        EML_SPHERE_CASE(KERNEL, 4, 16, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 4, 32, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 4, 64, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 4, 128, __VA_ARGS__)                                                    \
+        EML_SPHERE_CASE(KERNEL, 4, 256, __VA_ARGS__)                                                    \
+      }                                                                                                 \
+    } else {                                                                                            \
+      switch (tpr) {                                                                                    \
+        EML_SPHERE_CASE(KERNEL, 1, 4, __VA_ARGS__)                                                      \
+        EML_SPHERE_CASE(KERNEL, 1, 8, __VA_ARGS__)                                                      \
+        EML_SPHERE_CASE(KERNEL, 1, 16, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 1, 32, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 1, 64, __VA_ARGS__)                                                     \
+        EML_SPHERE_CASE(KERNEL, 1, 128, __VA_ARGS__)                                                    \
+        EML_SPHERE_CASE(KERNEL, 1, 256, __VA_ARGS__)                                                    \
+      }                                                                                                 \
+    }                                                                                                   \
   } while (0)
 
 extern "C" int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, float* A9, int B, int HW, int Po,
