@@ -48,6 +48,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert rc == -1 and b"W==2H" in L.eml_last_error()
     rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, one, None, None, one, 2, 0, None)
     assert rc == -1
+    # encoder / projector launchers: nulls, odd pooling sizes, misaligned channel counts
+    assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None) == -1
+    assert L.eml_dense_conv3x3_bwd_data_f32(one, 224, 24, one, one, one, one, one, 1, 8, 8, one, 512, one, 224, None,
+                                            None, None, None) == -1 and b"fused affine" in L.eml_last_error()
+    assert L.eml_sphere_im2col_f32(one, one, one, None, 1, 32, 32, 8, None) == -1
+    assert L.eml_sphere_col2im_f32(one, one, one, one, one, 1, 0, 32, 8, None) == -1
+    assert L.eml_spade_modulate_fwd_f32(one, 16, one, 16, one, 16, 4, 16, ctypes.c_float(0.2), None) == -1   # gb needs 2C
+    assert L.eml_spade_modulate_bwd_f32(one, 6, one, 6, one, 12, one, 6, one, 12, 4, 6, ctypes.c_float(1.0), None) == -1
+    assert L.eml_dense_conv1x1_bwd_data_multi_f32(3, None, None, None, None, None, None, None, None, None, None, one, 224,
+                                                  one, one, 10, 0, 16, one, 224, 512, None) == -1
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -60,6 +70,10 @@ def test_product_path_has_no_cpu_fallback():
         SamplesLoss(anchors=96)(x, x)
     with pytest.raises(_lib.EmlightHipError):
         convert_to_panorama(torch.rand(1, 12), torch.rand(1, 4), torch.rand(1, 12))
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    with pytest.raises(_lib.EmlightHipError):   # default engine is HIP; stock ops only on explicit engine="aten"
+        SphereConv2D(4, 4)(torch.rand(1, 4, 8, 16))
+    assert SphereConv2D(4, 4, engine="aten")(torch.rand(1, 4, 8, 16)).shape == (1, 4, 8, 16)
 
 
 def test_product_never_imports_oracle():
