@@ -19,7 +19,7 @@ and commits the input/output vectors as ``tests/golden/*.npz``.
 checked against the oracle on the GPU box (where ``/root/reference`` does not
 exist).
 """
-from .sinkhorn import (sphere_points, anchor_cost_matrix, spherical_cost,
+from .sinkhorn import (sphere_points, anchor_cost_matrix, geometric_points, cost_matrix_of, spherical_cost,
                        epsilon_schedule, max_diameter, log_weights, softmin,
                        sinkhorn_loop, sinkhorn_cost, samples_loss,
                        samples_loss_grad_analytic)
@@ -28,7 +28,7 @@ from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss
                        deterministic_projector_state_dict)
 
 __all__ = [
-    "sphere_points", "anchor_cost_matrix", "spherical_cost", "epsilon_schedule",
+    "sphere_points", "anchor_cost_matrix", "geometric_points", "cost_matrix_of", "spherical_cost", "epsilon_schedule",
     "max_diameter", "log_weights", "softmin", "sinkhorn_loop", "sinkhorn_cost",
     "samples_loss", "samples_loss_grad_analytic", "pano_grid",
     "convert_to_panorama", "OracleDenseNet", "deterministic_state_dict",

@@ -38,6 +38,26 @@ def anchor_cost_matrix(n):
     return m
 
 
+def geometric_points(n, anchor_depth):
+    """GMLight's depth-scaled anchors, float64 ``(n, 3)``: the Fibonacci azimuths and heights of ``sphere_points`` with
+    the horizontal radius replaced by ``anchor_depth`` (``gmloss/utils.py:63-74``)."""
+    k = np.arange(n)
+    azimuth = (np.pi * (3.0 - np.sqrt(5.0))) * k
+    z = np.linspace(1.0 - 1.0 / n, 1.0 / n - 1.0, n)
+    r = np.asarray(anchor_depth, dtype=np.float64)
+    return np.stack([r * np.cos(azimuth), r * np.sin(azimuth), z + 0.0 * r], axis=1)
+
+
+def cost_matrix_of(anchors):
+    """``M_ij = ||a_i - a_j||_2`` for arbitrary anchors cast to f32 first (``gmloss/utils.py:76-92``, the same N^2
+    ``torch.norm`` loop as ``geomloss/utils.py:65-76``)."""
+    a = torch.as_tensor(np.asarray(anchors)).float()
+    d = a[:, None, :] - a[None, :, :]
+    m = torch.sqrt((d * d).sum(-1))
+    m[m < 0] = 0
+    return m
+
+
 def spherical_cost(x, y, M):
     """``C = 0.5 * (0.1 * (|x_i|^2 - 2 x_i.y_j + |y_j|^2) + M_ij)``, ``(B, N, N)``.
 

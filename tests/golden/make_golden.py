@@ -172,6 +172,36 @@ def gen_sinkhorn():
     np.savez_compressed(os.path.join(HERE, "sinkhorn.npz"), **out)
 
 
+# --------------------------------------------------------------------------- gmloss (GMLight geometry cost)
+def gmloss_inputs(B, seed):
+    """x, y on the 128 anchors plus a per-anchor depth (``gmloss/utils.py:63-74``: radius = anchor_depth)."""
+    x, y = sinkhorn_inputs("softmax", B, 128, seed)
+    depth = rng(seed, 128).uniform(0.5, 3.0, 128)
+    return x, y, depth
+
+
+def gen_gmloss():
+    """``RegressionNetwork/gmloss``: SamplesLoss.forward(x, y, geometry) -- the chord matrix of depth-scaled anchors is
+    rebuilt per call (``gmloss/samples_loss.py:72``, an N^2 Python loop in ``gmloss/utils.py:76-92``)."""
+    sys.path.insert(0, os.path.join(REF, "RegressionNetwork"))
+    import gmloss  # noqa: the reference package
+    out = {}
+    for name, B, blur in (("b3_blur05", 3, .05), ("b2_blur025", 2, .025)):
+        x_np, y_np, depth = gmloss_inputs(B, 17)
+        x = torch.from_numpy(x_np).view(B, 128, 1).requires_grad_(True)
+        y = torch.from_numpy(y_np).view(B, 128, 1)
+        crit = gmloss.SamplesLoss("sinkhorn", p=2, blur=blur, batchsize=B)
+        loss = crit(x, y, depth)
+        loss.sum().backward()
+        out[name + "/loss"] = loss.detach().numpy()
+        out[name + "/grad_x"] = x.grad.numpy().reshape(B, 128)
+        out[name + "/M_rows8"] = crit.distance.M[0, ::8].numpy()
+        out[name + "/anchors"] = crit.distance.anchors[0].numpy()
+        out[name + "/blur"] = np.float64(blur)
+        print("gmloss", name, "loss0 %.4e" % float(loss[0]))
+    np.savez_compressed(os.path.join(HERE, "gmloss.npz"), **out)
+
+
 # --------------------------------------------------------------------------- rasteriser
 def stub_io_modules():
     for m in ["cv2", "OpenEXR", "Imath", "imageio", "imageio.plugins",
@@ -399,7 +429,7 @@ def gen_projector():
 
 if __name__ == "__main__":
     install_shims()
-    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector"]
+    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector", "gmloss"]
     if "sinkhorn" in which:
         gen_sinkhorn()
     if "rasteriser" in which:
@@ -408,3 +438,5 @@ if __name__ == "__main__":
         gen_densenet()
     if "projector" in which:
         gen_projector()
+    if "gmloss" in which:
+        gen_gmloss()

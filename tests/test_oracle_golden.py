@@ -117,3 +117,22 @@ def test_densenet_cfg1_240x320_128_anchors(golden_densenet):
     assert p["distribution"].shape == (1, 128)
     for k in ("distribution", "intensity", "rgb_ratio", "ambient"):
         np.testing.assert_allclose(p[k].numpy(), g["cfg1/" + k], rtol=0, atol=1e-5)
+
+
+def test_gmloss_geometry_cost_matches_reference():
+    """GMLight variant (RegressionNetwork/gmloss): depth-scaled anchors, per-call chord matrix, same Sinkhorn."""
+    from tests.conftest import Golden
+    from tests.golden.make_golden import gmloss_inputs
+    g = Golden("gmloss")
+    for name, B in (("b3_blur05", 3), ("b2_blur025", 2)):
+        x_np, y_np, depth = gmloss_inputs(B, 17)
+        anchors = oracle.geometric_points(128, depth)
+        np.testing.assert_allclose(anchors.astype(np.float32), g[name + "/anchors"], rtol=0, atol=1e-7)
+        M = oracle.cost_matrix_of(anchors)
+        np.testing.assert_allclose(M[::8].numpy(), g[name + "/M_rows8"], rtol=0, atol=1e-6)
+        x = torch.from_numpy(x_np).view(B, 128, 1).requires_grad_(True)
+        y = torch.from_numpy(y_np).view(B, 128, 1)
+        loss = oracle.samples_loss(x, y, M, blur=float(g[name + "/blur"]))
+        np.testing.assert_allclose(loss.detach().numpy(), g[name + "/loss"], rtol=1e-5, atol=1e-7)
+        loss.sum().backward()
+        np.testing.assert_allclose(x.grad.numpy().reshape(B, 128), g[name + "/grad_x"], rtol=1e-4, atol=1e-8)
