@@ -29,6 +29,9 @@ SIGNATURES = {
                                     ctypes.c_double, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                     _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
+    # ground-truth parametrisation
+    "eml_gt_anchor_index_i32": (_int, [_f32p, _int, _int, _int, _i32p, _stream]),
+    "eml_gt_parametrise_f64": (_int, [_f32p, _i32p, _i32p, _int, _int, _int, _int, _f32p, _f32p, _f32p, _stream]),
     # GenProjector SphereConv2D
     "eml_sphere_tap_table_f32": (_int, [_f32p, _int, _int, _int, _int, _i32p, _f32p, _stream]),
     "eml_sphere_im2col_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),

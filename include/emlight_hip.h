@@ -278,6 +278,17 @@ int eml_spade_modulate_bwd_f32(const float* gy, int ld_gy, const float* xn, int 
                                int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
                                float slope, eml_stream_t stream);
 
+/* ---------------------------------------------------------------- ground-truth parametrisation (data preparation)
+ * representation/distribution_representation.py:65-120 (`extract_mesh`), the inverse of the rasteriser.
+ * idx (H*W) = nearest anchor of every pixel of the endpoint-inclusive (theta, phi) grid (:74-87); anchors (N,3) f64. */
+int eml_gt_anchor_index_i32(const double* anchors, int N, int H, int W, int* idx, eml_stream_t stream);
+
+/* compute() for a batch (:90-107).  hdr (B,H,W,3) f32 -> maxv (B) = max steradian-weighted luminance,
+ * sums (B, N+1, 3) f64 = RGB energy of the lit (> 5 % of max) pixels of each anchor's cell, row N = ambient
+ * (the unlit remainder), map (B,H,W) u8 lit mask or NULL.  csr_ptr (N+1) / csr_pix (H*W): pixels grouped by idx. */
+int eml_gt_parametrise_f64(const float* hdr, const int* csr_ptr, const int* csr_pix, int B, int H, int W,
+                           int N, double* maxv, double* sums, unsigned char* map, eml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

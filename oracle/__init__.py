@@ -24,6 +24,7 @@ from .sinkhorn import (sphere_points, anchor_cost_matrix, geometric_points, cost
                        sinkhorn_loop, sinkhorn_cost, samples_loss,
                        samples_loss_grad_analytic)
 from .rasteriser import pano_grid, convert_to_panorama
+from .representation import ExtractMesh
 from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss,
                        deterministic_projector_state_dict)
 
@@ -31,6 +32,6 @@ __all__ = [
     "sphere_points", "anchor_cost_matrix", "geometric_points", "cost_matrix_of", "spherical_cost", "epsilon_schedule",
     "max_diameter", "log_weights", "softmin", "sinkhorn_loop", "sinkhorn_cost",
     "samples_loss", "samples_loss_grad_analytic", "pano_grid",
-    "convert_to_panorama", "OracleDenseNet", "deterministic_state_dict",
+    "convert_to_panorama", "ExtractMesh", "OracleDenseNet", "deterministic_state_dict",
     "regression_loss", "deterministic_projector_state_dict",
 ]

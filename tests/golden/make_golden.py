@@ -202,6 +202,55 @@ def gen_gmloss():
     np.savez_compressed(os.path.join(HERE, "gmloss.npz"), **out)
 
 
+# --------------------------------------------------------------------------- GT parametrisation
+def gt_hdr_inputs(B, h, w, seed):
+    """Synthetic HDR panoramas (B, h, w, 3) f32: a few bright lobes on a dim, smooth ambient field."""
+    g = rng(seed, B, h, w)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    out = np.zeros((B, h, w, 3), dtype=np.float64)
+    for b in range(B):
+        out[b] = 0.05 * (1 + np.sin(6 * xx + b)[..., None] * g.uniform(0.1, 0.3, 3))
+        for _ in range(3):
+            cy, cx, s = g.uniform(0.1, 0.9), g.uniform(0.05, 0.95), g.uniform(0.01, 0.04)
+            out[b] += (np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)) * g.uniform(20, 200))[..., None] * g.uniform(0.5, 1.0, 3)
+    return out.astype(np.float32)
+
+
+def ref_extract_mesh():
+    """The reference class itself: ``distribution_representation.py`` runs a dataset loop at import time, so only its
+    ``extract_mesh`` ClassDef is compiled (from the file where it lies) against the reference's own ``util`` module."""
+    import ast
+    stub_io_modules()
+    sys.modules.setdefault("detect_util", MagicMock())
+    rep = os.path.join(REF, "RegressionNetwork", "representation")
+    sys.path.insert(0, rep)
+    import importlib.util as ilu
+    spec = ilu.spec_from_file_location("ref_representation_util", os.path.join(rep, "util.py"))
+    util = ilu.module_from_spec(spec)
+    spec.loader.exec_module(util)
+    src = open(os.path.join(rep, "distribution_representation.py")).read()
+    node = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "extract_mesh"][0]
+    ns = {"np": np, "util": util}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "distribution_representation.py", "exec"), ns)
+    return ns["extract_mesh"]
+
+
+def gen_gt_param():
+    cls = ref_extract_mesh()
+    out = {}
+    for name, h, w, ln, B in (("h128_n128", 128, 256, 128, 2), ("h64_n96", 64, 128, 96, 2)):
+        ex = cls(h=h, w=w, ln=ln)
+        hdr = gt_hdr_inputs(B, h, w, 5)
+        out[name + "/idx"] = ex.idx.astype(np.int32)
+        for b in range(B):
+            para, mp = ex.compute(hdr[b])
+            for k in ("distribution", "intensity", "rgb_ratio", "ambient"):
+                out["%s/%d/%s" % (name, b, k)] = np.asarray(para[k], dtype=np.float64)
+            out["%s/%d/map_count" % (name, b)] = np.int64(mp.sum())
+        print("gt_param", name, "intensity %.4f" % float(para["intensity"]), "lit pixels", int(mp.sum()))
+    np.savez_compressed(os.path.join(HERE, "gt_param.npz"), **out)
+
+
 # --------------------------------------------------------------------------- rasteriser
 def stub_io_modules():
     for m in ["cv2", "OpenEXR", "Imath", "imageio", "imageio.plugins",
@@ -429,7 +478,7 @@ def gen_projector():
 
 if __name__ == "__main__":
     install_shims()
-    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector", "gmloss"]
+    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector", "gmloss", "gt_param"]
     if "sinkhorn" in which:
         gen_sinkhorn()
     if "rasteriser" in which:
@@ -440,3 +489,5 @@ if __name__ == "__main__":
         gen_projector()
     if "gmloss" in which:
         gen_gmloss()
+    if "gt_param" in which:
+        gen_gt_param()

@@ -136,3 +136,20 @@ def test_gmloss_geometry_cost_matches_reference():
         np.testing.assert_allclose(loss.detach().numpy(), g[name + "/loss"], rtol=1e-5, atol=1e-7)
         loss.sum().backward()
         np.testing.assert_allclose(x.grad.numpy().reshape(B, 128), g[name + "/grad_x"], rtol=1e-4, atol=1e-8)
+
+
+def test_gt_parametrisation_matches_reference():
+    """extract_mesh (representation/distribution_representation.py:65-120): nearest-anchor map and the four parameter
+    groups of synthetic HDR panoramas against the reference class itself."""
+    from tests.conftest import Golden
+    from tests.golden.make_golden import gt_hdr_inputs
+    g = Golden("gt_param")
+    for name, h, w, ln, B in (("h128_n128", 128, 256, 128, 2), ("h64_n96", 64, 128, 96, 2)):
+        ex = oracle.ExtractMesh(h=h, w=w, ln=ln)
+        np.testing.assert_array_equal(ex.idx.astype(np.int32), g[name + "/idx"])
+        hdr = gt_hdr_inputs(B, h, w, 5)
+        for b in range(B):
+            para, mp = ex.compute(hdr[b])
+            assert int(mp.sum()) == int(g["%s/%d/map_count" % (name, b)])
+            for k in ("distribution", "intensity", "rgb_ratio", "ambient"):
+                np.testing.assert_allclose(para[k], g["%s/%d/%s" % (name, b, k)], rtol=1e-12, atol=1e-14, err_msg=k)
