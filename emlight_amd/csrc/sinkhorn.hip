@@ -221,14 +221,21 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       const float4* hv4 = reinterpret_cast<const float4*>(hsrc + jbase);
       // four independent max / sum chains: with 2 waves per SIMD the sweep is latency-bound, not
       // throughput-bound, so instruction-level parallelism inside the wave is what shortens it
+      // the exponents t_j = h_j - C_ij / eps are kept in registers between the max pass and the exp pass (the
+      // sweep is VALU / transcendental-bound: recomputing them cost a second LDS read and an fma per element)
+      float tj[kCJ];
       float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
       for (int q = 0; q < kCJ / 4; ++q) {
         const float4 hv = hv4[q];
-        m0 = fmaxf(m0, fmaf(c[4 * q + 0], nie2, hv.x));
-        m1 = fmaxf(m1, fmaf(c[4 * q + 1], nie2, hv.y));
-        m2 = fmaxf(m2, fmaf(c[4 * q + 2], nie2, hv.z));
-        m3 = fmaxf(m3, fmaf(c[4 * q + 3], nie2, hv.w));
+        tj[4 * q + 0] = fmaf(c[4 * q + 0], nie2, hv.x);
+        tj[4 * q + 1] = fmaf(c[4 * q + 1], nie2, hv.y);
+        tj[4 * q + 2] = fmaf(c[4 * q + 2], nie2, hv.z);
+        tj[4 * q + 3] = fmaf(c[4 * q + 3], nie2, hv.w);
+        m0 = fmaxf(m0, tj[4 * q + 0]);
+        m1 = fmaxf(m1, tj[4 * q + 1]);
+        m2 = fmaxf(m2, tj[4 * q + 2]);
+        m3 = fmaxf(m3, tj[4 * q + 3]);
       }
       float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
       m = fmaxf(m, eml::lane_xor1(m));  // the 4 lanes of a row are a DPP quad
@@ -238,23 +245,21 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int q = 0; q < kCJ / 4; ++q) {
-          const float4 hv = hv4[q];
-          s0 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
-          s1 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
-          s2 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
-          s3 += __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
+          s0 += __builtin_amdgcn_exp2f(tj[4 * q + 0] - m);
+          s1 += __builtin_amdgcn_exp2f(tj[4 * q + 1] - m);
+          s2 += __builtin_amdgcn_exp2f(tj[4 * q + 2] - m);
+          s3 += __builtin_amdgcn_exp2f(tj[4 * q + 3] - m);
         }
         sum = (s0 + s1) + (s2 + s3);
       } else {
         const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
 #pragma unroll
         for (int q = 0; q < kCJ / 4; ++q) {
-          const float4 hv = hv4[q];
           const float4 qv = qrow[q];
-          const float e0 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 0], nie2, hv.x - m));
-          const float e1 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 1], nie2, hv.y - m));
-          const float e2 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 2], nie2, hv.z - m));
-          const float e3 = __builtin_amdgcn_exp2f(fmaf(c[4 * q + 3], nie2, hv.w - m));
+          const float e0 = __builtin_amdgcn_exp2f(tj[4 * q + 0] - m);
+          const float e1 = __builtin_amdgcn_exp2f(tj[4 * q + 1] - m);
+          const float e2 = __builtin_amdgcn_exp2f(tj[4 * q + 2] - m);
+          const float e3 = __builtin_amdgcn_exp2f(tj[4 * q + 3] - m);
           sum += (e0 + e1) + (e2 + e3);
           tq = fmaf(e0, qv.x, fmaf(e1, qv.y, fmaf(e2, qv.z, fmaf(e3, qv.w, tq))));
         }
