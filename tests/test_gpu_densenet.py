@@ -108,3 +108,47 @@ def test_backward_small_vs_oracle(crop_hw, B):
     for k in KEYS:
         np.testing.assert_allclose(pg[k].detach().cpu().numpy(), po[k].detach().numpy(), rtol=1e-5, atol=OUT_ATOL)
     _grad_check(net, ref)
+
+
+def test_properties_at_full_baseline_size():
+    """BASELINE configs[1] (B=64, 240x320, 128 anchors) is too large for the oracle, so the full-size check uses
+    properties of the encoder that do not depend on size: bitwise run-to-run determinism, sample independence in eval
+    mode, batch-permutation equivariance in train mode (batch statistics are order-free), and exact linearity of the
+    backward in the upstream gradient."""
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    torch.manual_seed(5)
+    net = DenseNet(anchors=128, crop_hw=(240, 320), engine="hip").cuda()
+    ref = oracle.OracleDenseNet(anchors=128, crop_hw=(240, 320))
+    net.load_state_dict(oracle.deterministic_state_dict(ref.state_dict(), seed=2))
+    x = torch.rand(64, 3, 240, 320, device="cuda")
+
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+        sub = net(x[8:12].contiguous())
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), "eval forward must be run-to-run exact (%s)" % k
+        np.testing.assert_allclose(a[k][8:12].cpu().numpy(), sub[k].cpu().numpy(), rtol=1e-5, atol=1e-5,
+                                   err_msg="eval outputs of a sample must not depend on its batch (%s)" % k)
+
+    net.train()
+    perm = torch.randperm(64, device="cuda")
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    out = net(x)
+    net.load_state_dict(state)  # same running statistics for the second pass
+    outp = net(x[perm].contiguous())
+    for k in KEYS:
+        scale = float(out[k].detach().abs().max())
+        np.testing.assert_allclose(outp[k].detach().cpu().numpy(), out[k].detach()[perm].cpu().numpy(), rtol=0,
+                                   atol=2e-5 * max(scale, 1.0), err_msg="batch permutation (%s)" % k)
+
+    def grads(factor):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        o = net(x)
+        (factor * sum((o[k] * (i + 1)).sum() for i, k in enumerate(KEYS))).backward()
+        return [p.grad.clone() for p in net.parameters()]
+    g1, g2 = grads(1.0), grads(2.0)
+    for p1, p2 in zip(g1, g2):
+        assert torch.equal(2.0 * p1, p2), "backward must be exactly linear in the upstream gradient"
+    assert all(bool(torch.isfinite(g).all()) for g in g1)

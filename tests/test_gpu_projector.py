@@ -146,3 +146,24 @@ def test_spade_modulate_hip_vs_stock_ops(slope):
     for name, r, h in zip(["y", "d_normalized", "d_actv", "dWg", "dbg", "dWb", "dbb"], outs[0], outs[1]):
         s = float(r.abs().max())
         np.testing.assert_allclose(h.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=3e-5 * s, err_msg=name)
+
+
+def test_sphere_conv_properties_at_full_size():
+    """cfg3 size (B=32, 128x256, 128 -> 64 channels) is checked through size-independent properties: exact linearity
+    and determinism of the forward, and the adjoint identity <conv(x), y> == <x, conv^T(y)> that ties the deterministic
+    col2im gather to the im2col gather it transposes."""
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    torch.manual_seed(9)
+    m = SphereConv2D(128, 64, bias=False).cuda()
+    x = torch.randn(32, 128, 128, 256, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y1 = m(x)
+    with torch.no_grad():
+        assert torch.equal(m(x), y1), "forward must be run-to-run exact"
+        assert torch.equal(m(2.0 * x), 2.0 * y1), "forward must be exactly linear in x"
+    gy = torch.randn_like(y1)
+    (gx,) = torch.autograd.grad(y1, x, gy, retain_graph=True)
+    (gx2,) = torch.autograd.grad(y1, x, gy)
+    assert torch.equal(gx, gx2), "gather backward must be run-to-run exact"
+    lhs = float((y1.detach().double() * gy.double()).sum())
+    rhs = float((x.detach().double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
