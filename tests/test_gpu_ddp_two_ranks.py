@@ -46,3 +46,45 @@ def test_two_ranks_hip_engine_ddp(tmp_path):
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     assert r0[0] == 0.0 and r1[0] == 0.0, "replicas diverged under DDP"
     assert r0[1] == 1.0 and r1[1] == 1.0
+
+
+def _projector_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world), EML_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.data import projector_batch
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    r, local, w = init_distributed()
+    torch.manual_seed(0)
+    tr = Trainer(networks.default_options(ngf=4, ndf=4), device="cuda:0", world=w)   # SyncBatchNorm + DDP(G), DDP(D)
+    assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in tr.model.netG.modules())
+    data = projector_batch(1, "cuda:0", seed=50 + rank)
+    tr.step(data)
+    ok = all(bool(torch.isfinite(v).all()) for v in tr.get_latest_losses().values())
+    diffs = []
+    for net in (tr.model.netG, tr.model.netD):
+        flat = torch.cat([q.detach().reshape(-1) for q in net.parameters()] +
+                         [b.detach().float().reshape(-1) for b in net.buffers()])   # incl. SyncBN running statistics
+        gathered = [torch.empty_like(flat) for _ in range(w)]
+        dist.all_gather(gathered, flat)
+        diffs.append(float((gathered[0] - gathered[1]).abs().max()))
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), np.array([float(ok)] + diffs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_projector_syncbn_hip_sphereconv(tmp_path):
+    """Projector trainer on two ranks: HIP SphereConv2D / SPADE kernels under DDP with SyncBatchNorm (the job of the
+    reference's vendored sync_batchnorm): parameters AND running statistics of both networks stay identical."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_projector_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert p0[0] == 1.0 and p1[0] == 1.0
+    assert p0[1] == 0.0 and p0[2] == 0.0, "projector replicas diverged: %s" % p0
