@@ -168,7 +168,11 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
 
   // ---- cached kernel: M -> LDS (coalesced), then this thread's costs -> registers
-  float c[kCJ];
+  // costs and exponents live in registers as float PAIRS so that the sweep's fma / subtract / add map onto
+  // v_pk_fma_f32 / v_pk_add_f32 (two elements per VALU slot): the sweep is VALU-throughput-bound on the one CU that
+  // holds a sample's coupled (yx, xy) problems
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f c2[kCJ / 2];
   int i = 0, jbase = 0;
   bool owner = false;
   if constexpr (kCached) {
@@ -193,10 +197,8 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     for (int q = 0; q < kCJ / 4; ++q) {
       const float4 mv = mrow[q];
       const float4 qv = qrow[q];
-      c[4 * q + 0] = (4 * q + 0 < cnt) ? cost_ij(pi, qv.x, mv.x) : kBig;
-      c[4 * q + 1] = (4 * q + 1 < cnt) ? cost_ij(pi, qv.y, mv.y) : kBig;
-      c[4 * q + 2] = (4 * q + 2 < cnt) ? cost_ij(pi, qv.z, mv.z) : kBig;
-      c[4 * q + 3] = (4 * q + 3 < cnt) ? cost_ij(pi, qv.w, mv.w) : kBig;
+      c2[2 * q + 0] = v2f{(4 * q + 0 < cnt) ? cost_ij(pi, qv.x, mv.x) : kBig, (4 * q + 1 < cnt) ? cost_ij(pi, qv.y, mv.y) : kBig};
+      c2[2 * q + 1] = v2f{(4 * q + 2 < cnt) ? cost_ij(pi, qv.z, mv.z) : kBig, (4 * q + 3 < cnt) ? cost_ij(pi, qv.w, mv.w) : kBig};
     }
   }
   // sweep 0 reads h = log w (potentials are zero): sinkhorn_divergence.py:82-85
@@ -223,43 +225,41 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       // throughput-bound, so instruction-level parallelism inside the wave is what shortens it
       // the exponents t_j = h_j - C_ij / eps are kept in registers between the max pass and the exp pass (the
       // sweep is VALU / transcendental-bound: recomputing them cost a second LDS read and an fma per element)
-      float tj[kCJ];
-      float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+      v2f t2[kCJ / 2];
+      const v2f n2 = v2f{nie2, nie2};
+      v2f mA = v2f{-INFINITY, -INFINITY}, mB = mA;   // four independent max chains, as two pairs
 #pragma unroll
       for (int q = 0; q < kCJ / 4; ++q) {
         const float4 hv = hv4[q];
-        tj[4 * q + 0] = fmaf(c[4 * q + 0], nie2, hv.x);
-        tj[4 * q + 1] = fmaf(c[4 * q + 1], nie2, hv.y);
-        tj[4 * q + 2] = fmaf(c[4 * q + 2], nie2, hv.z);
-        tj[4 * q + 3] = fmaf(c[4 * q + 3], nie2, hv.w);
-        m0 = fmaxf(m0, tj[4 * q + 0]);
-        m1 = fmaxf(m1, tj[4 * q + 1]);
-        m2 = fmaxf(m2, tj[4 * q + 2]);
-        m3 = fmaxf(m3, tj[4 * q + 3]);
+        t2[2 * q + 0] = c2[2 * q + 0] * n2 + v2f{hv.x, hv.y};   // contracted: v_pk_fma_f32
+        t2[2 * q + 1] = c2[2 * q + 1] * n2 + v2f{hv.z, hv.w};
+        mA = __builtin_elementwise_max(mA, t2[2 * q + 0]);
+        mB = __builtin_elementwise_max(mB, t2[2 * q + 1]);
       }
-      float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      float m = fmaxf(fmaxf(mA.x, mA.y), fmaxf(mB.x, mB.y));
       m = fmaxf(m, eml::lane_xor1(m));  // the 4 lanes of a row are a DPP quad
       m = fmaxf(m, eml::lane_xor2(m));
+      const v2f mm = v2f{m, m};
       float sum = 0.f, tq = 0.f;
       if (!final_sweep) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        v2f sA = v2f{0.f, 0.f}, sB = sA;   // s0, s1 | s2, s3 of the scalar form: same summation order
 #pragma unroll
         for (int q = 0; q < kCJ / 4; ++q) {
-          s0 += __builtin_amdgcn_exp2f(tj[4 * q + 0] - m);
-          s1 += __builtin_amdgcn_exp2f(tj[4 * q + 1] - m);
-          s2 += __builtin_amdgcn_exp2f(tj[4 * q + 2] - m);
-          s3 += __builtin_amdgcn_exp2f(tj[4 * q + 3] - m);
+          const v2f dA = t2[2 * q + 0] - mm, dB = t2[2 * q + 1] - mm;
+          sA += v2f{__builtin_amdgcn_exp2f(dA.x), __builtin_amdgcn_exp2f(dA.y)};
+          sB += v2f{__builtin_amdgcn_exp2f(dB.x), __builtin_amdgcn_exp2f(dB.y)};
         }
-        sum = (s0 + s1) + (s2 + s3);
+        sum = (sA.x + sA.y) + (sB.x + sB.y);
       } else {
         const float4* qrow = reinterpret_cast<const float4*>(Q + jbase);
 #pragma unroll
         for (int q = 0; q < kCJ / 4; ++q) {
           const float4 qv = qrow[q];
-          const float e0 = __builtin_amdgcn_exp2f(tj[4 * q + 0] - m);
-          const float e1 = __builtin_amdgcn_exp2f(tj[4 * q + 1] - m);
-          const float e2 = __builtin_amdgcn_exp2f(tj[4 * q + 2] - m);
-          const float e3 = __builtin_amdgcn_exp2f(tj[4 * q + 3] - m);
+          const v2f dA = t2[2 * q + 0] - mm, dB = t2[2 * q + 1] - mm;
+          const float e0 = __builtin_amdgcn_exp2f(dA.x);
+          const float e1 = __builtin_amdgcn_exp2f(dA.y);
+          const float e2 = __builtin_amdgcn_exp2f(dB.x);
+          const float e3 = __builtin_amdgcn_exp2f(dB.y);
           sum += (e0 + e1) + (e2 + e3);
           tq = fmaf(e0, qv.x, fmaf(e1, qv.y, fmaf(e2, qv.z, fmaf(e3, qv.w, tq))));
         }
