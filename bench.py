@@ -77,7 +77,7 @@ FAMILIES = {
     "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS)", 0),
     "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 1-2 dense layers per pass + ReLU "
                                              "mask + BN1-backward accumulate)", 0),
-    "eml_dense_conv1x1_bwd_data_f32": ("conv1x1_bwd_data_kernel<POOL> (transition dgrad)", 2),
+    "eml_dense_conv1x1_bwd_data_f32": ("transition_bwd_data_kernel (transition dgrad: un-pool, ReLU mask, BN backward accumulate)", 2),
     "eml_dense_pool_act_f32": ("pool_act_kernel (transition operand: 2x2 mean of relu(bn(x)))", 3),
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
     "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),

@@ -809,6 +809,178 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
         (sacc[e] + sacc[(size_t)Kp * 2 + e]) + (sacc[(size_t)2 * Kp * 2 + e] + sacc[(size_t)3 * Kp * 2 + e]);
 }
 
+// ------------------------------------------------------------------------------- transition (pooled) dgrad
+// The general kernel above runs the transitions (Ko = 112..176 output channels, 2x2 un-pooling) at one wave per SIMD
+// (296 VGPRs) and loads x inside the exec-masked epilogue.  This one is built like the dense-layer pass: 32 pooled
+// pixels per wave, two 16-channel tiles per chunk, the chunk's 16 x quads (4 input pixels per pooled pixel) requested
+// before its MFMAs, the next output-channel group's dz / weight fragments requested one step ahead, per-channel
+// vectors in LDS, unconditional operand use, DPP row reductions -- 2 waves per SIMD and no exposed round trips.
+template <int MT, int NCH, bool ACC /* G += instead of G = */>
+__global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
+    const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
+    const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
+    const float* __restrict__ X, int ldx, const float* __restrict__ scale1, const float* __restrict__ shift1,
+    const float* __restrict__ mean, const float* __restrict__ istd, int P, int Hin, int Win, int Kp,
+    float* __restrict__ Gd, int ldg, double* __restrict__ partials /*[grid][Kp][2]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double* sacc = reinterpret_cast<double*>(smem);                  // [4 waves][Kp][2]
+  float* vec_l = reinterpret_cast<float*>(sacc + (size_t)4 * Kp * 2);  // scale1, shift1, mean, istd [Kp]; cA, cB, cC [Ko]
+  float* co_l = vec_l + 4 * Kp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < 4 * Kp * 2; e += 256) sacc[e] = 0.0;
+  for (int e = tid; e < Kp; e += 256) {
+    vec_l[e] = scale1[e];
+    vec_l[Kp + e] = shift1[e];
+    vec_l[2 * Kp + e] = mean[e];
+    vec_l[3 * Kp + e] = istd[e];
+  }
+  for (int e = tid; e < Ko; e += 256) {
+    co_l[e] = cA[e];
+    co_l[Ko + e] = cB[e];
+    co_l[2 * Ko + e] = cC[e];
+  }
+  __syncthreads();
+  double* my = sacc + (size_t)wave * Kp * 2;
+  const int nnt = Kp >> 4, njo = Ko >> 4;
+  constexpr int TP = 64 * MT;
+  const int ntiles = (P + TP - 1) / TP;
+  const int Wo = Win >> 1, Ho = Hin >> 1;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = tile * TP + wave * 16 * MT;
+    long prow[MT];
+    size_t pin[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      pv[m] = p0 + 16 * m + r < P;
+      prow[m] = min(p0 + 16 * m + r, P - 1);
+      const int b = (int)(prow[m] / (Ho * Wo)), rem = (int)(prow[m] - (long)b * (Ho * Wo));
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      pin[m] = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;   // top-left input pixel of the pooling window
+    }
+    for (int nt0 = 0; nt0 < nnt; nt0 += NCH) {
+      // the chunk's x quads (and old G when accumulating): requested now, consumed after the MFMAs
+      float4 xv[MT][NCH][4], gs[ACC ? MT : 1][ACC ? NCH : 1][4];
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        const int k4 = 16 * min(nt0 + n, nnt - 1) + 4 * kk;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            const size_t pi = pin[m] + (sub >> 1) * (size_t)Win + (sub & 1);
+            xv[m][n][sub] = *reinterpret_cast<const float4*>(X + pi * ldx + k4);
+            if constexpr (ACC) gs[m][n][sub] = *reinterpret_cast<const float4*>(Gd + pi * ldg + k4);
+          }
+      }
+      f32x4 acc[MT][NCH];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // output-channel groups, fragments of group jo+1 in flight during the MFMAs of group jo
+      float4 ry[MT], rz[MT], wq[NCH];
+      auto load_group = [&](int jo) {
+        const int ch = 16 * jo + 4 * kk;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          ry[m] = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
+          rz[m] = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+        }
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+          const int nt = min(nt0 + n, nnt - 1);
+          wq[n] = *reinterpret_cast<const float4*>(Wd + ((((size_t)nt * njo + jo) * 4 + kk) * 16 + r) * 4);
+        }
+      };
+      load_group(0);
+      for (int jo = 0; jo < njo; ++jo) {
+        const int ch = 16 * jo + 4 * kk;
+        const float4 a4 = *reinterpret_cast<const float4*>(co_l + ch);
+        const float4 b4 = *reinterpret_cast<const float4*>(co_l + Ko + ch);
+        const float4 c4 = *reinterpret_cast<const float4*>(co_l + 2 * Ko + ch);
+        float4 dz[MT], wc[NCH];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          dz[m].x = fmaf(a4.x, ry[m].x, fmaf(b4.x, rz[m].x, c4.x));
+          dz[m].y = fmaf(a4.y, ry[m].y, fmaf(b4.y, rz[m].y, c4.y));
+          dz[m].z = fmaf(a4.z, ry[m].z, fmaf(b4.z, rz[m].z, c4.z));
+          dz[m].w = fmaf(a4.w, ry[m].w, fmaf(b4.w, rz[m].w, c4.w));
+        }
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) wc[n] = wq[n];
+        load_group(min(jo + 1, njo - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int n = 0; n < NCH; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][n] = mfma16(f4c(wc[n], t), f4c(dz[m], t), acc[m][n]);
+      }
+      // epilogue: lane owns channels k4..k4+3 of the 4 input pixels under each of its MT pooled pixels
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        const int nt = nt0 + n;
+        if (nt < nnt) {  // block-uniform
+          const int k4 = 16 * nt + 4 * kk;
+          const float4 sk = *reinterpret_cast<const float4*>(vec_l + k4);
+          const float4 tk = *reinterpret_cast<const float4*>(vec_l + Kp + k4);
+          const float4 mu = *reinterpret_cast<const float4*>(vec_l + 2 * Kp + k4);
+          const float4 is = *reinterpret_cast<const float4*>(vec_l + 3 * Kp + k4);
+          float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float da0 = 0.25f * acc[m][n][0], da1 = 0.25f * acc[m][n][1];
+            const float da2 = 0.25f * acc[m][n][2], da3 = 0.25f * acc[m][n][3];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+              const float4 x = xv[m][n][sub];
+              float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+              if constexpr (ACC) g = gs[m][n][sub];
+              const float d0 = (pv[m] && fmaf(x.x, sk.x, tk.x) > 0.f) ? da0 : 0.f;
+              const float d1 = (pv[m] && fmaf(x.y, sk.y, tk.y) > 0.f) ? da1 : 0.f;
+              const float d2 = (pv[m] && fmaf(x.z, sk.z, tk.z) > 0.f) ? da2 : 0.f;
+              const float d3 = (pv[m] && fmaf(x.w, sk.w, tk.w) > 0.f) ? da3 : 0.f;
+              g.x = fmaf(sk.x, d0, g.x);
+              g.y = fmaf(sk.y, d1, g.y);
+              g.z = fmaf(sk.z, d2, g.z);
+              g.w = fmaf(sk.w, d3, g.w);
+              if (pv[m]) {
+                const size_t pi = pin[m] + (sub >> 1) * (size_t)Win + (sub & 1);
+                *reinterpret_cast<float4*>(Gd + pi * ldg + k4) = g;
+              }
+              l1[0] += d0;
+              l1[1] += d1;
+              l1[2] += d2;
+              l1[3] += d3;
+              l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
+              l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
+              l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
+              l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            l1[g] = eml::row16_sum(l1[g]);
+            l2[g] = eml::row16_sum(l2[g]);
+            if (r == 0) {
+              my[2 * (k4 + g)] += (double)l1[g];
+              my[2 * (k4 + g) + 1] += (double)l2[g];
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < Kp * 2; e += 256)
+    partials[(size_t)blockIdx.x * Kp * 2 + e] =
+        (sacc[e] + sacc[(size_t)Kp * 2 + e]) + (sacc[(size_t)2 * Kp * 2 + e] + sacc[(size_t)3 * Kp * 2 + e]);
+}
+
 // ------------------------------------------------------------------------------- dense layers: 1 or 2 layers per pass
 // The dense-layer backward is HBM-bound on the O(L^2) traffic of X[:, :Cin] and G[:, :Cin].  Two
 // consecutive layers (l, l-1) touch the same channels [0, Cin_{l-1}), so their dgrad is done in ONE
@@ -1300,7 +1472,21 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
   // dense layers (Ko == 48): 2 channel tiles per chunk -> fewer accumulators, 3 waves/SIMD; measured
   // 10-20 % faster than 4 (the kernel is HBM-bound: more waves = more bytes in flight)
   if (pool) {
-    if (Ko == 48) EML_LAUNCH_BWD_DATA(true, true, 4); else EML_LAUNCH_BWD_DATA(true, false, 4);
+    if (Ko == 48) {
+      EML_LAUNCH_BWD_DATA(true, true, 4);
+    } else {  // transitions
+      const size_t lds_t = lds + (size_t)(4 * Kp + 3 * Ko) * sizeof(float);
+#define EML_LAUNCH_TRANSITION(ACCV)                                                                                    \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transition_bwd_data_kernel<2, 2, ACCV>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);                                 \
+    hipLaunchKernelGGL((transition_bwd_data_kernel<2, 2, ACCV>), dim3(grid), dim3(256), lds_t, (hipStream_t)stream, DY, \
+                       ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, \
+                       ldg, partials);                                                                                 \
+  } while (0)
+      if (accumulate) EML_LAUNCH_TRANSITION(true); else EML_LAUNCH_TRANSITION(false);
+#undef EML_LAUNCH_TRANSITION
+    }
   } else {
     if (Ko == 48) EML_LAUNCH_BWD_DATA(false, true, 2); else EML_LAUNCH_BWD_DATA(false, false, 4);
   }
