@@ -39,6 +39,7 @@ def run_backward(enc, ws, x, gpooled):
     dev = x.device
     B, _, H, W = x.shape
     G = enc._grid(dev)
+    G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
     Gb = min(enc.grid_max, 4 * enc._cu)
     if getattr(ws, "bwd", None) is None:
         ws.bwd = _BwdBuffers(enc, ws, dev)
@@ -110,13 +111,13 @@ def run_backward(enc, ws, x, gpooled):
             # the gradient of this layer's 12 output channels is complete: its deferred BN1 affine (sB, sC) is
             # applied inside the conv3x3 dgrad's tile staging, which also leaves the finished gradient in GF12
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gbuf), ld, cin, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
-                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G, p(blk["X"]), ld,
+                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3, p(blk["X"]), ld,
                                                         p(sB), p(sC), p(bw.GF12), st),
                        "eml_dense_conv3x3_bwd_data_f32")
             _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12), 12, 0, p(z), p(lay["scale2"]), p(lay["shift2"]),
-                                                          B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G, st),
+                                                          B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G3, st),
                        "eml_dense_conv3x3_bwd_weight_f32")
-            finalize(G, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
+            finalize(G3, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
