@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemlight_hip.so")
+LIB_PATH = os.environ.get("EML_LIB_PATH") or os.path.join(_HERE, "libemlight_hip.so")   # override: A/B builds (tools/exp_build.sh)
 
 _f32p = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _i32p = ctypes.c_void_p
