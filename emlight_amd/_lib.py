@@ -15,6 +15,8 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
+ABI_VERSION = 2   # == EML_ABI_VERSION of include/emlight_hip.h
+
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
     "eml_abi_version": (_int, []),
@@ -109,6 +111,10 @@ def lib():
             except AttributeError as e:
                 raise EmlightHipError("libemlight_hip.so lacks symbol %s" % name) from e
             fn.restype, fn.argtypes = res, args
+        got = handle.eml_abi_version()
+        if got != ABI_VERSION:  # a stale in-tree .so bound with the wrong argument lists would corrupt memory, not fail
+            raise EmlightHipError("libemlight_hip.so has ABI version %d, this binding expects %d -- rebuild it "
+                                  "(make -C emlight_amd/csrc)" % (got, ABI_VERSION))
         _lib = handle
     return _lib
 

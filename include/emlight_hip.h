@@ -34,7 +34,9 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 #define EML_MAX_EPS 64    /* capacity of an epsilon schedule buffer (floats) */
 
-/* Library ABI version (bumped on any signature change) and last-error text. */
+/* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
+ * version of this header) and last-error text. */
+#define EML_ABI_VERSION 2
 int eml_abi_version(void);
 const char* eml_last_error(void);
 

@@ -34,7 +34,8 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
 
 def test_loader_and_abi_version(built_lib):
     L = built_lib.lib()
-    assert L.eml_abi_version() >= 1
+    header = open(os.path.join(ROOT, "include", "emlight_hip.h")).read()
+    assert L.eml_abi_version() == built_lib.ABI_VERSION == int(re.search(r"#define EML_ABI_VERSION (\d+)", header).group(1))
     assert L.eml_sinkhorn_work_floats(3, 5) == 8 * 3 * 5
 
 
