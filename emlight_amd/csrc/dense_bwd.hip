@@ -1,18 +1,21 @@
 // Backward kernels of the DenseNet-BC encoder for gfx950 (f32 MFMA 16x16x4).
 //
 // Per dense layer (reverse order), with G the gradient buffer that mirrors the block buffer X:
-//   conv3x3_bwd_data   dzn = conv2^T(G[:, Cin:Cin+12])           + partial (sum dzn, sum dzn*zhat)
+//   conv3x3_bwd_data   dzn = conv2^T(g), g = G[:, Cin:Cin+12] + sB*x + sC (deferred BN1 affine applied while
+//                      staging; g also written compactly for the weight gradient) + partial (sum dzn, sum dzn*zhat)
 //   conv3x3_bwd_weight dW2 = sum_p g[p] (x) BN2(z)[p+tap]        (persistent accumulators, partials)
 //   bn_bwd_finalize    dgamma2, dbeta2, and the affine that turns dzn into dz on the fly:
 //                      dz = cA*dzn + cB*z + cC   (BatchNorm backward is affine per channel)
 //   conv1x1_bwd_weight dW1 = sum_p relu(bn1(x))[p] (x) dz[p]     (dz rebuilt in the operand load)
-//   conv1x1_bwd_data   dam = relu-mask * (dz W1);  G[:, :Cin] += scale1*dam in the epilogue (the
-//                      dy-coefficient of BN1's backward needs no statistics) + partial (sum, sum*xhat)
+//   conv1x1_bwd_data_multi   dam = relu-mask * (dz W1) for ONE or TWO consecutive layers per pass over X;
+//                      G[:, :Cin] += scale1*dam in the epilogue (the dy-coefficient of BN1's backward needs no
+//                      statistics) + partial (sum, sum*xhat) per layer
 //   bn_bwd_finalize    dgamma1, dbeta1; the statistics-dependent affine (cB*x + cC) is only summed
-//                      per channel into sB/sC and applied ONCE per channel by grad_materialize
-// The transitions reuse the conv1x1 kernels with the 2x2 average pool folded into the operand
-// (POOL) and last_norm's backward folded into the dz affine.  All reductions are per-block
-// partials + a finishing kernel: deterministic, no atomics.
+//                      per channel into sB/sC and applied ONCE per channel, where the channel is consumed
+//                      (conv3x3_bwd_data; grad_materialize for a block's input channels)
+// The transitions: weight gradient on the pooled activation the forward kept (pool_act), data gradient by
+// transition_bwd_data (un-pool, mask, accumulate), last_norm's backward folded into the dz affine.  All
+// reductions are per-block partials + a finishing kernel: deterministic, no atomics.
 #include "eml_common.h"
 
 #include <type_traits>

@@ -12,8 +12,12 @@
 //   of a 16-channel group takes lane (row r, kk) 's channel 16j+4kk+t and the weights are
 //   pre-permuted to match ([Kp/16][4][48][4], one ds_read_b128 per B fragment).  No LDS
 //   staging of activations, no barrier in the main loop.
+//   Transitions: pool_act writes the 2x2 mean of relu(bn(x)) once (the pool commutes with the 1x1 conv)
+//   and the same kernel runs on it with a unit BN; the POOL template path (pool folded into the
+//   operand load, one re-read of X per 48-channel output chunk) is kept for the C ABI's pool = 1.
 // conv3x3 (48 -> 12): BN2 (no ReLU, DenseNet.py:38-43) is applied while a 10x34x48 halo tile
-//   is staged into LDS (zero padding applied AFTER BN, as F.conv2d pads the BN output);
+//   is staged into LDS (zero padding applied AFTER BN, as F.conv2d pads the BN output); the tile is
+//   double-buffered and the next one is staged from inside the MFMA stream of the current one;
 //   the 9x48x16 weight fragments stay in registers for the whole persistent loop.
 // Batch statistics for train-mode BN are emitted by every producer's epilogue as per-block
 //   f64 partial (sum, sumsq) and finished by bn_prepare -- deterministic, no atomics.
