@@ -634,7 +634,9 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
         }
       }
       stage_write(dz_l[(it + 1) & 1]);
-      __syncthreads();
+      // LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the x operands of the NEXT chunk's first
+      // batch, requested a moment ago -- one exposed HBM round trip per 64-pixel chunk
+      eml::lds_barrier();
     }
   };
   switch (ngw) {  // wave-uniform
