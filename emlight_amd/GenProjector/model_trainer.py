@@ -5,7 +5,6 @@ its own process: G and D are wrapped in DistributedDataParallel (gradient all-re
 473 MB in 25 MB buckets overlapped with backward) and SPADE's param-free BatchNorm becomes ``nn.SyncBatchNorm``
 (an all-reduce of 2C+1 floats per norm layer), which is what the vendored ``sync_batchnorm`` package did."""
 import torch
-import torch.distributed as dist
 
 from .pix2pix_model import Pix2PixModel
 

@@ -7,7 +7,6 @@ loss}.py`` with the same module names (hence the same ``state_dict`` keys: refer
 """
 from argparse import Namespace
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

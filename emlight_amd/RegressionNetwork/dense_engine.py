@@ -11,7 +11,6 @@ Train-mode BatchNorm (the reference never calls ``.eval()`` on this network): ea
 kernel emits f64 partial sums of what it writes, ``eml_dense_bn_prepare_f32`` folds them and
 emits the (scale, shift) the next consumer applies while loading its MFMA operand.
 """
-import ctypes
 
 import os
 

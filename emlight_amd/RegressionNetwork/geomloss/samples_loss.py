@@ -9,7 +9,6 @@ and ``cost_matrix`` (a runtime (N,N) ground cost -- gives the GMLight variant,
 ``gmloss/utils.py:63-108``, for free).  ``batchsize`` is accepted and ignored: the chord
 matrix is stored once, not ``batchsize`` times (``utils.py:80-81``).
 """
-import numpy as np
 import torch
 from torch.nn import Module
 

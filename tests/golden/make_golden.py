@@ -17,7 +17,6 @@ imageio, vtk) are stubbed with ``MagicMock``.
 """
 import os
 import sys
-import types
 from unittest.mock import MagicMock
 
 import numpy as np

@@ -1,5 +1,5 @@
 """Which orientation of the SphereConv weight-gradient GEMM does rocBLAS/hipBLASLt run faster?"""
-import sys, os
+
 import torch
 def t(fn, n=5):
     fn(); torch.cuda.synchronize()
