@@ -294,6 +294,7 @@ def main_projector(args):
             "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "sphereconv_engine": args.engine,
                        "per_gpu_batch": B, "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
                        "parallelism": "dp%d" % world if world > 1 else "single"},
+            "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "roofline": {"kernel": "whole step (SphereConv2D = HIP im2col/col2im gathers + rocBLAS f32 GEMMs; norms and "
                                    "activations on stock ops)",
                          "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -350,6 +351,7 @@ def main():
                        "global_batch": args.batch * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
                        "sinkhorn_blur": args.blur, "engine": args.engine,
                        "parallelism": "dp%d" % world if world > 1 else "single"},
+            "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "step_tflops": round(STEP_GFLOP_240x320 * value / 1e3, 2) if crop_hw == (240, 320) else None,
             "step_frac_of_f32_mfma_peak": round(STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
             if crop_hw == (240, 320) else None,
