@@ -1248,15 +1248,32 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     is[k] = (k < nk && c < C) ? istd[c] : 0.f;
     a1[k] = a2[k] = 0.0;
   }
-  for (size_t p = (size_t)blockIdx.x * 4 + wave; p < P; p += (size_t)gridDim.x * 4) {
+  // kUN pixels per wave and iteration, all loads issued before the first use (see bn_apply_kernel)
+  constexpr int kUN = 4;
+  for (size_t p0 = ((size_t)blockIdx.x * 4 + wave) * kUN; p0 < P; p0 += (size_t)gridDim.x * 4 * kUN) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const int c = lane + 64 * k;
-      if (k < nk && c < C) {
-        float dy = DY[p * ld_dy + c];
-        if (relu && !(out[p * ld_out + c] > 0.f)) dy = 0.f;
-        a1[k] += (double)dy;
-        a2[k] += (double)(dy * ((raw[p * ld_raw + c] - mu[k]) * is[k]));
+      if (k < nk) {  // wave-uniform
+        const int c = min(lane + 64 * k, C - 1);
+        float dy[kUN], rw[kUN], ou[kUN];
+#pragma unroll
+        for (int u = 0; u < kUN; ++u) {
+          const size_t pu = (p0 + u < P) ? p0 + u : P - 1;
+          dy[u] = DY[pu * ld_dy + c];
+          rw[u] = raw[pu * ld_raw + c];
+          ou[u] = relu ? out[pu * ld_out + c] : 1.f;
+        }
+        float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < kUN; ++u) {
+          const float d = (p0 + u < P && ou[u] > 0.f) ? dy[u] : 0.f;
+          l1 += d;
+          l2 = fmaf(d, (rw[u] - mu[k]) * is[k], l2);
+        }
+        if (lane + 64 * k < C) {
+          a1[k] += (double)l1;
+          a2[k] += (double)l2;
+        }
       }
     }
   }

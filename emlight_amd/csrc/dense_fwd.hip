@@ -505,16 +505,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     t[k] = (k < nk && c < C) ? shift[c] : 0.f;
     acc_s[k] = acc_q[k] = 0.0;
   }
-  for (size_t p = (size_t)blockIdx.x * 4 + wave; p < P; p += (size_t)gridDim.x * 4) {
+  // kUN pixels per wave and iteration: all their loads are issued (unconditionally, from clamped rows) before the
+  // first is used -- one pixel at a time left a single 256-byte request per wave in flight (2 TB/s)
+  constexpr int kUN = 4;
+  for (size_t p0 = ((size_t)blockIdx.x * 4 + wave) * kUN; p0 < P; p0 += (size_t)gridDim.x * 4 * kUN) {
+    float v[kUN][6];
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const size_t pu = (p0 + u < P) ? p0 + u : P - 1;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[u][k] = src[pu * lds_ + min(lane + 64 * k, C - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int c = lane + 64 * k;
       if (k < nk && c < C) {
-        float v = fmaf(src[p * lds_ + c], s[k], t[k]);
-        if (relu) v = fmaxf(v, 0.f);
-        dst[p * ldd + c] = v;
-        acc_s[k] += (double)v;
-        acc_q[k] += (double)v * (double)v;
+        float ls = 0.f, lq = 0.f;
+#pragma unroll
+        for (int u = 0; u < kUN; ++u)
+          if (p0 + u < P) {
+            float w = fmaf(v[u][k], s[k], t[k]);
+            if (relu) w = fmaxf(w, 0.f);
+            dst[(p0 + u) * ldd + c] = w;
+            ls += w;
+            lq = fmaf(w, w, lq);
+          }
+        acc_s[k] += (double)ls;
+        acc_q[k] += (double)lq;
       }
     }
   }
