@@ -266,8 +266,7 @@ def main_projector(args):
     """SURVEY 8d metric (ii): GenProjector training images/sec, one G step + one D step (GenProjector/train.py:33-37)
     at BASELINE configs[2] (B=32 per GPU, 128x256 panoramas) unless --batch says otherwise.  SphereConv2D runs as HIP
     gather kernels (im2col_sphere / col2im_sphere) around rocBLAS GEMMs, the rest of row a15 on stock PyTorch-ROCm
-    ops; the roofline object prices the WHOLE step against the f32 MFMA peak (the GEMMs dominate).
-    --engine aten selects the reference's grid_sample + conv2d for an A/B run."""
+    ops; the roofline object prices the WHOLE step against the f32 MFMA peak (the GEMMs dominate)."""
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # fast find: the first step must not spend minutes tuning
     from emlight_amd.RegressionNetwork.engine import init_distributed
     from emlight_amd.GenProjector.networks import default_options
@@ -276,8 +275,6 @@ def main_projector(args):
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local
     B = args.batch if args.batch != 64 else 32
-    from emlight_amd.GenProjector.spherenet import SphereConv2D
-    SphereConv2D.default_engine = args.engine
     tr = Trainer(default_options(), device=dev, world=world)
     data = projector_batch(B, dev, ln=args.anchors, seed=1234 + rank)
     dt = run_timed(lambda: tr.step(data), args.steps, args.warmup, world, dev)
@@ -291,7 +288,7 @@ def main_projector(args):
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "sphereconv_engine": args.engine,
+            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", 
                        "per_gpu_batch": B, "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
@@ -315,7 +312,6 @@ def main():
     ap.add_argument("--anchors", type=int, default=128)
     ap.add_argument("--crop_hw", type=int, nargs=2, default=(240, 320))
     ap.add_argument("--blur", type=float, default=.05)
-    ap.add_argument("--engine", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--workload", default="regression", choices=["regression", "projector"],
                     help="regression = BASELINE's headline (default); projector = SURVEY 8d metric (ii), the "
@@ -331,13 +327,13 @@ def main():
     dev = "cuda:%d" % local
     crop_hw = tuple(args.crop_hw)
     tr = RegressionTrainer(anchors=args.anchors, crop_hw=crop_hw, blur=args.blur, device=dev,
-                           engine=args.engine, world=world)
+                           world=world)
     batch = synthetic_batch(args.batch, args.anchors, crop_hw, seed=1234 + rank, device=dev)
 
     dt = run_timed(lambda: tr.step(batch), args.steps, args.warmup, world, dev)
 
     # live per-kernel timing: EVERY rank runs the instrumented steps (they contain DDP's all-reduce)
-    fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) if args.engine == "hip" else None
+    fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) 
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -349,7 +345,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RegressionNetwork train step, BASELINE configs[1]", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
-                       "sinkhorn_blur": args.blur, "engine": args.engine,
+                       "sinkhorn_blur": args.blur,
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "step_tflops": round(STEP_GFLOP_240x320 * value / 1e3, 2) if crop_hw == (240, 320) else None,

@@ -20,12 +20,8 @@ class Trainer:
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
             self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
             self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)
-            # the model calls self.netG / self.netD: route those through the DDP wrappers
-            object.__setattr__(self.model, "_fwdG", self._ddpG)
-            object.__setattr__(self.model, "_fwdD", self._ddpD)
+            # the model calls generate_fake / discriminate: route those through the DDP wrappers
             self.model.generate_fake = lambda inp, crop: self._ddpG(inp, crop)
-            netD_plain = self.model.netD
-            self.model.__dict__["_netD_call"] = self._ddpD
             self.model.discriminate = self._discriminate_ddp
         self.optimizer_G, self.optimizer_D = self.model.create_optimizers(opt)
         self.old_lr = opt.lr

@@ -12,7 +12,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
-from .spherenet import SphereConv2D, spade_modulate
+from . import spherenet
+from .spherenet import SphereConv2D
 
 
 def default_options(**kw):
@@ -100,7 +101,7 @@ class SPADE(nn.Module):
         normalized = self.param_free_norm(x)
         segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
         actv = self.mlp_shared(segmap)
-        return spade_modulate(normalized, actv, self.mlp_gamma, self.mlp_beta, slope)
+        return spherenet.spade_modulate(normalized, actv, self.mlp_gamma, self.mlp_beta, slope)
 
 
 class SPADEResnetBlock(nn.Module):

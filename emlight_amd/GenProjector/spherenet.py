@@ -155,17 +155,10 @@ class _SphereConvFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-def sphere_conv_siblings(x, convs):
-    """Several SphereConv2D modules applied to the SAME input (SPADE's gamma / beta heads, ``normalization.py:108-109``):
-    one im2col and one GEMM over the concatenated output channels.  Falls back to separate calls for stock ops."""
-    engines = {c.engine or SphereConv2D.default_engine for c in convs}
-    same = len({(c.stride, c.bias is None) for c in convs}) == 1
-    if engines != {"hip"} or not same:
-        return [c(x) for c in convs]
-    w = torch.cat([c.weight for c in convs], 0)
-    b = None if convs[0].bias is None else torch.cat([c.bias for c in convs], 0)
-    y = _SphereConvFn.apply(x, w, b, convs[0].stride)
-    return list(torch.split(y, [c.weight.shape[0] for c in convs], dim=1))
+def sphere_conv(x, weight, bias, stride=1):
+    """``conv2d(grid_sample(x, grid(H, W, stride)), weight, bias, stride=3)`` on the MI355X (the one execution path;
+    tests swap this attribute for the oracle's stock-op restatement when they need a CPU run)."""
+    return _SphereConvFn.apply(x, weight, bias, stride)
 
 
 def _rows_view(t):
@@ -211,54 +204,36 @@ class _SpadeModulateFn(torch.autograd.Function):
 
 
 def spade_modulate(normalized, actv, conv_gamma, conv_beta, slope=1.0):
-    """SPADE's ``normalized * (1 + gamma(actv)) + beta(actv)`` followed by ``leaky_relu(., slope)`` (slope 1 = none).
-    HIP engine: gamma | beta from ONE SphereConv (one gather, one GEMM over the concatenated heads) feeding the fused
-    modulation kernel; stock-op engine: the reference's formula."""
-    engines = {c.engine or SphereConv2D.default_engine for c in (conv_gamma, conv_beta)}
-    if engines == {"hip"} and normalized.shape[1] % 4 == 0:
-        w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
-        b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
-        gb = _SphereConvFn.apply(actv, w, b, 1)
+    """SPADE's ``normalized * (1 + gamma(actv)) + beta(actv)`` followed by ``leaky_relu(., slope)`` (slope 1 = none):
+    gamma | beta come from ONE SphereConv (one gather, one GEMM over the concatenated heads) that feeds the fused
+    modulation kernel."""
+    w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
+    b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
+    gb = sphere_conv(actv, w, b, 1)
+    if normalized.shape[1] % 4 == 0:
         return _SpadeModulateFn.apply(normalized, gb, slope)
-    gamma, beta = sphere_conv_siblings(actv, [conv_gamma, conv_beta])
+    gamma, beta = torch.split(gb, normalized.shape[1], dim=1)   # odd widths (never in EMLight): 16-B rows unavailable
     out = normalized * (1 + gamma) + beta
     return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
 
 
-class sphere_engine:
-    """``with sphere_engine("aten"): ...`` -- run SphereConv2D modules without an explicit ``engine=`` on the
-    reference's stock ops (CPU host-logic tests, A/B measurements).  The default is "hip"."""
-
-    def __init__(self, name):
-        assert name in ("hip", "aten")
-        self.name = name
-
-    def __enter__(self):
-        self.prev, SphereConv2D.default_engine = SphereConv2D.default_engine, self.name
-
-    def __exit__(self, *exc):
-        SphereConv2D.default_engine = self.prev
-
-
 class SphereConv2D(nn.Module):
     """3x3 spherical convolution, same parameters (``weight`` (out,in,3,3), ``bias``) and init as the
-    reference (``sphere_cnn.py:87-109``).  ``engine="hip"`` (default): the MI355X path above, no CPU fallback.
-    ``engine="aten"``: the reference's two stock ops (grid_sample + conv2d), kept as the torch-f32 reference the
-    HIP path is tested against and for the CPU-only host-logic tests."""
+    reference (``sphere_cnn.py:87-109``).  Runs on the MI355X only (``sphere_conv`` above); the reference's two
+    stock ops (grid_sample + conv2d) are restated in ``oracle/projector.py`` for the tests."""
 
-    default_engine = "hip"
     keep_operand = True   # keep the im2col operand of a training forward for the weight gradient (else recompute)
 
-    def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear", engine=None):
+    def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError("SphereConv2D implements the reference's bilinear mode")
         self.in_c, self.out_c, self.stride, self.mode = in_c, out_c, stride, mode
-        self.engine = engine
         self.weight = Parameter(torch.empty(out_c, in_c, 3, 3))
         if bias:
             self.bias = Parameter(torch.empty(out_c))
         else:
             self.register_parameter("bias", None)
-        self._grids = {}
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -266,21 +241,5 @@ class SphereConv2D(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def grid_for(self, x):
-        key = (x.shape[2], x.shape[3], x.device)
-        g = self._grids.get(key)
-        if g is None:
-            g = sphere_sampling_grid(x.shape[2], x.shape[3], self.stride).to(x.device)
-            self._grids = {key: g}
-        return g
-
     def forward(self, x):
-        engine = self.engine or SphereConv2D.default_engine
-        if engine == "hip":
-            if self.mode != "bilinear":
-                raise NotImplementedError("the HIP SphereConv2D implements the reference's bilinear mode")
-            return _SphereConvFn.apply(x, self.weight, self.bias, self.stride)
-        grid = self.grid_for(x).expand(x.shape[0], -1, -1, -1)
-        # torch >= 1.3 default align_corners=False, zero padding: what the reference runs with today
-        x = nn.functional.grid_sample(x, grid, mode=self.mode, align_corners=False)
-        return nn.functional.conv2d(x, self.weight, self.bias, stride=3)
+        return sphere_conv(x, self.weight, self.bias, self.stride)

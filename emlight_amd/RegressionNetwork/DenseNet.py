@@ -9,20 +9,21 @@ checkpoints load.  Two optional arguments lift what the reference hard-codes:
 ``anchors`` (reference 96, ``DenseNet.py:126``) and ``crop_hw`` (reference ``fc`` is
 8208-wide == 192x256 crops, ``DenseNet.py:125``; 240x320 raises there).
 
-Engines
-  ``engine="hip"``  (default) the feature extractor runs on the hand-written gfx950 kernels
-      of ``csrc/dense_*.hip`` through ``libemlight_hip.so`` (NHWC block buffers, BN+ReLU
-      fused into the conv operand loads, f32 MFMA) -- see ``dense_engine.py``.
-  ``engine="aten"`` the same graph on stock PyTorch-ROCm ops (MIOpen convs).  Kept as the
-      measured comparison point on the same GPU; it is not a fallback (nothing selects it
-      automatically).
+There is ONE execution path: the feature extractor runs on the hand-written gfx950 kernels of
+``csrc/dense_*.hip`` through ``libemlight_hip.so`` (NHWC block buffers, BN+ReLU fused into the
+conv operand loads, f32 MFMA) -- see ``dense_engine.py``.  The sub-modules below are parameter
+containers (they give the reference's ``state_dict`` keys); they have no stock-op ``forward``.
+The same graph on stock PyTorch ops lives in ``oracle/densenet.py`` (test infrastructure).
+
+Supported configuration of the HIP engine: ``growth_rate=12``, ``bn_size=4`` (EMLight's
+constructor defaults), ``drop_rate=0``, any ``block_config`` whose widest block has at most 368
+channels (3 x 16 layers: 216 / 300 / 342); backward needs train-mode BatchNorm (EMLight trains
+and tests in train mode).  Anything else raises in the constructor or at the first call.
 """
 import math
 from collections import OrderedDict
 
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class _DenseLayer(nn.Module):
@@ -38,14 +39,10 @@ class _DenseLayer(nn.Module):
         self.drop_rate = drop_rate
 
     def forward(self, x):
-        z = self.conv1(F.relu(self.norm1(x)))
-        new = self.conv2(self.norm2(z))
-        if self.drop_rate > 0:
-            new = F.dropout(new, p=self.drop_rate, training=self.training)
-        return torch.cat([x, new], 1)
+        raise NotImplementedError("parameter container: the layer runs inside the HIP engine (DenseNet.pooled_features)")
 
 
-class _DenseBlock(nn.Sequential):
+class _DenseBlock(nn.Module):
     def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate):
         super().__init__()
         for i in range(num_layers):
@@ -62,17 +59,14 @@ class _Transition(nn.Module):
         self.conv = nn.Conv2d(num_input_features, num_output_features, kernel_size=1, stride=1, bias=False)
 
     def forward(self, x):
-        return F.avg_pool2d(self.conv(F.relu(self.norm(x))), kernel_size=2, stride=2)
+        raise NotImplementedError("parameter container: the transition runs inside the HIP engine")
 
 
 class DenseNet(nn.Module):
     def __init__(self, growth_rate=12, block_config=(16, 16, 16), compression=0.5,
                  num_init_features=24, bn_size=4, drop_rate=0, avgpool_size=4,
-                 anchors=96, crop_hw=(192, 256), engine="hip"):
+                 anchors=96, crop_hw=(192, 256)):
         super().__init__()
-        if engine not in ("hip", "aten"):
-            raise ValueError("engine must be 'hip' or 'aten'")
-        self.engine = engine
         self.avgpool_size = avgpool_size
         self.growth_rate, self.bn_size = growth_rate, bn_size
         self.block_config = tuple(block_config)
@@ -102,16 +96,14 @@ class DenseNet(nn.Module):
         self.fc_intensity = nn.Linear(1024, 1)
         self.fc_rgb_ratio = nn.Linear(1024, 3)
         self.fc_ambient = nn.Linear(1024, 3)
-        if drop_rate > 0 and engine == "hip":
+        if drop_rate > 0:
             raise NotImplementedError("drop_rate > 0 is not on EMLight's path (reference default 0)")
+        from .dense_engine import HipDenseEncoder
+        HipDenseEncoder.check_supported(self)   # reject configurations the kernels are not built for, up front
         self._hip = None
 
     def pooled_features(self, x):
         """relu(last_norm3(...)) average-pooled and flattened: ``(B, fc.in_features)``."""
-        if self.engine == "aten":
-            feat = self.features(x)
-            out = F.relu(feat)
-            return F.avg_pool2d(out, kernel_size=self.avgpool_size).reshape(feat.size(0), -1)
         if self._hip is None:
             from .dense_engine import HipDenseEncoder
             self._hip = HipDenseEncoder(self)

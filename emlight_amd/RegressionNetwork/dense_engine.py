@@ -13,6 +13,7 @@ emits the (scale, shift) the next consumer applies while loading its MFMA operan
 """
 
 import os
+import weakref
 
 import torch
 
@@ -76,7 +77,15 @@ class _Workspace:
         self.istd0 = torch.ones(enc.c_init, **f32)
         self.scale0 = torch.zeros(enc.c_init, **f32)
         self.shift0 = torch.zeros(enc.c_init, **f32)
-        self.partials = torch.zeros(4 * enc.grid_max * 96, dtype=torch.float64, device=dev)
+        # per-workgroup f64 partial sums: forward epilogues write [grid][<= 96 * chunks], the transition dgrad
+        # [grid][Kp][2] -- sized from the widest block / transition and the largest grid any launcher may use
+        self.partials = torch.zeros(enc.grid_max * max(96 * enc.chunks_max, 2 * enc.kp_max), dtype=torch.float64,
+                                    device=dev)
+        self.owner, self.done = None, True   # autograd ctx whose backward still needs these buffers (weakref)
+
+    def in_use(self):
+        """True while a graph built on this workspace is alive and its backward has not run."""
+        return (not self.done) and self.owner is not None and self.owner() is not None
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -86,24 +95,51 @@ class _EncoderFn(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad[2:])
         ws, pooled = enc.run_forward(x, keep_all=needs_grad)
         ctx.ws = ws
+        if needs_grad:   # the buffers now belong to this graph until its backward ran (or the graph is dropped)
+            ws.owner, ws.done = weakref.ref(ctx), False
         ctx.save_for_backward(x)
         return pooled
 
     @staticmethod
     def backward(ctx, gpooled):
         (x,) = ctx.saved_tensors
-        grads = ctx.enc.run_backward(ctx.ws, x, gpooled.contiguous())
+        ws = ctx.ws
+        if ws.owner is None or ws.owner() is not ctx:
+            raise RuntimeError("HIP DenseNet: the activations of this forward were overwritten (backward called twice "
+                               "on the same graph? retain_graph is not supported)")
+        grads = ctx.enc.run_backward(ws, x, gpooled.contiguous())
+        ws.done = True
         return (None, None) + tuple(grads)
 
 
 class HipDenseEncoder:
+    GRID_MAX = 1024   # upper bound of every persistent grid (scratch buffers are sized for it)
+
+    @staticmethod
+    def check_supported(model):
+        """The kernels are built for EMLight's DenseNet-BC (growth 12, bottleneck 48); per-channel vectors live in
+        384-entry LDS / coefficient arrays.  Reject everything else up front instead of corrupting memory."""
+        f = model.features
+        if model.bn_size * model.growth_rate != 48 or model.growth_rate != 12:
+            raise NotImplementedError("the HIP engine is built for growth_rate=12, bn_size=4 (EMLight's DenseNet)")
+        c = f.conv0.out_channels
+        if c > 32 or c % 2 or c < 8:
+            raise NotImplementedError("num_init_features must be even and in [8, 32] (got %d)" % c)
+        for bi, nl in enumerate(model.block_config):
+            ctot = c + nl * model.growth_rate
+            if nl < 1 or _r16(ctot) > 384:
+                raise NotImplementedError("dense block %d would be %d channels wide; the HIP kernels hold per-channel "
+                                          "vectors of at most 384 (EMLight: 216/300/342)" % (bi + 1, ctot))
+            c = getattr(f, "transition%d" % (bi + 1)).conv.out_channels
+            if c % 2 and bi + 1 < len(model.block_config):   # the next block's channel offsets must stay 8-byte aligned
+                raise NotImplementedError("transition %d feeds a dense block with an odd channel count (%d)" % (bi + 1, c))
+
     def __init__(self, model):
         f = model.features
+        self.check_supported(model)
         self.model = model
         self.growth = model.growth_rate
         self.inter = model.bn_size * model.growth_rate
-        if self.inter != 48 or self.growth != 12:
-            raise NotImplementedError("the HIP engine is built for growth_rate=12, bn_size=4 (EMLight's DenseNet)")
         self.c_init = f.conv0.out_channels
         self.block_layers = list(model.block_config)
         self.block_c0, self.trans_cout = [], []
@@ -114,7 +150,10 @@ class HipDenseEncoder:
             c = getattr(f, "transition%d" % (bi + 1)).conv.out_channels
             self.trans_cout.append(c)
         self.avgpool = model.avgpool_size
-        self.grid_max = 1024
+        self.grid_max = self.GRID_MAX
+        self.kp_max = max(_r16(c0 + nl * self.growth) for c0, nl in zip(self.block_c0, self.block_layers))
+        self.ko_max = max(_r16(c) for c in self.trans_cout)
+        self.chunks_max = max((c + 47) // 48 for c in self.trans_cout)
         self._ws = {}
         self._cu = None
 
@@ -138,9 +177,10 @@ class HipDenseEncoder:
         B, C, H, W = x.shape
         if C != 3:
             raise ValueError("expected (B,3,H,W) input")
-        if (H % (8 * self.avgpool)) or (W % (8 * self.avgpool)):
-            # three /2 transitions then avgpool(k): the reference silently floors; keep it exact
-            pass
+        div = 2 ** len(self.block_layers)
+        if H % div or W % div or (H // div) < self.avgpool or (W // div) < self.avgpool:
+            raise ValueError("crop %dx%d: each of the %d transitions halves the map (even sizes required) and the head "
+                             "pools %dx%d" % (H, W, len(self.block_layers), self.avgpool, self.avgpool))
         return _EncoderFn.apply(self, x, *self.param_list())
 
     def _grid(self, dev):
@@ -161,11 +201,19 @@ class HipDenseEncoder:
         return self._tuned("EML_GRID3", self._cu)
 
     def workspace(self, B, H, W, dev, keep_all):
+        """Buffers for this shape.  A workspace still owned by a live graph (a second grad-enabled forward of the same
+        shape before the first backward: summed losses, gradient accumulation, GAN-style double forward) is never
+        handed out again -- that forward gets its own buffers."""
         key = (B, H, W, dev, keep_all)
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = _Workspace(self, B, H, W, dev, keep_all)
-            self._ws = {key: ws}  # one live shape at a time (buffers are GBs at training sizes)
+        pool = self._ws.get(key)
+        if pool is None:
+            pool = []
+            self._ws = {key: pool}  # one live shape at a time (buffers are GBs at training sizes)
+        for ws in pool:
+            if not ws.in_use():
+                return ws
+        ws = _Workspace(self, B, H, W, dev, keep_all)
+        pool.append(ws)
         return ws
 
     # ------------------------------------------------------------------ forward

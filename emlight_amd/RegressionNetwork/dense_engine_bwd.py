@@ -22,11 +22,14 @@ class _BwdBuffers:
         maxP = ws.blocks[0]["P"]
         self.DZ = torch.empty(2, maxP, 48, **f32)   # one per layer of a pair
         self.GF12 = torch.empty(maxP, 12, **f32)    # finished gradient of a layer's 12 output channels (compact)
-        self.Wd = torch.empty(2, 352 * 176, **f32)
-        self.coef = torch.zeros(8, 384, **f32)  # two (cA,cB,cC) sets for dz, then sB, sC
-        self.part2 = torch.zeros(2, enc.grid_max * 352 * 2, dtype=torch.float64, device=dev)
-        g = enc.grid_max
-        self.partW = torch.empty(max(g * 2 * 352 * 48 // 2, g * 27 * 256, g * 4 * 1024), **f32)
+        # scratch sized from the network (widest block Kp, widest transition Ko) and the largest grid, not for
+        # EMLight's default only
+        kp, ko, g = enc.kp_max, max(enc.ko_max, 48), enc.grid_max
+        self.Wd = torch.empty(2, kp * ko, **f32)       # permuted conv1 / transition weights for the data gradient
+        self.coef = torch.zeros(8, max(kp, ko), **f32)  # two (cA,cB,cC) sets for dz, then sB, sC
+        self.part2 = torch.zeros(2, g * kp * 2, dtype=torch.float64, device=dev)
+        # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
+        self.partW = torch.empty(g * max(kp * 48, 2 * 27 * 256, 4 * 1024), **f32)
 
 
 def run_backward(enc, ws, x, gpooled):

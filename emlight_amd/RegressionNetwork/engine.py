@@ -49,12 +49,14 @@ class RegressionTrainer:
     """Model + Sinkhorn criterion + Adam(1e-4, (.9,.999)) (``train.py:55-61``)."""
 
     def __init__(self, anchors=96, crop_hw=(192, 256), blur=.025, diameter=None, lr=1e-4,
-                 betas=(0.9, 0.999), device="cuda", engine="hip", world=1, bucket_cap_mb=64):
+                 betas=(0.9, 0.999), device="cuda", world=1, bucket_cap_mb=64, model=None, sam_loss=None):
+        """``model`` / ``sam_loss``: pre-built modules to train instead of the HIP ``DenseNet`` / ``SamplesLoss``
+        (the CPU-only distributed tests inject the oracle's stock-op restatements; the product never does)."""
         self.ln = anchors
         self.device = torch.device(device)
-        self.model = DenseNet(anchors=anchors, crop_hw=crop_hw, engine=engine).to(self.device)
+        self.model = (DenseNet(anchors=anchors, crop_hw=crop_hw) if model is None else model).to(self.device)
         self.model.train()
-        self.sam_loss = SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors)
+        self.sam_loss = sam_loss or SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors)
         self.ddp = None
         if world > 1:
             # DenseNet BN stays per-rank (plain nn.BatchNorm2d in the reference); only the
@@ -71,4 +73,5 @@ class RegressionTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
+        self.last_pred = pred   # train.py visualises the training batch's own prediction (train.py:110-145)
         return loss, terms

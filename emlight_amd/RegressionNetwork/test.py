@@ -23,11 +23,10 @@ def main(argv=None):
     ap.add_argument("--crop_hw", type=int, nargs=2, default=(192, 256))
     ap.add_argument("--results_dir", default="./results")
     ap.add_argument("--max_images", type=int, default=100)
-    ap.add_argument("--engine", default="hip", choices=["hip", "aten"])
     args = ap.parse_args(argv)
 
     device = torch.device("cuda")
-    model = DenseNet(anchors=args.anchors, crop_hw=tuple(args.crop_hw), engine=args.engine).to(device)
+    model = DenseNet(anchors=args.anchors, crop_hw=tuple(args.crop_hw)).to(device)
     if args.checkpoint and os.path.exists(args.checkpoint):
         model.load_state_dict(torch.load(args.checkpoint, map_location=device))
         print("load trained model")

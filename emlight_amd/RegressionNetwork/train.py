@@ -50,13 +50,12 @@ def main(argv=None):
     ap.add_argument("--save_dir", default="./checkpoints")
     ap.add_argument("--summary_dir", default="./summary")
     ap.add_argument("--load", default=None, help="state_dict to resume from (reference .pth files load)")
-    ap.add_argument("--engine", default="hip", choices=["hip", "aten"])
     args = ap.parse_args(argv)
 
     rank, local, world = init_distributed()
     device = "cuda:%d" % local
     tr = RegressionTrainer(anchors=args.anchors, crop_hw=tuple(args.crop_hw), blur=args.blur,
-                           diameter=args.diameter, device=device, engine=args.engine, world=world)
+                           diameter=args.diameter, device=device, world=world)
     if args.load:
         tr.model.load_state_dict(torch.load(args.load, map_location=device))
         if rank == 0:
@@ -85,14 +84,13 @@ def main(argv=None):
                 print("epoch {:0>3d} batch {:0>3d}, ".format(epoch, i)
                       + ", ".join("{}:{}".format(k, v.item()) for k, v in terms.items()))
             if rank == 0 and i % 100 == 0:
-                with torch.no_grad():
-                    pred = tr.model(batch["crop"][:1])
+                # the reference renders the prediction of THIS training step (train.py:110-133), no extra forward
+                pred = {k: v.detach() for k, v in tr.last_pred.items()}
                 try:
                     save_visual(os.path.join(args.summary_dir, "{}_{}.jpg".format(epoch, i)),
                                 batch["crop"], pred, batch, args.anchors, tone)
                 except ImportError:
                     pass
-                tr.model.train()
             if rank == 0 and i % 500 == 0:
                 print("saving the latest model")
                 torch.save(tr.model.state_dict(), os.path.join(args.save_dir, "latest_net.pth"))

@@ -25,6 +25,7 @@ from .sinkhorn import (sphere_points, anchor_cost_matrix, geometric_points, cost
                        samples_loss_grad_analytic)
 from .rasteriser import pano_grid, convert_to_panorama
 from .representation import ExtractMesh
+from .projector import sampling_grid, sphere_conv, spade_modulate, stock_sphere_ops
 from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss,
                        deterministic_projector_state_dict)
 
@@ -34,4 +35,5 @@ __all__ = [
     "samples_loss", "samples_loss_grad_analytic", "pano_grid",
     "convert_to_panorama", "ExtractMesh", "OracleDenseNet", "deterministic_state_dict",
     "regression_loss", "deterministic_projector_state_dict",
+    "sampling_grid", "sphere_conv", "spade_modulate", "stock_sphere_ops",
 ]

@@ -1,0 +1,83 @@
+"""Oracle (test infrastructure): the projector's SphereNet ops on stock PyTorch ops.
+
+CPU restatement of ``GenProjector/models/networks/spherenet/sphere_cnn.py``: the gnomonic 3x3 sampling
+pattern (``cal_index`` ``:31-58``, ``gen_grid_coordinates`` ``:75-84``) and
+``SphereConv2D.forward`` = ``grid_sample`` + stride-3 ``conv2d`` (``:111-124``); plus SPADE's modulation
+formula (``normalization.py:113-115``) followed by the LeakyReLU of ``architecture.py:56-57``.
+
+The product (``emlight_amd/GenProjector/spherenet.py``) has ONE execution path, the HIP kernels.
+``stock_sphere_ops()`` lets a test swap the product's two dispatch points for these restatements, so that the
+host logic (module wiring, losses, trainers, DDP) can be exercised on CPU and the HIP path can be compared
+with the reference's own two ops on the GPU.  Only ``tests/`` may use it.
+"""
+import contextlib
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def tap_rows_cols(h, w, r):
+    """Sampling rows/cols of the 3x3 taps for every column of image row ``r``: two ``(w, 3, 3)`` float64 arrays.
+
+    ``cal_index`` (``sphere_cnn.py:31-58``) per pixel: the tangent-plane offsets ``(x, y)`` of ``get_xy``
+    (``:10-28``) are projected back to the sphere around ``(phi, theta)``; the centre tap is the pixel itself;
+    columns wrap modulo ``w``."""
+    d_phi, d_theta = np.pi / h, 2 * np.pi / w
+    tx, ty, sec = np.tan(d_theta), np.tan(d_phi), 1.0 / np.cos(d_theta)
+    x = np.array([[-tx, 0.0, tx], [-tx, 1.0, tx], [-tx, 0.0, tx]])
+    y = np.array([[sec * ty, ty, sec * ty], [0.0, 1.0, 0.0], [-sec * ty, -ty, -sec * ty]])
+    phi = -((r + 0.5) / h * np.pi - np.pi / 2)
+    rho = np.sqrt(x ** 2 + y ** 2)
+    v = np.arctan(rho)
+    new_phi = np.arcsin(np.cos(v) * np.sin(phi) + y * np.sin(v) * np.cos(phi) / rho)
+    d_th = np.arctan(x * np.sin(v) / (rho * np.cos(phi) * np.cos(v) - y * np.sin(phi) * np.sin(v)))
+    rows = np.empty((w, 3, 3))
+    cols = np.empty((w, 3, 3))
+    for c in range(w):
+        theta = (c + 0.5) / w * 2 * np.pi - np.pi
+        rows[c] = (-new_phi + np.pi / 2) * h / np.pi - 0.5
+        cols[c] = ((theta + d_th + np.pi) * w / 2 / np.pi - 0.5 + w) % w
+        rows[c, 1, 1], cols[c, 1, 1] = r, c
+    return rows, cols
+
+
+@lru_cache(None)
+def sampling_grid(h, w, stride=1):
+    """``gen_grid_coordinates`` (``sphere_cnn.py:75-84``): ``(1, 3h', 3w', 2)`` f32 grid, (x, y) in [-1, 1]."""
+    rr = list(range(0, h, stride))
+    cc = list(range(0, w, stride))
+    grid = np.empty((len(rr), 3, len(cc), 3, 2))
+    for i, r in enumerate(rr):
+        rows, cols = tap_rows_cols(h, w, r)
+        grid[i, :, :, :, 1] = (rows[cc] * 2 / h - 1).transpose(1, 0, 2)
+        grid[i, :, :, :, 0] = (cols[cc] * 2 / w - 1).transpose(1, 0, 2)
+    return torch.from_numpy(grid.reshape(1, 3 * len(rr), 3 * len(cc), 2)).float()
+
+
+def sphere_conv(x, weight, bias, stride=1):
+    """``SphereConv2D.forward`` (``sphere_cnn.py:111-124``): grid_sample (bilinear, torch >= 1.3 defaults:
+    ``align_corners=False``, zero padding) then a stride-3 3x3 convolution."""
+    grid = sampling_grid(x.shape[2], x.shape[3], stride).to(x.device).expand(x.shape[0], -1, -1, -1)
+    return F.conv2d(F.grid_sample(x, grid, mode="bilinear", align_corners=False), weight, bias, stride=3)
+
+
+def spade_modulate(normalized, actv, conv_gamma, conv_beta, slope=1.0):
+    """``normalized * (1 + gamma) + beta`` (``normalization.py:108-115``), then ``leaky_relu(., slope)``."""
+    gamma = sphere_conv(actv, conv_gamma.weight, conv_gamma.bias, conv_gamma.stride)
+    beta = sphere_conv(actv, conv_beta.weight, conv_beta.bias, conv_beta.stride)
+    out = normalized * (1 + gamma) + beta
+    return out if slope == 1.0 else F.leaky_relu(out, slope)
+
+
+@contextlib.contextmanager
+def stock_sphere_ops():
+    """Inside the block the product's SphereConv2D / SPADE modulation run the restatements above."""
+    from emlight_amd.GenProjector import spherenet
+    saved = spherenet.sphere_conv, spherenet.spade_modulate
+    spherenet.sphere_conv, spherenet.spade_modulate = sphere_conv, spade_modulate
+    try:
+        yield
+    finally:
+        spherenet.sphere_conv, spherenet.spade_modulate = saved

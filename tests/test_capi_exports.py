@@ -72,9 +72,17 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(_lib.EmlightHipError):
         convert_to_panorama(torch.rand(1, 12), torch.rand(1, 4), torch.rand(1, 12))
     from emlight_amd.GenProjector.spherenet import SphereConv2D
-    with pytest.raises(_lib.EmlightHipError):   # default engine is HIP; stock ops only on explicit engine="aten"
+    with pytest.raises(_lib.EmlightHipError):   # one execution path: HIP
         SphereConv2D(4, 4)(torch.rand(1, 4, 8, 16))
-    assert SphereConv2D(4, 4, engine="aten")(torch.rand(1, 4, 8, 16)).shape == (1, 4, 8, 16)
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    with pytest.raises(_lib.EmlightHipError):
+        DenseNet(anchors=8, crop_hw=(32, 32))(torch.rand(1, 3, 32, 32))
+    with pytest.raises(TypeError):              # the stock-op engines are gone from the product
+        DenseNet(engine="aten")
+    with pytest.raises(NotImplementedError):    # configurations the kernels are not built for are rejected up front
+        DenseNet(block_config=(24, 24, 24))
+    with pytest.raises(NotImplementedError):
+        DenseNet(growth_rate=32)
 
 
 def test_product_never_imports_oracle():

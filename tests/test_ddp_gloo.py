@@ -40,9 +40,11 @@ def _worker(rank, world, port, out_dir):
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
     anchors, crop = 16, (32, 32)
     torch.manual_seed(0)  # identical initial replicas, like loading one checkpoint on every rank
-    tr = RegressionTrainer(anchors=anchors, crop_hw=crop, blur=.05, device="cpu", engine="aten", world=w)
     M = oracle.anchor_cost_matrix(anchors)
-    tr.sam_loss = lambda x, y: oracle.samples_loss(x, y, M, blur=.05)
+    # CPU ranks: the oracle's stock-op encoder and Sinkhorn term are injected (the product's are HIP-only)
+    tr = RegressionTrainer(anchors=anchors, crop_hw=crop, blur=.05, device="cpu", world=w,
+                           model=oracle.OracleDenseNet(anchors=anchors, crop_hw=crop),
+                           sam_loss=lambda x, y: oracle.samples_loss(x, y, M, blur=.05))
     batch = synthetic_batch(2, anchors, crop, seed=1234 + rank)  # each rank its own shard
 
     # reference: local gradients on a private copy, averaged by hand over the ranks
@@ -96,10 +98,10 @@ def _projector_worker(rank, world, port, out_dir):
     from emlight_amd.RegressionNetwork.engine import init_distributed
     from emlight_amd.GenProjector import networks
     from emlight_amd.GenProjector.model_trainer import Trainer
-    from emlight_amd.GenProjector.spherenet import sphere_engine
+    import oracle
     r, local, w = init_distributed()
     torch.manual_seed(0)  # identical initial replicas
-    with sphere_engine("aten"):  # CPU ranks: the reference's stock ops (the HIP SphereConv2D has no CPU path)
+    with oracle.stock_sphere_ops():  # CPU ranks: the reference's stock ops (the HIP SphereConv2D has no CPU path)
         tr = Trainer(networks.default_options(ngf=2, ndf=2), device="cpu", world=w)
         g = torch.Generator().manual_seed(100 + rank)  # each rank its own shard
         data = {"input": torch.rand(1, 3, 128, 256, generator=g) * 5, "crop": torch.rand(1, 3, 128, 128, generator=g),

@@ -22,7 +22,7 @@ def _worker(rank, world, port, out_dir):
     from emlight_amd.RegressionNetwork.engine import RegressionTrainer, init_distributed
     r, local, w = init_distributed()
     torch.manual_seed(0)
-    tr = RegressionTrainer(anchors=32, crop_hw=(64, 96), blur=.05, device="cuda:0", engine="hip", world=w)
+    tr = RegressionTrainer(anchors=32, crop_hw=(64, 96), blur=.05, device="cuda:0", world=w)
     batch = synthetic_batch(2, 32, (64, 96), seed=1234 + rank, device="cuda:0")
     losses = []
     for _ in range(3):

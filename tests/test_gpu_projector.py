@@ -48,8 +48,8 @@ def test_sphere_conv_hip_vs_stock_ops(B, Cin, Cout, H, W, stride, bias):
     f32 on the same GPU: output, d/dx, d/dweight, d/dbias."""
     from emlight_amd.GenProjector.spherenet import SphereConv2D
     torch.manual_seed(B * 100 + Cin)
-    ref = SphereConv2D(Cin, Cout, stride=stride, bias=bias, engine="aten").cuda()
-    hip = SphereConv2D(Cin, Cout, stride=stride, bias=bias, engine="hip").cuda()
+    ref = SphereConv2D(Cin, Cout, stride=stride, bias=bias).cuda()   # parameters only; run through the oracle's ops
+    hip = SphereConv2D(Cin, Cout, stride=stride, bias=bias).cuda()
     hip.load_state_dict(ref.state_dict())
     if bias:
         with torch.no_grad():
@@ -57,7 +57,7 @@ def test_sphere_conv_hip_vs_stock_ops(B, Cin, Cout, H, W, stride, bias):
             hip.bias.copy_(ref.bias)
     x = torch.randn(B, Cin, H, W, device="cuda")
     xr, xh = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    yr, yh = ref(xr), hip(xh)
+    yr, yh = oracle.sphere_conv(xr, ref.weight, ref.bias, stride), hip(xh)
     assert yh.shape == yr.shape == (B, Cout, H // stride, W // stride)
     if B == 0:
         return
@@ -123,12 +123,11 @@ def test_projector_matches_reference_golden_on_hip_sphereconv():
 def test_spade_modulate_hip_vs_stock_ops(slope):
     """Fused gamma|beta SphereConv + modulation (+ LeakyReLU) against normalization.py:113-115 / architecture.py:56-57
     written with stock ops: output and the gradients w.r.t. normalized, actv and the four head parameters."""
-    import torch.nn.functional as F
     from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_modulate
     torch.manual_seed(3)
     B, C, H, W, nh = 2, 16, 8, 16, 12
-    ref_g, ref_b = SphereConv2D(nh, C, engine="aten").cuda(), SphereConv2D(nh, C, engine="aten").cuda()
-    hip_g, hip_b = SphereConv2D(nh, C, engine="hip").cuda(), SphereConv2D(nh, C, engine="hip").cuda()
+    ref_g, ref_b = SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()   # parameter holders for the oracle's ops
+    hip_g, hip_b = SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()
     for m in (ref_g, ref_b):
         with torch.no_grad():
             m.bias.uniform_(-0.3, 0.3)
@@ -136,13 +135,11 @@ def test_spade_modulate_hip_vs_stock_ops(slope):
     hip_b.load_state_dict(ref_b.state_dict())
     xn0, a0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, nh, H, W, device="cuda")
     outs = []
-    for g_, b_ in ((ref_g, ref_b), (hip_g, hip_b)):
+    for fn, g_, b_ in ((oracle.spade_modulate, ref_g, ref_b), (spade_modulate, hip_g, hip_b)):
         xn, actv = xn0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
-        y = spade_modulate(xn, actv, g_, b_, slope)
+        y = fn(xn, actv, g_, b_, slope)
         (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
         outs.append([y.detach(), xn.grad, actv.grad, g_.weight.grad, g_.bias.grad, b_.weight.grad, b_.bias.grad])
-    want = F.leaky_relu(xn0 * (1 + ref_g(a0)) + ref_b(a0), slope) if slope != 1.0 else xn0 * (1 + ref_g(a0)) + ref_b(a0)
-    np.testing.assert_allclose(outs[0][0].cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
     for name, r, h in zip(["y", "d_normalized", "d_actv", "dWg", "dbg", "dWb", "dbb"], outs[0], outs[1]):
         s = float(r.abs().max())
         np.testing.assert_allclose(h.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=3e-5 * s, err_msg=name)

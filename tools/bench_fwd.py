@@ -3,9 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from emlight_amd.RegressionNetwork.DenseNet import DenseNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-eng = sys.argv[2] if len(sys.argv) > 2 else "hip"
+eng = "hip"
 hw = (240, 320)
-net = DenseNet(anchors=128, crop_hw=hw, engine=eng).cuda().train()
+net = DenseNet(anchors=128, crop_hw=hw).cuda().train()
 x = torch.rand(B, 3, *hw, device="cuda")
 with torch.no_grad():
     for _ in range(2):

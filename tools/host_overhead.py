@@ -5,7 +5,7 @@ import torch
 from emlight_amd.RegressionNetwork.engine import RegressionTrainer
 from emlight_amd.RegressionNetwork.data import synthetic_batch
 for B in (64, 32, 8):
-    tr = RegressionTrainer(anchors=128, crop_hw=(240, 320), blur=.05, device="cuda:0", engine="hip", world=1)
+    tr = RegressionTrainer(anchors=128, crop_hw=(240, 320), blur=.05, device="cuda:0", world=1)
     batch = synthetic_batch(B, 128, (240, 320), seed=1, device="cuda:0")
     for _ in range(3):
         tr.step(batch)
