@@ -1,22 +1,34 @@
 #!/usr/bin/env python
-"""bench.py -- EMLight regression training throughput on MI355X (BASELINE.json metric).
+"""bench.py -- EMLight training throughput on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one synthetic batch: DenseNet-BC forward (HIP
-kernels), spherical mover's Sinkhorn loss (HIP), backward (HIP), Adam.  Workload at N=1:
-BASELINE configs[1] -- "RegressionNetwork train.py, batch 64, 128 anchors, Sinkhorn blur .05"
-on 240x320 crops.  N>1: one process per GPU (torchrun), the batch dimension shards, gradients
-all-reduce over RCCL/xGMI (DDP); per-GPU work is fixed -> weak scaling.
+Headline (`value`): the regression training step -- DenseNet-BC forward (HIP kernels), spherical mover's Sinkhorn loss
+(HIP), backward (HIP), Adam -- at BASELINE configs[1] ("RegressionNetwork train.py, batch 64, 128 anchors, Sinkhorn
+blur .05", 240x320 crops).  The same JSON line carries the other legs of BASELINE's metric ("regression+projector;
+Sinkhorn ms/iter") as objects, each timed in this process on the launch stream:
+  `projector`  GenProjector G step + D step at configs[2] (B=32/GPU, 128x256)        img/s, fraction of the f32-MFMA roof
+  `joint`      regression -> rasteriser -> projector step at configs[3] (32/GPU)     img/s, fraction of the f32-MFMA roof
+  `sinkhorn`   ms per eps-step at configs[1] and at configs[4]'s shape (B=16, N=256)  fraction of the 8 TB/s HBM roof
+  `rasteriser` SG lobes -> 128x256 panorama at configs[2]'s shape                     ms, GB/s on output bytes, Gexp/s
+A "step" is one pass of the hot path over one synthetic batch resident in HBM.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the dense-layer
-conv1x1 backward family: HBM-bound on the block buffer's O(L^2) re-reads), measured live with HIP events on the
-launch stream; `cpu_baseline` is the oracle (torch-CPU restatement, parity-pinned to the
-reference) timed on this box's host cores at a bounded batch.
+N>1: one process per GPU, the batch dimension shards, gradients all-reduce over RCCL/xGMI (DDP); per-GPU work is
+fixed -> weak scaling.  Launch either way:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    python bench.py --gpus N          (no WORLD_SIZE in the environment: bench.py starts the N ranks itself)
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the headline step, measured live with
+HIP events on the launch stream; `cpu_baseline` is the oracle (torch-CPU restatement, parity-pinned to the reference)
+timed on this box's host cores at a bounded batch.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+import glob
+import socket
+import subprocess
 
 import torch
 import torch.distributed as dist
@@ -136,47 +148,87 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes
-    of this same command; FETCH_SIZE under-reports wide reads 2x on gfx950), or None if not collected."""
+    """HBM bytes per launch of a kernel family from the newest committed PMC summary (`profiles/rNN_pmc_summary.csv`:
+    separate rocprofv3 --pmc passes of this same command; FETCH_SIZE under-reports 16-B/lane reads 2x on gfx950) and
+    where that number comes from (file + the commit stamped in its sidecar), or (None, None) if not collected."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.csv")))
+    if not files:
+        return None, None
+    path = files[-1]
     name = kernel_label.split(" ")[0]
-    if not os.path.exists(path):
-        return None
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
         if r["kernel"].startswith(name):
             d = int(r["dispatches"])
             tot += d * (2.0 * float(r["mean_FETCH_SIZE"]) + float(r["mean_WRITE_SIZE"])) * 1024.0
             n += d
-    return round(tot / n) if n else None
+    src = {"file": os.path.relpath(path, ROOT), "collected_at_commit": None,
+           "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, mean over the family's dispatches"}
+    meta = path[:-4] + ".meta.json"
+    if os.path.exists(meta):
+        src.update(json.load(open(meta)))
+    return (round(tot / n) if n else None), src
 
 
-def time_sinkhorn(B, anchors, blur, dev, reps=20):
-    """BASELINE's second metric: Sinkhorn ms per eps-step (1 iter = 4 softmin sweeps + averaging,
-    sinkhorn_divergence.py:87-97) of the HIP loss at the bench batch, by HIP events."""
-    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
-    g = torch.Generator().manual_seed(7)
-    x = torch.softmax(torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
-    y = torch.softmax(3 * torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
-    crit = SamplesLoss("sinkhorn", p=2, blur=blur, anchors=anchors)
-    r = crit.forward_raw(x, y)
-    n_eps = int(r["n_eps"].item())
+def _events(fn, reps):
+    """Mean GPU milliseconds of `fn()` over `reps` back-to-back calls, HIP events on torch's current stream (the stream
+    every launcher of this library enqueues on)."""
+    fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        crit.forward_raw(x, y)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps
+
+
+def time_sinkhorn(B, anchors, blur, dev, reps=50):
+    """BASELINE's second metric: Sinkhorn ms per eps-step (1 iter = 4 softmin sweeps + averaging,
+    sinkhorn_divergence.py:87-97) of the HIP loss.  Outputs are pre-allocated once, so the `reps` loss calls are
+    back-to-back kernel launches (loop kernel + finishing kernel) between two HIP events -- the figure is the kernels'."""
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    from emlight_amd.RegressionNetwork.geomloss.samples_loss import sinkhorn_outputs
+    g = torch.Generator().manual_seed(7)
+    x = torch.softmax(torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
+    y = torch.softmax(3 * torch.randn(B, anchors, generator=g), 1).view(B, anchors, 1).to(dev)
+    crit = SamplesLoss("sinkhorn", p=2, blur=blur, anchors=anchors)
+    out = sinkhorn_outputs(B, anchors, dev, True, True)
+    n_eps = int(crit.forward_raw(x, y, out=out)["n_eps"].item())
+    ms = _events(lambda: crit.forward_raw(x, y, out=out), reps)
     alg_bytes = 4.0 * (B * anchors * anchors * 4 + 2 * B * anchors * 4)  # per eps-step, SURVEY 8d
     per_step = ms / (n_eps + 2)
-    return {"ms_per_loss_call": round(ms, 4), "n_eps": n_eps, "sweeps": n_eps + 2,
-            "ms_per_eps_step": round(per_step, 5), "algorithmic_GBps": round(alg_bytes / (per_step * 1e-3) / 1e9, 1),
+    return {"batch": B, "anchors": anchors, "blur": blur, "ms_per_loss_call": round(ms, 4), "n_eps": n_eps,
+            "sweeps": n_eps + 2, "ms_per_eps_step": round(per_step, 5),
+            "algorithmic_GBps": round(alg_bytes / (per_step * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak_8TBps": round(alg_bytes / (per_step * 1e-3) / 8e12, 4),
-            "note": "loss call = schedule + loop + finish kernels (forward and unit gradients); "
-                    "algorithmic bytes = the reference's materialised-cost traffic"}
+            "note": "loss call = schedule + loop + finish kernels (forward and unit gradients), outputs pre-allocated; "
+                    "algorithmic bytes = the reference's materialised-cost traffic 4*(B*N*N*4 + 2*B*N*4) per eps-step"}
+
+
+def time_rasteriser(B, anchors, pano_hw, dev, reps=50):
+    """SG lobes -> equirect panorama (util.py:222-245) at configs[2]'s shape: one launch, B*3*H*W*4 output bytes +
+    B*7N*4 input bytes (12.6 MB at B=32), B*N*H*W exponentials; forward and the colour gradient."""
+    from emlight_amd.RegressionNetwork.util import convert_to_panorama, sphere_points
+    H, W = pano_hw
+    g = torch.Generator().manual_seed(11)
+    dirs = torch.from_numpy(sphere_points(anchors)).float().view(1, 3 * anchors).repeat(B, 1).to(dev)
+    sizes = torch.full((B, anchors), 0.0025, device=dev)
+    colors = torch.rand(B, 3 * anchors, generator=g).to(dev).requires_grad_(True)
+    ms_f = _events(lambda: convert_to_panorama(dirs, sizes, colors.detach(), pano_hw=pano_hw), reps)
+    out = convert_to_panorama(dirs, sizes, colors, pano_hw=pano_hw)
+    gout = torch.rand_like(out)
+    ms_b = _events(lambda: torch.autograd.grad(out, colors, gout, retain_graph=True), reps)
+    nbytes = B * 3 * H * W * 4 + B * 7 * anchors * 4
+    nexp = float(B) * anchors * H * W
+    return {"batch": B, "anchors": anchors, "pano_hw": [H, W], "ms_fwd": round(ms_f, 4), "ms_bwd_colors": round(ms_b, 4),
+            "algorithmic_MB": round(nbytes / 1e6, 2), "GBps_on_algorithmic_bytes": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
+            "Gexp_per_s": round(nexp / (ms_f * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak_8TBps": round(nbytes / (ms_f * 1e-3) / 8e12, 4),
+            "note": "transcendental-bound: B*N*H*W exp2 against 12 B per pixel; lights whose lobe underflows to 0 over a "
+                    "whole 64-pixel patch are culled (bit-identical), so Gexp/s counts the reference's exponentials"}
 
 
 def _cpu_baseline_worker(anchors, crop_hw, blur, batch, threads, q):
@@ -211,7 +263,8 @@ def cpu_baseline(anchors, crop_hw, blur, batch=2, budget_s=150):
     """Oracle (port of the reference's PyTorch-CPU maths) training step on this box's host cores:
     a BOUNDED sample (batch 2, <= 3 steps) in a child process with a wall-clock budget.  Thread count
     is capped at 32: at batch 2 the reference's ATen CPU kernels slow down, not up, beyond that
-    (measured: 256 threads -> 292 s per step on the MI355X host)."""
+    (measured: 256 threads -> 292 s per step on the MI355X host).  Deviation from SURVEY 8d's protocol (B=4, 1+3
+    steps, all cores), chosen so that the default bench run stays within minutes; recorded in DESIGN.md section 5."""
     import multiprocessing as mp
     threads = min(os.cpu_count() or 1, 32)
     ctx = mp.get_context("spawn")
@@ -260,47 +313,89 @@ def run_timed(step_fn, steps, warmup, world, device):
 
 
 G_FWD_GFLOP, D_PAIR_GFLOP = 154.1, 4.71   # SPADE generator forward / discriminator forward on a fake+real pair
+# G step: G fwd + bwd (3x) and D fwd/bwd-data on the pair (2x); D step: G fwd (no grad) + D fwd/bwd (3x)
+PROJECTOR_STEP_GFLOP = 3 * G_FWD_GFLOP + 2 * D_PAIR_GFLOP + G_FWD_GFLOP + 3 * D_PAIR_GFLOP
 
 
-def main_projector(args):
+def _free_gpu():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+
+
+def leg_projector(args, rank, world, dev, steps, warmup):
     """SURVEY 8d metric (ii): GenProjector training images/sec, one G step + one D step (GenProjector/train.py:33-37)
-    at BASELINE configs[2] (B=32 per GPU, 128x256 panoramas) unless --batch says otherwise.  SphereConv2D runs as HIP
-    gather kernels (im2col_sphere / col2im_sphere) around rocBLAS GEMMs, the rest of row a15 on stock PyTorch-ROCm
-    ops; the roofline object prices the WHOLE step against the f32 MFMA peak (the GEMMs dominate)."""
+    at BASELINE configs[2] (B=32 per GPU, 128x256 panoramas).  SphereConv2D and SPADE's modulation run on the HIP
+    kernels; the object prices the WHOLE step against the f32 MFMA peak (the convolutions' GEMMs dominate)."""
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # fast find: the first step must not spend minutes tuning
-    from emlight_amd.RegressionNetwork.engine import init_distributed
     from emlight_amd.GenProjector.networks import default_options
     from emlight_amd.GenProjector.model_trainer import Trainer
     from emlight_amd.GenProjector.data import projector_batch
-    rank, local, world = init_distributed()
-    dev = "cuda:%d" % local
-    B = args.batch if args.batch != 64 else 32
+    B = args.projector_batch
     tr = Trainer(default_options(), device=dev, world=world)
     data = projector_batch(B, dev, ln=args.anchors, seed=1234 + rank)
-    dt = run_timed(lambda: tr.step(data), args.steps, args.warmup, world, dev)
-    if rank == 0:
-        value = B * world * args.steps / dt
-        # G step: G fwd + bwd (3x) and D fwd/bwd-data on the pair (2x); D step: G fwd (no grad) + D fwd/bwd (3x)
-        gflop = 3 * G_FWD_GFLOP + 2 * D_PAIR_GFLOP + G_FWD_GFLOP + 3 * D_PAIR_GFLOP
-        tf = gflop * value / world / 1e3
-        print(json.dumps({
-            "metric": "training images/sec (projector step: SPADE generator + PatchGAN discriminator, G step + D step)",
-            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", 
-                       "per_gpu_batch": B, "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
-                       "parallelism": "dp%d" % world if world > 1 else "single"},
-            "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
-            "roofline": {"kernel": "whole step (SphereConv2D = HIP im2col/col2im gathers + rocBLAS f32 GEMMs; norms and "
-                                   "activations on stock ops)",
-                         "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D "
-                                 "step) + 5*%.2f (D) GFLOP, VGG / feature-matching terms excluded" % (G_FWD_GFLOP, D_PAIR_GFLOP)},
-        }), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
+    value = B * world * steps / dt
+    tf = PROJECTOR_STEP_GFLOP * value / world / 1e3
+    out = {"metric": "training images/sec (projector step: SPADE generator + PatchGAN discriminator, G step + D step)",
+           "value": round(value, 2), "unit": "images/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3),
+           "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "per_gpu_batch": B,
+                      "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64},
+           "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+           "roofline": {"kernel": "whole step", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D step) + "
+                                "5*%.2f (D) GFLOP, VGG / feature-matching terms excluded" % (G_FWD_GFLOP, D_PAIR_GFLOP)}}
+    del tr, data
+    _free_gpu()
+    return out
+
+
+def leg_joint(args, rank, world, dev, steps, warmup):
+    """SURVEY 8d metric (iii) / BASELINE configs[3]: the joint regression -> rasteriser -> projector step
+    (emlight_amd/joint.py) at 32 images per GPU (256 over 8), 240x320 crops, 128 anchors, 128x256 panoramas."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    from emlight_amd.joint import JointTrainer, joint_batch
+    B, crop_hw = args.joint_batch, tuple(args.crop_hw)
+    tr = JointTrainer(anchors=args.anchors, crop_hw=crop_hw, blur=args.blur, device=dev, world=world)
+    batch = joint_batch(B, dev, args.anchors, crop_hw, seed=1234 + rank)
+    dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
+    value = B * world * steps / dt
+    gflop = (STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0) + PROJECTOR_STEP_GFLOP
+    tf = gflop * value / world / 1e3
+    out = {"metric": "training images/sec (joint step: DenseNet -> SG rasteriser -> SPADE generator + PatchGAN, "
+                     "encoder+G step and D step)",
+           "value": round(value, 2), "unit": "images/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3),
+           "config": {"workload": "joint regression+projector train step, BASELINE configs[3] (256 over 8 GPUs)",
+                      "per_gpu_batch": B, "global_batch": B * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
+                      "pano_hw": [128, 256], "ngf": 64, "ndf": 64},
+           "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+           "roofline": {"kernel": "whole step", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": "algorithmic conv FLOPs per image = %.1f (encoder train step) + %.1f (projector G+D step) "
+                                "GFLOP" % (STEP_GFLOP_240x320, PROJECTOR_STEP_GFLOP)}}
+    del tr, batch
+    _free_gpu()
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks (one process per GPU) ourselves and
+    relay their output; the children see WORLD_SIZE and take the normal path."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, n_dev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -308,32 +403,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch of the regression step (configs[1])")
+    ap.add_argument("--projector_batch", type=int, default=32, help="per-GPU batch of the projector leg (configs[2])")
+    ap.add_argument("--joint_batch", type=int, default=32, help="per-GPU batch of the joint leg (configs[3]: 256 / 8)")
     ap.add_argument("--anchors", type=int, default=128)
     ap.add_argument("--crop_hw", type=int, nargs=2, default=(240, 320))
     ap.add_argument("--blur", type=float, default=.05)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--workload", default="regression", choices=["regression", "projector"],
-                    help="regression = BASELINE's headline (default); projector = SURVEY 8d metric (ii), the "
-                         "GenProjector G+D step of BASELINE configs[2] on stock ops (row a15)")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of the extra objects on the line: projector,joint,sinkhorn,rasteriser,families "
+                         "(default all; 'none' = the headline regression step only)")
+    ap.add_argument("--workload", default="regression", choices=["regression", "projector", "joint"],
+                    help="regression = BASELINE's headline line with every leg as an object (default); projector / joint = "
+                         "a line whose `value` is that leg alone (profiling runs)")
     args = ap.parse_args()
-    if args.workload == "projector":
-        return main_projector(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     from emlight_amd.RegressionNetwork.engine import RegressionTrainer, init_distributed
     from emlight_amd.RegressionNetwork.data import synthetic_batch
     rank, local, world = init_distributed()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree"
+                         % (args.gpus, world))
     dev = "cuda:%d" % local
     crop_hw = tuple(args.crop_hw)
-    tr = RegressionTrainer(anchors=args.anchors, crop_hw=crop_hw, blur=args.blur, device=dev,
-                           world=world)
+    legs = {"projector", "joint", "sinkhorn", "rasteriser", "families"} if args.legs == "all" else \
+        set(x for x in args.legs.split(",") if x and x != "none")
+    par = "dp%d" % world if world > 1 else "single"
+
+    if args.workload in ("projector", "joint"):
+        leg = (leg_projector if args.workload == "projector" else leg_joint)(args, rank, world, dev, args.steps, args.warmup)
+        if rank == 0:
+            leg.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                        "data": "synthetic"})
+            leg["config"]["parallelism"] = par
+            print(json.dumps(leg), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    tr = RegressionTrainer(anchors=args.anchors, crop_hw=crop_hw, blur=args.blur, device=dev, world=world)
     batch = synthetic_batch(args.batch, args.anchors, crop_hw, seed=1234 + rank, device=dev)
 
     dt = run_timed(lambda: tr.step(batch), args.steps, args.warmup, world, dev)
 
     # live per-kernel timing: EVERY rank runs the instrumented steps (they contain DDP's all-reduce)
-    fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) 
+    fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) if "families" in legs else None
+    peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+    del tr, batch
+    _free_gpu()
+    # the other legs of BASELINE's metric; every rank takes part (DDP collectives inside), rank 0 reports
+    short = (min(args.steps, 5), min(args.warmup, 2))
+    extra = {}
+    if "projector" in legs:
+        extra["projector"] = leg_projector(args, rank, world, dev, *short)
+    if "joint" in legs:
+        extra["joint"] = leg_joint(args, rank, world, dev, *short)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -345,9 +471,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RegressionNetwork train step, BASELINE configs[1]", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
-                       "sinkhorn_blur": args.blur,
-                       "parallelism": "dp%d" % world if world > 1 else "single"},
-            "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                       "sinkhorn_blur": args.blur, "parallelism": par},
+            "peak_hbm_GB": peak_gb,
             "step_tflops": round(STEP_GFLOP_240x320 * value / 1e3, 2) if crop_hw == (240, 320) else None,
             "step_frac_of_f32_mfma_peak": round(STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
             if crop_hw == (240, 320) else None,
@@ -359,26 +484,34 @@ def main():
             f_hbm = dom["algorithmic_GBps"] / HBM_PEAK_GBPS
             f_mfma = (dom["tflops"] or 0.0) / F32_MFMA_PEAK_TFLOPS
             hbm = f_hbm >= f_mfma
+            traffic, source = pmc_traffic(dom["kernel"])
             out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm" if hbm else "mfma",
                                "achieved": dom["algorithmic_GBps"] if hbm else dom["tflops"],
                                "peak": HBM_PEAK_GBPS if hbm else F32_MFMA_PEAK_TFLOPS,
                                "unit": "GB/s" if hbm else "TFLOP/s",
                                "frac": round(max(f_hbm, f_mfma), 4),
-                               "traffic": pmc_traffic(dom["kernel"]),
+                               "traffic": traffic, "traffic_source": source,
                                "algorithmic_bytes_per_launch": round(dom["algorithmic_GB_per_step"] * 1e9 /
                                                                      max(dom["launches_per_step"], 1)),
                                "other_roof_frac": round(min(f_hbm, f_mfma), 4),
                                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
                                "note": "achieved = algorithmic bytes (or conv FLOPs) of the family's launches / their "
-                                       "summed HIP-event duration; peaks: HBM3E 8 TB/s, f32 MFMA "
-                                       "(v_mfma_f32_16x16x4_f32) 157.3 TFLOP/s; traffic = HBM bytes per launch from the "
-                                       "committed rocprofv3 --pmc passes (profiles/), (2*FETCH_SIZE + WRITE_SIZE) KiB"}
+                                       "summed HIP-event duration, live in this run; peaks: HBM3E 8 TB/s, f32 MFMA "
+                                       "(v_mfma_f32_16x16x4_f32) 157.3 TFLOP/s; traffic = HBM bytes per launch from "
+                                       "separate rocprofv3 --pmc passes of this command (PMC cannot be read inside a "
+                                       "timed run): see traffic_source"}
             out["kernel_families"] = fams
+        if "sinkhorn" in legs:
             out["sinkhorn"] = time_sinkhorn(args.batch, args.anchors, args.blur, dev)
+            out["sinkhorn_n256"] = time_sinkhorn(16, 256, args.blur, dev)   # configs[4]'s per-GPU shape: B=16, N=256
+        if "rasteriser" in legs:
+            out["rasteriser"] = time_rasteriser(args.projector_batch, args.anchors, (128, 256), dev)
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

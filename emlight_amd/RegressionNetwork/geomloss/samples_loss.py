@@ -16,26 +16,28 @@ from ... import _lib
 from ..util import sphere_points
 
 
-def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False):
-    """One call into the HIP library; returns every device-side output (no autograd)."""
+def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
+    """Device buffers one ``eml_sinkhorn_fwd_f32`` call writes (the caller owns every buffer, include/emlight_hip.h)."""
+    f32 = dict(dtype=torch.float32, device=dev)
+    return {"eps_s": torch.empty(64, **f32), "n_eps": torch.empty(1, dtype=torch.int32, device=dev),
+            "diameter": torch.empty(1, **f32), "loss": torch.empty(B, **f32),
+            "gx": torch.empty(B, N, **f32) if need_gx else None, "gy": torch.empty(B, N, **f32) if need_gy else None,
+            "work": torch.empty(8, B, N, **f32)}
+
+
+def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False, out=None):
+    """One call into the HIP library; returns every device-side output (no autograd).  ``out``: buffers from
+    ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches)."""
     L = _lib.lib()
     B, N = x.shape
-    dev = x.device
-    eps_s = torch.empty(64, dtype=torch.float32, device=dev)
-    n_eps = torch.empty(1, dtype=torch.int32, device=dev)
-    diam = torch.empty(1, dtype=torch.float32, device=dev)
-    stream = _lib.current_stream()
-    loss = torch.empty(B, dtype=torch.float32, device=dev)
-    gx = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gx else None
-    gy = torch.empty(B, N, dtype=torch.float32, device=dev) if need_gy else None
-    work = torch.empty(8, B, N, dtype=torch.float32, device=dev)
+    o = out if out is not None else sinkhorn_outputs(B, N, x.device, need_gx, need_gy)
     _lib.check(L.eml_sinkhorn_fwd_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
         float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
-        _lib.ptr(eps_s), _lib.ptr(n_eps), _lib.ptr(diam), _lib.ptr(loss), _lib.ptr(gx), _lib.ptr(gy),
-        _lib.ptr(work), B, N, stream), "eml_sinkhorn_fwd_f32")
-    return {"loss": loss, "gx": gx, "gy": gy, "eps_s": eps_s, "n_eps": n_eps, "diameter": diam,
-            "duals": work[:4]}
+        _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
+        _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
+    return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
+            "diameter": o["diameter"], "duals": o["work"][:4]}
 
 
 class _SinkhornDivergence(torch.autograd.Function):
@@ -140,11 +142,11 @@ class SamplesLoss(Module):
         M, Mt = self.cost_matrix(x2.device)
         return _SinkhornDivergence.apply(x2, y2, a2, b2, M, Mt, self.p, self.blur, self.scaling, self.diameter)
 
-    def forward_raw(self, x, y, need_gx=True, need_gy=True):
-        """Every device output of one call (loss, unit grads, schedule, duals) -- for parity tests."""
+    def forward_raw(self, x, y, need_gx=True, need_gy=True, out=None):
+        """Every device output of one call (loss, unit grads, schedule, duals) -- for parity tests and timing."""
         B = x.shape[0]
         x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
         y2 = _lib.require_gpu_tensor(y.reshape(B, self.N), "y")
         M, Mt = self.cost_matrix(x2.device)
         return sinkhorn_raw(x2, y2, None, None, M, Mt, self.p, self.blur, self.scaling, self.diameter,
-                            need_gx, need_gy)
+                            need_gx, need_gy, out)

@@ -1,0 +1,135 @@
+"""GPU parity of the joint regression -> rasteriser -> projector step (BASELINE configs[3], emlight_amd/joint.py).
+
+Small size: one full iteration of the HIP path (DenseNet engine, Sinkhorn, SG rasteriser forward + colour gradient,
+SphereConv2D / SPADE kernels, three Adam updates) against the same composition built from oracle pieces on the CPU
+(oracle.joint_step: OracleDenseNet, oracle Sinkhorn, oracle rasteriser, the projector modules on stock ops).
+Full size (32 per GPU, 240x320 crops, ngf = ndf = 64): size-independent properties."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+KEYS = ("distribution", "intensity", "rgb_ratio", "ambient")
+
+
+def _rel_l2(a, b, floor):
+    rms = lambda t: float(np.sqrt(np.mean(np.square(t))))
+    return rms(a - b) / max(rms(b), floor)
+
+
+def test_joint_step_small_vs_oracle_composition():
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    from emlight_amd.joint import JointTrainer, joint_batch
+    ln, crop, B = 128, (64, 96), 2
+    opt = networks.default_options(ngf=8, ndf=8)
+    tr = JointTrainer(opt, anchors=ln, crop_hw=crop, blur=.05, device="cuda:0")
+    enc_o = oracle.OracleDenseNet(anchors=ln, crop_hw=crop).train()
+    sd = oracle.deterministic_state_dict(enc_o.state_dict(), seed=21)
+    enc_o.load_state_dict(sd)
+    tr.reg.model.load_state_dict(sd)
+    pm_o = Pix2PixModel(opt).train()
+    sdG = oracle.deterministic_projector_state_dict(pm_o.netG.state_dict(), seed=11)
+    sdD = oracle.deterministic_projector_state_dict(pm_o.netD.state_dict(), seed=12)
+    for m in (pm_o, tr.proj.model):
+        m.netG.load_state_dict(sdG)
+        m.netD.load_state_dict(sdD)
+    batch = joint_batch(B, "cuda:0", ln, crop, seed=77)
+    batch_cpu = {k: v.cpu() for k, v in batch.items()}
+
+    got = tr.step(batch)
+    M = oracle.anchor_cost_matrix(ln)
+    opt_E = torch.optim.Adam(enc_o.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    opt_G, opt_D = pm_o.create_optimizers(opt)
+    with oracle.stock_sphere_ops():
+        want = oracle.joint_step(enc_o, pm_o, opt_E, opt_G, opt_D, batch_cpu,
+                                 lambda a, b: oracle.samples_loss(a, b, M, blur=.05), ln)
+
+    # forward: guide map (HDR map: north_star 1e-2 rel, held to 1e-4 of peak), generated panorama, every loss term
+    gm = want["gmap"].detach().numpy()
+    np.testing.assert_allclose(tr.guide.detach().cpu().numpy(), gm, rtol=1e-4, atol=1e-4 * np.abs(gm).max())
+    fk = want["fake"].detach().numpy()
+    np.testing.assert_allclose(tr.generated.detach().cpu().numpy(), fk, rtol=1e-3, atol=2e-3)
+    ref_losses = {**want["terms"], **want["g_losses"], **want["d_losses"]}
+    assert set(got) == set(ref_losses)
+    for k, v in ref_losses.items():
+        np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=1e-4, atol=1e-6, err_msg=k)
+
+    # backward: relative L2 per tensor (element-wise agreement is impossible across two f32 ReLU networks)
+    def check(named_got, named_want, max_bound, med_bound, what):
+        grads = {k: p.grad.numpy() for k, p in named_want.items() if p.grad is not None}
+        floor = 1e-3 * float(np.median([np.sqrt(np.mean(np.square(g))) for g in grads.values()]))
+        errs = sorted(((_rel_l2(named_got[k].grad.cpu().numpy(), g, floor), k) for k, g in grads.items()), reverse=True)
+        assert all(np.isfinite(e) for e, _ in errs), what
+        assert errs[0][0] < max_bound, "%s: largest relative L2 grad errors %s" % (what, errs[:6])
+        assert np.median([e for e, _ in errs]) < med_bound, "%s: median %g" % (what, np.median([e for e, _ in errs]))
+    check(dict(tr.reg.model.named_parameters()), dict(enc_o.named_parameters()), 5e-2, 5e-3, "encoder")
+    check(dict(tr.proj.model.netG.named_parameters()), dict(pm_o.netG.named_parameters()), 2e-2, 2e-3, "generator")
+    check(dict(tr.proj.model.netD.named_parameters()), dict(pm_o.netD.named_parameters()), 2e-2, 2e-3, "discriminator")
+
+    # the projector's losses really reach the encoder through the rasteriser: the regression-only gradient differs
+    enc_r = oracle.OracleDenseNet(anchors=ln, crop_hw=crop).train()
+    enc_r.load_state_dict(sd)
+    l_reg, _ = oracle.regression_loss(enc_r(batch_cpu["crop"]), batch_cpu, lambda a, b: oracle.samples_loss(a, b, M, blur=.05), ln)
+    l_reg.backward()
+    d = (enc_r.fc_intensity.weight.grad - enc_o.fc_intensity.weight.grad).abs().max()
+    assert float(d) > 1e-6 * float(enc_r.fc_intensity.weight.grad.abs().max())
+
+
+def test_joint_step_properties_at_cfg4_size():
+    """32 images per GPU (BASELINE configs[3]: 256 over 8), 240x320 crops, 128 anchors, ngf = ndf = 64: too large for
+    the CPU oracle, so: (1) bitwise run-to-run determinism of two whole iterations (the HIP kernels use no atomics);
+    (2) additivity of the backward -- the encoder gradient of L_reg + L_G equals grad(L_reg) + grad(L_G);
+    (3) every loss finite, guide map == rasteriser of the predicted parameters + ambient."""
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.joint import JointTrainer, joint_batch, predicted_gaussian_map
+    from emlight_amd.RegressionNetwork.engine import regression_loss
+    dev, ln, crop, B = "cuda:0", 128, (240, 320), 32
+    batch = joint_batch(B, dev, ln, crop, seed=5)
+
+    def run(n):
+        torch.manual_seed(3)
+        tr = JointTrainer(networks.default_options(), anchors=ln, crop_hw=crop, blur=.05, device=dev)
+        out = [{k: v.detach().clone() for k, v in tr.step(batch).items()} for _ in range(n)]
+        return tr, out
+    tr, a = run(2)
+    enc_w = tr.reg.model.fc_dist.weight.detach().clone()
+    g_w = tr.proj.model.netG.sphere_conv1.weight.detach().clone()
+    del tr
+    torch.cuda.empty_cache()
+    tr, b = run(2)
+    for la, lb in zip(a, b):
+        for k in la:
+            assert torch.isfinite(la[k]).all(), k
+            assert torch.equal(la[k], lb[k]), "joint step must be run-to-run exact (%s)" % k
+    assert torch.equal(enc_w, tr.reg.model.fc_dist.weight.detach()) and torch.equal(g_w, tr.proj.model.netG.sphere_conv1.weight.detach())
+
+    # (2) additivity on the encoder, no optimiser steps
+    enc, pm = tr.reg.model, tr.proj.model
+    state = copy.deepcopy(enc.state_dict())
+
+    def enc_grads(use_reg, use_g):
+        enc.load_state_dict(state)
+        enc.zero_grad(set_to_none=True)
+        pm.zero_grad(set_to_none=True)
+        pred = enc(batch["crop"])
+        l_reg, _ = regression_loss(pred, batch, tr.reg.sam_loss, ln)
+        data = tr.projector_inputs(batch, pred)
+        g_losses, _ = pm(data, mode="generator")
+        total = (l_reg if use_reg else 0.0) + (sum(g_losses.values()).mean() if use_g else 0.0)
+        total.backward()
+        return [p.grad.clone() for p in enc.parameters()], data["input"].detach(), pred
+    pm.eval()   # freeze spectral-norm power iterations / BN statistics between the three passes
+    both, gmap, pred = enc_grads(True, True)
+    reg_only, _, _ = enc_grads(True, False)
+    g_only, _, _ = enc_grads(False, True)
+    for gb, gr, gg in zip(both, reg_only, g_only):
+        s = float(gb.abs().max()) + 1e-20
+        assert float((gb - (gr + gg)).abs().max()) <= 2e-4 * s + 1e-9
+    assert any(float(g.abs().max()) > 0 for g in g_only), "the generator losses must reach the encoder"
+    want = predicted_gaussian_map({k: v.detach() for k, v in pred.items()}, ln)
+    assert torch.equal(want, gmap)
