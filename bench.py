@@ -68,12 +68,14 @@ def family_bytes(B, crop_hw):
         for l in range(16):
             k = c + 12 * l
             by["eml_dense_conv1x1_fwd_f32"] += (k + 48) * 4 * P          # X[:, :k] in, Z out
-            by["eml_dense_conv1x1_bwd_weight_f32"] += (k + 96) * 4 * P   # X[:, :k], DZ, Z in
+            by["eml_dense_conv1x1_bwd_weight_f32"] += (k + 96 + 48) * 4 * P   # X[:, :k], dzn, Z in; dz out (materialised)
             by["eml_dense_conv3x3_fwd_f32"] += (48 + 12) * 4 * P         # Z in, 12 new channels out
-            by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 12 + 48 + 48 + 12) * 4 * P  # G, X (deferred affine), Z in; DZ, GF out
+            # G, X (deferred affine), Z in; dzn, GF out; the lower layer of a pair also reads the compact N12
+            by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 12 + 48 + 48 + 12 + (12 if l % 2 == 0 else 0)) * 4 * P
             by["eml_dense_conv3x3_bwd_weight_f32"] += (12 + 48) * 4 * P  # dY, Z in
             if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
-                by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((3 * 12 + 96) + (3 * k + 192)) * 4 * P
+                by["eml_dense_conv1x1_bwd_narrow_f32"] += (48 + 12 + 12) * 4 * P      # dz, X slice in; N12 out
+                by["eml_dense_conv1x1_bwd_data_multi_f32"] += (3 * k + 96) * 4 * P    # X, old G in, new G out; 2 x dz in
         ct = c + 192
         by["eml_dense_pool_act_f32"] += (ct + ct // 4) * 4 * P           # transition: X in, pooled activation A out
         by["eml_dense_conv1x1_fwd_f32"] += (ct // 4 + ct // 8) * 4 * P   # transition conv on A: A in, pooled out
@@ -86,9 +88,11 @@ def family_bytes(B, crop_hw):
 # launcher -> (kernel family, which algorithmic FLOP count one pass over its launches performs)
 FAMILIES = {
     "eml_dense_conv1x1_fwd_f32": ("conv1x1_fwd_kernel (BN1+ReLU fused into the MFMA operand load)", 0),
-    "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS)", 0),
-    "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 1-2 dense layers per pass + ReLU "
+    "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS and materialised)", 0),
+    "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 2 dense layers per pass + ReLU "
                                              "mask + BN1-backward accumulate)", 0),
+    "eml_dense_conv1x1_bwd_narrow_f32": ("conv1x1_bwd_narrow_kernel (upper layer's dgrad over the lower layer's 12 channels, "
+                                         "compact output)", 3),
     "eml_dense_conv1x1_bwd_data_f32": ("transition_bwd_data_kernel (transition dgrad: un-pool, ReLU mask, BN backward accumulate)", 2),
     "eml_dense_pool_act_f32": ("pool_act_kernel (transition operand: 2x2 mean of relu(bn(x)))", 3),
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),

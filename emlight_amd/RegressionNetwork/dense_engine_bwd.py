@@ -22,6 +22,7 @@ class _BwdBuffers:
         maxP = ws.blocks[0]["P"]
         self.DZ = torch.empty(2, maxP, 48, **f32)   # one per layer of a pair
         self.GF12 = torch.empty(maxP, 12, **f32)    # finished gradient of a layer's 12 output channels (compact)
+        self.N12 = torch.empty(maxP, 12, **f32)     # narrow pass: finished gradient of the lower layer's 12 channels
         # scratch sized from the network (widest block Kp, widest transition Ko) and the largest grid, not for
         # EMLight's default only
         kp, ko, g = enc.kp_max, max(enc.ko_max, 48), enc.grid_max
@@ -106,16 +107,19 @@ def run_backward(enc, ws, x, gpooled):
         finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False)
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
-        def conv2_backward(l, slot):
-            """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad."""
+        def conv2_backward(l, slot, n12=False):
+            """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad, which
+            also materialises dz = cA*dzn + cB*z + cC in place over DZ[slot] for the data-gradient passes.
+            n12: the layer above left the finished gradient of this layer's channels in the compact bw.N12."""
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
             cin, kp, z, dz = lay["Cin"], lay["Kp"], blk["Z"][l], bw.DZ[slot]
             # the gradient of this layer's 12 output channels is complete: its deferred BN1 affine (sB, sC) is
             # applied inside the conv3x3 dgrad's tile staging, which also leaves the finished gradient in GF12
-            _lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gbuf), ld, cin, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
+            gsrc = (p(bw.N12), 12, 0) if n12 else (p(Gbuf), ld, cin)
+            _lib.check(L.eml_dense_conv3x3_bwd_data_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
                                                         p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3, p(blk["X"]), ld,
-                                                        p(sB), p(sC), p(bw.GF12), st),
+                                                        cin, p(sB), p(sC), p(bw.GF12), st),
                        "eml_dense_conv3x3_bwd_data_f32")
             _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12), 12, 0, p(z), p(lay["scale2"]), p(lay["shift2"]),
                                                           B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G3, st),
@@ -124,7 +128,7 @@ def run_backward(enc, ws, x, gpooled):
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
-                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
+                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, p(dz), st), "eml_dense_conv1x1_bwd_weight_f32")
             _lib.check(L.eml_dense_permute_w1_bwd_f32(p(Lm.conv1.weight), 48, cin, kp, 48, p(bw.Wd[slot]), st),
                        "eml_dense_permute_w1_bwd_f32")
             return Lm
@@ -133,13 +137,21 @@ def run_backward(enc, ws, x, gpooled):
             """G[:, k_lo:k_hi] += sum over `layers` of scale1*dam; BN1 partial sums -> bw.part2[slot]."""
             lays = [blk["layers"][l] for l in layers]
             _lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
-                len(layers), parr([bw.DZ[s_] for s_ in slots]), parr([blk["Z"][l] for l in layers]),
-                parr([coefs[s_][0] for s_ in slots]), parr([coefs[s_][1] for s_ in slots]),
-                parr([coefs[s_][2] for s_ in slots]), parr([bw.Wd[s_] for s_ in slots]),
+                len(layers), parr([bw.DZ[s_] for s_ in slots]), None, None, None, None,   # DZ holds the materialised dz
+                parr([bw.Wd[s_] for s_ in slots]),
                 parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
                 parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
                 p(blk["X"]), ld, p(blk["mean"]), p(blk["istd"]), P, k_lo, k_hi, p(Gbuf), ld, G, st),
                 "eml_dense_conv1x1_bwd_data_multi_f32")
+
+        def narrow(l, Lm, slot, k_lo):
+            """Layer l's data gradient over the 12 channels [k_lo, k_lo+12) -> compact bw.N12 (+ BN1 partial sums)."""
+            lay = blk["layers"][l]
+            _lib.check(L.eml_dense_conv1x1_bwd_narrow_f32(
+                p(bw.DZ[slot]), p(Lm.conv1.weight), lay["Cin"], k_lo, p(blk["X"]), ld, p(lay["scale1"]),
+                p(lay["shift1"]), p(blk["mean"]), p(blk["istd"]), P, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot]),
+                lay["Kp"], G, st),
+                "eml_dense_conv1x1_bwd_narrow_f32")
 
         def bn1_finalize(l, Lm, slot, c_lo, c_hi):
             lay = blk["layers"][l]
@@ -152,9 +164,9 @@ def run_backward(enc, ws, x, gpooled):
                 la, lb = l, l - 1
                 cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
                 Lma = conv2_backward(la, 0)
-                dgrad([la], [0], cin_b, cin_a)                 # narrow pass: layer lb's output channels only
+                narrow(la, Lma, 0, cin_b)                      # narrow pass: layer lb's output channels only -> N12
                 bn1_finalize(la, Lma, 0, cin_b, cin_a)
-                Lmb = conv2_backward(lb, 1)
+                Lmb = conv2_backward(lb, 1, n12=True)
                 dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once
                 bn1_finalize(la, Lma, 0, 0, cin_b)
                 bn1_finalize(lb, Lmb, 1, 0, blk["layers"][lb]["Kp"])

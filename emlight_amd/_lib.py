@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 2   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 3   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -59,7 +59,7 @@ SIGNATURES = {
     "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),
     # DenseNet-BC encoder, backward
     "eml_dense_conv3x3_bwd_data_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
-                                              _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _stream]),
+                                              _f32p, _int, _f32p, _int, _int, _f32p, _f32p, _f32p, _stream]),
     "eml_dense_conv3x3_bwd_weight_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _int, _int, _int, _f32p,
                                                 _f32p, _int, _stream]),
     "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,
@@ -67,7 +67,9 @@ SIGNATURES = {
                                              _stream]),
     "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
                                                 _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
-                                                _f32p, _int, _stream]),
+                                                _f32p, _int, _f32p, _stream]),
+    "eml_dense_conv1x1_bwd_narrow_f32": (_int, [_f32p, _f32p, _int, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
+                                                ctypes.c_long, _f32p, _int, _f32p, _f32p, _int, _int, _stream]),
     "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,

@@ -6,7 +6,11 @@
 //   conv3x3_bwd_weight dW2 = sum_p g[p] (x) BN2(z)[p+tap]        (persistent accumulators, partials)
 //   bn_bwd_finalize    dgamma2, dbeta2, and the affine that turns dzn into dz on the fly:
 //                      dz = cA*dzn + cB*z + cC   (BatchNorm backward is affine per channel)
-//   conv1x1_bwd_weight dW1 = sum_p relu(bn1(x))[p] (x) dz[p]     (dz rebuilt in the operand load)
+//   conv1x1_bwd_weight dW1 = sum_p relu(bn1(x))[p] (x) dz[p]     (dz rebuilt in the operand load and MATERIALISED
+//                      in place over dzn: the data-gradient passes read 48 floats per pixel, not dzn + z = 96)
+//   conv1x1_bwd_narrow the upper layer of a pair: its data gradient over the lower layer's 12 output channels, added
+//                      to the G slice and written as a compact (P,12) tensor that the lower layer's conv3x3_bwd_data
+//                      stages instead of the slice
 //   conv1x1_bwd_data_multi   dam = relu-mask * (dz W1) for ONE or TWO consecutive layers per pass over X;
 //                      G[:, :Cin] += scale1*dam in the epilogue (the dy-coefficient of BN1's backward needs no
 //                      statistics) + partial (sum, sum*xhat) per layer
@@ -50,11 +54,14 @@ constexpr int kGPass = kHH / kGRows;                        // 5 passes of float
 // FUSE: g = G + sB*X + sC (the deferred BN1 affine of the block gradient, see grad_materialize_kernel) is applied
 // while the halo tile is staged, and the finished 12-channel gradient of the tile's own pixels is written to the
 // compact GF (P,12) for conv3x3_bwd_weight -- instead of a separate read-modify-write pass over G.
+// G may be the block gradient (ldg = ld, c0 = the layer's channel offset) or the compact (P,12) tensor that
+// conv1x1_bwd_narrow_kernel leaves for the lower layer of a pair (ldg = 12, c0 = 0); cx is the layer's channel
+// offset in X / sB / sC either way.
 template <bool FUSE>
 __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
-    double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx,
+    double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx, int cx,
     const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF) {
   __shared__ __attribute__((aligned(16))) float g_l[2][kHH * kHW * kPSG];
   __shared__ double red[8 * 48 * 2];
@@ -86,8 +93,8 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   float2 gt[kGPass], xt[FUSE ? kGPass : 1];
   float2 fb = make_float2(0.f, 0.f), fc = make_float2(0.f, 0.f);
   if constexpr (FUSE) {
-    fb = *reinterpret_cast<const float2*>(sB + c0 + 2 * s_q);
-    fc = *reinterpret_cast<const float2*>(sC + c0 + 2 * s_q);
+    fb = *reinterpret_cast<const float2*>(sB + cx + 2 * s_q);
+    fc = *reinterpret_cast<const float2*>(sC + cx + 2 * s_q);
   }
   const float* s_src = G;
   const float* s_srcx = Xb;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const size_t col = (size_t)b * H * W + min(max(gx, 0), W - 1);
     s_src = G + col * ldg + c0 + 2 * s_q;
     if constexpr (FUSE) {
-      s_srcx = Xb + col * ldx + c0 + 2 * s_q;
+      s_srcx = Xb + col * ldx + cx + 2 * s_q;
       s_gf = GF + col * 12 + 2 * s_q;
       s_own = s_col && tid < kGRows * kHW * 6 && s_hx >= 1 && s_hx <= kTW;  // a column of the tile itself (not halo)
     }
@@ -481,7 +488,9 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ shift1, const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr,
     int ld_z, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n_valid,
     int n_load /* columns (multiple of 4) that may be read without leaving the DY / Zr rows */,
-    float* __restrict__ partial /*[grid][Kp][48]*/) {
+    float* __restrict__ partial /*[grid][Kp][48]*/,
+    float* __restrict__ dz_out /* NULL, or (P,48): the rebuilt dz is materialised here for the data-gradient passes
+                                  (may alias DY: every element is read and written by the same thread) */) {
   __shared__ __attribute__((aligned(16))) float dz_l[2][64 * 48];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
@@ -532,10 +541,12 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
   // dz tile of a chunk: global -> registers (issued early) -> affine -> LDS (written late)
   float4 rdy[3], rzr[3];
   bool rpv = false;
+  int rp = 0;
   auto stage_load = [&](int chunk) {
     const int p = chunk * 64 + spix;
     rpv = chunk < nchunks && p < P;
     const size_t pc = rpv ? p : 0;
+    rp = (int)pc;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int col = 4 * (sq + 4 * j);
@@ -554,6 +565,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
       v.z = rpv ? fmaf(sa[j].z, rdy[j].z, fmaf(sb[j].z, rzr[j].z, sc[j].z)) : 0.f;
       v.w = rpv ? fmaf(sa[j].w, rdy[j].w, fmaf(sb[j].w, rzr[j].w, sc[j].w)) : 0.f;
       *reinterpret_cast<float4*>(dzb + spix * 48 + col) = v;
+      if (dz_out && rpv) *reinterpret_cast<float4*>(dz_out + (size_t)rp * 48 + col) = v;
     }
   };
   // The chunk loop, specialised on the (wave-uniform) number of channel groups so that the operand
@@ -1007,7 +1019,7 @@ struct BwdLayer {
   int Kp;
 };
 
-template <int NL, int MT /* 16-pixel tiles per wave */>
+template <int NL, int MT /* 16-pixel tiles per wave */, bool RAW = false /* DZ already holds dz (materialised) */>
 __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer L0, BwdLayer L1,
                                                                         const float* __restrict__ X, int ldx,
                                                                         const float* __restrict__ mean,
@@ -1068,17 +1080,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
 #pragma unroll
       for (int jo = 0; jo < 3; ++jo) {
         const int ch = 16 * jo + 4 * kk;
-        const float4 a4 = *reinterpret_cast<const float4*>(Ls[j].cA + ch);
-        const float4 b4 = *reinterpret_cast<const float4*>(Ls[j].cB + ch);
-        const float4 c4 = *reinterpret_cast<const float4*>(Ls[j].cC + ch);
+        if constexpr (RAW) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 dy = *reinterpret_cast<const float4*>(Ls[j].DZ + prow[m] * 48 + ch);
-          const float4 zr = *reinterpret_cast<const float4*>(Ls[j].Zr + prow[m] * 48 + ch);
-          dz[j][jo][m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
-          dz[j][jo][m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
-          dz[j][jo][m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
-          dz[j][jo][m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
+          for (int m = 0; m < MT; ++m) dz[j][jo][m] = *reinterpret_cast<const float4*>(Ls[j].DZ + prow[m] * 48 + ch);
+        } else {
+          const float4 a4 = *reinterpret_cast<const float4*>(Ls[j].cA + ch);
+          const float4 b4 = *reinterpret_cast<const float4*>(Ls[j].cB + ch);
+          const float4 c4 = *reinterpret_cast<const float4*>(Ls[j].cC + ch);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 dy = *reinterpret_cast<const float4*>(Ls[j].DZ + prow[m] * 48 + ch);
+            const float4 zr = *reinterpret_cast<const float4*>(Ls[j].Zr + prow[m] * 48 + ch);
+            dz[j][jo][m].x = fmaf(a4.x, dy.x, fmaf(b4.x, zr.x, c4.x));
+            dz[j][jo][m].y = fmaf(a4.y, dy.y, fmaf(b4.y, zr.y, c4.y));
+            dz[j][jo][m].z = fmaf(a4.z, dy.z, fmaf(b4.z, zr.z, c4.z));
+            dz[j][jo][m].w = fmaf(a4.w, dy.w, fmaf(b4.w, zr.w, c4.w));
+          }
         }
       }
     for (int nt0 = nt_lo; nt0 < nt_hi; nt0 += NCH) {
@@ -1190,6 +1207,103 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
     for (int e = tid; e < Kp * 2; e += 256)
       Ls[j].partials[(size_t)blockIdx.x * Kp * 2 + e] = (base[e] + base[(size_t)KpMax * 2 + e]) +
                                                         (base[(size_t)2 * KpMax * 2 + e] + base[(size_t)3 * KpMax * 2 + e]);
+  }
+}
+
+// =============================================================================== conv1x1 backward: narrow data pass
+// The data gradient of layer l over the 12 output channels of layer l-1 -- [k_lo, k_lo+12) of the block buffer -- has
+// to be finished before layer l-1's own backward can start.  It is a 48 -> 12 product per pixel, so it gets its own
+// streaming kernel on compact operands: dz (P,48, materialised by the weight-gradient kernel) in, the increment
+// N12[p][c] = G[p][k_lo+c] + scale1[k_lo+c] * mask * sum_o dz[p][o] W1[o][k_lo+c], i.e. the FINISHED gradient of those
+// 12 channels, out as a compact (P,12) tensor that the lower layer's conv3x3_bwd_data stages instead of the G slice
+// (the wide G rows are read once here for 48 bytes and never written).
+// D^T form: A = W1 (rows = 12 channels of 16, k = o), B = dz (k = o, columns = 16 pixels); the k index is a
+// summation label, so lane (r, kk) feeds dz[p][16jo + 4kk + t] at step (jo, t) straight from its float4 load.
+// Statistics (sum dam, sum dam*xhat) accumulate per element in f64.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv1x1_bwd_narrow_kernel(
+    const float* __restrict__ DZ, const float* __restrict__ W1 /*[48][Cin]*/, int Cin, int k_lo,
+    const float* __restrict__ X, int ldx, const float* __restrict__ scale1, const float* __restrict__ shift1,
+    const float* __restrict__ mean, const float* __restrict__ istd, int P, const float* __restrict__ Gd, int ldg,
+    float* __restrict__ N12, double* __restrict__ partials /*[grid][Kp][2]*/, int Kp) {
+  __shared__ double red[4][12][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  float aw[3][4];
+#pragma unroll
+  for (int jo = 0; jo < 3; ++jo)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aw[jo][t] = r < 12 ? W1[(size_t)(16 * jo + 4 * kk + t) * Cin + k_lo + r] : 0.f;
+  const bool cv = kk < 3;                 // lanes of row group 3 hold the padding channels 12..15
+  const int cq = k_lo + 4 * (cv ? kk : 2);  // first of this lane's 4 channels (clamped for the padding lanes)
+  float sk[4], tk[4], mu[4], is[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sk[g] = scale1[cq + g];
+    tk[g] = shift1[cq + g];
+    mu[g] = mean[cq + g];
+    is[g] = istd[cq + g];
+  }
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int TP = 64 * MT;
+  const int ntiles = (P + TP - 1) / TP;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int p0 = tile * TP + wave * 16 * MT;
+    size_t prow[MT];
+    bool pv[MT];
+    float4 dz[MT][3];
+    float2 xa[MT], xb[MT], ga[MT], gb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      pv[m] = p0 + 16 * m + r < P;
+      prow[m] = (size_t)min(p0 + 16 * m + r, P - 1);
+#pragma unroll
+      for (int jo = 0; jo < 3; ++jo) dz[m][jo] = *reinterpret_cast<const float4*>(DZ + prow[m] * 48 + 16 * jo + 4 * kk);
+      xa[m] = *reinterpret_cast<const float2*>(X + prow[m] * ldx + cq);       // k_lo is even: 8-byte aligned
+      xb[m] = *reinterpret_cast<const float2*>(X + prow[m] * ldx + cq + 2);
+      ga[m] = *reinterpret_cast<const float2*>(Gd + prow[m] * ldg + cq);
+      gb[m] = *reinterpret_cast<const float2*>(Gd + prow[m] * ldg + cq + 2);
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jo = 0; jo < 3; ++jo)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = mfma16(aw[jo][t], f4c(dz[m][jo], t), acc[m]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float x[4] = {xa[m].x, xa[m].y, xb[m].x, xb[m].y};
+      const float gold[4] = {ga[m].x, ga[m].y, gb[m].x, gb[m].y};
+      float o[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float d = (pv[m] && cv && fmaf(x[g], sk[g], tk[g]) > 0.f) ? acc[m][g] : 0.f;
+        o[g] = fmaf(sk[g], d, gold[g]);
+        s1[g] += (double)d;
+        s2[g] += (double)(d * ((x[g] - mu[g]) * is[g]));
+      }
+      if (pv[m] && cv) *reinterpret_cast<float4*>(N12 + prow[m] * 12 + 4 * kk) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      s1[g] += shfl_xor_d(s1[g], o);
+      s2[g] += shfl_xor_d(s2[g], o);
+    }
+    if (r == 0 && cv) {
+      red[wave][4 * kk + g][0] = s1[g];
+      red[wave][4 * kk + g][1] = s2[g];
+    }
+  }
+  __syncthreads();
+  if (tid < 24) {
+    const int c = tid >> 1, e = tid & 1;
+    partials[((size_t)blockIdx.x * Kp + k_lo + c) * 2 + e] = (red[0][c][e] + red[1][c][e]) + (red[2][c][e] + red[3][c][e]);
   }
 }
 
@@ -1386,19 +1500,20 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
 // =============================================================================== C ABI
 extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                               const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
-                                              double* partials, int grid, const float* X, int ldx, const float* sB,
-                                              const float* sC, float* GF, eml_stream_t stream) {
+                                              double* partials, int grid, const float* X, int ldx, int cx,
+                                              const float* sB, const float* sC, float* GF, eml_stream_t stream) {
   if (!G || !W2 || !Z || !zmean || !zistd || !DZ || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || (c0 & 1) ||
       (ldg & 1))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: bad arguments");
   if (X) {
     if (!sB || !sC || !GF || (ldx & 1))
       return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: fused affine needs X, sB, sC, GF");
+    if (cx < 0 || (cx & 1)) return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: cx must be even");
     hipLaunchKernelGGL(conv3x3_bwd_data_kernel<true>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
-                       zmean, zistd, DZ, B, H, W, partials, X, ldx, sB, sC, GF);
+                       zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
   } else {
     hipLaunchKernelGGL(conv3x3_bwd_data_kernel<false>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
-                       zmean, zistd, DZ, B, H, W, partials, nullptr, 0, nullptr, nullptr, nullptr);
+                       zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
   }
   return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
 }
@@ -1440,7 +1555,9 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
                                                 int Cin, const float* scale1, const float* shift1, const float* DY,
                                                 int ld_dy, const float* Zr, int ld_z, const float* cA, const float* cB,
                                                 const float* cC, int Cout, float* partial, float* dW, int grid,
-                                                eml_stream_t stream) {
+                                                float* dz_out, eml_stream_t stream) {
+  if (dz_out && (Cout != 48 || pool))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: dz_out is for dense layers (Cout == 48, no pool)");
   if (!X || !scale1 || !shift1 || !DY || !Zr || !cA || !cB || !cC || !partial || !dW || P < 1 || grid < 1 || Kp < 32 ||
       (Kp & 15) || Cin > Kp || Cout < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: bad arguments");
@@ -1453,11 +1570,11 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
     if (pool)
       hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)P,
                          Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0, nv,
-                         n_load, partial);
+                         n_load, partial, nullptr);
     else
       hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
                          (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
-                         nv, n_load, partial);
+                         nv, n_load, partial, dz_out);
     int rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((Cin * 48 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
@@ -1526,32 +1643,55 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
                                                     double* const* partials, const int* Kp, const float* X, int ldx,
                                                     const float* mean, const float* istd, long P, int k_lo, int k_hi,
                                                     float* G, int ldg, int grid, eml_stream_t stream) {
-  if (n_layers < 1 || n_layers > 2 || !DZ || !Zr || !cA || !cB || !cC || !Wd || !scale1 || !shift1 || !partials ||
+  if (n_layers < 1 || n_layers > 2 || !DZ || !Wd || !scale1 || !shift1 || !partials ||
       !Kp || !X || !mean || !istd || !G || P < 1 || grid < 1 || k_lo < 0 || k_hi <= k_lo || (ldx & 3) || (ldg & 3))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad arguments");
+  // Zr == NULL: DZ holds the materialised dz (eml_dense_conv1x1_bwd_weight_f32's dz_out); else dz = cA*DZ + cB*Zr + cC
+  const bool raw = Zr == nullptr;
+  if (!raw && (!cA || !cB || !cC))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Zr given without cA/cB/cC");
   BwdLayer L[2];
   int kmax = 0;
   for (int j = 0; j < 2; ++j) {
     const int s = j < n_layers ? j : 0;
-    L[j] = BwdLayer{DZ[s], Zr[s], cA[s], cB[s], cC[s], Wd[s], scale1[s], shift1[s], partials[s], Kp[s]};
-    if (!DZ[s] || !Zr[s] || !Wd[s] || !partials[s] || (Kp[s] & 15) || Kp[s] > ldx || Kp[s] > ldg)
+    L[j] = raw ? BwdLayer{DZ[s], nullptr, nullptr, nullptr, nullptr, Wd[s], scale1[s], shift1[s], partials[s], Kp[s]}
+               : BwdLayer{DZ[s], Zr[s], cA[s], cB[s], cC[s], Wd[s], scale1[s], shift1[s], partials[s], Kp[s]};
+    if (!DZ[s] || (!raw && !Zr[s]) || !Wd[s] || !partials[s] || (Kp[s] & 15) || Kp[s] > ldx || Kp[s] > ldg)
       return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad layer %d", s);
     if (Kp[s] > kmax) kmax = Kp[s];
   }
   if (((k_hi + 15) & ~15) > kmax) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: range beyond Kp");
   const size_t lds = (size_t)n_layers * 4 * kmax * 2 * sizeof(double) + (size_t)(2 + 2 * n_layers) * kmax * sizeof(float);
   if (lds > 80 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Kp=%d does not fit LDS", kmax);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<1, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<2, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (n_layers == 1)
-    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<1, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, L[0],
-                       L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);
-  else  // two layers: 32 pixels per wave keeps both layers' dz fragments resident at 2 waves/SIMD
-    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<2, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, L[0],
-                       L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);
+#define EML_LAUNCH_MULTI(NLV, MTV, RAWV)                                                                             \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV>), dim3(grid), dim3(256), lds,                  \
+                       (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);       \
+  } while (0)
+  // two layers: 32 pixels per wave keeps both layers' dz fragments resident at 2 waves/SIMD
+  if (n_layers == 1) {
+    if (raw) EML_LAUNCH_MULTI(1, 4, true); else EML_LAUNCH_MULTI(1, 4, false);
+  } else {
+    if (raw) EML_LAUNCH_MULTI(2, 2, true); else EML_LAUNCH_MULTI(2, 2, false);
+  }
+#undef EML_LAUNCH_MULTI
   return eml::check_launch("eml_dense_conv1x1_bwd_data_multi_f32");
+}
+
+// Narrow pass: N12 (P,12) = G[:, k_lo:k_lo+12] + scale1 * relu-mask * (dz W1[:, k_lo:k_lo+12]) and the BN1 partial sums
+// of those 12 channels into partials[grid][Kp][2] (only entries k_lo..k_lo+11 are written).
+extern "C" int eml_dense_conv1x1_bwd_narrow_f32(const float* DZ, const float* W1, int Cin, int k_lo, const float* X,
+                                                int ldx, const float* scale1, const float* shift1, const float* mean,
+                                                const float* istd, long P, const float* G, int ldg, float* N12,
+                                                double* partials, int Kp, int grid, eml_stream_t stream) {
+  if (!DZ || !W1 || !X || !scale1 || !shift1 || !mean || !istd || !G || !N12 || !partials || P < 1 || grid < 1 ||
+      k_lo < 0 || (k_lo & 1) || k_lo + 12 > Cin || Cin > Kp || (ldx & 1) || (ldg & 1) || Kp > ldx || Kp > ldg)
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_narrow_f32: bad arguments");
+  hipLaunchKernelGGL((conv1x1_bwd_narrow_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, DZ, W1, Cin, k_lo, X,
+                     ldx, scale1, shift1, mean, istd, (int)P, G, ldg, N12, partials, Kp);
+  return eml::check_launch("eml_dense_conv1x1_bwd_narrow_f32");
 }
 
 extern "C" int eml_dense_grad_materialize_f32(float* G, int ldg, const float* X, int ldx, const float* sB,

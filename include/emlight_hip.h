@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 2
+#define EML_ABI_VERSION 3
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -169,11 +169,13 @@ int eml_dense_head_pool_fwd_f32(const float* F, int ldf, int C, int B, int H, in
 
 /* dzn = conv2^T(g) -> DZ (B,H,W,48); partials [grid][48][2] = (sum dzn, sum dzn*zhat).
  * X == NULL: g = G[:, c0:c0+12].  X != NULL: the deferred BN1 affine is applied on the fly,
- * g = G[:, c] + sB[c]*X[:, c] + sC[c] (what eml_dense_grad_materialize_f32 would write), and g is also
- * stored compactly to GF (B*H*W, 12) for eml_dense_conv3x3_bwd_weight_f32(GF, 12, 0, ...). */
+ * g = G[:, c0+i] + sB[cx+i]*X[:, cx+i] + sC[cx+i] (what eml_dense_grad_materialize_f32 would write), and g is also
+ * stored compactly to GF (B*H*W, 12) for eml_dense_conv3x3_bwd_weight_f32(GF, 12, 0, ...).  cx = the layer's channel
+ * offset in X / sB / sC; (G, ldg, c0) is either the block gradient (ld, cx) or the compact tensor (12, 0) written by
+ * eml_dense_conv1x1_bwd_narrow_f32. */
 int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                    const float* zmean, const float* zistd, float* DZ, int B, int H,
-                                   int W, double* partials, int grid, const float* X, int ldx,
+                                   int W, double* partials, int grid, const float* X, int ldx, int cx,
                                    const float* sB, const float* sC, float* GF, eml_stream_t stream);
 
 /* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: 2*grid*27*256 floats (two pixel halves per block). */
@@ -194,12 +196,15 @@ int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, do
 
 /* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).
- * partial: grid*2*Kp*48 floats of scratch. */
+ * partial: grid*Kp*48 floats of scratch.
+ * dz_out (may be NULL; dense layers only, Cout == 48, pool == 0): the rebuilt dz is also written to this (P,48)
+ * buffer for the data-gradient passes; it may alias DY (in place). */
 int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, int Win, int pool,
                                      int Kp, int Cin, const float* scale1, const float* shift1,
                                      const float* DY, int ld_dy, const float* Zr, int ld_z,
                                      const float* cA, const float* cB, const float* cC, int Cout,
-                                     float* partial, float* dW, int grid, eml_stream_t stream);
+                                     float* partial, float* dW, int grid, float* dz_out,
+                                     eml_stream_t stream);
 
 /* W (Cout,Cin) -> Wd [Kp/16][Ko/16][4][16][4], the B-fragment order of the data-gradient kernel. */
 int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int Ko, float* Wd,
@@ -218,7 +223,8 @@ int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, 
 /* The same data gradient for 1 or 2 CONSECUTIVE dense layers in one pass over the channel range
  * [k_lo, k_hi): G[p][k] += sum_j scale1_j[k]*dam_j[p][k] -- X is read once and G read-modify-written once
  * for both layers (the backward of a dense block is HBM-bound on exactly that traffic).  Per-layer
- * arrays of length n_layers (1 or 2); DZ/Zr are (P,48); partials_j is [grid][Kp_j][2]. */
+ * arrays of length n_layers (1 or 2); DZ/Zr are (P,48); partials_j is [grid][Kp_j][2].
+ * Zr == NULL (then cA/cB/cC are ignored): DZ_j already holds dz_j (dz_out of eml_dense_conv1x1_bwd_weight_f32). */
 int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
                                          const float* const* cA, const float* const* cB,
                                          const float* const* cC, const float* const* Wd,
@@ -226,6 +232,16 @@ int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, c
                                          double* const* partials, const int* Kp, const float* X, int ldx,
                                          const float* mean, const float* istd, long P, int k_lo,
                                          int k_hi, float* G, int ldg, int grid, eml_stream_t stream);
+
+/* Narrow data pass (autograd of DenseNet.py:50-55 restricted to 12 channels): the data gradient of a dense layer
+ * over the 12 output channels [k_lo, k_lo+12) of the layer below it, added to what G holds there and written as the
+ * compact tensor N12 (P,12) = G[p][k] + scale1[k] * relu-mask * sum_o DZ[p][o] * W1[o][k]  (DZ = materialised dz
+ * (P,48), W1 = conv1.weight (48,Cin)), which eml_dense_conv3x3_bwd_data_f32 then takes as its (G, 12, 0);
+ * partials[grid][Kp][2] receives (sum dam, sum dam*xhat) at channels k_lo..k_lo+11 for the BN1 backward. */
+int eml_dense_conv1x1_bwd_narrow_f32(const float* DZ, const float* W1, int Cin, int k_lo, const float* X,
+                                     int ldx, const float* scale1, const float* shift1,
+                                     const float* mean, const float* istd, long P, const float* G, int ldg,
+                                     float* N12, double* partials, int Kp, int grid, eml_stream_t stream);
 
 /* G[p][c] += sB[c]*X[p][c] + sC[c] for c in [c0, c0+n): applies the deferred BN1-backward affine once
  * the gradient of those channels is complete. */

@@ -204,15 +204,24 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
     sB, sC = rnd(ld, scale=0.3), rnd(ld, scale=0.3)
     GF = torch.full((P, 12), 7.0, device=DEV)
     lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, c0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
-                                               p(X), ld, p(sB), p(sC), p(GF), st), "c3 bwd data (fused affine)")
+                                               p(X), ld, c0, p(sB), p(sC), p(GF), st), "c3 bwd data (fused affine)")
     gfull = Gd[:, c0:c0 + 12].double() + sB[c0:c0 + 12].double() * X[:, c0:c0 + 12].double() + sC[c0:c0 + 12].double()
     close(GF, gfull, what="GF", rtol=1e-6, atol=1e-6)
     zn0 = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
     (F.conv2d(zn0, W2.double(), padding=1) * nchw(gfull, B, H, W)).sum().backward()
     close(DZ, nhwc(zn0.grad), what="dzn (fused affine)")
+    # the gradient slice taken from the compact (P,12) tensor of the narrow pass: g = N12 + sB*X + sC
+    N12 = rnd(P, 12)
+    lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(N12), 12, 0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
+                                               p(X), ld, c0, p(sB), p(sC), p(GF), st), "c3 bwd data (compact g)")
+    gfull2 = N12.double() + sB[c0:c0 + 12].double() * X[:, c0:c0 + 12].double() + sC[c0:c0 + 12].double()
+    close(GF, gfull2, what="GF (compact g)", rtol=1e-6, atol=1e-6)
+    zn1 = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
+    (F.conv2d(zn1, W2.double(), padding=1) * nchw(gfull2, B, H, W)).sum().backward()
+    close(DZ, nhwc(zn1.grad), what="dzn (compact g)")
     # plain form (X == NULL)
     lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(Gd), ld, c0, p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W, p(part), G,
-                                               None, 0, None, None, None, st), "c3 bwd data")
+                                               None, 0, 0, None, None, None, st), "c3 bwd data")
     zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
     w = W2.double().requires_grad_(True)
     g = nchw(Gd[:, c0:c0 + 12].double(), B, H, W)
@@ -295,8 +304,22 @@ def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
     partW = torch.empty(G * Kp * 48, device=DEV)
     dW = torch.empty(Cout, Cin, device=DEV)
     lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
-                                                 p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, st), "wgrad")
+                                                 p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, None, st), "wgrad")
     close(dW, dz.t() @ a, what="dW", rtol=1e-4)
+    if not pool and Cout == 48:   # dense layer: dz materialised for the data-gradient passes, separately and in place
+        dz_out = torch.full((P, 48), 5.0, device=DEV)
+        lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(dz_out), st), "wgrad+dz")
+        close(dW, dz.t() @ a, what="dW (dz_out)", rtol=1e-4)
+        close(dz_out, dz, what="dz_out", rtol=1e-6, atol=1e-6)
+        DYc = DY[:, :48].contiguous()
+        lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DYc), 48, p(Zr), Ko,
+                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DYc), st), "wgrad in place")
+        close(dW, dz.t() @ a, what="dW (in place)", rtol=1e-4)
+        close(DYc, dz, what="dz in place", rtol=1e-6, atol=1e-6)
+    else:
+        assert L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                  p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DY), st) == -1
     # ---- data gradient, accumulate and overwrite modes, + BN1-backward partial sums
     Wd = torch.empty(Kp * Ko, device=DEV)
     lib.check(L.eml_dense_permute_w1_bwd_f32(p(Wt), Cout, Cin, Kp, Ko, p(Wd), st), "permute bwd")
@@ -386,15 +409,20 @@ def test_conv1x1_bwd_data_two_layers_per_pass(lib, Cin_a, B, H, W):
         lib.check(L.eml_dense_permute_w1_bwd_f32(p(d["W"]), 48, Cin, Kp, 48, p(d["Wd"]), st), "permute")
         dz = d["cA"].double() * d["DZ"].double() + d["cB"].double() * d["Zr"].double() + d["cC"].double()
         pre = X[:, :Cin].double() * s1[:Cin].double() + t1[:Cin].double()
+        d["dzf"] = dz.float().contiguous()
         d["dam"] = torch.where(pre > 0, dz @ d["W"].double(), torch.zeros(P, Cin, device=DEV, dtype=torch.float64))
         return d
     A, Bl = layer(Cin_a, Kpa), layer(Cin_b, Kpb)
     xh = (X.double() - mean.double()) * istd.double()
 
-    def run(layers, k_lo, k_hi, Gd):
+    def run(layers, k_lo, k_hi, Gd, raw=False):
         arr = lambda key: (ctypes.c_void_p * len(layers))(*[y[key].data_ptr() for y in layers])
+        if raw:   # DZ already holds the materialised dz: Zr == NULL
+            args = (arr("dzf"), None, None, None, None)
+        else:
+            args = (arr("DZ"), arr("Zr"), arr("cA"), arr("cB"), arr("cC"))
         lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
-            len(layers), arr("DZ"), arr("Zr"), arr("cA"), arr("cB"), arr("cC"), arr("Wd"), arr("s1"), arr("t1"),
+            len(layers), *args, arr("Wd"), arr("s1"), arr("t1"),
             arr("part"), (ctypes.c_int * len(layers))(*[y["Kp"] for y in layers]), p(X), ld, p(mean), p(istd), P, k_lo,
             k_hi, p(Gd), ld, G, st), "multi")
 
@@ -415,3 +443,58 @@ def test_conv1x1_bwd_data_two_layers_per_pass(lib, Cin_a, B, H, W):
         S1, S2 = fold_partials(y["part"], G, Kp)
         close(S1[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="fused S1", rtol=1e-5, atol=1e-4)
         close(S2[:Cin_b], (y["dam"][:, :Cin_b] * xh[:, :Cin_b]).sum(0), what="fused S2", rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 20, 44), (330, 1, 12, 20), (162, 3, 6, 10), (174, 2, 9, 7)])
+def test_conv1x1_bwd_narrow_and_raw_dz_passes(lib, Cin_a, B, H, W):
+    """The engine's pair schedule on materialised dz: the narrow pass of layer a as a compact (P,12) increment
+    (eml_dense_conv1x1_bwd_narrow_f32; channel offsets with k_lo % 4 == 2 occur in block 3), then the fused pass of both
+    layers with Zr == NULL -- against f64 torch."""
+    import ctypes
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Cin_b = Cin_a - 12
+    Kpa, Kpb = r16(Cin_a), r16(Cin_b)
+    ld = Kpa + 16
+    P = B * H * W
+    X = rnd(P, ld)
+    mean, istd = rnd(ld, scale=0.1), torch.rand(ld, device=DEV) + 0.5
+    xh = (X.double() - mean.double()) * istd.double()
+
+    def layer(Cin, Kp):
+        s1, t1 = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+        s1[:Cin], t1[:Cin] = torch.rand(Cin, device=DEV) + 0.5, rnd(Cin, scale=0.3)
+        d = dict(dz=rnd(P, 48), s1=s1, t1=t1, W=rnd(48, Cin, scale=0.15), Wd=torch.empty(Kp * 48, device=DEV),
+                 part=torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV), Kp=Kp, Cin=Cin)
+        lib.check(L.eml_dense_permute_w1_bwd_f32(p(d["W"]), 48, Cin, Kp, 48, p(d["Wd"]), st), "permute")
+        pre = X[:, :Cin].double() * s1[:Cin].double() + t1[:Cin].double()
+        d["dam"] = torch.where(pre > 0, d["dz"].double() @ d["W"].double(), torch.zeros(P, Cin, device=DEV, dtype=torch.float64))
+        return d
+    A, Bl = layer(Cin_a, Kpa), layer(Cin_b, Kpb)
+    N12 = torch.full((P, 12), 3.0, device=DEV)
+    G0 = rnd(P, ld)
+    Gd = G0.clone()
+    lib.check(L.eml_dense_conv1x1_bwd_narrow_f32(p(A["dz"]), p(A["W"]), Cin_a, Cin_b, p(X), ld, p(A["s1"]), p(A["t1"]), p(mean),
+                                                 p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st), "narrow")
+    close(N12, G0[:, Cin_b:Cin_a].double() + A["s1"][Cin_b:Cin_a].double() * A["dam"][:, Cin_b:Cin_a], what="N12", rtol=1e-4)
+    assert torch.equal(Gd, G0)   # the block gradient itself is only read
+    S1, S2 = fold_partials(A["part"], G, Kpa)
+    close(S1[Cin_b:Cin_a], A["dam"][:, Cin_b:Cin_a].sum(0), what="narrow S1", rtol=1e-5, atol=1e-4)
+    close(S2[Cin_b:Cin_a], (A["dam"] * xh[:, :Cin_a])[:, Cin_b:Cin_a].sum(0), what="narrow S2", rtol=1e-5, atol=1e-4)
+    assert float(S1[:Cin_b].abs().max()) == 0.0   # nothing else of the partial rows is written
+    layers = [A, Bl]
+    arr = lambda key: (ctypes.c_void_p * 2)(*[y[key].data_ptr() for y in layers])
+    lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
+        2, arr("dz"), None, None, None, None, arr("Wd"), arr("s1"), arr("t1"), arr("part"),
+        (ctypes.c_int * 2)(Kpa, Kpb), p(X), ld, p(mean), p(istd), P, 0, Cin_b, p(Gd), ld, G, st), "multi raw")
+    want = G0.double()
+    want[:, :Cin_b] += A["s1"][:Cin_b].double() * A["dam"][:, :Cin_b] + Bl["s1"][:Cin_b].double() * Bl["dam"]
+    close(Gd, want, what="fused G (raw dz)", rtol=1e-4)
+    for y, Kp in ((A, Kpa), (Bl, Kpb)):
+        S1, S2 = fold_partials(y["part"], G, Kp)
+        close(S1[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="fused S1", rtol=1e-5, atol=1e-4)
+        close(S2[:Cin_b], (y["dam"][:, :Cin_b] * xh[:, :Cin_b]).sum(0), what="fused S2", rtol=1e-5, atol=1e-4)
+    # bad arguments: odd channel offset, range past Cin
+    assert L.eml_dense_conv1x1_bwd_narrow_f32(p(A["dz"]), p(A["W"]), Cin_a, Cin_b + 1, p(X), ld, p(A["s1"]), p(A["t1"]), p(mean),
+                                              p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st) == -1
+    assert L.eml_dense_conv1x1_bwd_narrow_f32(p(A["dz"]), p(A["W"]), Cin_a, Cin_a - 2, p(X), ld, p(A["s1"]), p(A["t1"]), p(mean),
+                                              p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st) == -1

@@ -9,7 +9,12 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 OUT_ATOL = 1e-4
-GOLDEN_GRAD_MAX, GOLDEN_GRAD_MEDIAN = 5e-2, 5e-3   # tightened to the measured values once run on the GPU
+# Sampled-entry error of the golden train-step gradients in units of the tensor's RMS gradient.  Measured on the
+# MI355X: worst 3.3e-2 (denseblock1.denselayer1.conv1.weight), median 1.4e-2.  That is the f32 conditioning of this
+# network's gradient, not a kernel defect: test_gradient_error_is_f32_conditioning below shows the reference's own
+# stock-op graph in f32 is just as far from the f64 gradient (relative L2 per tensor: median 1e-3..3e-3, up to 1e-2
+# on the norm weights, at 192x256 / 64x96 / 240x320).
+GOLDEN_GRAD_MAX, GOLDEN_GRAD_MEDIAN = 6e-2, 2.5e-2
 KEYS = ("distribution", "intensity", "rgb_ratio", "ambient")
 
 
@@ -100,8 +105,8 @@ def test_golden_train_step_reference_geometry(golden_densenet):
         worst.append((float(np.abs(got - want).max() / rms), key))
     worst.sort(reverse=True)
     print("golden train step: worst sampled |dgrad| / rms(grad) per tensor:", worst)
-    # two f32 implementations of a ReLU network: a flipped mask moves single entries; the bound is
-    # on sampled entries relative to the tensor's RMS gradient
+    # two f32 evaluations of a 100-BN-layer train-mode network agree to ~1e-2 of the RMS gradient per entry (see the
+    # constants above and test_gradient_error_is_f32_conditioning); the bound is on sampled entries
     assert worst[0][0] < GOLDEN_GRAD_MAX, worst[:4]
     assert np.median([e for e, _ in worst]) < GOLDEN_GRAD_MEDIAN, worst
     np.testing.assert_allclose(tr.model.features.norm0.running_mean.cpu().numpy(), g["train/running_mean/features.norm0"],
@@ -111,6 +116,40 @@ def test_golden_train_step_reference_geometry(golden_densenet):
     # Adam's first step moves every entry by lr * g / (|g| + 1e-8): +-1e-4 unless the gradient is ~1e-8
     np.testing.assert_allclose(tr.model.fc_dist.bias.detach().cpu().numpy(), g["train/post_step/fc_dist.bias"], rtol=0,
                                atol=2e-6)
+
+
+@pytest.mark.parametrize("crop_hw,B,anchors", [((192, 256), 2, 96), ((64, 96), 2, 32)])
+def test_gradient_error_is_f32_conditioning(crop_hw, B, anchors):
+    """Whole-network gradients of the HIP engine (f32) and of the oracle's stock-op graph in f32 are both compared with
+    the oracle in f64 on the same weights and input.  The HIP engine must be as close to the f64 gradient as the
+    reference's own f32 arithmetic is (per-tensor relative L2: median within 2x, worst tensor within 3x of the stock-op
+    f32 graph's worst) -- the residual 1e-3..1e-2 is conditioning, shared by any f32 implementation.  The analytically
+    zero gradients (last_norm{1,2}.bias feed only train-mode BNs) are excluded."""
+    ref32, net = _pair(anchors, crop_hw, seed=0)
+    ref64 = oracle.OracleDenseNet(anchors=anchors, crop_hw=crop_hw).double()
+    ref64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ref32.state_dict().items()})
+    ref32, ref64 = ref32.cuda().train(), ref64.cuda().train()   # stock ops on the GPU (fast f64); same maths as on CPU
+    net.train()
+    g = np.random.default_rng(0)
+    x = torch.from_numpy(g.random((B, 3) + crop_hw, dtype=np.float32)).cuda()
+    w = {k: torch.from_numpy(g.standard_normal(s).astype(np.float32)).cuda()
+         for k, s in (("distribution", (B, anchors)), ("intensity", (B, 1)), ("rgb_ratio", (B, 3)), ("ambient", (B, 3)))}
+    for m, xx in ((ref32, x), (ref64, x.double()), (net, x)):
+        out = m(xx)
+        sum((out[k] * w[k].to(out[k].dtype)).sum() for k in KEYS).backward()
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a))))
+    n64, n32 = dict(ref64.named_parameters()), dict(ref32.named_parameters())
+    e_hip, e_o32 = [], []
+    for name, p in net.named_parameters():
+        if name in ("features.last_norm1.bias", "features.last_norm2.bias"):
+            continue
+        t = n64[name].grad.cpu().numpy()
+        e_hip.append(rms(p.grad.cpu().numpy().astype(np.float64) - t) / rms(t))
+        e_o32.append(rms(n32[name].grad.cpu().numpy().astype(np.float64) - t) / rms(t))
+    print("rel-L2 vs f64: HIP median %.2e max %.2e | stock f32 median %.2e max %.2e"
+          % (np.median(e_hip), max(e_hip), np.median(e_o32), max(e_o32)))
+    assert np.median(e_hip) <= 2.0 * np.median(e_o32) + 1e-5
+    assert max(e_hip) <= 3.0 * max(e_o32) + 1e-5
 
 
 def test_two_forwards_before_backward_keep_their_own_activations():
