@@ -97,7 +97,7 @@ def run_backward(enc, ws, x, gpooled):
         # weight grad on the pooled activation A kept by the forward (unit BN: relu(1*A + 0) == A)
         _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
             p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, ctot, p(tr["one"]), p(tr["zero"]), p(dY), ld_dy, p(tr["T"]),
-            Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, st), "eml_dense_conv1x1_bwd_weight_f32")
+            Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, None, st), "eml_dense_conv1x1_bwd_weight_f32")
         _lib.check(L.eml_dense_permute_w1_bwd_f32(p(T.conv.weight), cout, ctot, kpt, Ko, p(bw.Wd), st),
                    "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(

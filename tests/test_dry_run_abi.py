@@ -1,0 +1,85 @@
+"""CPU: every launcher call the host orchestration makes is checked against the bound C signature WITHOUT a GPU.
+
+The HIP library is replaced by a recorder that validates each call's argument count and converts every argument with
+the ctypes type declared in ``emlight_amd/_lib.py`` (== ``include/emlight_hip.h``, held together by
+``test_capi_exports.py``).  A forward + backward of the DenseNet engine, the Sinkhorn loss and the rasteriser are then
+driven on CPU tensors: the numbers are meaningless (nothing computes), but a call site that drifts from the ABI fails
+here instead of on the GPU box."""
+import ctypes
+
+import pytest
+import torch
+
+
+class _Recorder:
+    def __init__(self, signatures):
+        self.signatures, self.calls = signatures, []
+
+    def __getattr__(self, name):
+        if name not in self.signatures:
+            raise AttributeError(name)
+        _, argtypes = self.signatures[name]
+
+        def call(*args):
+            assert len(args) == len(argtypes), "%s takes %d arguments, call site passes %d" % (name, len(argtypes), len(args))
+            for k, (a, t) in enumerate(zip(args, argtypes)):
+                try:
+                    t.from_param(a)
+                except (TypeError, ctypes.ArgumentError) as e:
+                    raise AssertionError("%s: argument %d (%r) does not convert to %s" % (name, k, a, t.__name__)) from e
+            self.calls.append(name)
+            return 0
+        return call
+
+
+@pytest.fixture
+def recorder(monkeypatch):
+    from emlight_amd import _lib
+    rec = _Recorder(_lib.SIGNATURES)
+    monkeypatch.setattr(_lib, "lib", lambda: rec)
+    monkeypatch.setattr(_lib, "current_stream", lambda: None)
+    monkeypatch.setattr(_lib, "require_gpu_tensor", lambda t, name, dtype=None: t.contiguous())
+    return rec
+
+
+def test_densenet_engine_calls_match_the_abi(recorder):
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    from emlight_amd.RegressionNetwork.dense_engine import HipDenseEncoder
+    net = DenseNet(anchors=8, crop_hw=(32, 32)).train()
+    net._hip = HipDenseEncoder(net)
+    net._hip._cu = 256
+    out = net(torch.rand(2, 3, 32, 32))
+    sum(v.sum() for v in out.values()).backward()
+    for name in ("eml_dense_conv0_fwd_f32", "eml_dense_conv1x1_fwd_f32", "eml_dense_conv3x3_fwd_f32", "eml_dense_pool_act_f32",
+                 "eml_dense_conv3x3_bwd_data_f32", "eml_dense_conv3x3_bwd_weight_f32", "eml_dense_conv1x1_bwd_weight_f32",
+                 "eml_dense_conv1x1_bwd_narrow_f32", "eml_dense_conv1x1_bwd_data_multi_f32", "eml_dense_conv1x1_bwd_data_f32",
+                 "eml_dense_bn_bwd_finalize_f32", "eml_dense_grad_materialize_f32", "eml_dense_conv0_bwd_weight_f32",
+                 "eml_dense_head_pool_bwd_f32"):
+        assert name in recorder.calls, name
+    # the pair schedule: 8 narrow passes and 8 two-layer passes per block of 16 layers
+    assert recorder.calls.count("eml_dense_conv1x1_bwd_narrow_f32") == 24
+    assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 24
+    assert all(p.grad is not None for p in net.parameters())
+
+
+def test_odd_block_config_uses_the_single_layer_pass(recorder):
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    from emlight_amd.RegressionNetwork.dense_engine import HipDenseEncoder
+    net = DenseNet(block_config=(2, 3, 1), anchors=8, crop_hw=(32, 32)).train()
+    net._hip = HipDenseEncoder(net)
+    net._hip._cu = 256
+    sum(v.sum() for v in net(torch.rand(1, 3, 32, 32)).values()).backward()
+    assert recorder.calls.count("eml_dense_conv1x1_bwd_narrow_f32") == 2      # pairs (1,0) of block 1 and (2,1) of block 2
+    assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 4  # + the single layers 0 of blocks 2 and 3
+
+
+def test_sinkhorn_and_rasteriser_calls_match_the_abi(recorder):
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    from emlight_amd.RegressionNetwork.util import convert_to_panorama
+    x = torch.rand(2, 16, 1, requires_grad=True)
+    SamplesLoss(anchors=16)(x, torch.rand(2, 16, 1)).sum().backward()
+    c = torch.rand(2, 48, requires_grad=True)
+    convert_to_panorama(torch.rand(2, 48), torch.rand(2, 16), c, pano_hw=(8, 16)).sum().backward()
+    for name in ("eml_emd_anchor_cost_f32", "eml_sinkhorn_fwd_f32", "eml_sinkhorn_bwd_f32", "eml_sg_rasterise_f32",
+                 "eml_sg_rasterise_bwd_colors_f32"):
+        assert name in recorder.calls, name
