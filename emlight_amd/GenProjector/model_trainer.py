@@ -2,8 +2,9 @@
 
 The reference wraps the model in a single-process multi-thread ``DataParallelWithCallback``; here each GPU is
 its own process: G and D are wrapped in DistributedDataParallel (gradient all-reduce over RCCL/xGMI, G's
-473 MB in 25 MB buckets overlapped with backward) and SPADE's param-free BatchNorm becomes ``nn.SyncBatchNorm``
-(an all-reduce of 2C+1 floats per norm layer), which is what the vendored ``sync_batchnorm`` package did."""
+473 MB in 25 MB buckets overlapped with backward); SPADE's param-free BatchNorm all-reduces its (2C+1)-float sums
+itself (``spherenet.spade_batch_stats`` / the modulation's backward), which is what the vendored ``sync_batchnorm``
+package did."""
 import torch
 
 from .pix2pix_model import Pix2PixModel
@@ -15,8 +16,6 @@ class Trainer:
         self.model = Pix2PixModel(opt).to(device)
         self.world = world
         if world > 1:
-            if str(device).startswith("cuda"):
-                self.model.netG = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model.netG)
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
             self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
             self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)

@@ -77,9 +77,10 @@ def nonspade_norm(norm_type):
 
 
 class SPADE(nn.Module):
-    """``out = norm(x) * (1 + gamma(seg)) + beta(seg)`` (``normalization.py:68-115``).  The param-free norm is
-    a BatchNorm2d(affine=False); under DDP it is converted to ``nn.SyncBatchNorm`` (RCCL all-reduce of the
-    statistics) -- the job of the reference's vendored ``sync_batchnorm`` package."""
+    """``out = norm(x) * (1 + gamma(seg)) + beta(seg)`` (``normalization.py:68-115``).  The param-free norm is a
+    BatchNorm2d(affine=False) module only as the holder of the running statistics (reference state_dict keys); its
+    arithmetic is folded into the HIP modulation kernels, and with more than one rank its (2C+1)-float sums are
+    all-reduced over RCCL -- the job of the reference's vendored ``sync_batchnorm`` package."""
 
     def __init__(self, config_text, norm_nc, label_nc):
         super().__init__()
@@ -96,12 +97,12 @@ class SPADE(nn.Module):
         self.mlp_gamma = SphereConv2D(nhidden, norm_nc)
         self.mlp_beta = SphereConv2D(nhidden, norm_nc)
 
-    def forward(self, x, segmap, slope=1.0):
-        """``slope`` != 1 folds the LeakyReLU that follows this norm in SPADEResnetBlock (architecture.py:56-57) in."""
-        normalized = self.param_free_norm(x)
+    def forward(self, x, segmap, slope=1.0, stats=None):
+        """``slope`` != 1 folds the LeakyReLU that follows this norm in SPADEResnetBlock (architecture.py:56-57) in;
+        ``stats``: (mean, istd) of this x when a sibling norm already reduced it (norm_0 / norm_s share their input)."""
         segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
         actv = self.mlp_shared(segmap)
-        return spherenet.spade_modulate(normalized, actv, self.mlp_gamma, self.mlp_beta, slope)
+        return spherenet.spade_norm_modulate(x, self.param_free_norm, actv, self.mlp_gamma, self.mlp_beta, slope, stats)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -126,8 +127,14 @@ class SPADEResnetBlock(nn.Module):
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
     def forward(self, x, seg):
-        x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = self.conv_0(self.norm_0(x, seg, slope=2e-1))   # leaky_relu(norm(.), 0.2), fused into the modulation
+        stats = None
+        n0 = self.norm_0.param_free_norm
+        if self.learned_shortcut and isinstance(n0, nn.BatchNorm2d) and x.shape[1] % 4 == 0 and x.is_cuda:
+            # norm_0 and norm_s normalise the same x with parameter-free BatchNorms: one reduction serves both
+            stats = spherenet.spade_batch_stats(x, n0)
+            spherenet.adopt_batch_stats(self.norm_s.param_free_norm, n0)
+        x_s = self.conv_s(self.norm_s(x, seg, stats=stats)) if self.learned_shortcut else x
+        dx = self.conv_0(self.norm_0(x, seg, slope=2e-1, stats=stats))   # leaky_relu(norm(.), 0.2), fused into the modulation
         dx = self.conv_1(self.norm_1(dx, seg, slope=2e-1))
         return x_s + dx
 

@@ -203,17 +203,126 @@ class _SpadeModulateFn(torch.autograd.Function):
         return dxn, dgb, None
 
 
-def spade_modulate(normalized, actv, conv_gamma, conv_beta, slope=1.0):
-    """SPADE's ``normalized * (1 + gamma(actv)) + beta(actv)`` followed by ``leaky_relu(., slope)`` (slope 1 = none):
-    gamma | beta come from ONE SphereConv (one gather, one GEMM over the concatenated heads) that feeds the fused
-    modulation kernel."""
+def _stats_grid(rows, C):
+    cvp = 1
+    while cvp < C // 4 and cvp < 256:
+        cvp <<= 1
+    rpp = 256 // cvp
+    return max(1, min(512, (rows + rpp - 1) // rpp))
+
+
+def _bn_sync():
+    """SPADE's norm is SYNCHRONISED batch norm in the reference (sync_batchnorm/batchnorm.py:105-126, across the
+    DataParallel replicas); here replicas are processes: the (2C+1)-float sums are all-reduced over RCCL."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _reduce_sums(partials, rows, C):
+    """[grid][C][2] f64 partials -> sums (2C+1,) f64 = per-channel pairs then the row count; all-reduced across ranks."""
+    from .. import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=partials.device)
+    sums[2 * C] = float(rows)
+    _lib.check(L.eml_bn_fold_f64(p(partials), partials.shape[0], 2 * C, p(sums), st), "eml_bn_fold_f64")
+    if _bn_sync():
+        import torch.distributed as dist
+        dist.all_reduce(sums)
+    return sums
+
+
+def spade_batch_stats(x, bn):
+    """(mean, istd) of SPADE's parameter-free BatchNorm for input ``x`` (normalization.py:101-104): batch statistics in
+    training (one read of x, f64 accumulation; running statistics of ``bn`` updated like nn.BatchNorm2d), running
+    statistics in eval.  Not differentiable: the statistics' gradient is part of ``spade_norm_modulate``'s backward."""
+    from .. import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    _require_gpu_f32(x, "SPADE input")
+    B, C, H, W = x.shape
+    if not bn.training:
+        return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+    with torch.no_grad():
+        xr, ld = _rows_view(x)
+        rows = B * H * W
+        grid = _stats_grid(rows, C)
+        partials = torch.empty(grid, C, 2, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_bn_stats_f32(p(xr), ld, rows, C, p(partials), grid, st), "eml_bn_stats_f32")
+        sums = _reduce_sums(partials, rows, C)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        istd = torch.empty(C, dtype=torch.float32, device=x.device)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        _lib.check(L.eml_bn_finalize_f32(p(sums), C, float(bn.eps), float(mom), p(mean), p(istd), p(bn.running_mean),
+                                         p(bn.running_var), st), "eml_bn_finalize_f32")
+        bn.num_batches_tracked += 1
+    return mean, istd
+
+
+def adopt_batch_stats(bn, src):
+    """A second norm over the SAME input (SPADEResnetBlock's norm_s next to norm_0): same statistics, so its running
+    buffers follow ``src``'s update instead of a second reduction over x."""
+    if bn.training:
+        with torch.no_grad():
+            bn.running_mean.copy_(src.running_mean)
+            bn.running_var.copy_(src.running_var)
+            bn.num_batches_tracked += 1
+
+
+class _SpadeNormModulateFn(torch.autograd.Function):
+    """``leaky_relu(BN(x) * (1 + gamma) + beta, slope)`` with the parameter-free BatchNorm folded in: the forward
+    normalises inline from (mean, istd); the backward emits BatchNorm's reduction (sum dxn, sum dxn*xhat) from the
+    modulation pass itself and finishes dx = istd*(dxn - S1/n - xhat*S2/n) in one more streaming pass."""
+
+    @staticmethod
+    def forward(ctx, x, gb, mean, istd, slope, training):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        _require_gpu_f32(x, "SPADE input")
+        B, C, H, W = x.shape
+        x, ldx = _rows_view(x)
+        gb, ldg = _rows_view(gb)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        _lib.check(L.eml_spade_norm_modulate_fwd_f32(p(x), ldx, p(gb), ldg, p(y), C, B * H * W, C, float(slope), p(mean),
+                                                     p(istd), st), "eml_spade_norm_modulate_fwd_f32")
+        ctx.save_for_backward(x, gb, mean, istd)
+        ctx.slope, ctx.training = float(slope), bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        x, gb, mean, istd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        rows = B * H * W
+        gy, ldy = _rows_view(gy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        grid = _stats_grid(rows, C)
+        partials = torch.empty(grid, C, 2, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_spade_norm_modulate_bwd_f32(p(gy), ldy, p(x), x.stride(3), p(gb), gb.stride(3), p(dx), C, p(dgb),
+                                                     2 * C, rows, C, ctx.slope, p(mean), p(istd), p(partials), grid, st),
+                   "eml_spade_norm_modulate_bwd_f32")
+        sums = _reduce_sums(partials, rows, C) if ctx.training else None
+        _lib.check(L.eml_bn_bwd_apply_f32(p(dx), C, p(x), x.stride(3), rows, C, p(mean), p(istd), p(sums), p(dx), C, st),
+                   "eml_bn_bwd_apply_f32")
+        return dx, dgb, None, None, None, None
+
+
+def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=None):
+    """SPADE (normalization.py:101-115) + the LeakyReLU that follows it (architecture.py:56-57; slope 1 = none):
+    ``leaky_relu(BN(x) * (1 + gamma(actv)) + beta(actv), slope)``.  gamma | beta come from ONE SphereConv (one gather,
+    one GEMM over the concatenated heads); BatchNorm's statistics come from ``spade_batch_stats`` (or ``stats`` when
+    the caller already has them for this x) and its normalisation / backward are folded into the modulation kernels."""
     w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
     b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
     gb = sphere_conv(actv, w, b, 1)
-    if normalized.shape[1] % 4 == 0:
-        return _SpadeModulateFn.apply(normalized, gb, slope)
-    gamma, beta = torch.split(gb, normalized.shape[1], dim=1)   # odd widths (never in EMLight): 16-B rows unavailable
-    out = normalized * (1 + gamma) + beta
+    C = x.shape[1]
+    if C % 4 == 0 and isinstance(bn, nn.BatchNorm2d):
+        mean, istd = stats if stats is not None else spade_batch_stats(x, bn)
+        return _SpadeNormModulateFn.apply(x, gb, mean.detach(), istd.detach(), slope, bn.training)
+    # widths that are not a multiple of 4 (never in EMLight) or an instance norm: library norm + elementwise formula
+    gamma, beta = torch.split(gb, C, dim=1)
+    out = bn(x) * (1 + gamma) + beta
     return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
 
 

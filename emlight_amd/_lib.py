@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 3   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 4   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -42,6 +42,15 @@ SIGNATURES = {
                                           _stream]),
     "eml_spade_modulate_bwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, ctypes.c_long,
                                           _int, ctypes.c_float, _stream]),
+    "eml_bn_stats_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _f32p, _int, _stream]),
+    "eml_bn_fold_f64": (_int, [_f32p, _int, _int, _f32p, _stream]),
+    "eml_bn_finalize_f32": (_int, [_f32p, _int, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _stream]),
+    "eml_spade_norm_modulate_fwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, ctypes.c_long, _int, ctypes.c_float,
+                                               _f32p, _f32p, _stream]),
+    "eml_spade_norm_modulate_bwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int,
+                                               ctypes.c_long, _int, ctypes.c_float, _f32p, _f32p, _f32p, _int, _stream]),
+    "eml_bn_bwd_apply_f32": (_int, [_f32p, _int, _f32p, _int, ctypes.c_long, _int, _f32p, _f32p, _f32p, _f32p, _int,
+                                    _stream]),
     # DenseNet-BC encoder, forward
     "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
     "eml_dense_bn_apply_f32": (_int, [_f32p, _int, _f32p, _int, _int, ctypes.c_long, _f32p, _f32p, _int, _f32p,

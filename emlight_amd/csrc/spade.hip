@@ -4,6 +4,13 @@
 // and as many again in the backward, plus a split / cat of the (gamma | beta) tensor the fused SphereConv produces.
 // Here: one streaming pass each way over pixel-major (channels-last) rows, 16-byte accesses; gamma and beta are
 // read from, and their gradients written to, the two channel halves of ONE (rows, 2C) tensor.
+//
+// SPADE's parameter-free BatchNorm (normalization.py:86-104; sync_batchnorm/batchnorm.py:105-126 across replicas) is
+// folded into the same passes: `bn_stats` reads x once for the per-channel (sum, sum of squares) in f64 partials,
+// the modulation normalises inline ((x - mean) * istd never exists in memory), the backward pass emits the partial
+// sums (sum dxn, sum dxn*xhat) of BatchNorm's backward in its epilogue, and `bn_bwd_apply` finishes
+// dx = istd * (dxn - S1/n - xhat * S2/n).  Between partials and finalisation the host can all-reduce the (2C+1)-float
+// sums across ranks (one process per GPU): that is the whole of SynchronizedBatchNorm.
 #include "eml_common.h"
 
 namespace {
@@ -66,6 +73,182 @@ __global__ __launch_bounds__(256) void spade_modulate_bwd_kernel(const float* __
   }
 }
 
+// ---- fixed-column layout of the reducing kernels: thread -> (row lane, 4-channel group); cvp = the power of two
+// >= C/4 (<= 256); a block covers 256/cvp rows per pass.  Channel groups beyond 256*4 channels loop (cg += 256).
+struct ColMap {
+  int cv, cvp, rpp, rl, cl;
+  __device__ ColMap(int C) {
+    cv = C >> 2;
+    cvp = 1;
+    while (cvp < cv && cvp < 256) cvp <<= 1;
+    rpp = 256 / cvp;
+    rl = threadIdx.x / cvp;
+    cl = threadIdx.x % cvp;
+  }
+};
+
+// block-level reduction of per-thread f64 pairs over the row lanes, then one partial row per block
+template <int NV>
+__device__ __forceinline__ void reduce_rows_and_store(const ColMap& m, int cg, double (&v)[NV], double* red /*[256][NV]*/,
+                                                      double* __restrict__ out /*[C][NV/4]... see callers*/, int C) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) red[threadIdx.x * NV + k] = v[k];
+  __syncthreads();
+  if (m.rl == 0 && cg < m.cv) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double t = red[m.cl * NV + k];
+      for (int r = 1; r < m.rpp; ++r) t += red[(r * m.cvp + m.cl) * NV + k];
+      // v = {s1[0..3], s2[0..3]}: channel 4*cg + (k & 3), statistic k >> 2
+      out[(size_t)(4 * cg + (k & 3)) * 2 + (k >> 2)] = t;
+    }
+  }
+}
+
+// partials[block][c][2] = (sum x, sum x^2) over this block's rows, accumulated per element in f64
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ld, int rows, int C,
+                                                       double* __restrict__ partials) {
+  __shared__ double red[256 * 8];
+  const ColMap m(C);
+  double* out = partials + (size_t)blockIdx.x * C * 2;
+  for (int cg = m.cl; cg < ((m.cv + m.cvp - 1) / m.cvp) * m.cvp; cg += m.cvp) {
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cg < m.cv) {
+      for (int row = blockIdx.x * m.rpp + m.rl; row < rows; row += gridDim.x * m.rpp) {
+        const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * ld + 4 * cg);
+        const double d0 = a.x, d1 = a.y, d2 = a.z, d3 = a.w;
+        v[0] += d0; v[1] += d1; v[2] += d2; v[3] += d3;
+        v[4] = fma(d0, d0, v[4]); v[5] = fma(d1, d1, v[5]); v[6] = fma(d2, d2, v[6]); v[7] = fma(d3, d3, v[7]);
+      }
+    }
+    reduce_rows_and_store<8>(m, cg, v, red, out, C);
+  }
+}
+
+// sums[k] = sum over the R partial rows (k < n), deterministic order
+__global__ __launch_bounds__(256) void bn_fold_kernel(const double* __restrict__ partials, int R, int n,
+                                                      double* __restrict__ sums) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  double t = 0.0;
+  for (int r = 0; r < R; ++r) t += partials[(size_t)r * n + k];
+  sums[k] = t;
+}
+
+// mean, istd from (sum, sum sq, count); running statistics as nn.BatchNorm2d (momentum, unbiased variance)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums /*[C][2] then count*/, int C,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ istd, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = sums[2 * C];
+  const double mu = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  mean[c] = (float)mu;
+  istd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+    rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+  }
+}
+
+// y = leaky_relu(((x - mean) * istd) * (1 + gamma) + beta): the normalised activation is never stored
+__global__ __launch_bounds__(256) void spade_norm_modulate_fwd_kernel(const float* __restrict__ x, int ld_x,
+                                                                      const float* __restrict__ gb, int ld_gb,
+                                                                      float* __restrict__ y, int ld_y, int rows, int C,
+                                                                      float slope, const float* __restrict__ mean,
+                                                                      const float* __restrict__ istd) {
+  const int cv = C >> 2;
+  const size_t total = (size_t)rows * cv;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t row = e / cv;
+    const int c = (int)(e - row * cv) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(x + row * ld_x + c);
+    const float4 g = *reinterpret_cast<const float4*>(gb + row * ld_gb + c);
+    const float4 b = *reinterpret_cast<const float4*>(gb + row * ld_gb + C + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(istd + c);
+    float4 o;
+    o.x = lrelu(fmaf((a.x - mu.x) * is.x, 1.f + g.x, b.x), slope);
+    o.y = lrelu(fmaf((a.y - mu.y) * is.y, 1.f + g.y, b.y), slope);
+    o.z = lrelu(fmaf((a.z - mu.z) * is.z, 1.f + g.z, b.z), slope);
+    o.w = lrelu(fmaf((a.w - mu.w) * is.w, 1.f + g.w, b.w), slope);
+    *reinterpret_cast<float4*>(y + row * ld_y + c) = o;
+  }
+}
+
+// backward of the above w.r.t. the NORMALISED activation (dxn) and (gamma | beta), + the per-block partial sums
+// (sum dxn, sum dxn*xhat) BatchNorm's backward needs; fixed-column layout so that a thread keeps its channels
+__global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
+    const float* __restrict__ gy, int ld_gy, const float* __restrict__ x, int ld_x, const float* __restrict__ gb, int ld_gb,
+    float* __restrict__ dxn, int ld_dx, float* __restrict__ dgb, int ld_dgb, int rows, int C, float slope,
+    const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials) {
+  __shared__ double red[256 * 8];
+  const ColMap m(C);
+  double* out = partials + (size_t)blockIdx.x * C * 2;
+  for (int cg = m.cl; cg < ((m.cv + m.cvp - 1) / m.cvp) * m.cvp; cg += m.cvp) {
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cg < m.cv) {
+      const int c = 4 * cg;
+      const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+      const float4 is = *reinterpret_cast<const float4*>(istd + c);
+      for (int row = blockIdx.x * m.rpp + m.rl; row < rows; row += gridDim.x * m.rpp) {
+        const float4 u = *reinterpret_cast<const float4*>(gy + (size_t)row * ld_gy + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ld_x + c);
+        const float4 g = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + c);
+        const float4 b = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + C + c);
+        const float a[4] = {(xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z, (xv.w - mu.w) * is.w};
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w}, uu[4] = {u.x, u.y, u.z, u.w};
+        float d[4], dx[4], dg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d[k] = fmaf(a[k], 1.f + gg[k], bb[k]) > 0.f ? uu[k] : slope * uu[k];
+          dx[k] = d[k] * (1.f + gg[k]);
+          dg[k] = d[k] * a[k];
+          v[k] += (double)dx[k];
+          v[4 + k] = fma((double)dx[k], (double)a[k], v[4 + k]);
+        }
+        *reinterpret_cast<float4*>(dxn + (size_t)row * ld_dx + c) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+        *reinterpret_cast<float4*>(dgb + (size_t)row * ld_dgb + c) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+        *reinterpret_cast<float4*>(dgb + (size_t)row * ld_dgb + C + c) = make_float4(d[0], d[1], d[2], d[3]);
+      }
+    }
+    reduce_rows_and_store<8>(m, cg, v, red, out, C);
+  }
+}
+
+// dx = istd * (dxn - S1/n - xhat * S2/n)   (train mode; sums == NULL: eval mode, dx = istd * dxn).  dx may alias dxn.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dxn, int ld_d, const float* __restrict__ x,
+                                                           int ld_x, int rows, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ istd, const double* __restrict__ sums,
+                                                           float* __restrict__ dx, int ld_o) {
+  const int cv = C >> 2;
+  const size_t total = (size_t)rows * cv;
+  const double n = sums ? sums[2 * C] : 1.0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t row = e / cv;
+    const int c = (int)(e - row * cv) * 4;
+    const float4 d = *reinterpret_cast<const float4*>(dxn + row * ld_d + c);
+    const float4 xv = *reinterpret_cast<const float4*>(x + row * ld_x + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(istd + c);
+    const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float m1 = sums ? (float)(sums[2 * (c + k)] / n) : 0.f;
+      const float m2 = sums ? (float)(sums[2 * (c + k) + 1] / n) : 0.f;
+      o[k] = ii[k] * (dd[k] - m1 - (xx[k] - mm[k]) * ii[k] * m2);
+    }
+    *reinterpret_cast<float4*>(dx + row * ld_o + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 inline int grid_for(size_t n4) {
   const size_t g = (n4 + 255) / 256;
   return (int)(g < 8192 ? (g ? g : 1) : 8192);
@@ -96,4 +279,64 @@ extern "C" int eml_spade_modulate_bwd_f32(const float* gy, int ld_gy, const floa
   hipLaunchKernelGGL(spade_modulate_bwd_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      gy, ld_gy, xn, ld_x, gb, ld_gb, dxn, ld_dx, dgb, ld_dgb, (int)rows, C, slope);
   return eml::check_launch("eml_spade_modulate_bwd_f32");
+}
+
+// ------------------------------------------------------------------------- parameter-free BatchNorm folded into SPADE
+extern "C" int eml_bn_stats_f32(const float* x, int ld, long rows, int C, double* partials, int grid, eml_stream_t stream) {
+  if (!x || !partials || rows < 1 || rows > 2147483647L || C < 4 || (C & 3) || bad_ld(ld, C) || grid < 1)
+    return eml::fail(EML_EINVAL, "eml_bn_stats_f32: bad arguments");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ld, (int)rows, C, partials);
+  return eml::check_launch("eml_bn_stats_f32");
+}
+
+extern "C" int eml_bn_fold_f64(const double* partials, int R, int n, double* sums, eml_stream_t stream) {
+  if (!partials || !sums || R < 1 || n < 1) return eml::fail(EML_EINVAL, "eml_bn_fold_f64: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, R, n, sums);
+  return eml::check_launch("eml_bn_fold_f64");
+}
+
+extern "C" int eml_bn_finalize_f32(const double* sums, int C, float eps, float momentum, float* mean, float* istd,
+                                   float* running_mean, float* running_var, eml_stream_t stream) {
+  if (!sums || !mean || !istd || C < 1 || (running_mean && !running_var) || !(eps > 0.f))
+    return eml::fail(EML_EINVAL, "eml_bn_finalize_f32: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, eps, momentum,
+                     mean, istd, running_mean, running_var);
+  return eml::check_launch("eml_bn_finalize_f32");
+}
+
+extern "C" int eml_spade_norm_modulate_fwd_f32(const float* x, int ld_x, const float* gb, int ld_gb, float* y, int ld_y,
+                                               long rows, int C, float slope, const float* mean, const float* istd,
+                                               eml_stream_t stream) {
+  if (!x || !gb || !y || !mean || !istd || rows < 0 || rows > 2147483647L || C < 4 || (C & 3) || bad_ld(ld_x, C) ||
+      bad_ld(ld_gb, 2 * C) || bad_ld(ld_y, C))
+    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_fwd_f32: bad arguments");
+  if (rows == 0) return EML_OK;
+  hipLaunchKernelGGL(spade_norm_modulate_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, ld_x, gb, ld_gb, y, ld_y, (int)rows, C, slope, mean, istd);
+  return eml::check_launch("eml_spade_norm_modulate_fwd_f32");
+}
+
+extern "C" int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, int ld_x, const float* gb,
+                                               int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
+                                               float slope, const float* mean, const float* istd, double* partials,
+                                               int grid, eml_stream_t stream) {
+  if (!gy || !x || !gb || !dxn || !dgb || !mean || !istd || !partials || rows < 1 || rows > 2147483647L || C < 4 ||
+      (C & 3) || bad_ld(ld_gy, C) || bad_ld(ld_x, C) || bad_ld(ld_gb, 2 * C) || bad_ld(ld_dx, C) || bad_ld(ld_dgb, 2 * C) ||
+      grid < 1)
+    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, ld_gy, x, ld_x, gb,
+                     ld_gb, dxn, ld_dx, dgb, ld_dgb, (int)rows, C, slope, mean, istd, partials);
+  return eml::check_launch("eml_spade_norm_modulate_bwd_f32");
+}
+
+extern "C" int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
+                                    const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
+                                    eml_stream_t stream) {
+  if (!dxn || !x || !mean || !istd || !dx || rows < 0 || rows > 2147483647L || C < 4 || (C & 3) || bad_ld(ld_d, C) ||
+      bad_ld(ld_x, C) || bad_ld(ld_o, C))
+    return eml::fail(EML_EINVAL, "eml_bn_bwd_apply_f32: bad arguments");
+  if (rows == 0) return EML_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, dxn,
+                     ld_d, x, ld_x, (int)rows, C, mean, istd, sums, dx, ld_o);
+  return eml::check_launch("eml_bn_bwd_apply_f32");
 }

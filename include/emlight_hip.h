@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 3
+#define EML_ABI_VERSION 4
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -295,6 +295,33 @@ int eml_spade_modulate_fwd_f32(const float* xn, int ld_x, const float* gb, int l
 int eml_spade_modulate_bwd_f32(const float* gy, int ld_gy, const float* xn, int ld_x, const float* gb,
                                int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
                                float slope, eml_stream_t stream);
+
+/* SPADE's parameter-free BatchNorm (normalization.py:86-104; across replicas: sync_batchnorm/batchnorm.py:105-126)
+ * folded into the modulation.  Rows are pixel-major (channels-last), C % 4 == 0.
+ *   eml_bn_stats_f32     partials[grid][C][2] (f64) = per-block (sum x, sum x^2), accumulated per element in f64
+ *   eml_bn_fold_f64      sums[k] = sum_r partials[r][k], k < n (n = 2C); the caller appends the row count at sums[2C]
+ *                        and may all-reduce sums[0..2C] across ranks before finalising (= SynchronizedBatchNorm)
+ *   eml_bn_finalize_f32  mean, istd = rsqrt(var + eps) from sums (count at sums[2C]); running_mean / running_var
+ *                        (NULL to skip) updated like nn.BatchNorm2d (momentum, unbiased variance)
+ *   eml_spade_norm_modulate_fwd_f32   y = leaky_relu(((x-mean)*istd) * (1 + gamma) + beta, slope)
+ *   eml_spade_norm_modulate_bwd_f32   dxn, dgb as eml_spade_modulate_bwd_f32 with xn = (x-mean)*istd rebuilt inline,
+ *                        + partials[grid][C][2] = (sum dxn, sum dxn*xhat)
+ *   eml_bn_bwd_apply_f32 dx = istd * (dxn - S1/n - xhat*S2/n) with (S1,S2) = sums[c][0..1], n = sums[2C];
+ *                        sums == NULL: eval mode, dx = istd * dxn.  dx may alias dxn. */
+int eml_bn_stats_f32(const float* x, int ld, long rows, int C, double* partials, int grid, eml_stream_t stream);
+int eml_bn_fold_f64(const double* partials, int R, int n, double* sums, eml_stream_t stream);
+int eml_bn_finalize_f32(const double* sums, int C, float eps, float momentum, float* mean, float* istd,
+                        float* running_mean, float* running_var, eml_stream_t stream);
+int eml_spade_norm_modulate_fwd_f32(const float* x, int ld_x, const float* gb, int ld_gb, float* y, int ld_y,
+                                    long rows, int C, float slope, const float* mean, const float* istd,
+                                    eml_stream_t stream);
+int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, int ld_x, const float* gb,
+                                    int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
+                                    float slope, const float* mean, const float* istd, double* partials,
+                                    int grid, eml_stream_t stream);
+int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
+                         const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
+                         eml_stream_t stream);
 
 /* ---------------------------------------------------------------- ground-truth parametrisation (data preparation)
  * representation/distribution_representation.py:65-120 (`extract_mesh`), the inverse of the rasteriser.

@@ -25,7 +25,7 @@ from .sinkhorn import (sphere_points, anchor_cost_matrix, geometric_points, cost
                        samples_loss_grad_analytic)
 from .rasteriser import pano_grid, convert_to_panorama
 from .representation import ExtractMesh
-from .projector import sampling_grid, sphere_conv, spade_modulate, stock_sphere_ops
+from .projector import sampling_grid, sphere_conv, spade_modulate, spade_norm_modulate, stock_sphere_ops
 from .joint import predicted_gaussian_map, joint_step, stock_rasteriser
 from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss,
                        deterministic_projector_state_dict)
@@ -37,5 +37,5 @@ __all__ = [
     "convert_to_panorama", "ExtractMesh", "OracleDenseNet", "deterministic_state_dict",
     "regression_loss", "deterministic_projector_state_dict",
     "predicted_gaussian_map", "joint_step", "stock_rasteriser",
-    "sampling_grid", "sphere_conv", "spade_modulate", "stock_sphere_ops",
+    "sampling_grid", "sphere_conv", "spade_modulate", "spade_norm_modulate", "stock_sphere_ops",
 ]

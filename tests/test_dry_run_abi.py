@@ -83,3 +83,24 @@ def test_sinkhorn_and_rasteriser_calls_match_the_abi(recorder):
     for name in ("eml_emd_anchor_cost_f32", "eml_sinkhorn_fwd_f32", "eml_sinkhorn_bwd_f32", "eml_sg_rasterise_f32",
                  "eml_sg_rasterise_bwd_colors_f32"):
         assert name in recorder.calls, name
+
+
+def test_spade_norm_modulate_calls_match_the_abi(recorder, monkeypatch):
+    import oracle
+    from emlight_amd.GenProjector import spherenet
+    monkeypatch.setattr(spherenet, "_require_gpu_f32", lambda t, name: None)
+    monkeypatch.setattr(spherenet, "sphere_conv", oracle.sphere_conv)   # the SphereConv itself needs real tap tables
+    C, nh = 8, 4
+    bn = torch.nn.BatchNorm2d(C, affine=False).train()
+    g_, b_ = spherenet.SphereConv2D(nh, C), spherenet.SphereConv2D(nh, C)
+    x = torch.rand(2, C, 4, 8, requires_grad=True)
+    y = spherenet.spade_norm_modulate(x, bn, torch.rand(2, nh, 4, 8), g_, b_, 0.2)
+    y.sum().backward()
+    for name in ("eml_bn_stats_f32", "eml_bn_fold_f64", "eml_bn_finalize_f32", "eml_spade_norm_modulate_fwd_f32",
+                 "eml_spade_norm_modulate_bwd_f32", "eml_bn_bwd_apply_f32"):
+        assert name in recorder.calls, name
+    assert x.grad is not None and g_.weight.grad is not None
+    bn.eval()
+    n = len(recorder.calls)
+    spherenet.spade_norm_modulate(x, bn, torch.rand(2, nh, 4, 8), g_, b_, 1.0).sum().backward()
+    assert "eml_bn_stats_f32" not in recorder.calls[n:]   # eval: running statistics, no reduction

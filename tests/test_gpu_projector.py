@@ -119,13 +119,22 @@ def test_projector_matches_reference_golden_on_hip_sphereconv():
         np.testing.assert_allclose(float(d[k].detach()), float(g["d_loss/" + k]), rtol=5e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("slope", [1.0, 0.2])
-def test_spade_modulate_hip_vs_stock_ops(slope):
-    """Fused gamma|beta SphereConv + modulation (+ LeakyReLU) against normalization.py:113-115 / architecture.py:56-57
-    written with stock ops: output and the gradients w.r.t. normalized, actv and the four head parameters."""
-    from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_modulate
+@pytest.mark.parametrize("mode", [True, False])
+@pytest.mark.parametrize("slope,B,C,H,W", [(1.0, 2, 16, 8, 16), (0.2, 2, 16, 8, 16), (0.2, 3, 1024, 4, 8), (0.2, 1, 64, 32, 64),
+                                           (1.0, 2, 1280, 2, 4)])
+def test_spade_norm_modulate_hip_vs_stock_ops(slope, B, C, H, W, mode):
+    """Parameter-free BatchNorm (train: batch statistics + running update; eval: running statistics) folded into the
+    fused gamma|beta SphereConv + modulation (+ LeakyReLU), against normalization.py:101-115 / architecture.py:56-57
+    written with stock ops: output, running statistics, and the gradients w.r.t. x (through the statistics), actv and
+    the four head parameters."""
+    from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_norm_modulate
     torch.manual_seed(3)
-    B, C, H, W, nh = 2, 16, 8, 16, 12
+    nh = 12
+    bn_ref, bn_hip = torch.nn.BatchNorm2d(C, affine=False).cuda().train(mode), torch.nn.BatchNorm2d(C, affine=False).cuda().train(mode)
+    with torch.no_grad():
+        for bn in (bn_ref, bn_hip):
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.3, C))
+            bn.running_var.copy_(torch.linspace(0.5, 2.0, C))
     ref_g, ref_b = SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()   # parameter holders for the oracle's ops
     hip_g, hip_b = SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()
     for m in (ref_g, ref_b):
@@ -133,16 +142,19 @@ def test_spade_modulate_hip_vs_stock_ops(slope):
             m.bias.uniform_(-0.3, 0.3)
     hip_g.load_state_dict(ref_g.state_dict())
     hip_b.load_state_dict(ref_b.state_dict())
-    xn0, a0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, nh, H, W, device="cuda")
+    xn0, a0 = torch.randn(B, C, H, W, device="cuda") * 1.7 + 0.4, torch.randn(B, nh, H, W, device="cuda")
     outs = []
-    for fn, g_, b_ in ((oracle.spade_modulate, ref_g, ref_b), (spade_modulate, hip_g, hip_b)):
+    for fn, bn, g_, b_ in ((oracle.spade_norm_modulate, bn_ref, ref_g, ref_b), (spade_norm_modulate, bn_hip, hip_g, hip_b)):
         xn, actv = xn0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
-        y = fn(xn, actv, g_, b_, slope)
+        y = fn(xn, bn, actv, g_, b_, slope)
         (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
         outs.append([y.detach(), xn.grad, actv.grad, g_.weight.grad, g_.bias.grad, b_.weight.grad, b_.bias.grad])
-    for name, r, h in zip(["y", "d_normalized", "d_actv", "dWg", "dbg", "dWb", "dbb"], outs[0], outs[1]):
+    for name, r, h in zip(["y", "d_x", "d_actv", "dWg", "dbg", "dWb", "dbb"], outs[0], outs[1]):
         s = float(r.abs().max())
         np.testing.assert_allclose(h.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=3e-5 * s, err_msg=name)
+    np.testing.assert_allclose(bn_hip.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_hip.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
 def test_sphere_conv_properties_at_full_size():
