@@ -109,9 +109,11 @@ def test_joint_step_properties_at_cfg4_size():
             assert torch.isfinite(la[k]).all(), k
             # GAN / D terms are O(1e-2) differences of O(1) discriminator outputs at initialisation: absolute bound
             torch.testing.assert_close(la[k], lb[k], rtol=1e-3, atol=2e-4, msg=lambda m, k=k: "joint step must be reproducible (%s): %s" % (k, m))
-    # Adam's first steps move every weight by ~lr: weights after two iterations agree far below that
-    assert float((enc_w - tr.reg.model.fc_dist.weight.detach()).abs().max()) < 2e-5
-    assert float((g_w - tr.proj.model.netG.sphere_conv1.weight.detach()).abs().max()) < 2e-5
+    # Adam's first steps move every weight by +-lr (1e-4): an entry whose gradient is ~0 may take the other sign in a
+    # rerun (at most 2 * lr per step), everything else agrees far below lr -- so: mean far below lr, max within 4 * lr
+    for a_w, b_w in ((enc_w, tr.reg.model.fc_dist.weight.detach()), (g_w, tr.proj.model.netG.sphere_conv1.weight.detach())):
+        d = (a_w - b_w).abs()
+        assert float(d.mean()) < 5e-6 and float(d.max()) <= 4.1e-4, (float(d.mean()), float(d.max()))
 
     # (2) additivity on the encoder, no optimiser steps
     enc, pm = tr.reg.model, tr.proj.model
