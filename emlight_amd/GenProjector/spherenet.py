@@ -95,8 +95,13 @@ def sphere_geometry(h, w, stride, device):
 
 
 class _SphereConvFn(torch.autograd.Function):
-    """``conv2d(grid_sample(x, grid), weight, bias, stride=3)`` (``sphere_cnn.py:121-124``) as
-    im2col_sphere (HIP) -> GEMM (rocBLAS) forward, GEMMs + col2im_sphere (HIP, deterministic gather) backward.
+    """``conv2d(grid_sample(x, grid), weight, bias, stride=3)`` (``sphere_cnn.py:121-124``).
+
+    Large layers (operand ``A9`` of at least ``SphereConv2D.fused_min_bytes``; channel counts that tile): the FUSED
+    kernels of ``csrc/sphere_conv_fused.hip`` -- taps gathered straight into the LDS operand of an f32-MFMA implicit
+    GEMM, forward and weight gradient, so the 9x blown-up operand never exists in HBM.  Small / odd layers:
+    im2col_sphere (HIP) -> library GEMM.  The input gradient is ``dY W2`` (library GEMM) -> col2im_sphere (HIP,
+    deterministic gather over the CSR transpose of the tap table) in both cases.
     Activations are pixel-major: inputs in ``torch.channels_last`` are used in place, the output is returned as a
     channels-last (B, O, H', W') tensor, so a chain of SphereConvs never transposes."""
 
@@ -111,18 +116,34 @@ class _SphereConvFn(torch.autograd.Function):
         return a9
 
     @staticmethod
+    def _big(B, po, C):
+        return B > 0 and B * po * 9 * C * 4 >= SphereConv2D.fused_min_bytes
+
+    @staticmethod
     def forward(ctx, x, weight, bias, stride):
         from .. import _lib
         _require_gpu_f32(x, "SphereConv2D input")
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         B, C, H, W = x.shape
         geo = sphere_geometry(H, W, stride, x.device)
+        po = geo.ho * geo.wo
         xr = x.permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C); a view when x is channels-last
         O = weight.shape[0]
         w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
-        a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
-        y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
-        # the weight gradient needs A9 again: keep it (9x the input, sized for 288 GB of HBM) or rebuild it from x
-        ctx.keep = SphereConv2D.keep_operand and weight.requires_grad
+        big = _SphereConvFn._big(B, po, C)
+        ctx.fused_fwd = big and C % 32 == 0 and O % 64 == 0
+        ctx.fused_wgrad = big and C % 64 == 0 and O >= 64 and O % 16 == 0
+        a9 = None
+        if ctx.fused_fwd:
+            y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
+            _lib.check(L.eml_sphere_conv_fwd_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+                                                       p(bias.contiguous()) if bias is not None else None, p(y), B,
+                                                       H * W, po, C, O, st), "eml_sphere_conv_fwd_fused_f32")
+        else:
+            a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
+            y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
+        # the library weight gradient needs A9 again: keep it (9x the input) or rebuild it from x; the fused one never does
+        ctx.keep = (a9 is not None and not ctx.fused_wgrad and SphereConv2D.keep_operand and weight.requires_grad)
         ctx.save_for_backward(a9 if ctx.keep else xr, weight)
         ctx.geo, ctx.has_bias, ctx.shape = geo, bias is not None, (B, C, H, W, O)
         return y.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
@@ -140,10 +161,22 @@ class _SphereConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gyr.sum(0)
         if ctx.needs_input_grad[1]:
-            a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
-            # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
-            gw = (a9.t() @ gyr).view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
-            del a9
+            if ctx.fused_wgrad and B:
+                bn = 128 if C % 128 == 0 else 64
+                tiles = 9 * (C // bn) * ((O + 127) // 128)
+                nchunks = (B * po + 31) // 32
+                split = max(1, min(nchunks, 2048 // tiles, (512 << 20) // (O * 9 * C * 4)))
+                part = torch.empty(L.eml_sphere_conv_wgrad_partial_floats(C, O, split), dtype=torch.float32, device=gy.device)
+                gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
+                _lib.check(L.eml_sphere_conv_wgrad_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B,
+                                                             H * W, po, C, O, split, st), "eml_sphere_conv_wgrad_fused_f32")
+                gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+                del part
+            else:
+                a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
+                # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
+                gw = (a9.t() @ gyr).view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
+                del a9
         if ctx.needs_input_grad[0]:
             w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
             da9 = gyr @ w2                                           # (B*Po, 9C)
@@ -331,7 +364,8 @@ class SphereConv2D(nn.Module):
     reference (``sphere_cnn.py:87-109``).  Runs on the MI355X only (``sphere_conv`` above); the reference's two
     stock ops (grid_sample + conv2d) are restated in ``oracle/projector.py`` for the tests."""
 
-    keep_operand = True   # keep the im2col operand of a training forward for the weight gradient (else recompute)
+    keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
+    fused_min_bytes = 64 << 20   # layers whose im2col operand would be at least this large take the fused kernels
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

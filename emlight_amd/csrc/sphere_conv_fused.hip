@@ -1,0 +1,383 @@
+// Fused SphereConv2D for gfx950: the 9 bilinear taps of every output pixel are gathered straight into the LDS tile
+// that feeds the f32 MFMAs -- the (B*H'*W', 9C) operand A9 of the unfused path (sphere_conv.hip: im2col -> library
+// GEMM) is never written to HBM, neither in the forward nor for the weight gradient.
+// Reference: models/networks/spherenet/sphere_cnn.py:111-124,  y = conv2d(grid_sample(x, grid), w, b, stride=3).
+//
+//   forward   Y[m][o]        = bias[o] + sum_{tap,c} Ag[m][tap][c] * W2[o][tap*C + c]
+//   wgrad     dW2[o][tap*C+c] = sum_m dY[m][o] * Ag[m][tap][c]
+//   with      Ag[m][tap][c]  = sum_{k<4} wgt[p,tap,k] * X[b][idx[p,tap,k]][c],   m = b*Po + p   (the tap table of
+//                              eml_sphere_tap_table_f32: grid_sample's own corners and weights; -1 = zero padding)
+//
+// Both are 128 x {64,128} x 32 tiled GEMMs, 256 threads = 2 x 2 waves, v_mfma_f32_16x16x4_f32 (exact f32), double-
+// buffered LDS with ONE LDS-only barrier per K-chunk; the global loads of chunk i+1 (16 gathered float4 per thread +
+// the dense operand) are in flight during the MFMAs of chunk i, the tap-table entries one step further ahead.
+// Loads are unconditional from clamped addresses (zero weights / masked stores handle the borders).
+//   forward: D^T form (weights = MFMA A operand, pixels = B operand): a lane owns 4 consecutive output channels of a
+//            pixel -> 16-byte stores; MFMA's k index is only a summation label, so a lane's 8 consecutive floats of
+//            the 32-wide K-chunk serve k-steps 0..7 (two ds_read_b128 per fragment, LDS row stride 36: conflict-free).
+//   wgrad:   K = pixels; tiles keep their natural [pixel][channel] layout (row stride 144 puts the four k-rows of a
+//            ds_read_b32 on disjoint bank quarters); split-K over blockIdx.z, partials + a deterministic reduction.
+#include "eml_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+constexpr int kBM = 128;   // pixels per tile (forward) / output channels per tile (wgrad)
+constexpr int kBK = 32;    // K-chunk: 32 channels of one tap (forward) / 32 pixels (wgrad)
+constexpr int kLdF = 36;   // forward LDS row stride (floats)
+constexpr int kLdW = 144;  // wgrad LDS row stride (floats)
+
+struct Tap {
+  int4 id;
+  float4 w;
+};
+
+// bilinear combination in grid_sample's order: nw, ne, sw, se.  Written on explicit register PAIRS (x,y) / (z,w) of
+// each loaded float4 so that it maps onto v_pk_mul_f32 / v_pk_fma_f32 without any lane repacking: left to itself the
+// SLP vectoriser paired the same component of DIFFERENT corners, which costs v_mov shuffles right after the loads --
+// and a vmcnt wait for them in front of the MFMA block.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 combine(const float4 (&v)[4], const float4& w) {
+  v2f lo = v2f{v[0].x, v[0].y} * v2f{w.x, w.x};
+  v2f hi = v2f{v[0].z, v[0].w} * v2f{w.x, w.x};
+  lo += v2f{v[1].x, v[1].y} * v2f{w.y, w.y};
+  hi += v2f{v[1].z, v[1].w} * v2f{w.y, w.y};
+  lo += v2f{v[2].x, v[2].y} * v2f{w.z, w.z};
+  hi += v2f{v[2].z, v[2].w} * v2f{w.z, w.z};
+  lo += v2f{v[3].x, v[3].y} * v2f{w.w, w.w};
+  hi += v2f{v[3].z, v[3].w} * v2f{w.w, w.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int BN>
+__global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
+    const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
+    const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
+    int HW, int Po, int C, int O) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][kBM][kLdF]
+  float* Bs = smem + 2 * kBM * kLdF;      // [2][BN][kLdF]
+  constexpr int NI = BN / 32;             // 16-channel tiles per wave along N
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * kBM, o0 = blockIdx.y * BN;
+
+  // staging roles: A -- pixel sp = tid / 2, 16 channels (half); B -- output channel sp (threads < 2*BN), 16 channels
+  const int sp = tid >> 1, half = tid & 1;
+  const int ms = min(m0 + sp, M - 1);
+  const int sb = ms / Po, spix = ms - sb * Po;
+  const float* xb = X + (size_t)sb * HW * C + 16 * half;
+  const int* idp = idx + (size_t)spix * 36;
+  const float* wgp = wgt + (size_t)spix * 36;
+  const bool stage_b = tid < 2 * BN;
+  const float* wrow = W2 + (size_t)(o0 + min(sp, BN - 1)) * 9 * C + 16 * half;
+
+  const int cpt = C / kBK;            // chunks per tap
+  const int nchunks = 9 * cpt;
+
+  auto load_tap = [&](int tap) {
+    Tap t;
+    t.id = *reinterpret_cast<const int4*>(idp + 4 * tap);
+    t.w = *reinterpret_cast<const float4*>(wgp + 4 * tap);
+    return t;
+  };
+  float4 av[4][4];          // in-flight operands of the next chunk: A[corner][j] ...
+  float4 bv0, bv1, bv2, bv3;  // ... and B (named scalars: as an array the compiler parked them in scratch)
+  auto load_chunk = [&](int chunk, const Tap& t) {
+    const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
+    const int ids[4] = {t.id.x, t.id.y, t.id.z, t.id.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* src = xb + (size_t)max(ids[k], 0) * C + c0;   // out-of-bounds corners carry weight 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+    }
+    const float* ws = wrow + tap * C + c0;
+    bv0 = *reinterpret_cast<const float4*>(ws);
+    bv1 = *reinterpret_cast<const float4*>(ws + 4);
+    bv2 = *reinterpret_cast<const float4*>(ws + 8);
+    bv3 = *reinterpret_cast<const float4*>(ws + 12);
+  };
+  auto commit_chunk = [&](int buf, const Tap& t) {
+    float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
+      *reinterpret_cast<float4*>(ad + 4 * j) = combine(v, t.w);
+    }
+    if (stage_b) {
+      float* bd = Bs + (size_t)buf * BN * kLdF + sp * kLdF + 16 * half;
+      *reinterpret_cast<float4*>(bd) = bv0;
+      *reinterpret_cast<float4*>(bd + 4) = bv1;
+      *reinterpret_cast<float4*>(bd + 8) = bv2;
+      *reinterpret_cast<float4*>(bd + 12) = bv3;
+    }
+  };
+
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // t_use: table entry of the tap whose chunk is being loaded / committed; t_pref: the next tap's entry, requested a
+  // whole tap (>= one chunk of MFMAs) before it is needed
+  Tap t_use = load_tap(0);
+  Tap t_pref = load_tap(1);
+  load_chunk(0, t_use);
+  commit_chunk(0, t_use);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    const int nxt = chunk + 1;
+    const bool has_next = nxt < nchunks;
+    if (has_next) {
+      if (nxt % cpt == 0) {   // block-uniform: chunk nxt opens a new tap
+        t_use = t_pref;
+        t_pref = load_tap(min(nxt / cpt + 1, 8));
+      }
+      load_chunk(nxt, t_use);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* ab = As + (size_t)buf * kBM * kLdF + (64 * wm + r) * kLdF + 8 * kk;
+    const float* bb = Bs + (size_t)buf * BN * kLdF + ((BN / 2) * wn + r) * kLdF + 8 * kk;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 af[4], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const float4*>(ab + 16 * mi * kLdF + 4 * h);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(bb + 16 * ni * kLdF + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(f4c(bf[ni], t), f4c(af[mi], t), acc[ni][mi]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) commit_chunk(buf ^ 1, t_use);
+    eml::lds_barrier();
+  }
+  // epilogue: lane (r, kk) owns output channels 4kk..4kk+3 of tile ni for pixel r of tile mi
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int o = o0 + (BN / 2) * wn + 16 * ni + 4 * kk;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bq = *reinterpret_cast<const float4*>(bias + o);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + 64 * wm + 16 * mi + r;
+      if (m < M)
+        *reinterpret_cast<float4*>(Y + (size_t)m * O + o) =
+            make_float4(acc[ni][mi][0] + bq.x, acc[ni][mi][1] + bq.y, acc[ni][mi][2] + bq.z, acc[ni][mi][3] + bq.w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// grid = (column tiles of the (tap, c) axis, row tiles of O, split-K); partial[z][O][9C]
+template <int BN>
+__global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
+    const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
+    const float* __restrict__ dY /*[M][O]*/, float* __restrict__ partial, int M, int HW, int Po, int C, int O) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;                       // [2][kBK][kLdW]  dY tile   [pixel][o]
+  float* Gs = smem + 2 * kBK * kLdW;      // [2][kBK][kLdW]  Ag tile   [pixel][c]
+  constexpr int NI = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_per_tap = C / BN;
+  const int tap = blockIdx.x / tiles_per_tap, c0 = (blockIdx.x - tap * tiles_per_tap) * BN;
+  const int o0 = blockIdx.y * kBM;
+  const int S = gridDim.z;
+  const int nchunks_all = (M + kBK - 1) / kBK;
+
+  // staging roles: pixel sp = tid / 8 of the chunk; 16 consecutive columns starting at 16 * (tid % 8)
+  const int sp = tid >> 3, sq = tid & 7;
+  const bool stage_g = 16 * sq < BN;      // BN = 64: half of the threads gather
+  const bool stage_d = true;
+  const int ocol = min(o0 + 16 * sq, O - 16);   // O >= 64 and a multiple of 16: clamped columns are masked by valid_o
+
+  float4 dv[4], gv[4][4];
+  float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pvalid = false;
+  auto tap_of = [&](int chunk, Tap& t, size_t& xoff) {
+    const int m = min(chunk * kBK + sp, M - 1);
+    const int b = m / Po, p = m - b * Po;
+    t.id = *reinterpret_cast<const int4*>(idx + ((size_t)p * 9 + tap) * 4);
+    t.w = *reinterpret_cast<const float4*>(wgt + ((size_t)p * 9 + tap) * 4);
+    xoff = (size_t)b * HW * C;
+  };
+  auto load_chunk = [&](int chunk, const Tap& t, size_t xoff) {
+    const int m = chunk * kBK + sp;
+    pvalid = m < M;
+    const int mc = min(m, M - 1);
+    const float* dsrc = dY + (size_t)mc * O + ocol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dv[j] = *reinterpret_cast<const float4*>(dsrc + 4 * j);
+    const int ids[4] = {t.id.x, t.id.y, t.id.z, t.id.w};
+    const int cc = c0 + (stage_g ? 16 * sq : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* src = X + xoff + (size_t)max(ids[k], 0) * C + cc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gv[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+    }
+    gw = t.w;
+  };
+  auto commit_chunk = [&](int buf) {
+    float* dd = Ds + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
+    const bool ov = o0 + 16 * sq + 16 <= O;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = dv[j];
+      if (!(pvalid && ov && stage_d)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // pixels past M / columns past O add 0
+      *reinterpret_cast<float4*>(dd + 4 * j) = v;
+    }
+    if (stage_g) {
+      float* gd = Gs + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v[4] = {gv[0][j], gv[1][j], gv[2][j], gv[3][j]};
+        *reinterpret_cast<float4*>(gd + 4 * j) = combine(v, gw);
+      }
+    }
+  };
+
+  f32x4 acc[4][NI];   // [o tile][c tile]
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int chunk = blockIdx.z;
+  Tap t0, t1;
+  size_t x0 = 0, x1 = 0;
+  if (chunk < nchunks_all) {
+    tap_of(chunk, t0, x0);
+    load_chunk(chunk, t0, x0);
+    commit_chunk(0);
+    tap_of(min(chunk + S, nchunks_all - 1), t1, x1);
+  }
+  __syncthreads();
+  int it = 0;
+  for (; chunk < nchunks_all; chunk += S, ++it) {
+    const int buf = it & 1;
+    const int nxt = chunk + S;
+    const bool has_next = nxt < nchunks_all;
+    if (has_next) {
+      load_chunk(nxt, t1, x1);
+      tap_of(min(nxt + S, nchunks_all - 1), t1, x1);   // the table entry for the chunk after that
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* db = Ds + (size_t)buf * kBK * kLdW + 64 * wm + r;
+    const float* gb = Gs + (size_t)buf * kBK * kLdW + (BN / 2) * wn + r;
+#pragma unroll
+    for (int ks = 0; ks < kBK / 4; ++ks) {
+      float a[4], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = gb[(4 * ks + kk) * kLdW + 16 * ni];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(a[mi], b[ni], acc[mi][ni]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) commit_chunk(buf ^ 1);
+    eml::lds_barrier();
+  }
+  // partial[z][o][tap*C + c]: lane (r, kk) holds rows o = 4kk + g, column c = r of each 16x16 tile
+  float* out = partial + (size_t)blockIdx.z * O * 9 * C;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int o = o0 + 64 * wm + 16 * mi + 4 * kk + g;
+      if (o < O) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          out[(size_t)o * 9 * C + tap * C + c0 + (BN / 2) * wn + 16 * ni + r] = acc[mi][ni][g];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int S, size_t n,
+                                                           float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += partial[(size_t)s * n + e];
+  out[e] = t;
+}
+
+}  // namespace
+
+extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                             const float* bias, float* Y, int B, int HW, int Po, int C, int O,
+                                             eml_stream_t stream) {
+  if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
+  if (B == 0) return EML_OK;
+  const long M = (long)B * Po;
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: too many pixels");
+  const int bn = (O % 128 == 0) ? 128 : 64;
+  const size_t lds = (size_t)(2 * kBM * kLdF + 2 * bn * kLdF) * sizeof(float);
+  const dim3 grid((unsigned)((M + kBM - 1) / kBM), O / bn);
+  if (bn == 128) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
+                       Y, (int)M, HW, Po, C, O);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
+                       Y, (int)M, HW, Po, C, O);
+  }
+  return eml::check_launch("eml_sphere_conv_fwd_fused_f32");
+}
+
+extern "C" size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k) {
+  return (size_t)split_k * O * 9 * C;
+}
+
+extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, const float* wgt, const float* dY,
+                                               float* partial, float* dW2, int B, int HW, int Po, int C, int O,
+                                               int split_k, eml_stream_t stream) {
+  if (!X || !idx || !wgt || !dY || !partial || !dW2 || B < 1 || HW < 1 || Po < 1 || C < 64 || (C % 64) || O < 64 ||
+      (O % 16) || split_k < 1 || split_k > 65535)
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_wgrad_fused_f32: need C %% 64 == 0, O >= 64, O %% 16 == 0 (C=%d, O=%d)", C, O);
+  const long M = (long)B * Po;
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_wgrad_fused_f32: too many pixels");
+  const int bn = (C % 128 == 0) ? 128 : 64;
+  const size_t lds = (size_t)(4 * kBK * kLdW) * sizeof(float);
+  const dim3 grid(9 * (C / bn), (O + kBM - 1) / kBM, split_k);
+  if (bn == 128) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sphere_conv_wgrad_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, dY,
+                       partial, (int)M, HW, Po, C, O);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sphere_conv_wgrad_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, dY,
+                       partial, (int)M, HW, Po, C, O);
+  }
+  int rc = eml::check_launch("eml_sphere_conv_wgrad_fused_f32");
+  if (rc) return rc;
+  const size_t n = (size_t)O * 9 * C;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     split_k, n, dW2);
+  return eml::check_launch("eml_sphere_conv_wgrad_fused_f32(reduce)");
+}

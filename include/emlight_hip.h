@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 4
+#define EML_ABI_VERSION 5
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -285,6 +285,20 @@ int eml_sphere_im2col_f32(const float* X, const int* idx, const float* wgt, floa
  * table (src = p*9 + tap), built once per geometry by the caller. */
 int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, const float* w, float* dX,
                           int B, int HW, int Po, int C, eml_stream_t stream);
+
+/* Fused SphereConv2D (sphere_cnn.py:111-124): the taps are gathered straight into the LDS operand tile of an f32-MFMA
+ * implicit GEMM, so the (B*Po, 9C) operand of eml_sphere_im2col_f32 is never written.  X (B, HW, C) pixel-major,
+ * idx / wgt = eml_sphere_tap_table_f32's table, W2 (O, 9C) with columns ordered (tap, c) (= weight.permute(0,2,3,1)),
+ * bias (O) or NULL, Y (B*Po, O).  Forward: C % 32 == 0, O % 64 == 0.
+ * Weight gradient dW2 (O, 9C) = sum_m dY[m] (x) Ag[m]: C % 64 == 0, O >= 64, O % 16 == 0; split_k workgroups share the
+ * pixel axis, partial = eml_sphere_conv_wgrad_partial_floats(C, O, split_k) floats of scratch (deterministic sum). */
+int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                  const float* bias, float* Y, int B, int HW, int Po, int C, int O,
+                                  eml_stream_t stream);
+size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k);
+int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, const float* wgt, const float* dY,
+                                    float* partial, float* dW2, int B, int HW, int Po, int C, int O,
+                                    int split_k, eml_stream_t stream);
 
 /* SPADE modulation (normalization.py:113-115 + the LeakyReLU of architecture.py:56-57) on pixel-major rows:
  * y[r][c] = leaky_relu(xn[r][c] * (1 + gb[r][c]) + gb[r][C + c], slope), slope = 1 for the plain modulation.
