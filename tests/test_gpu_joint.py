@@ -104,11 +104,16 @@ def test_joint_step_properties_at_cfg4_size():
     del tr
     torch.cuda.empty_cache()
     tr, b = run(2)
-    for la, lb in zip(a, b):
+    for it, (la, lb) in enumerate(zip(a, b)):
         for k in la:
             assert torch.isfinite(la[k]).all(), k
-            # GAN / D terms are O(1e-2) differences of O(1) discriminator outputs at initialisation: absolute bound
-            torch.testing.assert_close(la[k], lb[k], rtol=1e-3, atol=2e-4, msg=lambda m, k=k: "joint step must be reproducible (%s): %s" % (k, m))
+            # iteration 1 is a pure function of the initial weights: tight (GAN / D terms are O(1e-2) differences of
+            # O(1) discriminator outputs, hence the absolute part).  Iteration 2 follows Adam's FIRST update, which moves
+            # every weight by lr * sign(g): entries with g ~ 0 amplify the library calls' summation-order noise, so
+            # only a loose bound is meaningful there.
+            rtol, atol = (1e-3, 2e-4) if it == 0 else (1e-1, 5e-3)
+            torch.testing.assert_close(la[k], lb[k], rtol=rtol, atol=atol,
+                                       msg=lambda m, k=k, it=it: "joint iteration %d must be reproducible (%s): %s" % (it + 1, k, m))
     # Adam's first steps move every weight by +-lr (1e-4): an entry whose gradient is ~0 may take the other sign in a
     # rerun (at most 2 * lr per step), everything else agrees far below lr -- so: mean far below lr, max within 4 * lr
     for a_w, b_w in ((enc_w, tr.reg.model.fc_dist.weight.detach()), (g_w, tr.proj.model.netG.sphere_conv1.weight.detach())):
