@@ -97,10 +97,10 @@ def sphere_geometry(h, w, stride, device):
 class _SphereConvFn(torch.autograd.Function):
     """``conv2d(grid_sample(x, grid), weight, bias, stride=3)`` (``sphere_cnn.py:121-124``).
 
-    Large layers (operand ``A9`` of at least ``SphereConv2D.fused_min_bytes``; channel counts that tile): the FUSED
-    kernels of ``csrc/sphere_conv_fused.hip`` -- taps gathered straight into the LDS operand of an f32-MFMA implicit
-    GEMM, forward and weight gradient, so the 9x blown-up operand never exists in HBM.  Small / odd layers:
-    im2col_sphere (HIP) -> library GEMM.  The input gradient is ``dY W2`` (library GEMM) -> col2im_sphere (HIP,
+    Large layers (by the size of the would-be im2col operand ``A9``, thresholds in ``forward``; channel counts that
+    tile): the FUSED kernels of ``csrc/sphere_conv_fused.hip`` -- taps gathered straight into the LDS operand of an
+    f32-MFMA implicit GEMM, forward and weight gradient, so the 9x blown-up operand never exists in HBM.  Small / odd
+    layers: im2col_sphere (HIP) -> library GEMM.  The input gradient is ``dY W2`` (library GEMM) -> col2im_sphere (HIP,
     deterministic gather over the CSR transpose of the tap table) in both cases.
     Activations are pixel-major: inputs in ``torch.channels_last`` are used in place, the output is returned as a
     channels-last (B, O, H', W') tensor, so a chain of SphereConvs never transposes."""
@@ -116,10 +116,6 @@ class _SphereConvFn(torch.autograd.Function):
         return a9
 
     @staticmethod
-    def _big(B, po, C):
-        return B > 0 and B * po * 9 * C * 4 >= SphereConv2D.fused_min_bytes
-
-    @staticmethod
     def forward(ctx, x, weight, bias, stride):
         from .. import _lib
         _require_gpu_f32(x, "SphereConv2D input")
@@ -130,9 +126,14 @@ class _SphereConvFn(torch.autograd.Function):
         xr = x.permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C); a view when x is channels-last
         O = weight.shape[0]
         w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
-        big = _SphereConvFn._big(B, po, C)
-        ctx.fused_fwd = big and C % 32 == 0 and O % 64 == 0
-        ctx.fused_wgrad = big and C % 64 == 0 and O >= 64 and O % 16 == 0
+        # which layers take the fused kernels: measured per shape (tools/sphere_layers.py, profiles/r02_sphere_layers.jsonl).
+        # They run at 85-98 TF/s whatever the shape; im2col + the library GEMM is faster only where the GEMM is wide
+        # (O >= 256) and the operand small -- there the library's 115-125 TF/s wins and A9 costs little memory.
+        a9_bytes = B * po * 9 * C * 4
+        lim = SphereConv2D.fused_min_bytes
+        ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
+                         (a9_bytes >= 32 * lim or (O <= 128 and a9_bytes >= lim)))
+        ctx.fused_wgrad = B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim
         a9 = None
         if ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
@@ -163,7 +164,8 @@ class _SphereConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if ctx.fused_wgrad and B:
                 bn = 128 if C % 128 == 0 else 64
-                tiles = 9 * (C // bn) * ((O + 127) // 128)
+                bmo = 128 if (O % 128 == 0 or O > 192) else 64
+                tiles = 9 * (C // bn) * ((O + bmo - 1) // bmo)
                 nchunks = (B * po + 31) // 32
                 split = max(1, min(nchunks, 2048 // tiles, (512 << 20) // (O * 9 * C * 4)))
                 part = torch.empty(L.eml_sphere_conv_wgrad_partial_floats(C, O, split), dtype=torch.float32, device=gy.device)
@@ -365,7 +367,7 @@ class SphereConv2D(nn.Module):
     stock ops (grid_sample + conv2d) are restated in ``oracle/projector.py`` for the tests."""
 
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
-    fused_min_bytes = 64 << 20   # layers whose im2col operand would be at least this large take the fused kernels
+    fused_min_bytes = 64 << 20   # unit of the fused-kernel thresholds on the size of the im2col operand (see forward)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-// grid = (column tiles of the (tap, c) axis, row tiles of O, split-K); partial[z][O][9C]
-template <int BN>
+// grid = (column tiles of the (tap, c) axis, row tiles of O, split-K); partial[z][O][9C].  BMO = output channels per
+// tile: 128, or 64 for the 64-channel layers (a 128-row tile would spend half of its MFMAs on padding).
+template <int BN, int BMO>
 __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ dY /*[M][O]*/, float* __restrict__ partial, int M, int HW, int Po, int C, int O) {
@@ -192,20 +193,21 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   float* Ds = smem;                       // [2][kBK][kLdW]  dY tile   [pixel][o]
   float* Gs = smem + 2 * kBK * kLdW;      // [2][kBK][kLdW]  Ag tile   [pixel][c]
   constexpr int NI = BN / 32;
+  constexpr int MI = BMO / 32;            // 16-row tiles per wave along O
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_per_tap = C / BN;
   const int tap = blockIdx.x / tiles_per_tap, c0 = (blockIdx.x - tap * tiles_per_tap) * BN;
-  const int o0 = blockIdx.y * kBM;
+  const int o0 = blockIdx.y * BMO;
   const int S = gridDim.z;
   const int nchunks_all = (M + kBK - 1) / kBK;
 
   // staging roles: pixel sp = tid / 8 of the chunk; 16 consecutive columns starting at 16 * (tid % 8)
   const int sp = tid >> 3, sq = tid & 7;
   const bool stage_g = 16 * sq < BN;      // BN = 64: half of the threads gather
-  const bool stage_d = true;
-  const int ocol = min(o0 + 16 * sq, O - 16);   // O >= 64 and a multiple of 16: clamped columns are masked by valid_o
+  const bool stage_d = 16 * sq < BMO;     // BMO = 64: half of the threads stage dY
+  const int ocol = min(o0 + 16 * sq, O - 16);   // O >= 64 and a multiple of 16: clamped columns are zeroed at commit
 
   float4 dv[4], gv[4][4];
   float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 v = dv[j];
-      if (!(pvalid && ov && stage_d)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // pixels past M / columns past O add 0
-      *reinterpret_cast<float4*>(dd + 4 * j) = v;
+      if (!(pvalid && ov)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // pixels past M / columns past O add 0
+      if (stage_d) *reinterpret_cast<float4*>(dd + 4 * j) = v;
     }
     if (stage_g) {
       float* gd = Gs + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     }
   };
 
-  f32x4 acc[4][NI];   // [o tile][c tile]
+  f32x4 acc[MI][NI];   // [o tile][c tile]
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -279,17 +281,17 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
       tap_of(min(nxt + S, nchunks_all - 1), t1, x1);   // the table entry for the chunk after that
     }
     __builtin_amdgcn_sched_barrier(0);
-    const float* db = Ds + (size_t)buf * kBK * kLdW + 64 * wm + r;
+    const float* db = Ds + (size_t)buf * kBK * kLdW + (BMO / 2) * wm + r;
     const float* gb = Gs + (size_t)buf * kBK * kLdW + (BN / 2) * wn + r;
 #pragma unroll
     for (int ks = 0; ks < kBK / 4; ++ks) {
-      float a[4], b[NI];
+      float a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
+      for (int mi = 0; mi < MI; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b[ni] = gb[(4 * ks + kk) * kLdW + 16 * ni];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(a[mi], b[ni], acc[mi][ni]);
     }
@@ -300,10 +302,10 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   // partial[z][o][tap*C + c]: lane (r, kk) holds rows o = 4kk + g, column c = r of each 16x16 tile
   float* out = partial + (size_t)blockIdx.z * O * 9 * C;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int o = o0 + 64 * wm + 16 * mi + 4 * kk + g;
+      const int o = o0 + (BMO / 2) * wm + 16 * mi + 4 * kk + g;
       if (o < O) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -361,19 +363,22 @@ extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, c
   const long M = (long)B * Po;
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_wgrad_fused_f32: too many pixels");
   const int bn = (C % 128 == 0) ? 128 : 64;
+  const int bmo = (O % 128 == 0 || O > 192) ? 128 : 64;   // 64-wide row tiles when a 128-row tile would be mostly padding
   const size_t lds = (size_t)(4 * kBK * kLdW) * sizeof(float);
-  const dim3 grid(9 * (C / bn), (O + kBM - 1) / kBM, split_k);
+  const dim3 grid(9 * (C / bn), (O + bmo - 1) / bmo, split_k);
+#define EML_LAUNCH_WGRAD(BNV, BMV)                                                                                   \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<BNV, BMV>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
+                       wgt, dY, partial, (int)M, HW, Po, C, O);                                                      \
+  } while (0)
   if (bn == 128) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(sphere_conv_wgrad_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, dY,
-                       partial, (int)M, HW, Po, C, O);
+    if (bmo == 128) EML_LAUNCH_WGRAD(128, 128); else EML_LAUNCH_WGRAD(128, 64);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<64>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(sphere_conv_wgrad_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, dY,
-                       partial, (int)M, HW, Po, C, O);
+    if (bmo == 128) EML_LAUNCH_WGRAD(64, 128); else EML_LAUNCH_WGRAD(64, 64);
   }
+#undef EML_LAUNCH_WGRAD
   int rc = eml::check_launch("eml_sphere_conv_wgrad_fused_f32");
   if (rc) return rc;
   const size_t n = (size_t)O * 9 * C;

@@ -1,0 +1,65 @@
+"""Per-layer timing of SphereConv2D at the projector's shapes (B = 32, cfg3): fused implicit-GEMM kernels vs the
+unfused im2col + library-GEMM path, forward and weight gradient.  Writes one JSON line per layer (profiles/ evidence
+for which path each shape takes).    python tools/sphere_layers.py [B]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emlight_amd.GenProjector.spherenet import SphereConv2D  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+LAYERS = [  # name, C, O, H, W, stride
+    ("up_3 gamma|beta 128->256 @128x256", 128, 256, 128, 256, 1),
+    ("up_3 gamma|beta 128->128 @128x256", 128, 128, 128, 256, 1),
+    ("up_3 conv_0 128->64 @128x256", 128, 64, 128, 256, 1),
+    ("up_3 conv_1 64->64 @128x256", 64, 64, 128, 256, 1),
+    ("up_2 gamma|beta 128->512 @64x128", 128, 512, 64, 128, 1),
+    ("up_2 gamma|beta 128->256 @64x128", 128, 256, 64, 128, 1),
+    ("up_2 conv_0 256->128 @64x128", 256, 128, 64, 128, 1),
+    ("up_2 conv_1 128->128 @64x128", 128, 128, 64, 128, 1),
+    ("up_1 gamma|beta 128->1024 @32x64", 128, 1024, 32, 64, 1),
+    ("up_1 conv_0 512->256 @32x64", 512, 256, 32, 64, 1),
+    ("up_0 gamma|beta 128->2048 @16x32", 128, 2048, 16, 32, 1),
+    ("up_0 conv_0 1024->512 @16x32", 1024, 512, 16, 32, 1),
+    ("G_middle conv 1024->1024 @8x16", 1024, 1024, 8, 16, 1),
+    ("D model1 64->128 s2 @64x128 (B*2)", 64, 128, 64, 128, 2),
+]
+
+
+def events(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for name, C, O, H, W, stride in LAYERS:
+    bb = B * 2 if name.startswith("D ") else B
+    m = SphereConv2D(C, O, stride=stride).cuda()
+    x = torch.randn(bb, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    po = (H // stride) * (W // stride)
+    gflop = 2.0 * bb * po * 9 * C * O / 1e9
+    row = {"layer": name, "B": bb, "gflop": round(gflop, 1), "A9_GB": round(bb * po * 9 * C * 4 / 1e9, 2)}
+    default = SphereConv2D.fused_min_bytes
+    for mode, thr in (("fused", 0), ("unfused", 1 << 62), ("auto", 64 << 20)):
+        SphereConv2D.fused_min_bytes = thr
+        with torch.no_grad():
+            t_f = events(lambda: m(x))
+        xg = x.clone().requires_grad_(False)
+        y = m(xg)
+        gy = torch.randn_like(y)
+        t_w = events(lambda: torch.autograd.grad(y, m.weight, gy, retain_graph=True))   # weight gradient only
+        row[mode] = {"fwd_ms": round(t_f, 3), "fwd_tflops": round(gflop / t_f, 1), "wgrad_ms": round(t_w, 3),
+                     "wgrad_tflops": round(gflop / t_w, 1)}
+        del y, gy
+    print(json.dumps(row), flush=True)
+    del m, x
+    torch.cuda.empty_cache()
