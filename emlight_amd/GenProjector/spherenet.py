@@ -133,7 +133,9 @@ class _SphereConvFn(torch.autograd.Function):
         lim = SphereConv2D.fused_min_bytes
         ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
                          (a9_bytes >= 32 * lim or (O <= 128 and a9_bytes >= lim)))
-        ctx.fused_wgrad = B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim
+        # weight gradient: K = pixels; below ~32k pixels the split-K tiles are short and the library's long-K GEMM wins
+        ctx.fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
+                           (B * po >= 32768 or lim == 0))
         a9 = None
         if ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
