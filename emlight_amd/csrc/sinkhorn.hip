@@ -18,8 +18,9 @@
 // reads).  A sweep is one fma+max pass and one fma+exp2+add pass over those registers, the
 // row reduction is two lane shuffles, and the dual vectors h = log w + f/eps
 // travel between the two groups through a double-buffered LDS array with ONE barrier per
-// sweep.  N > 128 ("stream" kernel): thread = row, costs recomputed per sweep from Mt
-// (coalesced, L2-resident).
+// sweep.  128 < N <= 512, N % 4 == 0 ("tiled" kernel): the chord matrix streams through LDS in column tiles shared by
+// both problems of the workgroup, online log-sum-exp per row.  Other N ("stream" kernel): thread = row, costs
+// recomputed per sweep from Mt (coalesced, L2-resident).
 //
 // Roofline: algorithmic bytes per eps-step = 4*(B*N^2*4 + 2*B*N*4), i.e. the
 // reference's materialised-cost traffic; this kernel's real HBM traffic is x, y, M and the
@@ -49,6 +50,75 @@ __device__ __forceinline__ float cost_ij(float p, float q, float m) {
 //   pot [2][NP]  potentials (stream kernel)      M [N][ldm] (cached kernel)
 constexpr int kSmemVecs = 2 + 2 + 4 + 2;
 
+// ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
+// d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
+// eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p] in f64 like numpy
+template <int kWG>
+__device__ __forceinline__ void device_schedule(const float* __restrict__ x, const float* __restrict__ y, int B, int N,
+                                                double blur, double scaling, int p_exp, double diameter, float* eps_l,
+                                                int* n_eps_l, float* __restrict__ eps_out, int* __restrict__ n_eps_out,
+                                                float* __restrict__ diameter_out) {
+  __shared__ float red_lo[16], red_hi[16];
+  const int tid0 = threadIdx.x;
+  float lo = INFINITY, hi = -INFINITY;
+  if (diameter <= 0.0) {
+    const long n_all = (long)B * N, n4 = n_all >> 2;   // hipMalloc'd buffers: 16-B aligned
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    for (long k = tid0; k < n4; k += kWG) {
+      const float4 a = x4[k], c2 = y4[k];
+      lo = fminf(fminf(fminf(lo, fminf(a.x, a.y)), fminf(a.z, a.w)), fminf(fminf(c2.x, c2.y), fminf(c2.z, c2.w)));
+      hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)), fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w)));
+    }
+    for (long k = 4 * n4 + tid0; k < n_all; k += kWG) {
+      lo = fminf(lo, fminf(x[k], y[k]));
+      hi = fmaxf(hi, fmaxf(x[k], y[k]));
+    }
+    lo = eml::wave_min(lo);
+    hi = eml::wave_max(hi);
+    if ((tid0 & 63) == 0) {
+      red_lo[tid0 >> 6] = lo;
+      red_hi[tid0 >> 6] = hi;
+    }
+  }
+  __syncthreads();
+  double d = diameter;
+  if (diameter <= 0.0) {
+    lo = red_lo[0];
+    hi = red_hi[0];
+#pragma unroll
+    for (int w = 1; w < kWG / 64; ++w) {
+      lo = fminf(lo, red_lo[w]);
+      hi = fmaxf(hi, red_hi[w]);
+    }
+    d = (double)(hi - lo);  // f32 subtraction, then .item()
+  }
+  int cnt = 0;
+  double start = 0.0, step = 0.0;
+  if (d > 0.0) {
+    start = p_exp * log(d);
+    step = p_exp * log(scaling);
+    const double cntd = ceil((p_exp * log(blur) - start) / step);  // numpy.arange length
+    cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
+  }
+  if (tid0 < cnt + 2) {  // one schedule entry per thread, in parallel
+    double e;
+    if (tid0 == 0) e = (p_exp == 2) ? d * d : pow(d, (double)p_exp);
+    else if (tid0 == cnt + 1) e = (p_exp == 2) ? blur * blur : pow(blur, (double)p_exp);
+    else e = exp(start + (tid0 - 1) * step);
+    eps_l[tid0] = (float)e;
+    if (blockIdx.x == 0 && eps_out) eps_out[tid0] = (float)e;
+  }
+  if (tid0 == 0) {
+    *n_eps_l = cnt + 2;
+    if (blockIdx.x == 0) {
+      if (n_eps_out) *n_eps_out = cnt + 2;
+      if (diameter_out) *diameter_out = (float)d;
+    }
+  }
+  __syncthreads();
+}
+
 // threads per softmin group: cached kernel 512 (128 rows x 4 lanes), stream kernel 256 (row per thread)
 template <bool kCached>
 __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
@@ -57,74 +127,11 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     double blur, double scaling, int p_exp, double diameter, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
-  // ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
-  // d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
-  // eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p] in f64 like numpy
   constexpr int kGT = kCached ? 512 : 256;  // threads per softmin group
   constexpr int kWG = 2 * kGT;              // two groups per workgroup
   __shared__ float eps_l[EML_MAX_EPS];
-  __shared__ float red_lo[16], red_hi[16];
   __shared__ int n_eps_l;
-  {
-    const int tid0 = threadIdx.x;
-    float lo = INFINITY, hi = -INFINITY;
-    if (diameter <= 0.0) {
-      const long n_all = (long)B * N, n4 = n_all >> 2;   // hipMalloc'd buffers: 16-B aligned
-      const float4* x4 = reinterpret_cast<const float4*>(x);
-      const float4* y4 = reinterpret_cast<const float4*>(y);
-      for (long k = tid0; k < n4; k += kWG) {
-        const float4 a = x4[k], c2 = y4[k];
-        lo = fminf(fminf(fminf(lo, fminf(a.x, a.y)), fminf(a.z, a.w)), fminf(fminf(c2.x, c2.y), fminf(c2.z, c2.w)));
-        hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)), fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w)));
-      }
-      for (long k = 4 * n4 + tid0; k < n_all; k += kWG) {
-        lo = fminf(lo, fminf(x[k], y[k]));
-        hi = fmaxf(hi, fmaxf(x[k], y[k]));
-      }
-      lo = eml::wave_min(lo);
-      hi = eml::wave_max(hi);
-      if ((tid0 & 63) == 0) {
-        red_lo[tid0 >> 6] = lo;
-        red_hi[tid0 >> 6] = hi;
-      }
-    }
-    __syncthreads();
-    double d = diameter;
-    if (diameter <= 0.0) {
-      lo = red_lo[0];
-      hi = red_hi[0];
-#pragma unroll
-      for (int w = 1; w < kWG / 64; ++w) {
-        lo = fminf(lo, red_lo[w]);
-        hi = fmaxf(hi, red_hi[w]);
-      }
-      d = (double)(hi - lo);  // f32 subtraction, then .item()
-    }
-    int cnt = 0;
-    double start = 0.0, step = 0.0;
-    if (d > 0.0) {
-      start = p_exp * log(d);
-      step = p_exp * log(scaling);
-      const double cntd = ceil((p_exp * log(blur) - start) / step);  // numpy.arange length
-      cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
-    }
-    if (tid0 < cnt + 2) {  // one schedule entry per thread, in parallel
-      double e;
-      if (tid0 == 0) e = (p_exp == 2) ? d * d : pow(d, (double)p_exp);
-      else if (tid0 == cnt + 1) e = (p_exp == 2) ? blur * blur : pow(blur, (double)p_exp);
-      else e = exp(start + (tid0 - 1) * step);
-      eps_l[tid0] = (float)e;
-      if (blockIdx.x == 0 && eps_out) eps_out[tid0] = (float)e;
-    }
-    if (tid0 == 0) {
-      n_eps_l = cnt + 2;
-      if (blockIdx.x == 0) {
-        if (n_eps_out) *n_eps_out = cnt + 2;
-        if (diameter_out) *diameter_out = (float)d;
-      }
-    }
-    __syncthreads();
-  }
+  device_schedule<kWG>(x, y, B, N, blur, scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
   const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NP = round_up4(N) + kJPT;
@@ -310,6 +317,164 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   }
 }
 
+// ---- "tiled" kernel, 128 < N <= 512 (N % 4 == 0): the N x N cost blocks do not fit registers any more, so the chord
+// matrix streams through LDS in column tiles (256 rows x 32 columns, or 512 x 16: 8192 floats, double-buffered) that
+// BOTH softmin problems of the workgroup consume; a row is shared by LPR lanes, each folding its 16 columns of a tile
+// into a running (max, sum) pair -- an online log-sum-exp, one pass per sweep instead of the stream kernel's two passes
+// over an L2-resident Mt.  The tile sequence is the same in every sweep, so the next tile's global loads are always in
+// flight during the current tile's arithmetic, across sweep boundaries too.  One LDS-only barrier per tile.
+template <int LPR /* lanes per row: 2 (N <= 256) or 1 (N <= 512) */>
+__global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
+    const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double scaling, int p_exp,
+    double diameter, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
+    float* __restrict__ work, int B, int N) {
+  constexpr int kGT = 512, kWG = 1024;
+  constexpr int NR = 512 / LPR;            // row capacity of a softmin group
+  constexpr int TJ = 16 * LPR;             // tile columns; every lane folds 16 of them
+  constexpr int TS = TJ + 4;               // LDS row stride of a tile
+  __shared__ float eps_l[EML_MAX_EPS];
+  __shared__ int n_eps_l;
+  device_schedule<kWG>(x, y, B, N, blur, scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
+  const float* eps_s = eps_l;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NP = round_up4(N) + kJPT;
+  float* pts = smem;
+  float* lw2 = pts + 2 * NP;
+  float* h2 = lw2 + 2 * NP;
+  float* Mtile = h2 + 4 * NP;              // [2][NR][TS]
+
+  const int b = blockIdx.x >> 1, role = blockIdx.x & 1, tid = threadIdx.x;
+  const int gl = tid / kGT, g = 2 * role + gl, t = tid & (kGT - 1);
+  const bool rows_x = (g == 0 || g == 3), cols_x = (g == 0 || g == 2);
+  const int consumer_l = role ? (1 - gl) : gl;
+  const int n_eps = n_eps_l;
+
+  const float unif = 1.0f / (float)N;
+  for (int i = tid; i < 2 * NP; i += kWG) {
+    const int which = i / NP, k = i - which * NP;
+    float p = 0.f, l = 0.f;
+    if (k < N) {
+      p = (which == 0 ? x : y)[(size_t)b * N + k];
+      const float* wp = which == 0 ? alpha : beta;
+      const float w = wp ? wp[(size_t)b * N + k] : unif;
+      l = (w > 0.f) ? logf(w) : -100000.0f;
+    }
+    pts[i] = p;
+    lw2[i] = l * kLog2e;
+  }
+  for (int i = tid; i < 4 * NP; i += kWG) h2[i] = 0.f;
+  __syncthreads();
+  const float* P = pts + (rows_x ? 0 : NP);
+  const float* Q = pts + (cols_x ? 0 : NP);
+  const float* lw2_rows = lw2 + (rows_x ? 0 : NP);
+  const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
+  for (int k = t; k < N; k += kGT) h2[gl * NP + k] = lw2_cols[k];
+
+  const int i = t / LPR, part = t % LPR;
+  const bool owner = part == 0 && i < N;
+  const int ic = min(i, N - 1);
+  const float pi = P[ic];
+  const int ntiles = (N + TJ - 1) / TJ;
+  // staging role: row srow, 8 consecutive columns of the tile
+  const int srow = tid / (TJ / 8), sq = tid % (TJ / 8);
+  const float* mrow = M + (size_t)min(srow, N - 1) * N;
+  float4 s0, s1;
+  auto stage_load = [&](int tile) {   // unconditional, clamped: N % 4 == 0, so a float4 is entirely inside or outside
+    const int j = tile * TJ + 8 * sq;
+    s0 = *reinterpret_cast<const float4*>(mrow + min(j, N - 4));
+    s1 = *reinterpret_cast<const float4*>(mrow + min(j + 4, N - 4));
+  };
+  auto stage_commit = [&](int buf) {
+    float* d = Mtile + (size_t)buf * NR * TS + srow * TS + 8 * sq;
+    *reinterpret_cast<float4*>(d) = s0;
+    *reinterpret_cast<float4*>(d + 4) = s1;
+  };
+  stage_load(0);
+  stage_commit(0);
+  __syncthreads();
+
+  const size_t plane = (size_t)B * N;
+  float* fin_out = work + (size_t)g * plane + (size_t)b * N;
+  float* e_out = work + (size_t)(4 + g) * plane + (size_t)b * N;
+  float pot = 0.f;
+  int buf = 0;
+  for (int s = 0; s < n_eps + 2; ++s) {
+    const bool final_sweep = (s == n_eps + 1);
+    const float eps = eps_s[(s == 0) ? 0 : min(s - 1, n_eps - 1)];
+    const float eps_next = eps_s[min(s, n_eps - 1)];
+    const float nie2 = -kLog2e / eps, k_next = kLog2e / eps_next;
+    const float* hsrc = h2 + (s & 1) * 2 * NP + gl * NP;
+    float* hdst = h2 + ((s + 1) & 1) * 2 * NP + consumer_l * NP;
+    float m_run = -INFINITY, s_run = 0.f, tq_run = 0.f;
+    for (int tile = 0; tile < ntiles; ++tile) {
+      stage_load(tile + 1 < ntiles ? tile + 1 : 0);   // wraps: the first tile of the next sweep
+      __builtin_amdgcn_sched_barrier(0);
+      const int j0 = tile * TJ + 16 * part;
+      const float* mt = Mtile + (size_t)buf * NR * TS + min(i, NR - 1) * TS + 16 * part;
+      float tv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 mv = *reinterpret_cast<const float4*>(mt + 4 * u);
+        const float4 qv = *reinterpret_cast<const float4*>(Q + j0 + 4 * u);      // pads of pts / h2 are zero-filled
+        const float4 hv = *reinterpret_cast<const float4*>(hsrc + j0 + 4 * u);
+        const bool jv = j0 + 4 * u < N;
+        tv[4 * u + 0] = jv ? fmaf(cost_ij(pi, qv.x, mv.x), nie2, hv.x) : -INFINITY;
+        tv[4 * u + 1] = jv ? fmaf(cost_ij(pi, qv.y, mv.y), nie2, hv.y) : -INFINITY;
+        tv[4 * u + 2] = jv ? fmaf(cost_ij(pi, qv.z, mv.z), nie2, hv.z) : -INFINITY;
+        tv[4 * u + 3] = jv ? fmaf(cost_ij(pi, qv.w, mv.w), nie2, hv.w) : -INFINITY;
+        mx = fmaxf(fmaxf(mx, fmaxf(tv[4 * u], tv[4 * u + 1])), fmaxf(tv[4 * u + 2], tv[4 * u + 3]));
+      }
+      const float m_new = fmaxf(m_run, mx);   // finite from the first tile on (its first columns are always valid)
+      const float rescale = __builtin_amdgcn_exp2f(m_run - m_new);
+      float sA = 0.f, sB = 0.f, qA = 0.f, qB = 0.f;
+      if (!final_sweep) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          sA += __builtin_amdgcn_exp2f(tv[u] - m_new);
+          sB += __builtin_amdgcn_exp2f(tv[u + 1] - m_new);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(tv[u] - m_new), e1 = __builtin_amdgcn_exp2f(tv[u + 1] - m_new);
+          sA += e0;
+          sB += e1;
+          qA = fmaf(e0, Q[j0 + u], qA);
+          qB = fmaf(e1, Q[j0 + u + 1], qB);
+        }
+      }
+      s_run = fmaf(s_run, rescale, sA + sB);
+      tq_run = fmaf(tq_run, rescale, qA + qB);
+      m_run = m_new;
+      __builtin_amdgcn_sched_barrier(0);
+      stage_commit(buf ^ 1);
+      eml::lds_barrier();
+      buf ^= 1;
+    }
+    float m = m_run, sum = s_run, tq = tq_run;
+    if constexpr (LPR == 2) {   // the two lanes of a row are DPP neighbours
+      const float mo = eml::lane_xor1(m_run), so = eml::lane_xor1(s_run), qo = eml::lane_xor1(tq_run);
+      m = fmaxf(m_run, mo);
+      const float fa = __builtin_amdgcn_exp2f(m_run - m), fb = __builtin_amdgcn_exp2f(mo - m);
+      sum = s_run * fa + so * fb;
+      tq = tq_run * fa + qo * fb;
+    }
+    const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
+    if (final_sweep) {
+      if (owner) {
+        fin_out[i] = sm;
+        e_out[i] = tq / sum;
+      }
+    } else {
+      pot = (s == 0) ? sm : 0.5f * (pot + sm);
+      if (owner) hdst[i] = fmaf(pot, k_next, lw2_rows[i]);
+    }
+    __syncthreads();
+  }
+}
+
 // loss_b = <alpha, b_x - a_x> + <beta, a_y - b_y>  (sinkhorn_divergence.py:65-69) and the
 // analytic backward of the last extrapolation: the gradient reaches x only through the final
 // xx / xy softmins and only through the cost's first argument (utils.py:88), and since the
@@ -443,6 +608,21 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
                        alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+  } else if (N <= 512 && (N & 3) == 0) {
+    // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
+    const int lpr = N <= 256 ? 2 : 1;
+    lds = (size_t)(8 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
+    if (lpr == 2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
+                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
+                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+    }
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
