@@ -25,32 +25,17 @@ def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
             "work": torch.empty(8, B, N, **f32)}
 
 
-_SYNC = {}
-
-
-def _arrival_counters(B, dev):
-    """Zero-filled ONCE per (batch, device, stream): the loop kernel's per-sample arrival counters advance by 2 per call
-    and never need a reset (include/emlight_hip.h).  One buffer per stream, since calls must be stream-ordered."""
-    st = _lib.current_stream()
-    key = (B, str(dev), st.value if st is not None else None)
-    buf = _SYNC.get(key)
-    if buf is None:
-        buf = _SYNC[key] = torch.zeros(B, dtype=torch.int32, device=dev)
-    return buf
-
-
 def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False, out=None):
-    """One call into the HIP library -- one kernel; returns every device-side output (no autograd).  ``out``: buffers
-    from ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches)."""
+    """One call into the HIP library; returns every device-side output (no autograd).  ``out``: buffers from
+    ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches)."""
     L = _lib.lib()
     B, N = x.shape
     o = out if out is not None else sinkhorn_outputs(B, N, x.device, need_gx, need_gy)
-    sync = _arrival_counters(B, x.device)
     _lib.check(L.eml_sinkhorn_fwd_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
         float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
         _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
-        _lib.ptr(o["gy"]), _lib.ptr(o["work"]), _lib.ptr(sync), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
+        _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
     return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
             "diameter": o["diameter"], "duals": o["work"][:4]}
 

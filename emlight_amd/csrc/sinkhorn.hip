@@ -5,9 +5,8 @@
 // step costs 4 materialised (B,N,N) cost tensors and ~200-300 tiny ATen launches
 // (4*(n_eps+2) softmins x ~6 ops) plus a .item() host sync for the diameter.
 //
-// Here one C-ABI call enqueues ONE kernel: the loop kernel derives the diameter and the epsilon schedule on the
-// device (redundantly per workgroup), and the last-arriving of a sample's two workgroups computes its loss and unit
-// gradients (finish_by_last_arriver; without a `sync` buffer a tiny finishing kernel is launched instead).  The four coupled
+// Here one C-ABI call enqueues the loop kernel (which also derives the diameter and the epsilon
+// schedule on the device, redundantly per workgroup) + a tiny finishing kernel.  The four coupled
 // softmin problems      g=0 xx -> a_x   g=1 yy -> b_y   g=2 yx -> a_y   g=3 xy -> b_x
 // each own 8 wavefronts (512 threads); a sample is two 1024-thread workgroups -- role 0 runs
 // the independent pair (xx, yy), role 1 the coupled pair (yx, xy) -- so 2*B workgroups spread
@@ -50,50 +49,6 @@ __device__ __forceinline__ float cost_ij(float p, float q, float m) {
 //   h2  [2][2][NP] double-buffered log2(e)*(log w + f/eps), per consuming local group
 //   pot [2][NP]  potentials (stream kernel)      M [N][ldm] (cached kernel)
 constexpr int kSmemVecs = 2 + 2 + 4 + 2;
-
-// ---- loss and unit gradients of sample b, computed by whichever of the sample's two workgroups finishes LAST (so the
-// separate finishing launch -- 4.4 us + a launch gap on a 27 us loop -- disappears).  Hand-off: every thread's stores
-// to `work` are released at agent scope, the workgroup meets at a barrier, one lane bumps the sample's arrival counter;
-// the workgroup that reads an odd count is second: it acquires and reads both halves.  The counter only ever advances
-// by 2 per call, so it needs no reset (the caller zero-fills it once); nobody waits on anybody, so no dispatch-order or
-// residency assumption is made.
-//   loss_b = <alpha, b_x - a_x> + <beta, a_y - b_y>   (sinkhorn_divergence.py:65-69)
-//   dL_b/dx_i = alpha_i * 0.1 * (E^xx_i[x] - E^xy_i[y])  (same for y) -- see sinkhorn_finish_kernel
-template <int kWG>
-__device__ __forceinline__ void finish_by_last_arriver(const float* __restrict__ work, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, float* __restrict__ loss,
-                                                       float* __restrict__ gx, float* __restrict__ gy,
-                                                       int* __restrict__ sync, int b, int B, int N) {
-  __shared__ int second_s;
-  __shared__ float red_s[kWG / 64];
-  const int tid = threadIdx.x;
-  __threadfence();   // release this thread's potentials / E rows
-  __syncthreads();
-  if (tid == 0) second_s = __hip_atomic_fetch_add(&sync[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) & 1;
-  __syncthreads();
-  if (!second_s) return;
-  __threadfence();   // acquire the other workgroup's half
-  const size_t plane = (size_t)B * N, row = (size_t)b * N;
-  const float unif = 1.0f / (float)N;
-  float part = 0.f;
-  for (int k = tid; k < N; k += kWG) {
-    const size_t o = row + k;
-    const float a_x = work[o], b_y = work[plane + o], a_y = work[2 * plane + o], b_x = work[3 * plane + o];
-    const float al = alpha ? alpha[o] : unif, be = beta ? beta[o] : unif;
-    part += al * (b_x - a_x) + be * (a_y - b_y);
-    if (gx) gx[o] = al * 0.1f * (work[4 * plane + o] - work[7 * plane + o]);
-    if (gy) gy[o] = be * 0.1f * (work[5 * plane + o] - work[6 * plane + o]);
-  }
-  part = eml::wave_sum(part);
-  if ((tid & 63) == 0) red_s[tid >> 6] = part;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWG / 64; ++w) t += red_s[w];
-    loss[b] = t;
-  }
-}
 
 // ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
 // d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
@@ -171,8 +126,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     const float* __restrict__ Mt, const float* __restrict__ alpha, const float* __restrict__ beta,
     double blur, double scaling, int p_exp, double diameter, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
-    float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N, float* __restrict__ loss,
-    float* __restrict__ gx, float* __restrict__ gy, int* __restrict__ sync) {
+    float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
   constexpr int kGT = kCached ? 512 : 256;  // threads per softmin group
   constexpr int kWG = 2 * kGT;              // two groups per workgroup
   __shared__ float eps_l[EML_MAX_EPS];
@@ -361,7 +315,6 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     }
     __syncthreads();
   }
-  if (sync) finish_by_last_arriver<kWG>(work, alpha, beta, loss, gx, gy, sync, b, B, N);
 }
 
 // ---- "tiled" kernel, 128 < N <= 512 (N % 4 == 0): the N x N cost blocks do not fit registers any more, so the chord
@@ -375,8 +328,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
     const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double scaling, int p_exp,
     double diameter, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
-    float* __restrict__ work, int B, int N, float* __restrict__ loss, float* __restrict__ gx, float* __restrict__ gy,
-    int* __restrict__ sync) {
+    float* __restrict__ work, int B, int N) {
   constexpr int kGT = 512, kWG = 1024;
   constexpr int NR = 512 / LPR;            // row capacity of a softmin group
   constexpr int TJ = 16 * LPR;             // tile columns; every lane folds 16 of them
@@ -532,7 +484,6 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
     }
     __syncthreads();
   }
-  if (sync) finish_by_last_arriver<kWG>(work, alpha, beta, loss, gx, gy, sync, b, B, N);
 }
 
 // loss_b = <alpha, b_x - a_x> + <beta, a_y - b_y>  (sinkhorn_divergence.py:65-69) and the
@@ -653,7 +604,7 @@ extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)8 * B 
 extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                                     const float* alpha, const float* beta, double blur, double scaling, int p,
                                     double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
-                                    float* loss, float* gx, float* gy, float* work, int* sync, int B, int N,
+                                    float* loss, float* gx, float* gy, float* work, int B, int N,
                                     eml_stream_t stream) {
   if (!x || !y || !M || !Mt || !loss || !work) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
   if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
@@ -667,7 +618,7 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N, loss, gx, gy, sync);
+                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   } else if (N <= 512 && (N & 3) == 0) {
     // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
     const int lpr = N <= 256 ? 2 : 1;
@@ -676,21 +627,21 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N, loss, gx, gy, sync);
+                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N, loss, gx, gy, sync);
+                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
     }
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N, loss, gx, gy, sync);
+                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   }
   int rc = eml::check_launch("eml_sinkhorn_fwd_f32(loop)");
-  if (rc || sync) return rc;   // sync != NULL: the loop kernel's last-arriving workgroup of each sample finished it
+  if (rc) return rc;
   hipLaunchKernelGGL(sinkhorn_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, work, alpha, beta, loss,
                      gx, gy, B, N);
   return eml::check_launch("eml_sinkhorn_fwd_f32(finish)");

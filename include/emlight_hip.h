@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 6
+#define EML_ABI_VERSION 5
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -73,7 +73,7 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
                               double scaling, int p, double diameter, float* eps_out,
                               int* n_eps_out, float* diameter_out, eml_stream_t stream);
 
-/* Whole debiased Sinkhorn divergence in one call (ONE kernel when `sync` is given): the diameter and the
+/* Whole debiased Sinkhorn divergence in one call (loop kernel + finishing kernel): the diameter and the
  * epsilon schedule (as eml_sinkhorn_schedule_f32, computed inside the loop kernel), cost build
  * C = .5*(.1*(x_i-y_j)^2 + M_ij) (never materialised in HBM), init sweep, n_eps symmetrised eps-scaling
  * sweeps, last extrapolation, loss_b = <alpha,b_x-a_x> + <beta,a_y-b_y>, and the analytic gradients
@@ -89,16 +89,12 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
  *   loss        (B)
  *   gx, gy      (B,N)  d loss_b / d x_i, d loss_b / d y_j, or NULL
  *   work        (8,B,N) caller-owned scratch, eml_sinkhorn_work_floats(B,N) floats; on return
- *                      planes 0..3 hold the final duals a_x, b_y, a_y, b_x
- *   sync        (B) ints, or NULL.  Arrival counters of the samples' two workgroups: the caller zero-fills the buffer
- *                      ONCE and hands the same buffer to later calls on the same stream (each call advances every
- *                      counter by 2; the second-arriving workgroup of a sample computes its loss and gradients inside
- *                      the loop kernel).  NULL: a separate finishing kernel is launched instead. */
+ *                      planes 0..3 hold the final duals a_x, b_y, a_y, b_x */
 size_t eml_sinkhorn_work_floats(int B, int N);
 int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                          const float* alpha, const float* beta, double blur, double scaling, int p,
                          double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
-                         float* loss, float* gx, float* gy, float* work, int* sync, int B, int N,
+                         float* loss, float* gx, float* gy, float* work, int B, int N,
                          eml_stream_t stream);
 
 /* Backward of the loss vector: gout[b,i] = gloss[b] * gunit[b,i]  (gunit = gx or gy above). */

@@ -152,31 +152,3 @@ def test_gmloss_samples_loss_matches_reference_golden():
         np.testing.assert_allclose(loss.detach().cpu().numpy(), g[name + "/loss"], rtol=0, atol=1e-6)
         loss.sum().backward()
         np.testing.assert_allclose(x.grad.cpu().numpy().reshape(B, 128), g[name + "/grad_x"], rtol=1e-4, atol=1e-7)
-
-
-@pytest.mark.parametrize("B,n", [(64, 128), (5, 33), (16, 256), (2, 202)])
-def test_in_kernel_finish_equals_the_finishing_kernel(B, n):
-    """eml_sinkhorn_fwd_f32 with a `sync` buffer (loss / gradients computed by the last-arriving workgroup of each
-    sample inside the loop kernel) against sync == NULL (separate finishing kernel): bitwise equal, over repeated calls
-    on one counter buffer (it advances by 2 per call and is never reset)."""
-    from emlight_amd import _lib
-    from emlight_amd.RegressionNetwork.geomloss.samples_loss import sinkhorn_outputs
-    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-    g = torch.Generator().manual_seed(3)
-    x = torch.softmax(torch.randn(B, n, generator=g), 1).cuda()
-    y = torch.softmax(2 * torch.randn(B, n, generator=g), 1).cuda()
-    M, _ = _crit(n, .05).cost_matrix(x.device)
-    sync = torch.zeros(B, dtype=torch.int32, device="cuda")
-
-    def run(sync_buf):
-        o = sinkhorn_outputs(B, n, x.device, True, True)
-        _lib.check(L.eml_sinkhorn_fwd_f32(p(x), p(y), p(M), p(M), None, None, .05, .5, 2, -1.0, p(o["eps_s"]), p(o["n_eps"]),
-                                          p(o["diameter"]), p(o["loss"]), p(o["gx"]), p(o["gy"]), p(o["work"]), p(sync_buf), B, n,
-                                          st), "fwd")
-        return o
-    ref = run(None)
-    for call in range(1, 4):
-        o = run(sync)
-        for k in ("loss", "gx", "gy"):
-            assert torch.equal(o[k], ref[k]), (k, call)
-        assert bool((sync == 2 * call).all())
