@@ -82,6 +82,36 @@ class SphereGeometry:
         self.csr_w = wk[order].contiguous()
         self.csr_ptr = torch.zeros(h * w + 1, dtype=torch.int32, device=device)
         self.csr_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=h * w), 0).to(torch.int32)
+        self._transposed = None
+
+    def transposed_table(self):
+        """The tap table seen from the INPUT pixels, for the fused input-gradient kernel: for input pixel q and tap t the
+        (at most ke) output pixels whose tap t samples q with their bilinear weights, padded with (-1, 0).  Almost every
+        (q, t) has exactly 4 entries at stride 1; the rows next to the poles have up to 8 (``rowmax`` tells the kernel
+        which tiles need slots 4..7).  Returns None when a (q, t) has more than 8 entries (tiny geometries)."""
+        if self._transposed is None:
+            hw = self.h * self.w
+            dst = self.idx.view(-1).long()
+            keep = dst >= 0
+            src = torch.arange(self.idx.shape[0], device=dst.device).repeat_interleave(4)[keep]
+            key = dst[keep] * 9 + src % 9                       # (input pixel, tap)
+            order = torch.argsort(key, stable=True)
+            key, pix, wk = key[order], (src // 9)[order], self.wgt.view(-1)[keep][order]
+            counts = torch.bincount(key, minlength=hw * 9)
+            kmax = int(counts.max())
+            if kmax > 8:
+                self._transposed = (None,)
+            else:
+                ke = 4 if kmax <= 4 else 8
+                first = torch.cumsum(counts, 0) - counts
+                rank = torch.arange(key.numel(), device=key.device) - first[key]
+                tidx = torch.full((hw * 9, ke), -1, dtype=torch.int32, device=key.device)
+                twgt = torch.zeros(hw * 9, ke, dtype=torch.float32, device=key.device)
+                tidx[key, rank] = pix.to(torch.int32)
+                twgt[key, rank] = wk
+                rowmax = counts.view(hw, 9).max(1).values.to(torch.uint8).contiguous()
+                self._transposed = (tidx.contiguous(), twgt.contiguous(), rowmax, ke)
+        return self._transposed if self._transposed[0] is not None else None
 
 
 _GEOMETRY = {}
@@ -133,6 +163,9 @@ class _SphereConvFn(torch.autograd.Function):
         lim = SphereConv2D.fused_min_bytes
         ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
                          (a9_bytes >= 32 * lim or (O <= 128 and a9_bytes >= lim)))
+        # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C)
+        ctx.fused_dgrad = (B > 0 and O % 32 == 0 and C % 64 == 0 and stride == 1 and
+                           B * po * 9 * max(C, O) * 4 >= SphereConv2D.fused_dgrad_factor * lim)
         # weight gradient: K = pixels; below ~32k pixels the split-K tiles are short and the library's long-K GEMM wins
         ctx.fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
                            (B * po >= 32768 or lim == 0))
@@ -182,12 +215,20 @@ class _SphereConvFn(torch.autograd.Function):
                 gw = (a9.t() @ gyr).view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
                 del a9
         if ctx.needs_input_grad[0]:
-            w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
-            da9 = gyr @ w2                                           # (B*Po, 9C)
             gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
-            if B:
-                _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
-                                                   H * W, po, C, st), "eml_sphere_col2im_f32")
+            tt = geo.transposed_table() if (ctx.fused_dgrad and B) else None
+            if tt is not None:
+                # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
+                tidx, twgt, rowmax, ke = tt
+                w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
+                _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gyr), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gxr), B,
+                                                             H * W, po, C, O, st), "eml_sphere_conv_dgrad_fused_f32")
+            else:
+                w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
+                da9 = gyr @ w2                                           # (B*Po, 9C)
+                if B:
+                    _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
+                                                       H * W, po, C, st), "eml_sphere_col2im_f32")
             gx = gxr.permute(0, 3, 1, 2)
         return gx, gw, gb, None
 
@@ -370,6 +411,7 @@ class SphereConv2D(nn.Module):
 
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
     fused_min_bytes = 64 << 20   # unit of the fused-kernel thresholds on the size of the im2col operand (see forward)
+    fused_dgrad_factor = 4       # fused input gradient above this many units (tools/sphere_layers.py)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

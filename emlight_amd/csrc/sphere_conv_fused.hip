@@ -4,6 +4,8 @@
 // Reference: models/networks/spherenet/sphere_cnn.py:111-124,  y = conv2d(grid_sample(x, grid), w, b, stride=3).
 //
 //   forward   Y[m][o]        = bias[o] + sum_{tap,c} Ag[m][tap][c] * W2[o][tap*C + c]
+//   dgrad     dX[q][c]       = sum_{tap,o} Dg[q][tap][o] * W2[o][tap*C + c]     (Dg: dY gathered through the transposed
+//                              table -- the forward kernel with the roles of the two pixel grids swapped)
 //   wgrad     dW2[o][tap*C+c] = sum_m dY[m][o] * Ag[m][tap][c]
 //   with      Ag[m][tap][c]  = sum_{k<4} wgt[p,tap,k] * X[b][idx[p,tap,k]][c],   m = b*Po + p   (the tap table of
 //                              eml_sphere_tap_table_f32: grid_sample's own corners and weights; -1 = zero padding)
@@ -55,11 +57,17 @@ __device__ __forceinline__ float4 combine(const float4 (&v)[4], const float4& w)
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// The same kernel serves the INPUT gradient: dx[q][c] = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o] with
+// Dg[q][tap][o] = sum_e w_e dY[p_e][o] gathered through the TRANSPOSED tap table (entries of input pixel q grouped by
+// tap: almost always 4, up to 8 in the few rows next to the poles).  `ke` = table entries per (pixel, tap): 4, or 8 with
+// `rowmax` (per destination pixel: its largest entry count) telling a tile whether any of its pixels needs the second
+// group of four at all (block-uniform; those tiles fetch it at commit time).
 template <int BN>
 __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
-    int HW, int Po, int C, int O) {
+    int HW /* source pixels per sample */, int Po /* destination pixels per sample */, int C, int O, int ke,
+    const unsigned char* __restrict__ rowmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][kBM][kLdF]
   float* Bs = smem + 2 * kBM * kLdF;      // [2][BN][kLdF]
@@ -74,8 +82,9 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   const int ms = min(m0 + sp, M - 1);
   const int sb = ms / Po, spix = ms - sb * Po;
   const float* xb = X + (size_t)sb * HW * C + 16 * half;
-  const int* idp = idx + (size_t)spix * 36;
-  const float* wgp = wgt + (size_t)spix * 36;
+  const int* idp = idx + (size_t)spix * 9 * ke;
+  const float* wgp = wgt + (size_t)spix * 9 * ke;
+  const bool ng2 = (ke == 8) && __syncthreads_or(rowmax ? rowmax[spix] > 4 : 1);   // block-uniform
   const bool stage_b = tid < 2 * BN;
   const float* wrow = W2 + (size_t)(o0 + min(sp, BN - 1)) * 9 * C + 16 * half;
 
@@ -84,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
 
   auto load_tap = [&](int tap) {
     Tap t;
-    t.id = *reinterpret_cast<const int4*>(idp + 4 * tap);
-    t.w = *reinterpret_cast<const float4*>(wgp + 4 * tap);
+    t.id = *reinterpret_cast<const int4*>(idp + ke * tap);
+    t.w = *reinterpret_cast<const float4*>(wgp + ke * tap);
     return t;
   };
   float4 av[4][4];          // in-flight operands of the next chunk: A[corner][j] ...
@@ -105,13 +114,37 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     bv2 = *reinterpret_cast<const float4*>(ws + 8);
     bv3 = *reinterpret_cast<const float4*>(ws + 12);
   };
-  auto commit_chunk = [&](int buf, const Tap& t) {
+  auto commit_chunk = [&](int buf, const Tap& t, int chunk) {
     float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
+    float4 out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
-      *reinterpret_cast<float4*>(ad + 4 * j) = combine(v, t.w);
+      out[j] = combine(v, t.w);
     }
+    if (ng2) {   // rare tiles (pole rows of the transposed table): entries 4..7 of this (pixel, tap), latency exposed
+      const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
+      const int4 id2 = *reinterpret_cast<const int4*>(idp + ke * tap + 4);
+      const float4 w2 = *reinterpret_cast<const float4*>(wgp + ke * tap + 4);
+      const int ids[4] = {id2.x, id2.y, id2.z, id2.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* src = xb + (size_t)max(ids[k], 0) * C + c0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
+        const float4 e = combine(v, w2);
+        out[j].x += e.x;
+        out[j].y += e.y;
+        out[j].z += e.z;
+        out[j].w += e.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(ad + 4 * j) = out[j];
     if (stage_b) {
       float* bd = Bs + (size_t)buf * BN * kLdF + sp * kLdF + 16 * half;
       *reinterpret_cast<float4*>(bd) = bv0;
@@ -132,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   Tap t_use = load_tap(0);
   Tap t_pref = load_tap(1);
   load_chunk(0, t_use);
-  commit_chunk(0, t_use);
+  commit_chunk(0, t_use, 0);
   __syncthreads();
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
@@ -163,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
           for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(f4c(bf[ni], t), f4c(af[mi], t), acc[ni][mi]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (has_next) commit_chunk(buf ^ 1, t_use);
+    if (has_next) commit_chunk(buf ^ 1, t_use, nxt);
     eml::lds_barrier();
   }
   // epilogue: lane (r, kk) owns output channels 4kk..4kk+3 of tile ni for pixel r of tile mi
@@ -325,14 +358,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
-                                             const float* bias, float* Y, int B, int HW, int Po, int C, int O,
-                                             eml_stream_t stream) {
-  if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
-    return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
+namespace {
+int launch_gather_gemm(const char* what, const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
+                       float* Y, int B, int HW, int Po, int C, int O, int ke, const unsigned char* rowmax,
+                       eml_stream_t stream) {
   if (B == 0) return EML_OK;
   const long M = (long)B * Po;
-  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: too many pixels");
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
   const int bn = (O % 128 == 0) ? 128 : 64;
   const size_t lds = (size_t)(2 * kBM * kLdF + 2 * bn * kLdF) * sizeof(float);
   const dim3 grid((unsigned)((M + kBM - 1) / kBM), O / bn);
@@ -340,14 +372,37 @@ extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, con
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
-                       Y, (int)M, HW, Po, C, O);
+                       Y, (int)M, HW, Po, C, O, ke, rowmax);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<64>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
-                       Y, (int)M, HW, Po, C, O);
+                       Y, (int)M, HW, Po, C, O, ke, rowmax);
   }
-  return eml::check_launch("eml_sphere_conv_fwd_fused_f32");
+  return eml::check_launch(what);
+}
+}  // namespace
+
+extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                             const float* bias, float* Y, int B, int HW, int Po, int C, int O,
+                                             eml_stream_t stream) {
+  if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
+  return launch_gather_gemm("eml_sphere_conv_fwd_fused_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, 4, nullptr, stream);
+}
+
+// dX (B*HW, C) = gather-GEMM over the transposed tap table: tidx / twgt (HW*9*ke) = for input pixel q and tap t the
+// output pixels whose tap t samples q (-1 = empty slot, weight 0) and their bilinear weights; W2t (C, 9*O), columns (tap, o)
+extern "C" int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const float* twgt,
+                                               const unsigned char* rowmax, int ke, const float* W2t, float* dX, int B,
+                                               int HW, int Po, int C, int O, eml_stream_t stream) {
+  if (!dY || !tidx || !twgt || !W2t || !dX || B < 0 || HW < 1 || Po < 1 || O < 32 || (O % 32) || C < 64 || (C % 64) ||
+      (ke != 4 && ke != 8) || (ke == 8 && !rowmax))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_dgrad_fused_f32: need O %% 32 == 0, C %% 64 == 0, ke in {4, 8} (C=%d, O=%d)",
+                     C, O);
+  // roles swap: the rows gathered are dY's (Po per sample, O wide), the destination pixels are the HW input pixels
+  return launch_gather_gemm("eml_sphere_conv_dgrad_fused_f32", dY, tidx, twgt, W2t, nullptr, dX, B, Po, HW, O, C, ke, rowmax,
+                            stream);
 }
 
 extern "C" size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k) {

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 5
+#define EML_ABI_VERSION 6
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -295,6 +295,14 @@ int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, cons
 int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                   const float* bias, float* Y, int B, int HW, int Po, int C, int O,
                                   eml_stream_t stream);
+/* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
+ * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
+ * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the
+ * largest slot count over its taps, so that only tiles with pole rows fetch slots 4..7.  W2t (C, 9*O) = weight.permute(1,2,3,0).
+ * O % 32 == 0, C % 64 == 0.  Deterministic (a gather, no atomics); neither dA9 nor its col2im pass exist. */
+int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const float* twgt, const unsigned char* rowmax,
+                                    int ke, const float* W2t, float* dX, int B, int HW, int Po, int C, int O,
+                                    eml_stream_t stream);
 size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k);
 int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, const float* wgt, const float* dY,
                                     float* partial, float* dW2, int B, int HW, int Po, int C, int O,

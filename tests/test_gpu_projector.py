@@ -74,7 +74,8 @@ def test_sphere_conv_hip_vs_stock_ops(B, Cin, Cout, H, W, stride, bias):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride,bias", [(2, 32, 64, 8, 16, 1, True), (2, 64, 128, 16, 32, 1, True),
                                                         (3, 128, 64, 16, 32, 2, False), (1, 64, 192, 6, 10, 1, True),
-                                                        (2, 256, 256, 8, 16, 1, True), (1, 96, 64, 12, 20, 1, True)])
+                                                        (2, 256, 256, 8, 16, 1, True), (1, 96, 64, 12, 20, 1, True),
+                                                        (1, 64, 64, 64, 128, 1, True), (2, 128, 64, 32, 64, 1, False)])
 def test_sphere_conv_fused_kernels_vs_stock_ops(B, Cin, Cout, H, W, stride, bias, monkeypatch):
     """The fused implicit-GEMM kernels (taps gathered straight into the MFMA operand tile: forward, and the weight
     gradient where Cin % 64 == 0) against grid_sample + conv2d(stride 3) in torch f32 on the same GPU; pixel counts that
@@ -114,6 +115,9 @@ def test_sphere_conv_fused_kernels_vs_stock_ops(B, Cin, Cout, H, W, stride, bias
     yr.backward(gy)
     yh.backward(gy)
     assert "eml_sphere_conv_fwd_fused_f32" in seen
+    # the fused input gradient: stride-1 layers with Cout % 32 == 0 and Cin % 64 == 0 (else dY W2 + col2im)
+    assert ("eml_sphere_conv_dgrad_fused_f32" in seen) == (stride == 1 and Cin % 64 == 0)
+    assert ("eml_sphere_col2im_f32" in seen) != ("eml_sphere_conv_dgrad_fused_f32" in seen)
     assert ("eml_sphere_conv_wgrad_fused_f32" in seen) == (Cin % 64 == 0)
     assert ("eml_sphere_im2col_f32" in seen) == (Cin % 64 != 0)   # A9 is rebuilt only where the fused wgrad does not tile
     for name, a, b in [("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, ref.weight.grad)] + \

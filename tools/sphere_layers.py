@@ -1,5 +1,5 @@
 """Per-layer timing of SphereConv2D at the projector's shapes (B = 32, cfg3): fused implicit-GEMM kernels vs the
-unfused im2col + library-GEMM path, forward and weight gradient.  Writes one JSON line per layer (profiles/ evidence
+unfused im2col + library-GEMM (+ col2im) path: forward, weight gradient, input gradient.  Writes one JSON line per layer (profiles/ evidence
 for which path each shape takes).    python tools/sphere_layers.py [B]"""
 import json
 import os
@@ -53,12 +53,13 @@ for name, C, O, H, W, stride in LAYERS:
         SphereConv2D.fused_min_bytes = thr
         with torch.no_grad():
             t_f = events(lambda: m(x))
-        xg = x.clone().requires_grad_(False)
+        xg = x.clone().requires_grad_(True)
         y = m(xg)
         gy = torch.randn_like(y)
         t_w = events(lambda: torch.autograd.grad(y, m.weight, gy, retain_graph=True))   # weight gradient only
+        t_d = events(lambda: torch.autograd.grad(y, xg, gy, retain_graph=True))         # input gradient only
         row[mode] = {"fwd_ms": round(t_f, 3), "fwd_tflops": round(gflop / t_f, 1), "wgrad_ms": round(t_w, 3),
-                     "wgrad_tflops": round(gflop / t_w, 1)}
+                     "wgrad_tflops": round(gflop / t_w, 1), "dgrad_ms": round(t_d, 3), "dgrad_tflops": round(gflop / t_d, 1)}
         del y, gy
     print(json.dumps(row), flush=True)
     del m, x
