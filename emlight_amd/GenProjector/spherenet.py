@@ -163,9 +163,10 @@ class _SphereConvFn(torch.autograd.Function):
         lim = SphereConv2D.fused_min_bytes
         ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
                          (a9_bytes >= 32 * lim or (O <= 128 and a9_bytes >= lim)))
-        # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C)
+        # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C).  Measured: it beats
+        # dY W2 (library) + col2im where the pixel count is large and O <= 256; wide heads (K = 9*O >= 4608) stay unfused
         ctx.fused_dgrad = (B > 0 and O % 32 == 0 and C % 64 == 0 and stride == 1 and
-                           B * po * 9 * max(C, O) * 4 >= SphereConv2D.fused_dgrad_factor * lim)
+                           (lim == 0 or (O <= 256 and B * po >= 131072)))
         # weight gradient: K = pixels; below ~32k pixels the split-K tiles are short and the library's long-K GEMM wins
         ctx.fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
                            (B * po >= 32768 or lim == 0))
@@ -411,7 +412,6 @@ class SphereConv2D(nn.Module):
 
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
     fused_min_bytes = 64 << 20   # unit of the fused-kernel thresholds on the size of the im2col operand (see forward)
-    fused_dgrad_factor = 4       # fused input gradient above this many units (tools/sphere_layers.py)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()
