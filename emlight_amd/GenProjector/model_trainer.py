@@ -5,6 +5,8 @@ its own process: G and D are wrapped in DistributedDataParallel (gradient all-re
 473 MB in 25 MB buckets overlapped with backward); SPADE's param-free BatchNorm all-reduces its (2C+1)-float sums
 itself (``spherenet.spade_batch_stats`` / the modulation's backward), which is what the vendored ``sync_batchnorm``
 package did."""
+import os
+
 import torch
 
 from .pix2pix_model import Pix2PixModel
@@ -52,6 +54,18 @@ class Trainer:
 
     def get_latest_losses(self):
         return {**self.g_losses, **self.d_losses}
+
+    def save(self, epoch, save_dir):
+        """``<epoch>_net_G.pth`` / ``<epoch>_net_D.pth`` (reference ``util.py:173-178``, ``pix2pix_model.py:66-70``)."""
+        os.makedirs(save_dir, exist_ok=True)
+        for label, net in (("G", self.model.netG), ("D", self.model.netD)):
+            torch.save(net.state_dict(), os.path.join(save_dir, "%s_net_%s.pth" % (epoch, label)))
+
+    def load(self, epoch, save_dir):
+        """Resume: ``--continue_train --which_epoch <epoch>`` (reference ``util.py:181-191``, ``pix2pix_model.py:80-88``)."""
+        dev = next(self.model.netG.parameters()).device
+        for label, net in (("G", self.model.netG), ("D", self.model.netD)):
+            net.load_state_dict(torch.load(os.path.join(save_dir, "%s_net_%s.pth" % (epoch, label)), map_location=dev))
 
     def update_learning_rate(self, epoch, niter=50, niter_decay=0):
         """Linear decay after ``niter`` epochs with TTUR (``model_trainer.py:68-88``)."""

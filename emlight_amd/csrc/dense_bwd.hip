@@ -1377,16 +1377,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
           rw[u] = raw[pu * ld_raw + c];
           ou[u] = relu ? out[pu * ld_out + c] : 1.f;
         }
-        float l1 = 0.f, l2 = 0.f;
+        // per-element f64 accumulation (the loads above are batched; only the converts / adds are per element)
+        const bool cv = lane + 64 * k < C;
 #pragma unroll
         for (int u = 0; u < kUN; ++u) {
-          const float d = (p0 + u < P && ou[u] > 0.f) ? dy[u] : 0.f;
-          l1 += d;
-          l2 = fmaf(d, (rw[u] - mu[k]) * is[k], l2);
-        }
-        if (lane + 64 * k < C) {
-          a1[k] += (double)l1;
-          a2[k] += (double)l2;
+          const float d = (cv && p0 + u < P && ou[u] > 0.f) ? dy[u] : 0.f;
+          a1[k] += (double)d;
+          a2[k] += (double)(d * ((rw[u] - mu[k]) * is[k]));
         }
       }
     }

@@ -520,18 +520,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (int k = 0; k < 6; ++k) {
       const int c = lane + 64 * k;
       if (k < nk && c < C) {
-        float ls = 0.f, lq = 0.f;
+        // per-element f64 accumulation (batched loads, per-element converts): sum and sum of squares of 4.9 M pixels
 #pragma unroll
         for (int u = 0; u < kUN; ++u)
           if (p0 + u < P) {
             float w = fmaf(v[u][k], s[k], t[k]);
             if (relu) w = fmaxf(w, 0.f);
             dst[(p0 + u) * ldd + c] = w;
-            ls += w;
-            lq = fmaf(w, w, lq);
+            const double wd = (double)w;
+            acc_s[k] += wd;
+            acc_q[k] = fma(wd, wd, acc_q[k]);
           }
-        acc_s[k] += (double)ls;
-        acc_q[k] += (double)lq;
       }
     }
   }

@@ -268,6 +268,8 @@ def test_training_curve_tracks_stock_op_oracle():
         tr = RegressionTrainer(anchors=32, crop_hw=(64, 96), blur=.05, device="cuda:0", lr=1e-3, model=model)
         tr.model.load_state_dict(sd)
         curves[eng] = np.array([float(tr.step(batches[i % 4])[0].detach()) for i in range(24)])
+    dev = np.abs(curves["hip"] / curves["aten"] - 1.0)
+    print("training curve: max relative deviation first 6 steps %.2e, all 24 steps %.2e" % (dev[:6].max(), dev.max()))
     assert curves["hip"][0] == pytest.approx(curves["aten"][0], rel=1e-5)
     np.testing.assert_allclose(curves["hip"][:6], curves["aten"][:6], rtol=0.01)
     # later steps: training at this rate is chaotic in f32 (a change in summation order moves single points by

@@ -104,3 +104,39 @@ def test_trainer_runs_one_iteration_and_reference_keys():
     assert set(losses) == {"GAN", "GAN_Feat", "COS", "D_Fake", "D_real"}
     assert all(torch.isfinite(v).all() for v in losses.values())
     assert not torch.equal(w0, tr.model.netG.sphere_conv1.weight.detach())
+
+
+def test_iteration_counter_and_resume(tmp_path):
+    """--continue_train plumbing (reference iter_counter.py:19-29,57-64 / util.py:173-191): iter.txt round trip, the
+    resumed epoch continues at the recorded offset, and <epoch>_net_{G,D}.pth reload bit-exactly."""
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.iter_counter import IterationCounter
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    ck, name = str(tmp_path), "run"
+    (tmp_path / name).mkdir()
+    c = IterationCounter(ck, name, dataset_size=40, batch_size=4, niter=3, continue_train=False, print_freq=8, save_latest_freq=12)
+    assert list(c.training_epochs()) == [1, 2, 3]
+    c.record_epoch_start(1)
+    hits = []
+    for _ in range(5):
+        c.record_one_iteration()
+        hits.append((c.needs_printing(), c.needs_saving()))
+    assert hits == [(False, False), (True, False), (False, True), (True, False), (False, False)]   # samples 4..20
+    c.record_current_iter()
+    r = IterationCounter(ck, name, dataset_size=40, batch_size=4, niter=3, continue_train=True)
+    assert (r.first_epoch, r.epoch_iter, r.total_steps_so_far) == (1, 20, 20)
+    r.record_epoch_start(1)
+    assert r.epoch_iter == 20            # the resumed epoch keeps its offset ...
+    r.record_epoch_start(2)
+    assert r.epoch_iter == 0             # ... later epochs start from 0
+    fresh = IterationCounter(ck, "missing", dataset_size=40, batch_size=4, niter=3, continue_train=True)
+    assert (fresh.first_epoch, fresh.epoch_iter) == (1, 0)
+
+    opt = networks.default_options(ngf=2, ndf=2)
+    a = Trainer(opt, device="cpu")
+    a.save("latest", str(tmp_path / name))
+    b = Trainer(opt, device="cpu")
+    b.load("latest", str(tmp_path / name))
+    for net_a, net_b in ((a.model.netG, b.model.netG), (a.model.netD, b.model.netD)):
+        for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
