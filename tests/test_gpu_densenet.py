@@ -10,11 +10,12 @@ import oracle
 pytestmark = pytest.mark.gpu
 OUT_ATOL = 1e-4
 # Sampled-entry error of the golden train-step gradients in units of the tensor's RMS gradient.  Measured on the
-# MI355X: worst 3.3e-2 (denseblock1.denselayer1.conv1.weight), median 1.4e-2.  That is the f32 conditioning of this
-# network's gradient, not a kernel defect: test_gradient_error_is_f32_conditioning below shows the reference's own
-# stock-op graph in f32 is just as far from the f64 gradient (relative L2 per tensor: median 1e-3..3e-3, up to 1e-2
-# on the norm weights, at 192x256 / 64x96 / 240x320).
-GOLDEN_GRAD_MAX, GOLDEN_GRAD_MEDIAN = 6e-2, 2.5e-2
+# MI355X: worst 6.8e-3 (conv0.weight), then 5.9e-3 (denseblock1.denselayer1.conv1.weight), 5.0e-3 (transition1.conv.weight);
+# head tensors 3e-6.  (With BatchNorm sums pre-accumulated over 4 pixels in f32 the worst was 3.3e-2 -- ADVICE round 1 was
+# right; they accumulate per element in f64 again.)  What remains is the f32 conditioning of this network's gradient:
+# test_gradient_error_is_f32_conditioning below shows the reference's own stock-op graph in f32 is just as far from the
+# f64 gradient (relative L2 per tensor: median 4e-4..3e-3, up to 1e-2..3e-2 on the norm weights).
+GOLDEN_GRAD_MAX, GOLDEN_GRAD_MEDIAN = 2e-2, 8e-3
 KEYS = ("distribution", "intensity", "rgb_ratio", "ambient")
 
 
@@ -258,7 +259,7 @@ def test_properties_at_full_baseline_size():
 def test_training_curve_tracks_stock_op_oracle():
     """24 Adam steps (10x the reference learning rate) with the HIP engine and with the oracle's stock-op encoder (run
     on the same GPU) from the same initial weights and batches: the loss curves stay together.  (Element-wise agreement is impossible across two f32
-    implementations of a ReLU network -- DESIGN.md section 4 -- so this bounds the drift of the whole training loop: measured 1-8 % per point, depending on summation order.)"""
+    implementations of a ReLU network -- DESIGN.md section 4 -- so this bounds the drift of the whole training loop: measured <= 6 % per point.)"""
     from emlight_amd.RegressionNetwork.data import synthetic_batch
     from emlight_amd.RegressionNetwork.engine import RegressionTrainer
     batches = [synthetic_batch(4, 32, (64, 96), seed=100 + i, device="cuda:0") for i in range(4)]
@@ -275,5 +276,5 @@ def test_training_curve_tracks_stock_op_oracle():
     np.testing.assert_allclose(curves["hip"][:6], curves["aten"][:6], rtol=0.01)
     # later steps: training at this rate is chaotic in f32 (a change in summation order moves single points by
     # several per cent), so the bound is loose; what matters is that the curves do not separate
-    np.testing.assert_allclose(curves["hip"], curves["aten"], rtol=0.2)
+    np.testing.assert_allclose(curves["hip"], curves["aten"], rtol=0.1)   # measured: 2.2e-3 over the first 6 steps, 5.8e-2 over all 24
     assert curves["hip"][-1] < 0.8 * curves["hip"][:8].max()  # and it trains

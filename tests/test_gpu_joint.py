@@ -141,9 +141,10 @@ def test_joint_step_properties_at_cfg4_size():
     g_only, _, _ = enc_grads(False, True)
     # exact in real arithmetic; in f32 the two upstream gradients take different rounding paths through ~100 layers
     # (measured 2.5e-3 of the tensor's largest entry, the conditioning of section 4 of DESIGN.md)
-    for gb, gr, gg in zip(both, reg_only, g_only):
-        s = float(gb.abs().max()) + 1e-20
-        assert float((gb - (gr + gg)).abs().max()) <= 1e-2 * s + 1e-9
+    rms = lambda t: float(t.double().square().mean().sqrt())
+    floor = 1e-2 * float(np.median([rms(g) for g in both]))   # tensors whose gradient nearly cancels: absolute scale
+    worst = max(rms(gb - (gr + gg)) / max(rms(gb), floor) for gb, gr, gg in zip(both, reg_only, g_only))
+    assert worst <= 2e-2, worst
     assert any(float(g.abs().max()) > 0 for g in g_only), "the generator losses must reach the encoder"
     want = predicted_gaussian_map({k: v.detach() for k, v in pred.items()}, ln)
     assert torch.equal(want, gmap)   # the rasteriser itself is bitwise reproducible
