@@ -16,6 +16,7 @@ OUT_ATOL = 1e-4
 # test_gradient_error_is_f32_conditioning below shows the reference's own stock-op graph in f32 is just as far from the
 # f64 gradient (relative L2 per tensor: median 4e-4..3e-3, up to 1e-2..3e-2 on the norm weights).
 GOLDEN_GRAD_MAX, GOLDEN_GRAD_MEDIAN = 2e-2, 8e-3
+GRAD_L2_MAX, GRAD_L2_MEDIAN = 2e-2, 4e-3   # per-tensor relative L2 vs the f32 oracle at toy sizes; measured max 9.6e-3, median 2.4e-3
 KEYS = ("distribution", "intensity", "rgb_ratio", "ambient")
 
 
@@ -177,7 +178,8 @@ def _grad_check(net, ref):
     """Whole-network gradient parity.  Two f32 implementations of a ReLU network cannot agree
     element-wise: forward values differ by ~1e-5 rel, so a few pre-activations per layer with
     |pre| < 1e-5 get the opposite ReLU mask (measured: exactly one channel of transition3.norm.bias
-    off by one element's gradient, every other channel < 5e-7).  The bounds below are therefore on
+    off by one element's gradient, every other channel < 5e-7) -- and, more importantly, the gradient of this network is
+    only conditioned to ~1e-3 in f32 (test_gradient_error_is_f32_conditioning).  The bounds below are therefore on
     the relative L2 error per tensor, scaled by the network's typical gradient magnitude so that
     analytically-zero gradients (last_norm{1,2}.bias feed only train-mode BNs) do not blow up;
     the per-kernel tests in test_gpu_dense_kernels.py hold each kernel to f32 round-off."""
@@ -190,8 +192,9 @@ def _grad_check(net, ref):
         assert np.isfinite(gg).all(), name
         errs.append((rms(gg - gr) / max(rms(gr), floor), name))
     errs.sort(reverse=True)
-    assert errs[0][0] < 5e-2, "largest relative L2 grad errors: %s" % errs[:8]
-    assert np.median([e for e, _ in errs]) < 5e-3, "median relative L2 grad error %g" % np.median([e for e, _ in errs])
+    print("whole-network gradient vs oracle: max rel-L2 %.2e (%s), median %.2e" % (errs[0][0], errs[0][1], np.median([e for e, _ in errs])))
+    assert errs[0][0] < GRAD_L2_MAX, "largest relative L2 grad errors: %s" % errs[:8]
+    assert np.median([e for e, _ in errs]) < GRAD_L2_MEDIAN, "median relative L2 grad error %g" % np.median([e for e, _ in errs])
 
 
 @pytest.mark.parametrize("crop_hw,B", [((64, 96), 2), ((32, 64), 3)])
