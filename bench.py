@@ -510,6 +510,7 @@ def main():
             out["sinkhorn_n256"] = time_sinkhorn(16, 256, args.blur, dev)   # configs[4]'s per-GPU shape: B=16, N=256
         if "rasteriser" in legs:
             out["rasteriser"] = time_rasteriser(args.projector_batch, args.anchors, (128, 256), dev)
+            out["rasteriser_n256"] = time_rasteriser(16, 256, (256, 512), dev)   # configs[4]'s per-GPU shape
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)

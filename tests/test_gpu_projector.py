@@ -145,10 +145,16 @@ def test_sphere_conv_hip_is_deterministic_and_has_no_cpu_path():
         SphereConv2D(8, 8)(torch.randn(1, 8, 16, 32))
 
 
-def test_projector_matches_reference_golden_on_hip_sphereconv():
+@pytest.mark.parametrize("force_fused", [False, True])
+def test_projector_matches_reference_golden_on_hip_sphereconv(force_fused, monkeypatch):
     """The golden vectors of the REAL reference networks (ngf = ndf = 8, tests/golden/projector.npz) through the
-    HIP SphereConv2D path: generator output, losses, parameter-gradient samples, discriminator losses."""
+    HIP SphereConv2D path: generator output, losses, parameter-gradient samples, discriminator losses.  force_fused:
+    every layer whose channel counts tile takes the fused gather-GEMM kernels (forward, weight and input gradient), which
+    at this width would otherwise only serve the large layers."""
     from tests.conftest import Golden
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    if force_fused:
+        monkeypatch.setattr(SphereConv2D, "fused_min_bytes", 0)
     from tests.golden.make_golden import projector_inputs
     from emlight_amd.GenProjector import networks
     from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
