@@ -21,6 +21,8 @@
 //            ds_read_b32 on disjoint bank quarters); split-K over blockIdx.z, partials + a deterministic reduction.
 #include "eml_common.h"
 
+#include <type_traits>
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -99,20 +101,40 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   };
   float4 av[4][4];          // in-flight operands of the next chunk: A[corner][j] ...
   float4 bv0, bv1, bv2, bv3;  // ... and B (named scalars: as an array the compiler parked them in scratch)
-  auto load_chunk = [&](int chunk, const Tap& t) {
+  // the 20 operand loads of a chunk, one at a time: the main loop issues them BETWEEN MFMAs.  Issued back to back
+  // in front of the MFMA block they held every wave at the texture-address unit (one 1-KB wave load per ~16 cycles,
+  // shared by the CU's 8 waves) for ~2000 cycles per chunk with the matrix pipe idle (measured: 91 -> 139 TF/s when the
+  // staging was removed altogether).
+  auto load_piece = [&](int piece, int chunk, const Tap& t) {
     const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
-    const int ids[4] = {t.id.x, t.id.y, t.id.z, t.id.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float* src = xb + (size_t)max(ids[k], 0) * C + c0;   // out-of-bounds corners carry weight 0
-#pragma unroll
-      for (int j = 0; j < 4; ++j) av[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+    if (piece < 16) {
+      const int k = piece >> 2, j = piece & 3;
+      const int id = k == 0 ? t.id.x : k == 1 ? t.id.y : k == 2 ? t.id.z : t.id.w;
+      const float* src = xb + (size_t)max(id, 0) * C + c0;   // out-of-bounds corners carry weight 0
+      av[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+    } else {
+      const float* ws = wrow + tap * C + c0 + 4 * (piece - 16);
+      const float4 v = *reinterpret_cast<const float4*>(ws);
+      if (piece == 16) bv0 = v; else if (piece == 17) bv1 = v; else if (piece == 18) bv2 = v; else bv3 = v;
     }
-    const float* ws = wrow + tap * C + c0;
-    bv0 = *reinterpret_cast<const float4*>(ws);
-    bv1 = *reinterpret_cast<const float4*>(ws + 4);
-    bv2 = *reinterpret_cast<const float4*>(ws + 8);
-    bv3 = *reinterpret_cast<const float4*>(ws + 12);
+  };
+  auto load_chunk = [&](int chunk, const Tap& t) {
+#pragma unroll
+    for (int piece = 0; piece < 20; ++piece) load_piece(piece, chunk, t);
+  };
+  // commit = bilinear combine + LDS store of the staged operands.  Tiles without pole rows (ng2 == false, 97 % of
+  // them) commit piecewise from INSIDE the second K-half's MFMA stream (commit_a / commit_b); the rare ng2 tiles
+  // commit after it, fetching slots 4..7 of the transposed table with the latency exposed.
+  auto commit_a = [&](int buf, const Tap& t, int j) {
+    float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
+    const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
+    *reinterpret_cast<float4*>(ad + 4 * j) = combine(v, t.w);
+  };
+  auto commit_b = [&](int buf, int j) {
+    if (stage_b) {
+      float* bd = Bs + (size_t)buf * BN * kLdF + sp * kLdF + 16 * half;
+      *reinterpret_cast<float4*>(bd + 4 * j) = j == 0 ? bv0 : j == 1 ? bv1 : j == 2 ? bv2 : bv3;
+    }
   };
   auto commit_chunk = [&](int buf, const Tap& t, int chunk) {
     float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
@@ -122,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
       const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
       out[j] = combine(v, t.w);
     }
-    if (ng2) {   // rare tiles (pole rows of the transposed table): entries 4..7 of this (pixel, tap), latency exposed
+    if (ng2) {   // entries 4..7 of this (pixel, tap)
       const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
       const int4 id2 = *reinterpret_cast<const int4*>(idp + ke * tap + 4);
       const float4 w2 = *reinterpret_cast<const float4*>(wgp + ke * tap + 4);
@@ -145,13 +167,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(ad + 4 * j) = out[j];
-    if (stage_b) {
-      float* bd = Bs + (size_t)buf * BN * kLdF + sp * kLdF + 16 * half;
-      *reinterpret_cast<float4*>(bd) = bv0;
-      *reinterpret_cast<float4*>(bd + 4) = bv1;
-      *reinterpret_cast<float4*>(bd + 8) = bv2;
-      *reinterpret_cast<float4*>(bd + 12) = bv3;
-    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) commit_b(buf, j);
   };
 
   f32x4 acc[NI][4];
@@ -167,38 +184,58 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   load_chunk(0, t_use);
   commit_chunk(0, t_use, 0);
   __syncthreads();
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int buf = chunk & 1;
-    const int nxt = chunk + 1;
-    const bool has_next = nxt < nchunks;
-    if (has_next) {
-      if (nxt % cpt == 0) {   // block-uniform: chunk nxt opens a new tap
+  auto chunk_loop = [&](auto ng2_c) {
+    constexpr bool NG2 = decltype(ng2_c)::value;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const int buf = chunk & 1;
+      const int nxt = chunk + 1;
+      const bool has_next = nxt < nchunks;
+      if (has_next && nxt % cpt == 0) {   // block-uniform: chunk nxt opens a new tap
         t_use = t_pref;
         t_pref = load_tap(min(nxt / cpt + 1, 8));
       }
-      load_chunk(nxt, t_use);
+      const int nxc = has_next ? nxt : chunk;   // the last chunk re-requests its own operands (committed to the idle buffer)
+      __builtin_amdgcn_sched_barrier(0);
+      const float* ab = As + (size_t)buf * kBM * kLdF + (64 * wm + r) * kLdF + 8 * kk;
+      const float* bb = Bs + (size_t)buf * BN * kLdF + ((BN / 2) * wn + r) * kLdF + 8 * kk;
+      constexpr int kHalf = 4 * NI * 4;       // MFMAs per K-half: 64 (BN = 128) or 32 (BN = 64)
+      constexpr int kEvery = kHalf / 20;      // first half: one operand load per kEvery MFMAs
+      constexpr int kCommit0 = kHalf / 2;     // second half: commits start here, one every kHalf / 16 MFMAs
+      constexpr int kCommitEvery = kHalf / 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 af[4], bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const float4*>(ab + 16 * mi * kLdF + 4 * h);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(bb + 16 * ni * kLdF + 4 * h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              acc[ni][mi] = mfma16(f4c(bf[ni], t), f4c(af[mi], t), acc[ni][mi]);
+              const int cnt = (t * NI + ni) * 4 + mi;          // MFMA index within this K-half
+              if (h == 0 && cnt % kEvery == kEvery - 1 && cnt / kEvery < 20) {
+                load_piece(cnt / kEvery, nxc, t_use);
+                __builtin_amdgcn_sched_barrier(0);             // keep the request here (the scheduler would sink it)
+              }
+              if (!NG2 && h == 1 && cnt >= kCommit0 && (cnt - kCommit0) % kCommitEvery == kCommitEvery - 1) {
+                const int piece = (cnt - kCommit0) / kCommitEvery;   // 0..7: four A quads, then four B quads
+                if (piece < 4) commit_a(buf ^ 1, t_use, piece); else commit_b(buf ^ 1, piece - 4);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // unconditional (the last chunk commits its own operands again into the idle buffer): under `if (has_next)` the
+      // loads' only use sat in a successor block and LLVM sank all 20 of them there, behind the MFMAs
+      if constexpr (NG2) commit_chunk(buf ^ 1, t_use, nxc);
+      eml::lds_barrier();
     }
-    __builtin_amdgcn_sched_barrier(0);
-    const float* ab = As + (size_t)buf * kBM * kLdF + (64 * wm + r) * kLdF + 8 * kk;
-    const float* bb = Bs + (size_t)buf * BN * kLdF + ((BN / 2) * wn + r) * kLdF + 8 * kk;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float4 af[4], bf[NI];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const float4*>(ab + 16 * mi * kLdF + 4 * h);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(bb + 16 * ni * kLdF + 4 * h);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(f4c(bf[ni], t), f4c(af[mi], t), acc[ni][mi]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) commit_chunk(buf ^ 1, t_use, nxt);
-    eml::lds_barrier();
-  }
+  };
+  if (ng2) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
   // epilogue: lane (r, kk) owns output channels 4kk..4kk+3 of tile ni for pixel r of tile mi
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -252,40 +289,47 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     t.w = *reinterpret_cast<const float4*>(wgt + ((size_t)p * 9 + tap) * 4);
     xoff = (size_t)b * HW * C;
   };
-  auto load_chunk = [&](int chunk, const Tap& t, size_t xoff) {
+  // the 20 operand loads of a chunk one at a time (pieces 0..3: dY, 4..19: the gathered corners) and its commit in 8
+  // pieces: the main loop issues them BETWEEN MFMAs (see the forward kernel)
+  const float* dsrc_n = dY;
+  auto begin_chunk = [&](int chunk, const Tap& t) {
     const int m = chunk * kBK + sp;
     pvalid = m < M;
-    const int mc = min(m, M - 1);
-    const float* dsrc = dY + (size_t)mc * O + ocol;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dv[j] = *reinterpret_cast<const float4*>(dsrc + 4 * j);
-    const int ids[4] = {t.id.x, t.id.y, t.id.z, t.id.w};
-    const int cc = c0 + (stage_g ? 16 * sq : 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float* src = X + xoff + (size_t)max(ids[k], 0) * C + cc;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gv[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
-    }
+    dsrc_n = dY + (size_t)min(m, M - 1) * O + ocol;
     gw = t.w;
   };
-  auto commit_chunk = [&](int buf) {
-    float* dd = Ds + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
-    const bool ov = o0 + 16 * sq + 16 <= O;
+  auto load_piece = [&](int piece, const Tap& t, size_t xoff) {
+    if (piece < 4) {
+      dv[piece] = *reinterpret_cast<const float4*>(dsrc_n + 4 * piece);
+    } else {
+      const int k = (piece - 4) >> 2, j = (piece - 4) & 3;
+      const int id = k == 0 ? t.id.x : k == 1 ? t.id.y : k == 2 ? t.id.z : t.id.w;
+      const float* src = X + xoff + (size_t)max(id, 0) * C + c0 + (stage_g ? 16 * sq : 0);
+      gv[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+    }
+  };
+  auto load_chunk = [&](int chunk, const Tap& t, size_t xoff) {
+    begin_chunk(chunk, t);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 v = dv[j];
+    for (int piece = 0; piece < 20; ++piece) load_piece(piece, t, xoff);
+  };
+  auto commit_piece = [&](int buf, int piece) {   // 0..3: dY quads, 4..7: gathered quads
+    if (piece < 4) {
+      float* dd = Ds + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
+      const bool ov = o0 + 16 * sq + 16 <= O;
+      float4 v = dv[piece];
       if (!(pvalid && ov)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // pixels past M / columns past O add 0
-      if (stage_d) *reinterpret_cast<float4*>(dd + 4 * j) = v;
-    }
-    if (stage_g) {
+      if (stage_d) *reinterpret_cast<float4*>(dd + 4 * piece) = v;
+    } else if (stage_g) {
+      const int j = piece - 4;
       float* gd = Gs + (size_t)buf * kBK * kLdW + sp * kLdW + 16 * sq;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v[4] = {gv[0][j], gv[1][j], gv[2][j], gv[3][j]};
-        *reinterpret_cast<float4*>(gd + 4 * j) = combine(v, gw);
-      }
+      const float4 v[4] = {gv[0][j], gv[1][j], gv[2][j], gv[3][j]};
+      *reinterpret_cast<float4*>(gd + 4 * j) = combine(v, gw);
     }
+  };
+  auto commit_chunk = [&](int buf) {
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) commit_piece(buf, piece);
   };
 
   f32x4 acc[MI][NI];   // [o tile][c tile]
@@ -305,19 +349,22 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   }
   __syncthreads();
   int it = 0;
+  constexpr int kSteps = kBK / 4;                  // 8 k-steps of MI*NI MFMAs
+  constexpr int kPerStep = MI * NI;
+  constexpr int kLoadEvery = (kPerStep * 4 >= 20) ? (kPerStep * 4) / 20 : 1;   // loads ride on the first 4 k-steps
   for (; chunk < nchunks_all; chunk += S, ++it) {
     const int buf = it & 1;
-    const int nxt = chunk + S;
-    const bool has_next = nxt < nchunks_all;
-    if (has_next) {
-      load_chunk(nxt, t1, x1);
-      tap_of(min(nxt + S, nchunks_all - 1), t1, x1);   // the table entry for the chunk after that
-    }
+    // the last chunk re-requests its own operands and commits them into the idle buffer: an `if (has_next)` around the
+    // commit would let LLVM sink the loads into that branch, behind the MFMAs
+    const int nxt = min(chunk + S, nchunks_all - 1);
+    const Tap tn = t1;
+    const size_t xn = x1;
+    begin_chunk(nxt, tn);
     __builtin_amdgcn_sched_barrier(0);
     const float* db = Ds + (size_t)buf * kBK * kLdW + (BMO / 2) * wm + r;
     const float* gb = Gs + (size_t)buf * kBK * kLdW + (BN / 2) * wn + r;
 #pragma unroll
-    for (int ks = 0; ks < kBK / 4; ++ks) {
+    for (int ks = 0; ks < kSteps; ++ks) {
       float a[MI], b[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
@@ -326,10 +373,24 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(a[mi], b[ni], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = mfma16(a[mi], b[ni], acc[mi][ni]);
+          const int cnt = ks * kPerStep + mi * NI + ni;      // MFMA index within the chunk
+          if (cnt % kLoadEvery == kLoadEvery - 1 && cnt / kLoadEvery < 20) {
+            load_piece(cnt / kLoadEvery, tn, xn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (cnt == kLoadEvery * 20) {                      // the table entry for the chunk after that
+            tap_of(min(nxt + S, nchunks_all - 1), t1, x1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (ks >= kSteps - 4) {                                // commits ride on the last 4 k-steps, two pieces each
+        commit_piece(buf ^ 1, 2 * (ks - (kSteps - 4)));
+        commit_piece(buf ^ 1, 2 * (ks - (kSteps - 4)) + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) commit_chunk(buf ^ 1);
     eml::lds_barrier();
   }
   // partial[z][o][tap*C + c]: lane (r, kk) holds rows o = 4kk + g, column c = r of each 16x16 tile
