@@ -157,12 +157,12 @@ class _SphereConvFn(torch.autograd.Function):
         O = weight.shape[0]
         w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)          # columns ordered (tap, c) like A9
         # which layers take the fused kernels: measured per shape (tools/sphere_layers.py, profiles/r02_sphere_layers.jsonl).
-        # They run at 85-98 TF/s whatever the shape; im2col + the library GEMM is faster only where the GEMM is wide
-        # (O >= 256) and the operand small -- there the library's 115-125 TF/s wins and A9 costs little memory.
+        # They run at 85-115 TF/s; im2col + the library GEMM is faster only where the GEMM is wide (O >= 512) and the
+        # operand small -- there the library's 115-125 TF/s wins and A9 costs little memory.
         a9_bytes = B * po * 9 * C * 4
         lim = SphereConv2D.fused_min_bytes
         ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
-                         (a9_bytes >= 32 * lim or (O <= 128 and a9_bytes >= lim)))
+                         (a9_bytes >= 32 * lim or (O <= 256 and a9_bytes >= lim)))
         # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C).  Measured: it beats
         # dY W2 (library) + col2im where the pixel count is large and O <= 256; wide heads (K = 9*O >= 4608) stay unfused
         ctx.fused_dgrad = (B > 0 and O % 32 == 0 and C % 64 == 0 and stride == 1 and
