@@ -212,8 +212,21 @@ class _SphereConvFn(torch.autograd.Function):
                 del part
             else:
                 a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
-                # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
-                gw = (a9.t() @ gyr).view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
+                m_rows, split = B * po, 1
+                if 9 * C <= 64 and m_rows >= 65536:
+                    # skinny product (the 3- / 6-channel input layers: 27 or 54 columns against ~1 M rows): as ONE GEMM
+                    # the library runs it on a handful of workgroups (1.6 ms for 7 GFLOP); as a batched split-K it is
+                    # the HBM-bound read of dY it should be, followed by a fixed-order sum of the partials
+                    split = 512
+                    while m_rows % split:
+                        split //= 2
+                if split > 1:
+                    gw2 = torch.bmm(a9.view(split, m_rows // split, 9 * C).transpose(1, 2),
+                                    gyr.view(split, m_rows // split, O)).sum(0)
+                else:
+                    # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
+                    gw2 = a9.t() @ gyr
+                gw = gw2.view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
                 del a9
         if ctx.needs_input_grad[0]:
             gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
