@@ -213,8 +213,9 @@ class _SphereConvFn(torch.autograd.Function):
             else:
                 a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
                 m_rows, split = B * po, 1
-                if 9 * C <= 64 and m_rows >= 65536:
-                    # skinny product (the 3- / 6-channel input layers: 27 or 54 columns against ~1 M rows): as ONE GEMM
+                if (9 * C <= 64 or O <= 16) and m_rows >= 65536:
+                    # skinny product (the 3- / 6-channel input layers: 27 or 54 columns against ~1 M rows; the 3-channel
+                    # output layers: 1.9 TF/s as one GEMM): as ONE GEMM
                     # the library runs it on a handful of workgroups (1.6 ms for 7 GFLOP); as a batched split-K it is
                     # the HBM-bound read of dY it should be, followed by a fixed-order sum of the partials
                     split = 512

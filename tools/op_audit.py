@@ -27,3 +27,24 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=45,
                                                          max_name_column_width=40, max_shapes_column_width=70))
+
+# library GEMMs: achieved TF/s per shape (find the badly served ones)
+rows = []
+for ev in prof.key_averages(group_by_input_shape=True):
+    if ev.key not in ("aten::mm", "aten::addmm", "aten::bmm") or not ev.input_shapes:
+        continue
+    sh = [s for s in ev.input_shapes if s]
+    try:
+        if ev.key == "aten::addmm":
+            a, b = sh[1], sh[2]
+        else:
+            a, b = sh[0], sh[1]
+        fl = 2.0 * a[-2] * a[-1] * b[-1] * (a[0] if len(a) == 3 else 1)
+    except Exception:
+        continue
+    t = ev.self_device_time_total / max(ev.count, 1)
+    if t > 0:
+        rows.append((ev.self_device_time_total / 1e3, ev.count, t / 1e3, fl / t / 1e6, ev.key, a, b))
+print("library GEMMs by total device time: total ms, calls, ms/call, TF/s, op, A, B")
+for r in sorted(rows, reverse=True)[:30]:
+    print("  %7.2f %3d %7.3f %7.1f  %-11s %s x %s" % r)
