@@ -59,6 +59,20 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_spade_modulate_bwd_f32(one, 6, one, 6, one, 12, one, 6, one, 12, 4, 6, ctypes.c_float(1.0), None) == -1
     assert L.eml_dense_conv1x1_bwd_data_multi_f32(3, None, None, None, None, None, None, None, None, None, None, one, 224,
                                                   one, one, 10, 0, 16, one, 224, 512, None) == -1
+    # round-2 entry points: fused SphereConv (channel counts must tile), BatchNorm fold, narrow dgrad
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 48, 64, None) == -1     # C % 32
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 96, None) == -1     # O % 64
+    assert b"C %" in L.eml_last_error()
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, None) == 0      # empty batch
+    assert L.eml_sphere_conv_wgrad_fused_f32(one, one, one, one, one, one, 1, 32, 32, 32, 64, 4, None) == -1  # C % 64
+    assert L.eml_sphere_conv_wgrad_partial_floats(128, 256, 7) == 7 * 256 * 9 * 128
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 8, one, one, 1, 32, 32, 64, 64, None) == -1   # ke = 8 needs rowmax
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 5, one, one, 1, 32, 32, 64, 64, None) == -1   # ke in {4, 8}
+    assert L.eml_bn_stats_f32(one, 6, 10, 6, one, 4, None) == -1                                               # C % 4
+    assert L.eml_bn_finalize_f32(one, 8, ctypes.c_float(0.0), ctypes.c_float(0.1), one, one, None, None, None) == -1   # eps > 0
+    assert L.eml_bn_bwd_apply_f32(one, 8, one, 8, 0, 8, one, one, None, one, 8, None) == 0                       # no rows
+    assert L.eml_dense_conv1x1_bwd_narrow_f32(one, one, 48, 37, one, 64, one, one, one, one, 10, one, 64, one, one, 48, 4,
+                                              None) == -1                                                       # odd channel offset
 
 
 def test_product_path_has_no_cpu_fallback():
