@@ -11,8 +11,11 @@
 //                              eml_sphere_tap_table_f32: grid_sample's own corners and weights; -1 = zero padding)
 //
 // Both are 128 x {64,128} x 32 tiled GEMMs, 256 threads = 2 x 2 waves, v_mfma_f32_16x16x4_f32 (exact f32), double-
-// buffered LDS with ONE LDS-only barrier per K-chunk; the global loads of chunk i+1 (16 gathered float4 per thread +
-// the dense operand) are in flight during the MFMAs of chunk i, the tap-table entries one step further ahead.
+// buffered LDS with ONE LDS-only barrier per K-chunk.  The operands of chunk i+1 (16 gathered float4 per thread + the
+// dense operand) are requested ONE AT A TIME BETWEEN the MFMAs of chunk i's first K-half and committed (bilinear
+// combine + ds_write) between the MFMAs of its second half; the tap-table entries are requested a whole tap ahead.
+// (Requested back to back in front of the MFMA block, the loads held each wave at the texture-address unit for
+// ~2000 cycles per chunk with the matrix pipe idle: 91 TF/s; interleaved: 112-115 TF/s; the bare MFMA + ds_read loop: 139.)
 // Loads are unconditional from clamped addresses (zero weights / masked stores handle the borders).
 //   forward: D^T form (weights = MFMA A operand, pixels = B operand): a lane owns 4 consecutive output channels of a
 //            pixel -> 16-byte stores; MFMA's k index is only a summation label, so a lane's 8 consecutive floats of
