@@ -27,6 +27,8 @@
 // outputs only, so it is latency/transcendental-bound: (n_eps+2)*4*N^2 exp2 per sample.
 #include "eml_common.h"
 
+#include <cmath>
+
 namespace {
 
 constexpr int kJPT = 64;   // LDS padding unit (unrolled reads past a row's end stay in-bounds)
@@ -53,9 +55,10 @@ constexpr int kSmemVecs = 2 + 2 + 4 + 2;
 // ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
 // d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
 // eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p] in f64 like numpy
-template <int kWG>
+template <int kWG, bool kFinalBarrier = true>
 __device__ __forceinline__ void device_schedule(const float* __restrict__ x, const float* __restrict__ y, int B, int N,
-                                                double blur, double scaling, int p_exp, double diameter, float* eps_l,
+                                                double blur, double log_blur, double log_scaling, int p_exp,
+                                                double diameter, float* eps_l,
                                                 int* n_eps_l, float* __restrict__ eps_out, int* __restrict__ n_eps_out,
                                                 float* __restrict__ diameter_out) {
   __shared__ float red_lo[16], red_hi[16];
@@ -65,10 +68,14 @@ __device__ __forceinline__ void device_schedule(const float* __restrict__ x, con
     const long n_all = (long)B * N, n4 = n_all >> 2;   // hipMalloc'd buffers: 16-B aligned
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* y4 = reinterpret_cast<const float4*>(y);
-    for (long k = tid0; k < n4; k += kWG) {
-      const float4 a = x4[k], c2 = y4[k];
+    // two strides per trip, four loads in flight (cfg2 is exactly one trip): every trip exposes one memory latency
+    for (long k = tid0; k < n4; k += 2 * kWG) {
+      const long k2 = (k + kWG < n4) ? k + kWG : k;   // past the end: this trip's first element again (min / max idempotent)
+      const float4 a = x4[k], c2 = y4[k], a2 = x4[k2], c3 = y4[k2];
       lo = fminf(fminf(fminf(lo, fminf(a.x, a.y)), fminf(a.z, a.w)), fminf(fminf(c2.x, c2.y), fminf(c2.z, c2.w)));
       hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)), fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w)));
+      lo = fminf(fminf(fminf(lo, fminf(a2.x, a2.y)), fminf(a2.z, a2.w)), fminf(fminf(c3.x, c3.y), fminf(c3.z, c3.w)));
+      hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a2.x, a2.y)), fmaxf(a2.z, a2.w)), fmaxf(fmaxf(c3.x, c3.y), fmaxf(c3.z, c3.w)));
     }
     for (long k = 4 * n4 + tid0; k < n_all; k += kWG) {
       lo = fminf(lo, fminf(x[k], y[k]));
@@ -82,41 +89,45 @@ __device__ __forceinline__ void device_schedule(const float* __restrict__ x, con
     }
   }
   __syncthreads();
-  double d = diameter;
-  if (diameter <= 0.0) {
-    lo = red_lo[0];
-    hi = red_hi[0];
+  // the f64 part (one log, one exp per schedule entry: a few hundred instructions) runs on wave 0 ONLY -- executed
+  // redundantly by all 16 waves it held every SIMD for ~3 us of a 25 us kernel; the other waves go on to their staging
+  if (tid0 < 64) {
+    double d = diameter;
+    if (diameter <= 0.0) {
+      lo = red_lo[0];
+      hi = red_hi[0];
 #pragma unroll
-    for (int w = 1; w < kWG / 64; ++w) {
-      lo = fminf(lo, red_lo[w]);
-      hi = fmaxf(hi, red_hi[w]);
+      for (int w = 1; w < kWG / 64; ++w) {
+        lo = fminf(lo, red_lo[w]);
+        hi = fmaxf(hi, red_hi[w]);
+      }
+      d = (double)(hi - lo);  // f32 subtraction, then .item()
     }
-    d = (double)(hi - lo);  // f32 subtraction, then .item()
-  }
-  int cnt = 0;
-  double start = 0.0, step = 0.0;
-  if (d > 0.0) {
-    start = p_exp * log(d);
-    step = p_exp * log(scaling);
-    const double cntd = ceil((p_exp * log(blur) - start) / step);  // numpy.arange length
-    cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
-  }
-  if (tid0 < cnt + 2) {  // one schedule entry per thread, in parallel
-    double e;
-    if (tid0 == 0) e = (p_exp == 2) ? d * d : pow(d, (double)p_exp);
-    else if (tid0 == cnt + 1) e = (p_exp == 2) ? blur * blur : pow(blur, (double)p_exp);
-    else e = exp(start + (tid0 - 1) * step);
-    eps_l[tid0] = (float)e;
-    if (blockIdx.x == 0 && eps_out) eps_out[tid0] = (float)e;
-  }
-  if (tid0 == 0) {
-    *n_eps_l = cnt + 2;
-    if (blockIdx.x == 0) {
-      if (n_eps_out) *n_eps_out = cnt + 2;
-      if (diameter_out) *diameter_out = (float)d;
+    int cnt = 0;
+    double start = 0.0;
+    const double step = p_exp * log_scaling;
+    if (d > 0.0) {
+      start = p_exp * log(d);
+      const double cntd = ceil((p_exp * log_blur - start) / step);  // numpy.arange length
+      cnt = (cntd > 0.0) ? (int)fmin(cntd, (double)(EML_MAX_EPS - 2)) : 0;
+    }
+    if (tid0 < cnt + 2) {  // one schedule entry per lane (EML_MAX_EPS = 64 = one wave)
+      double e;
+      if (tid0 == 0) e = (p_exp == 2) ? d * d : pow(d, (double)p_exp);
+      else if (tid0 == cnt + 1) e = (p_exp == 2) ? blur * blur : pow(blur, (double)p_exp);
+      else e = exp(start + (tid0 - 1) * step);
+      eps_l[tid0] = (float)e;
+      if (blockIdx.x == 0 && eps_out) eps_out[tid0] = (float)e;
+    }
+    if (tid0 == 0) {
+      *n_eps_l = cnt + 2;
+      if (blockIdx.x == 0) {
+        if (n_eps_out) *n_eps_out = cnt + 2;
+        if (diameter_out) *diameter_out = (float)d;
+      }
     }
   }
-  __syncthreads();
+  if (kFinalBarrier) __syncthreads();   // otherwise the caller's next barrier publishes eps_l / n_eps_l
 }
 
 // threads per softmin group: cached kernel 512 (128 rows x 4 lanes), stream kernel 256 (row per thread)
@@ -124,15 +135,13 @@ template <bool kCached>
 __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
     const float* __restrict__ Mt, const float* __restrict__ alpha, const float* __restrict__ beta,
-    double blur, double scaling, int p_exp, double diameter, float* __restrict__ eps_out,
+    double blur, double log_blur, double log_scaling, int p_exp, double diameter, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
   constexpr int kGT = kCached ? 512 : 256;  // threads per softmin group
   constexpr int kWG = 2 * kGT;              // two groups per workgroup
   __shared__ float eps_l[EML_MAX_EPS];
   __shared__ int n_eps_l;
-  device_schedule<kWG>(x, y, B, N, blur, scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
-  const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NP = round_up4(N) + kJPT;
   float* pts = smem;
@@ -144,30 +153,65 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   const int b = blockIdx.x >> 1;
   const int role = blockIdx.x & 1;     // 0: (xx, yy)   1: (yx, xy)
   const int tid = threadIdx.x;
-  const int gl = tid / kGT;            // local group 0/1
+  const int gl = tid / kGT;            // local group 0/1; its columns are x for gl = 0 and y for gl = 1 in both roles
   const int g = 2 * role + gl;         // global problem id 0..3
   const int t = tid & (kGT - 1);
   const bool rows_x = (g == 0 || g == 3);
   const bool cols_x = (g == 0 || g == 2);
   const int consumer_l = role ? (1 - gl) : gl;  // local group whose h this potential feeds
-  const int n_eps = n_eps_l;
-
-  // ---- stage points and log-weights; zero the h buffers (their pads are read)
   const float unif = 1.0f / (float)N;
-  for (int i = tid; i < 2 * NP; i += kWG) {
-    const int which = i / NP, k = i - which * NP;
-    float p = 0.f, l = 0.f;
-    if (k < N) {
-      p = (which == 0 ? x : y)[(size_t)b * N + k];
-      const float* wp = which == 0 ? alpha : beta;
-      const float w = wp ? wp[(size_t)b * N + k] : unif;
-      l = (w > 0.f) ? logf(w) : -100000.0f;  // sinkhorn_divergence.py:47-50
+
+  // ---- cached kernel: EVERY global read of the prologue is requested here, before anything waits -- this thread's
+  // 16 chord-matrix elements, its point and weight, and (inside device_schedule) the diameter scan: one exposed
+  // memory latency instead of four in a row (scan, points, weights, M), ~2.5 us of a 25 us kernel at cfg2
+  constexpr int kMPT = kCached ? (4 * kCJ) * (4 * kCJ) / kWG : 1;   // 16 elements of M per thread
+  float mreg[kMPT];
+  float my_p = 0.f, my_w = unif;
+  if constexpr (kCached) {
+    const int nn = N * N;
+    // (4-byte loads on purpose: staged as four float4 per thread the same 64 KB arrived 1.2 us later -- measured)
+#pragma unroll
+    for (int k = 0; k < kMPT; ++k) mreg[k] = M[min(tid + k * kWG, nn - 1)];
+    if (tid < 2 * NP) {   // 2 * NP <= 384 < kWG
+      const int which = tid >= NP, k = tid - which * NP;
+      if (k < N) {
+        my_p = (which == 0 ? x : y)[(size_t)b * N + k];
+        const float* wp = which == 0 ? alpha : beta;
+        if (wp) my_w = wp[(size_t)b * N + k];
+      }
     }
-    pts[i] = p;
-    lw2[i] = l * kLog2e;
   }
-  for (int i = tid; i < 4 * NP; i += kWG) h2[i] = 0.f;
-  __syncthreads();  // pts / lw2 / zeroed h2 visible to every thread before any cross-thread read
+  device_schedule<kWG, !kCached>(x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out,
+                                 diameter_out);
+  const float* eps_s = eps_l;
+
+  // ---- stage points and log-weights; h buffer 0 = log w of each group's columns (sweep 0 reads h = log w, potentials
+  // are zero: sinkhorn_divergence.py:82-85), buffer 1 zeroed (the pads of both are read)
+  if constexpr (kCached) {
+    if (tid < 2 * NP) {
+      const int k = tid - (tid >= NP) * NP;
+      const float l = (k < N) ? ((my_w > 0.f) ? logf(my_w) : -100000.0f) : 0.f;  // sinkhorn_divergence.py:47-50
+      pts[tid] = my_p;
+      lw2[tid] = l * kLog2e;
+      h2[tid] = l * kLog2e;        // h2[0][gl = which][k]
+      h2[2 * NP + tid] = 0.f;
+    }
+  } else {
+    for (int i = tid; i < 2 * NP; i += kWG) {
+      const int which = i / NP, k = i - which * NP;
+      float p = 0.f, l = 0.f;
+      if (k < N) {
+        p = (which == 0 ? x : y)[(size_t)b * N + k];
+        const float* wp = which == 0 ? alpha : beta;
+        const float w = wp ? wp[(size_t)b * N + k] : unif;
+        l = (w > 0.f) ? logf(w) : -100000.0f;  // sinkhorn_divergence.py:47-50
+      }
+      pts[i] = p;
+      lw2[i] = l * kLog2e;
+      h2[i] = l * kLog2e;
+      h2[2 * NP + i] = 0.f;
+    }
+  }
 
   const float* P = pts + (rows_x ? 0 : NP);
   const float* Q = pts + (cols_x ? 0 : NP);
@@ -184,12 +228,28 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   bool owner = false;
   if constexpr (kCached) {
     const int ldm = round_up4(N) + 4;
-#pragma unroll 8
-    for (int e = tid; e < N * N; e += kWG) {  // unrolled: 8 loads in flight per thread
-      const int r = e / N, cc = e - r * N;
-      Ml[r * ldm + cc] = M[e];
+    {
+      int r = tid / N, cc = tid - r * N;                 // element tid + k * kWG of M = (r, cc)
+      const int dr = kWG / N, dc = kWG - dr * N;
+      if (dc == 0) {   // N divides the workgroup size (N = 128, 64, ...): the column never changes, rows advance by dr
+        float* dst = Ml + r * ldm + cc;
+#pragma unroll
+        for (int k = 0; k < kMPT; ++k)
+          if (r + k * dr < N) dst[k * dr * ldm] = mreg[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMPT; ++k) {
+          if (r < N) Ml[r * ldm + cc] = mreg[k];
+          r += dr;
+          cc += dc;
+          if (cc >= N) {
+            cc -= N;
+            ++r;
+          }
+        }
+      }
     }
-    __syncthreads();
+    __syncthreads();   // pts / lw2 / h2 / Ml / eps_l visible to every thread
     const int split = round_up4((N + 3) >> 2);   // columns per lane: 4 lanes share row i
     const int quarter = t & 3;
     i = t >> 2;
@@ -204,13 +264,17 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     for (int q = 0; q < kCJ / 4; ++q) {
       const float4 mv = mrow[q];
       const float4 qv = qrow[q];
-      c2[2 * q + 0] = v2f{(4 * q + 0 < cnt) ? cost_ij(pi, qv.x, mv.x) : kBig, (4 * q + 1 < cnt) ? cost_ij(pi, qv.y, mv.y) : kBig};
-      c2[2 * q + 1] = v2f{(4 * q + 2 < cnt) ? cost_ij(pi, qv.z, mv.z) : kBig, (4 * q + 3 < cnt) ? cost_ij(pi, qv.w, mv.w) : kBig};
+      // cost_ij on register pairs (v_pk_mul / v_pk_fma): 4 waves per SIMD build 32 costs per thread here
+      const v2f p2 = v2f{pi, pi};
+      const v2f qa = v2f{qv.x, qv.y}, qb = v2f{qv.z, qv.w};
+      const v2f ca = ((p2 * p2 - 2.0f * (p2 * qa) + qa * qa) * 0.1f + v2f{mv.x, mv.y}) * 0.5f;
+      const v2f cb = ((p2 * p2 - 2.0f * (p2 * qb) + qb * qb) * 0.1f + v2f{mv.z, mv.w}) * 0.5f;
+      c2[2 * q + 0] = v2f{(4 * q + 0 < cnt) ? ca.x : kBig, (4 * q + 1 < cnt) ? ca.y : kBig};
+      c2[2 * q + 1] = v2f{(4 * q + 2 < cnt) ? cb.x : kBig, (4 * q + 3 < cnt) ? cb.y : kBig};
     }
   }
-  // sweep 0 reads h = log w (potentials are zero): sinkhorn_divergence.py:82-85
-  for (int k = t; k < N; k += kGT) h2[gl * NP + k] = lw2_cols[k];
-  __syncthreads();
+  if constexpr (!kCached) __syncthreads();   // (the cached kernel's barrier sits after its M staging)
+  const int n_eps = n_eps_l;
 
   const size_t plane = (size_t)B * N;
   float* fin_out = work + (size_t)g * plane + (size_t)b * N;        // a_x | b_y | a_y | b_x
@@ -326,7 +390,8 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
 template <int LPR /* lanes per row: 2 (N <= 256) or 1 (N <= 512) */>
 __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
-    const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double scaling, int p_exp,
+    const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
+    int p_exp,
     double diameter, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work, int B, int N) {
   constexpr int kGT = 512, kWG = 1024;
@@ -335,7 +400,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   constexpr int TS = TJ + 4;               // LDS row stride of a tile
   __shared__ float eps_l[EML_MAX_EPS];
   __shared__ int n_eps_l;
-  device_schedule<kWG>(x, y, B, N, blur, scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
+  device_schedule<kWG>(x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
   const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NP = round_up4(N) + kJPT;
@@ -611,6 +676,7 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
   if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
     return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need blur>0, 0<scaling<1, p>=1");
   if (B == 0) return EML_OK;
+  const double log_blur = std::log(blur), log_scaling = std::log(scaling);   // f64 like numpy; only log(diameter) is data
   const int NP = round_up4(N) + kJPT;
   size_t lds = (size_t)(kSmemVecs * NP) * sizeof(float);
   if (N <= 4 * kCJ) {
@@ -618,7 +684,7 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                       alpha, beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   } else if (N <= 512 && (N & 3) == 0) {
     // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
     const int lpr = N <= 256 ? 2 : 1;
@@ -627,18 +693,18 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                         beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                         beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
     }
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                       alpha, beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
   }
   int rc = eml::check_launch("eml_sinkhorn_fwd_f32(loop)");
   if (rc) return rc;
