@@ -80,7 +80,18 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * kBM, o0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  With the
+  // natural order an XCD would get every 8th 128-pixel tile -- never two vertical neighbours, although the 3 x 3 taps of
+  // a tile read the rows above and below it -- and a pixel tile's second O-tile would run a whole grid later: every XCD
+  // fetches the whole input from HBM.  Here XCD k walks a CONTIGUOUS band of pixel tiles, the O-tiles of a pixel tile back
+  // to back: the 64 tiles in flight on an XCD are ~16 image rows (2 MB at C = 128), which its 4 MB L2 holds, so the
+  // gathers of neighbouring taps / tiles / O-tiles are L2 hits.
+  const int n_ot = O / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt_local = slot / n_ot, ot = slot - mt_local * n_ot;
+  const int mt = xcd * (int)(gridDim.x / (8 * n_ot)) + mt_local;
+  if (mt * kBM >= M) return;   // padding of the last band (whole workgroup, before any barrier)
+  const int m0 = mt * kBM, o0 = ot * BN;
 
   // staging roles: A -- pixel sp = tid / 2, 16 channels (half); B -- output channel sp (threads < 2*BN), 16 channels
   const int sp = tid >> 1, half = tid & 1;
@@ -273,6 +284,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   const int r = lane & 15, kk = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_per_tap = C / BN;
+  // (natural 3-D grid order: sending all (tap, c-tile, O-tile) workgroups of a K-split to one XCD, the forward
+  // kernel's trick, made this kernel 10 % slower -- measured)
   const int tap = blockIdx.x / tiles_per_tap, c0 = (blockIdx.x - tap * tiles_per_tap) * BN;
   const int o0 = blockIdx.y * BMO;
   const int S = gridDim.z;
@@ -433,7 +446,8 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
   const int bn = (O % 128 == 0) ? 128 : 64;
   const size_t lds = (size_t)(2 * kBM * kLdF + 2 * bn * kLdF) * sizeof(float);
-  const dim3 grid((unsigned)((M + kBM - 1) / kBM), O / bn);
+  const long n_mt = (M + kBM - 1) / kBM, per_xcd = (n_mt + 7) / 8;
+  const dim3 grid((unsigned)(8 * per_xcd * (O / bn)));   // 1-D: the kernel maps id -> (XCD band, pixel tile, O-tile)
   if (bn == 128) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
