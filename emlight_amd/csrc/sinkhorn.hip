@@ -29,6 +29,25 @@
 
 #include <cmath>
 
+// ---- phase timestamps of the cached kernel, experiment builds only (tools/exp_build.sh stamps -DEML_STAMPS, then
+// EML_LIB_PATH=build_exp/lib_stamps.so python tools/sinkhorn_stamps.py): thread 0 of workgroup 1 (sample 0's coupled pair)
+// stores the 100 MHz wall clock at the phase boundaries.  This is how the prologue's share was found;
+// in the product build EML_STAMP compiles to nothing and the symbol below does not exist.
+#ifdef EML_STAMPS
+__device__ long long eml_sinkhorn_stamp_buf[64];
+extern "C" int eml_sinkhorn_read_stamps(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eml_sinkhorn_stamp_buf), sizeof(long long) * 64);
+}
+#define EML_STAMP(k)                                                                            \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x == 1 && (k) < 64) eml_sinkhorn_stamp_buf[k] = wall_clock64(); \
+  } while (0)
+#else
+#define EML_STAMP(k) \
+  do {               \
+  } while (0)
+#endif
+
 namespace {
 
 constexpr int kJPT = 64;   // LDS padding unit (unrolled reads past a row's end stay in-bounds)
@@ -164,6 +183,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   // ---- cached kernel: EVERY global read of the prologue is requested here, before anything waits -- this thread's
   // 16 chord-matrix elements, its point and weight, and (inside device_schedule) the diameter scan: one exposed
   // memory latency instead of four in a row (scan, points, weights, M), ~2.5 us of a 25 us kernel at cfg2
+  if constexpr (kCached) EML_STAMP(0);   // kernel start
   constexpr int kMPT = kCached ? (4 * kCJ) * (4 * kCJ) / kWG : 1;   // 16 elements of M per thread
   float mreg[kMPT];
   float my_p = 0.f, my_w = unif;
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   device_schedule<kWG, !kCached>(x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out,
                                  diameter_out);
   const float* eps_s = eps_l;
+  if constexpr (kCached) EML_STAMP(1);   // diameter scan + schedule issued (wave 0: computed)
 
   // ---- stage points and log-weights; h buffer 0 = log w of each group's columns (sweep 0 reads h = log w, potentials
   // are zero: sinkhorn_divergence.py:82-85), buffer 1 zeroed (the pads of both are read)
@@ -250,6 +271,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       }
     }
     __syncthreads();   // pts / lw2 / h2 / Ml / eps_l visible to every thread
+    EML_STAMP(2);      // staging done
     const int split = round_up4((N + 3) >> 2);   // columns per lane: 4 lanes share row i
     const int quarter = t & 3;
     i = t >> 2;
@@ -275,6 +297,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   }
   if constexpr (!kCached) __syncthreads();   // (the cached kernel's barrier sits after its M staging)
   const int n_eps = n_eps_l;
+  if constexpr (kCached) EML_STAMP(3);   // costs in registers
 
   const size_t plane = (size_t)B * N;
   float* fin_out = work + (size_t)g * plane + (size_t)b * N;        // a_x | b_y | a_y | b_x
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       }
     }
     __syncthreads();
+    if constexpr (kCached) EML_STAMP(4 + s);   // sweep s done
   }
 }
 
