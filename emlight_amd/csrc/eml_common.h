@@ -68,6 +68,31 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// min / max over the whole wave without LDS traffic: DPP inside the 16-lane rows, then the four row results through
+// v_readlane (wave-uniform result).  The __shfl_xor forms above cost 6 ds_bpermute round trips each.
+__device__ __forceinline__ float wave_min_dpp(float v) {
+  v = fminf(v, dpp_mov<0xB1>(v));
+  v = fminf(v, dpp_mov<0x4E>(v));
+  v = fminf(v, dpp_mov<0x141>(v));
+  v = fminf(v, dpp_mov<0x140>(v));
+  const int b = __builtin_bit_cast(int, v);
+  return fminf(fminf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+               fminf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const int b = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences GLOBAL memory at workgroup
 // scope, which the compiler implements as s_waitcnt vmcnt(0) before s_barrier: every barrier then waits for
 // all of the wave's outstanding global loads AND stores (a tile's epilogue stores, a prefetch in flight).

@@ -74,8 +74,32 @@ constexpr int kSmemVecs = 2 + 2 + 4 + 2;
 // ---- epsilon schedule, computed by every workgroup (no separate launch, no host sync):
 // d = diameter > 0 ? diameter : range(x U y) over the WHOLE batch (sinkhorn_divergence.py:9-18),
 // eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p] in f64 like numpy
+// The scan's first trip (four float4 per thread) is a separate step so that a kernel can REQUEST it early and do other
+// work (staging) while it is in flight: schedule_scan_begin issues the loads, device_schedule folds them.
+struct ScanHead {
+  float4 a, c, a2, c2;
+};
+template <int kWG>
+__device__ __forceinline__ ScanHead schedule_scan_begin(const float* __restrict__ x, const float* __restrict__ y, int B,
+                                                        int N, double diameter) {
+  ScanHead h;
+  h.a = h.c = h.a2 = h.c2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long n4 = ((long)B * N) >> 2;   // hipMalloc'd buffers: 16-B aligned
+  if (diameter <= 0.0 && n4 > 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    const long k = min((long)threadIdx.x, n4 - 1), k2 = min((long)threadIdx.x + kWG, n4 - 1);   // clamped: min / max idempotent
+    h.a = x4[k];
+    h.c = y4[k];
+    h.a2 = x4[k2];
+    h.c2 = y4[k2];
+  }
+  return h;
+}
+
 template <int kWG, bool kFinalBarrier = true>
-__device__ __forceinline__ void device_schedule(const float* __restrict__ x, const float* __restrict__ y, int B, int N,
+__device__ __forceinline__ void device_schedule(const ScanHead& head, const float* __restrict__ x,
+                                                const float* __restrict__ y, int B, int N,
                                                 double blur, double log_blur, double log_scaling, int p_exp,
                                                 double diameter, float* eps_l,
                                                 int* n_eps_l, float* __restrict__ eps_out, int* __restrict__ n_eps_out,
@@ -84,24 +108,29 @@ __device__ __forceinline__ void device_schedule(const float* __restrict__ x, con
   const int tid0 = threadIdx.x;
   float lo = INFINITY, hi = -INFINITY;
   if (diameter <= 0.0) {
-    const long n_all = (long)B * N, n4 = n_all >> 2;   // hipMalloc'd buffers: 16-B aligned
+    const long n_all = (long)B * N, n4 = n_all >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* y4 = reinterpret_cast<const float4*>(y);
-    // two strides per trip, four loads in flight (cfg2 is exactly one trip): every trip exposes one memory latency
-    for (long k = tid0; k < n4; k += 2 * kWG) {
-      const long k2 = (k + kWG < n4) ? k + kWG : k;   // past the end: this trip's first element again (min / max idempotent)
-      const float4 a = x4[k], c2 = y4[k], a2 = x4[k2], c3 = y4[k2];
+    auto fold = [&](const float4& a, const float4& c2) {
       lo = fminf(fminf(fminf(lo, fminf(a.x, a.y)), fminf(a.z, a.w)), fminf(fminf(c2.x, c2.y), fminf(c2.z, c2.w)));
       hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)), fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w)));
-      lo = fminf(fminf(fminf(lo, fminf(a2.x, a2.y)), fminf(a2.z, a2.w)), fminf(fminf(c3.x, c3.y), fminf(c3.z, c3.w)));
-      hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(a2.x, a2.y)), fmaxf(a2.z, a2.w)), fmaxf(fmaxf(c3.x, c3.y), fmaxf(c3.z, c3.w)));
+    };
+    if (n4 > 0) {
+      fold(head.a, head.c);
+      fold(head.a2, head.c2);
+    }
+    // further trips (B * N > 8 * kWG floats per array): two strides per trip, four loads in flight
+    for (long k = tid0 + 2 * kWG; k < n4; k += 2 * kWG) {
+      const long k2 = (k + kWG < n4) ? k + kWG : k;
+      fold(x4[k], y4[k]);
+      fold(x4[k2], y4[k2]);
     }
     for (long k = 4 * n4 + tid0; k < n_all; k += kWG) {
       lo = fminf(lo, fminf(x[k], y[k]));
       hi = fmaxf(hi, fmaxf(x[k], y[k]));
     }
-    lo = eml::wave_min(lo);
-    hi = eml::wave_max(hi);
+    lo = eml::wave_min_dpp(lo);
+    hi = eml::wave_max_dpp(hi);
     if ((tid0 & 63) == 0) {
       red_lo[tid0 >> 6] = lo;
       red_hi[tid0 >> 6] = hi;
@@ -201,14 +230,11 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       }
     }
   }
-  device_schedule<kWG, !kCached>(x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out,
-                                 diameter_out);
-  const float* eps_s = eps_l;
-  if constexpr (kCached) EML_STAMP(1);   // diameter scan + schedule issued (wave 0: computed)
-
-  // ---- stage points and log-weights; h buffer 0 = log w of each group's columns (sweep 0 reads h = log w, potentials
-  // are zero: sinkhorn_divergence.py:82-85), buffer 1 zeroed (the pads of both are read)
+  const ScanHead scan_head = schedule_scan_begin<kWG>(x, y, B, N, diameter);   // requested; folded in device_schedule
   if constexpr (kCached) {
+    // staging runs WHILE the scan is in flight (the M / point loads were issued first, so they land first): points,
+    // log-weights, h buffer 0 = log w of each group's columns (sweep 0 reads h = log w, potentials are zero:
+    // sinkhorn_divergence.py:82-85), buffer 1 zeroed (the pads of both are read), and the chord matrix
     if (tid < 2 * NP) {
       const int k = tid - (tid >= NP) * NP;
       const float l = (k < N) ? ((my_w > 0.f) ? logf(my_w) : -100000.0f) : 0.f;  // sinkhorn_divergence.py:47-50
@@ -217,7 +243,36 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       h2[tid] = l * kLog2e;        // h2[0][gl = which][k]
       h2[2 * NP + tid] = 0.f;
     }
-  } else {
+    const int ldm = round_up4(N) + 4;
+    {
+      int r = tid / N, cc = tid - r * N;                 // element tid + k * kWG of M = (r, cc)
+      const int dr = kWG / N, dc = kWG - dr * N;
+      if (dc == 0) {   // N divides the workgroup size (N = 128, 64, ...): the column never changes, rows advance by dr
+        float* dst = Ml + r * ldm + cc;
+#pragma unroll
+        for (int k = 0; k < kMPT; ++k)
+          if (r + k * dr < N) dst[k * dr * ldm] = mreg[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMPT; ++k) {
+          if (r < N) Ml[r * ldm + cc] = mreg[k];
+          r += dr;
+          cc += dc;
+          if (cc >= N) {
+            cc -= N;
+            ++r;
+          }
+        }
+      }
+    }
+    EML_STAMP(1);   // this thread's staging written
+  }
+  device_schedule<kWG, !kCached>(scan_head, x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out,
+                                 diameter_out);
+  const float* eps_s = eps_l;
+
+  // ---- stream kernel: stage points and log-weights; h buffer 0 = log w of each group's columns, buffer 1 zeroed
+  if constexpr (!kCached) {
     for (int i = tid; i < 2 * NP; i += kWG) {
       const int which = i / NP, k = i - which * NP;
       float p = 0.f, l = 0.f;
@@ -249,29 +304,8 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
   bool owner = false;
   if constexpr (kCached) {
     const int ldm = round_up4(N) + 4;
-    {
-      int r = tid / N, cc = tid - r * N;                 // element tid + k * kWG of M = (r, cc)
-      const int dr = kWG / N, dc = kWG - dr * N;
-      if (dc == 0) {   // N divides the workgroup size (N = 128, 64, ...): the column never changes, rows advance by dr
-        float* dst = Ml + r * ldm + cc;
-#pragma unroll
-        for (int k = 0; k < kMPT; ++k)
-          if (r + k * dr < N) dst[k * dr * ldm] = mreg[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < kMPT; ++k) {
-          if (r < N) Ml[r * ldm + cc] = mreg[k];
-          r += dr;
-          cc += dc;
-          if (cc >= N) {
-            cc -= N;
-            ++r;
-          }
-        }
-      }
-    }
     __syncthreads();   // pts / lw2 / h2 / Ml / eps_l visible to every thread
-    EML_STAMP(2);      // staging done
+    EML_STAMP(2);      // schedule computed, staging of every wave visible
     const int split = round_up4((N + 3) >> 2);   // columns per lane: 4 lanes share row i
     const int quarter = t & 3;
     i = t >> 2;
@@ -424,7 +458,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   constexpr int TS = TJ + 4;               // LDS row stride of a tile
   __shared__ float eps_l[EML_MAX_EPS];
   __shared__ int n_eps_l;
-  device_schedule<kWG>(x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
+  device_schedule<kWG>(schedule_scan_begin<kWG>(x, y, B, N, diameter), x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter,
+                       eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
   const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NP = round_up4(N) + kJPT;

@@ -17,7 +17,7 @@ B, N, blur = (int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])) if len(sys
 L = ctypes.CDLL(_lib.LIB_PATH)
 if not hasattr(L, "eml_sinkhorn_read_stamps"):
     raise SystemExit("this library was not built with -DEML_STAMPS (see the docstring)")
-names = ["start", "schedule", "staged", "costs"]
+names = ["start", "own-staging", "schedule+staged", "costs"]
 buf = (ctypes.c_longlong * 64)()
 for rep in range(3):
     r = bench.time_sinkhorn(B, N, blur, "cuda:0", reps=20 + rep)
