@@ -51,6 +51,10 @@ class _Workspace:
                     "zmean": torch.zeros(enc.inter, **f32), "zvar": torch.ones(enc.inter, **f32),
                     "zistd": torch.ones(enc.inter, **f32),
                     "W1p": torch.empty(kp * 48, **f32), "W2p": torch.empty(9 * 3 * 4 * 16 * 4, **f32),
+                    # ReLU mask of BN1's output as bits (training only): one 64-bit word per (16-pixel group, 16-channel
+                    # K-step, t), whole 256-pixel tiles -- what the data-gradient pass reads instead of X
+                    "mask": (torch.empty(((B * h * w + 255) // 256) * 16 * (kp // 16) * 4, dtype=torch.int64, device=dev)
+                             if keep_all else None),
                 })
             cout = enc.trans_cout[bi]
             kpt = _r16(ctot)
@@ -266,7 +270,8 @@ class HipDenseEncoder:
                 _lib.check(L.eml_dense_permute_w1_f32(p(Lm.conv1.weight), 48, cin, kp, p(lay["W1p"]), st),
                            "eml_dense_permute_w1_f32")
                 _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, P, Hb, Wb, 0, kp, p(lay["scale1"]),
-                                                       p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), G, st),
+                                                       p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), G,
+                                                       p(lay["mask"]) if (keep_all and training) else None, st),
                            "eml_dense_conv1x1_fwd_f32")
                 self._prepare(L, st, part, G, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
                               training, lay["scale2"], lay["shift2"])
@@ -290,7 +295,7 @@ class HipDenseEncoder:
                                                 p(tr["A"]), kpt, st), "eml_dense_pool_act_f32")
             _lib.check(L.eml_dense_conv1x1_fwd_f32(p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, p(tr["one"]),
                                                    p(tr["zero"]), p(tr["Wp"]), cout, p(tr["T"]), tr["Ko"], p(part), G,
-                                                   st), "eml_dense_conv1x1_fwd_f32(transition)")
+                                                   None, st), "eml_dense_conv1x1_fwd_f32(transition)")
             for ch in range(tr["nchunks"]):
                 nv = min(48, cout - 48 * ch)
                 last = ch == tr["nchunks"] - 1

@@ -57,15 +57,18 @@ def run_backward(enc, ws, x, gpooled):
     cA, cB, cC = coefs[0]
     sB, sC = bw.coef[6], bw.coef[7]
 
-    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=0, s_acc=None, src=None, c_lo=0, c_hi=None):
+    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=0, s_acc=None, src=None, c_lo=0, c_hi=None, conv=None):
         """dgamma/dbeta of `bn` for channels [c_lo, c_hi); coef: write the dz affine into coefficient set
-        `coef` (None: skip); s_acc: fold (cB,cC) into sB/sC (True: add, False: overwrite)."""
+        `coef` (None: skip); s_acc: fold (cB,cC) into sB/sC (True: add, False: overwrite).
+        conv: the 1x1 conv that follows bn + ReLU -- S2 then comes from its finished weight gradient
+        (sum_o W*dW = sum dy*bn(x)); the masked data-gradient passes accumulate S1 only."""
         a, b, c = coefs[coef] if coef is not None else (None, None, None)
+        wargs = (p(bn.bias), p(conv.weight), gr(conv.weight), conv.weight.shape[0]) if conv is not None else (None, None, None, 0)
         _lib.check(L.eml_dense_bn_bwd_finalize_f32(
             p(part if src is None else src), R, pstride, float(count), p(bn.weight), p(mean), p(istd), C, Cpad, 1,
             gr(bn.weight), gr(bn.bias), p(a), p(b), p(c),
             p(sB) if s_acc is not None else None, p(sC) if s_acc is not None else None, int(bool(s_acc)),
-            c_lo, Cpad if c_hi is None else c_hi, st), "eml_dense_bn_bwd_finalize_f32")
+            c_lo, Cpad if c_hi is None else c_hi, *wargs, st), "eml_dense_bn_bwd_finalize_f32")
 
     def parr(tensors):
         return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -141,7 +144,8 @@ def run_backward(enc, ws, x, gpooled):
                 parr([bw.Wd[s_] for s_ in slots]),
                 parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
                 parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
-                p(blk["X"]), ld, p(blk["mean"]), p(blk["istd"]), P, k_lo, k_hi, p(Gbuf), ld, G, st),
+                None, ld, None, None, P, k_lo, k_hi, p(Gbuf), ld, G,
+                parr([y["mask"] for y in lays]), st),   # ReLU masks from the forward's bits: X is not read
                 "eml_dense_conv1x1_bwd_data_multi_f32")
 
         def narrow(l, Lm, slot, k_lo):
@@ -156,7 +160,7 @@ def run_backward(enc, ws, x, gpooled):
         def bn1_finalize(l, Lm, slot, c_lo, c_hi):
             lay = blk["layers"][l]
             finalize(G, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,
-                     s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi)
+                     s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi, conv=Lm.conv1)
 
         l = len(blk["layers"]) - 1
         while l >= 0:

@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 6   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 7   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -67,7 +67,7 @@ SIGNATURES = {
     "eml_dense_permute_w1_f32": (_int, [_f32p, _int, _int, _int, _f32p, _stream]),
     "eml_dense_permute_w2_f32": (_int, [_f32p, _int, _f32p, _stream]),
     "eml_dense_conv1x1_fwd_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _f32p, _f32p, _f32p,
-                                         _int, _f32p, _int, _f32p, _int, _stream]),
+                                         _int, _f32p, _int, _f32p, _int, ctypes.c_void_p, _stream]),
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
                                          _int, _stream]),
     "eml_dense_pool_act_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _int, _stream]),
@@ -79,7 +79,7 @@ SIGNATURES = {
                                                 _f32p, _int, _stream]),
     "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,
                                              _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
-                                             _stream]),
+                                             _f32p, _f32p, _f32p, _int, _stream]),
     "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
                                                 _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
                                                 _f32p, _int, _f32p, _stream]),
@@ -90,7 +90,8 @@ SIGNATURES = {
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
                                               _int, _f32p, _int, _int, _f32p, _int, _stream]),
     "eml_dense_conv1x1_bwd_data_multi_f32": (_int, [_int] + [ctypes.c_void_p] * 10 + [_f32p, _int, _f32p, _f32p,
-                                                    ctypes.c_long, _int, _int, _f32p, _int, _int, _stream]),
+                                                    ctypes.c_long, _int, _int, _f32p, _int, _int, ctypes.c_void_p,
+                                                    _stream]),
     "eml_dense_grad_materialize_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _int, _int, ctypes.c_long,
                                               _stream]),
     "eml_dense_bn_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _int, _int, ctypes.c_long, _f32p,

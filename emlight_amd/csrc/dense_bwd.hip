@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const double* __restrict__ partials, int R, int pstride, double count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ istd, int C, int Cpad, int training,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
-    float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate, int c_lo, int c_hi) {
+    float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate, int c_lo, int c_hi,
+    const float* __restrict__ beta, const float* __restrict__ Wc, const float* __restrict__ dWc, int w_rows) {
   // one wavefront per channel; lanes stride over the R partial rows; only channels [c_lo, c_hi) are touched
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = c_lo + blockIdx.x * 4 + wave;
@@ -408,10 +409,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
       S1 += partials[(size_t)g * pstride + 2 * c];
       S2 += partials[(size_t)g * pstride + 2 * c + 1];
     }
+    double Q = 0.0;   // Wc != NULL: sum_o W[o][c] * dW[o][c] = sum_p dy * bn(x) (see the header)
+    if (Wc)
+      for (int o = lane; o < w_rows; o += 64) Q += (double)Wc[(size_t)o * C + c] * (double)dWc[(size_t)o * C + c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       S1 += __shfl_xor(S1, o, 64);
       S2 += __shfl_xor(S2, o, 64);
+      Q += __shfl_xor(Q, o, 64);
+    }
+    if (Wc) {
+      const double ga0 = gamma[c];
+      S2 = ga0 != 0.0 ? (Q - (double)beta[c] * S1) / ga0 : 0.0;
     }
     if (lane == 0) {
       dgamma[c] = (float)S2;
@@ -1019,13 +1028,19 @@ struct BwdLayer {
   int Kp;
 };
 
-template <int NL, int MT /* 16-pixel tiles per wave */, bool RAW = false /* DZ already holds dz (materialised) */>
+// MASKED: the ReLU mask of every layer comes from the bits the forward stored (BwdLayer::mask); X, mean, istd and the
+// layers' shift1 are not read at all and only S1 = sum dam is accumulated (BN1's S2 follows from the weight gradient,
+// bn_bwd_finalize_kernel) -- the pass moves old G, new G and dz only: (2k + 96) instead of (3k + 96) floats per pixel.
+template <int NL, int MT /* 16-pixel tiles per wave */, bool RAW = false /* DZ already holds dz (materialised) */,
+          bool MASKED = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer L0, BwdLayer L1,
                                                                         const float* __restrict__ X, int ldx,
                                                                         const float* __restrict__ mean,
                                                                         const float* __restrict__ istd, int P,
                                                                         int k_lo, int k_hi, float* __restrict__ Gd,
-                                                                        int ldg, int KpMax) {
+                                                                        int ldg, int KpMax,
+                                                                        const unsigned long long* __restrict__ M0,
+                                                                        const unsigned long long* __restrict__ M1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   double* sacc = reinterpret_cast<double*>(smem);                         // [NL][4 waves][KpMax][2]
   float* vec_l = reinterpret_cast<float*>(sacc + (size_t)NL * 4 * KpMax * 2);  // [2 + 2*NL][KpMax]: mean, istd, (scale1, shift1) per layer
@@ -1034,8 +1049,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
   const BwdLayer Ls[2] = {L0, L1};
   for (int e = tid; e < NL * 4 * KpMax * 2; e += 256) sacc[e] = 0.0;
   for (int e = tid; e < KpMax; e += 256) {
-    vec_l[e] = mean[e];
-    vec_l[KpMax + e] = istd[e];
+    vec_l[e] = MASKED ? 0.f : mean[e];
+    vec_l[KpMax + e] = MASKED ? 0.f : istd[e];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       vec_l[(2 + 2 * j) * KpMax + e] = e < Ls[j].Kp ? Ls[j].scale1[e] : 0.f;
@@ -1073,6 +1088,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
       pv[m] = p0 + 16 * m + r < P;
       prow[m] = min(p0 + 16 * m + r, P - 1);
     }
+    unsigned long long pvb[MT];   // MASKED: pixel validity as a lane mask (ANDed into the ReLU words on the scalar unit)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pvb[m] = MASKED ? __ballot(pv[m]) : 0ull;
     // dz fragments of every layer stay in registers for the whole tile
     float4 dz[NL][3][MT];
 #pragma unroll
@@ -1110,13 +1128,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           gs[m][n] = *reinterpret_cast<const float4*>(Gd + prow[m] * ldg + k4l);
-          xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4l);
+          if constexpr (!MASKED) xv[m][n] = *reinterpret_cast<const float4*>(X + prow[m] * ldx + k4l);
         }
       }
       const int nt_next = nt0 + NCH < nt_hi ? nt0 + NCH : nt_lo;  // the next tile starts at nt_lo again
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int nnt = Ls[j].Kp >> 4;
+        // MASKED: the forward's ballot words of this step's (pixel group, channel tile)s -- wave-uniform addresses of a
+        // read-only buffer, i.e. scalar loads; requested here, used after the step's MFMAs
+        unsigned long long mk[MT][NCH][4];
+        if constexpr (MASKED) {
+          const unsigned long long* __restrict__ Mj = j == 0 ? M0 : M1;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NCH; ++n) {
+              const size_t wi =
+                  ((size_t)__builtin_amdgcn_readfirstlane((p0 >> 4) + m) * nnt + min(nt0 + n, nnt - 1)) * 4;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) mk[m][n][g] = Mj[wi + g];
+            }
+        }
         // request the NEXT step's weights, then run this step
         const int cur = NL == 2 ? j : wsel;
         if (j + 1 < NL)
@@ -1150,15 +1183,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
             const float4 tk = *reinterpret_cast<const float4*>(vec_l + (3 + 2 * j) * KpMax + k4);
             const bool in0 = k4 + 0 >= k_lo && k4 + 0 < k_hi, in1 = k4 + 1 >= k_lo && k4 + 1 < k_hi;
             const bool in2 = k4 + 2 >= k_lo && k4 + 2 < k_hi, in3 = k4 + 3 >= k_lo && k4 + 3 < k_hi;
+            unsigned long long inb[4] = {0ull, 0ull, 0ull, 0ull};
+            if constexpr (MASKED) {
+              inb[0] = __ballot(in0);
+              inb[1] = __ballot(in1);
+              inb[2] = __ballot(in2);
+              inb[3] = __ballot(in3);
+            }
             float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-              // unconditional use of the loaded x / g (masked values): see conv3x3_bwd_data_kernel
-              const float4 x = xv[m][n];
-              const float d0 = (pv[m] && in0 && fmaf(x.x, sk.x, tk.x) > 0.f) ? acc[m][n][0] : 0.f;
-              const float d1 = (pv[m] && in1 && fmaf(x.y, sk.y, tk.y) > 0.f) ? acc[m][n][1] : 0.f;
-              const float d2 = (pv[m] && in2 && fmaf(x.z, sk.z, tk.z) > 0.f) ? acc[m][n][2] : 0.f;
-              const float d3 = (pv[m] && in3 && fmaf(x.w, sk.w, tk.w) > 0.f) ? acc[m][n][3] : 0.f;
+              float d0, d1, d2, d3;
+              if constexpr (MASKED) {
+                // bit `lane` of word g = this lane's ReLU mask for channel g: the word IS the select mask of v_cndmask
+                d0 = __builtin_amdgcn_inverse_ballot_w64(mk[m][n][0] & pvb[m] & inb[0]) ? acc[m][n][0] : 0.f;
+                d1 = __builtin_amdgcn_inverse_ballot_w64(mk[m][n][1] & pvb[m] & inb[1]) ? acc[m][n][1] : 0.f;
+                d2 = __builtin_amdgcn_inverse_ballot_w64(mk[m][n][2] & pvb[m] & inb[2]) ? acc[m][n][2] : 0.f;
+                d3 = __builtin_amdgcn_inverse_ballot_w64(mk[m][n][3] & pvb[m] & inb[3]) ? acc[m][n][3] : 0.f;
+              } else {
+                // unconditional use of the loaded x / g (masked values): see conv3x3_bwd_data_kernel
+                const float4 x = xv[m][n];
+                d0 = (pv[m] && in0 && fmaf(x.x, sk.x, tk.x) > 0.f) ? acc[m][n][0] : 0.f;
+                d1 = (pv[m] && in1 && fmaf(x.y, sk.y, tk.y) > 0.f) ? acc[m][n][1] : 0.f;
+                d2 = (pv[m] && in2 && fmaf(x.z, sk.z, tk.z) > 0.f) ? acc[m][n][2] : 0.f;
+                d3 = (pv[m] && in3 && fmaf(x.w, sk.w, tk.w) > 0.f) ? acc[m][n][3] : 0.f;
+                l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
+                l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
+                l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
+                l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
+              }
               gs[m][n].x = fmaf(sk.x, d0, gs[m][n].x);
               gs[m][n].y = fmaf(sk.y, d1, gs[m][n].y);
               gs[m][n].z = fmaf(sk.z, d2, gs[m][n].z);
@@ -1167,18 +1220,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
               l1[1] += d1;
               l1[2] += d2;
               l1[3] += d3;
-              l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
-              l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
-              l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
-              l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               l1[g] = eml::row16_sum(l1[g]);  // over the 16 pixels (lanes r) of this lane row: DPP, no LDS
-              l2[g] = eml::row16_sum(l2[g]);
+              if constexpr (!MASKED) l2[g] = eml::row16_sum(l2[g]);
               if (r == 0) {
                 my[2 * (k4 + g)] += (double)l1[g];
-                my[2 * (k4 + g) + 1] += (double)l2[g];
+                if constexpr (!MASKED) my[2 * (k4 + g) + 1] += (double)l2[g];
               }
             }
           }
@@ -1536,14 +1585,17 @@ extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int 
                                              const float* gamma, const float* mean, const float* istd, int C, int Cpad,
                                              int training, float* dgamma, float* dbeta, float* cA, float* cB,
                                              float* cC, float* sB, float* sC, int s_accumulate, int c_lo,
-                                             int c_hi, eml_stream_t stream) {
+                                             int c_hi, const float* beta, const float* W, const float* dW, int w_rows,
+                                             eml_stream_t stream) {
   if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || C < 1 || Cpad < C || R < 1 ||
       (cA && (!cB || !cC)) || (sB && !sC) || c_lo < 0 || c_hi <= c_lo)
     return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: bad arguments");
+  if (W && (!dW || !beta || w_rows < 1))
+    return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: W given without dW / beta / w_rows");
   if (c_hi > Cpad) c_hi = Cpad;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c_hi - c_lo + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials,
                      R, pstride, count, gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC, sB, sC,
-                     s_accumulate, c_lo, c_hi);
+                     s_accumulate, c_lo, c_hi, beta, W, dW, w_rows);
   return eml::check_launch("eml_dense_bn_bwd_finalize_f32");
 }
 
@@ -1639,39 +1691,52 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
                                                     const float* const* scale1, const float* const* shift1,
                                                     double* const* partials, const int* Kp, const float* X, int ldx,
                                                     const float* mean, const float* istd, long P, int k_lo, int k_hi,
-                                                    float* G, int ldg, int grid, eml_stream_t stream) {
+                                                    float* G, int ldg, int grid,
+                                                    const unsigned long long* const* relu_masks, eml_stream_t stream) {
   if (n_layers < 1 || n_layers > 2 || !DZ || !Wd || !scale1 || !shift1 || !partials ||
-      !Kp || !X || !mean || !istd || !G || P < 1 || grid < 1 || k_lo < 0 || k_hi <= k_lo || (ldx & 3) || (ldg & 3))
+      !Kp || (!relu_masks && (!X || !mean || !istd)) || !G || P < 1 || grid < 1 || k_lo < 0 || k_hi <= k_lo ||
+      (ldx & 3) || (ldg & 3))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad arguments");
   // Zr == NULL: DZ holds the materialised dz (eml_dense_conv1x1_bwd_weight_f32's dz_out); else dz = cA*DZ + cB*Zr + cC
   const bool raw = Zr == nullptr;
   if (!raw && (!cA || !cB || !cC))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Zr given without cA/cB/cC");
+  if (relu_masks && !raw)
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: relu_masks needs the materialised dz (Zr == NULL)");
   BwdLayer L[2];
+  const unsigned long long* Mk[2] = {nullptr, nullptr};
   int kmax = 0;
   for (int j = 0; j < 2; ++j) {
     const int s = j < n_layers ? j : 0;
+    const unsigned long long* mk = relu_masks ? relu_masks[s] : nullptr;
+    Mk[j] = mk;
     L[j] = raw ? BwdLayer{DZ[s], nullptr, nullptr, nullptr, nullptr, Wd[s], scale1[s], shift1[s], partials[s], Kp[s]}
                : BwdLayer{DZ[s], Zr[s], cA[s], cB[s], cC[s], Wd[s], scale1[s], shift1[s], partials[s], Kp[s]};
-    if (!DZ[s] || (!raw && !Zr[s]) || !Wd[s] || !partials[s] || (Kp[s] & 15) || Kp[s] > ldx || Kp[s] > ldg)
+    if (!DZ[s] || (!raw && !Zr[s]) || !Wd[s] || !partials[s] || (relu_masks && !mk) || (Kp[s] & 15) ||
+        (!relu_masks && Kp[s] > ldx) || Kp[s] > ldg)
       return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: bad layer %d", s);
     if (Kp[s] > kmax) kmax = Kp[s];
   }
   if (((k_hi + 15) & ~15) > kmax) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: range beyond Kp");
   const size_t lds = (size_t)n_layers * 4 * kmax * 2 * sizeof(double) + (size_t)(2 + 2 * n_layers) * kmax * sizeof(float);
   if (lds > 80 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Kp=%d does not fit LDS", kmax);
-#define EML_LAUNCH_MULTI(NLV, MTV, RAWV)                                                                             \
+#define EML_LAUNCH_MULTI(NLV, MTV, RAWV, MSKV)                                                                       \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV>),         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV>), dim3(grid), dim3(256), lds,                  \
-                       (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax);       \
+    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>), dim3(grid), dim3(256), lds,            \
+                       (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax,        \
+                       Mk[0], Mk[1]);                                                                               \
   } while (0)
   // two layers: 32 pixels per wave keeps both layers' dz fragments resident at 2 waves/SIMD
   if (n_layers == 1) {
-    if (raw) EML_LAUNCH_MULTI(1, 4, true); else EML_LAUNCH_MULTI(1, 4, false);
+    if (relu_masks) EML_LAUNCH_MULTI(1, 4, true, true);
+    else if (raw) EML_LAUNCH_MULTI(1, 4, true, false);
+    else EML_LAUNCH_MULTI(1, 4, false, false);
   } else {
-    if (raw) EML_LAUNCH_MULTI(2, 2, true); else EML_LAUNCH_MULTI(2, 2, false);
+    if (relu_masks) EML_LAUNCH_MULTI(2, 2, true, true);
+    else if (raw) EML_LAUNCH_MULTI(2, 2, true, false);
+    else EML_LAUNCH_MULTI(2, 2, false, false);
   }
 #undef EML_LAUNCH_MULTI
   return eml::check_launch("eml_dense_conv1x1_bwd_data_multi_f32");

@@ -75,7 +75,8 @@ template <bool POOL>
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ Wp,
-    float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials) {
+    float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials,
+    unsigned long long* __restrict__ relu_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                 // [Kp/16][4][48][4]
   float* sl = wl + (size_t)Kp * 48; // [Kp]
@@ -168,6 +169,23 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
         __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
+        if (relu_mask) {
+          // ReLU mask of this K-step as wave ballots: word (pixel group, K-step, t), bit r + 16*kk <-> pixel 16*pg + r,
+          // channel 16*j + 4*kk + t -- the lane layout of the data-gradient kernel, which then needs neither X nor
+          // BN1's affine to know where relu(bn1(x)) was active.  Lane i < 16 stores word (m = i / 4, t = i % 4).
+          // (tried: v_writelane of each ballot into its lane via inline asm -- no faster, and inline asm gets no hazard
+          // handling after the v_cmp that writes the SGPR pair: wrong bits)
+          unsigned long long mine = 0ull;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const unsigned long long w = __ballot(f4c(a[m], t) > 0.f);
+              mine = (lane == 4 * m + t) ? w : mine;
+            }
+          if (lane < 16)
+            relu_mask[((size_t)(tile * 16 + wave * 4 + (lane >> 2)) * nj + j) * 4 + (lane & 3)] = mine;
+        }
       }
       float4 bw[3];
 #pragma unroll
@@ -747,10 +765,13 @@ extern "C" int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, e
 // the operand load; P = B*(Hin/2)*(Win/2) output pixels).  partials: [chunks][grid][48][2] f64.
 extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, int Kp,
                                          const float* scale, const float* shift, const float* Wp, int Cout,
-                                         float* out, int ldo, double* partials, int grid, eml_stream_t stream) {
+                                         float* out, int ldo, double* partials, int grid,
+                                         unsigned long long* relu_mask, eml_stream_t stream) {
   if (!X || !scale || !shift || !Wp || !out || !partials || P < 1 || grid < 1 || Kp < 16 || (Kp & 15) || Kp > ldx ||
       (ldx & 3) || Cout < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: bad arguments");
+  if (relu_mask && (pool || Cout > 48))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: relu_mask is for dense layers (no pool, Cout <= 48)");
   if (pool && ((Hin & 1) || (Win & 1))) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: pool needs even H, W");
   const size_t lds = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double);
   if (lds > 160 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: Kp=%d does not fit LDS", Kp);
@@ -763,12 +784,12 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
-                         Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp);
+                         Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
-                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp);
+                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, relu_mask);
     }
     int rc = eml::check_launch("eml_dense_conv1x1_fwd_f32");
     if (rc) return rc;

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 6
+#define EML_ABI_VERSION 7
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -139,10 +139,14 @@ int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t
 /* out[p][o] = sum_k relu(scale_k*X[p][k] + shift_k) * W[o][k]:  BN1 -> ReLU -> conv1 of a dense layer
  * (DenseNet.py:30-37; Cout = 48) and, with pool != 0, a transition BN -> ReLU -> conv -> avgpool2
  * (DenseNet.py:14-21; the pool is applied to the operand: it commutes with the 1x1 conv).
- * P output pixels; partials [ceil(Cout/48)][grid][48][2]. */
+ * P output pixels; partials [ceil(Cout/48)][grid][48][2].
+ * relu_mask (may be NULL; dense layers only): the ReLU mask of the BN1 output as bits, for the backward --
+ * 64-bit words [ceil(P/256)*16 pixel groups][Kp/16][4]: word (pg, j, t), bit r + 16*q <-> pixel 16*pg + r,
+ * channel 16*j + 4*q + t (q < 4, r < 16); P * Kp / 8 bytes rounded up to whole 256-pixel tiles. */
 int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, int Kp,
                               const float* scale, const float* shift, const float* Wp, int Cout,
-                              float* out, int ldo, double* partials, int grid, eml_stream_t stream);
+                              float* out, int ldo, double* partials, int grid,
+                              unsigned long long* relu_mask, eml_stream_t stream);
 
 /* X[p][c_out0 + o] = conv3x3(scale2*Z + shift2)[p][o], o < 12: BN2 -> conv2 of a dense layer
  * (DenseNet.py:38-43, no ReLU between them); Z is (B,H,W,48); partials [grid][16][2]. */
@@ -187,12 +191,18 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
  * and the affine dx = cA*dy + cB*x + cC (cA = gamma*istd, cB = -gamma*istd^2*S2/n,
  * cC = -gamma*istd*S1/n + gamma*istd^2*S2/n*mean), zero-padded to Cpad.  cA/cB/cC may be NULL.
  * sB/sC (may be NULL): running per-channel sums of (cB, cC) -- the deferred x-affine of a dense
- * block's gradient (s_accumulate = 0 overwrites, 1 adds).  Only channels [c_lo, c_hi) are processed. */
+ * block's gradient (s_accumulate = 0 overwrites, 1 adds).  Only channels [c_lo, c_hi) are processed.
+ * W != NULL (BN1 of a dense layer, followed by ReLU and the 1x1 conv W [w_rows][C]): S2 is not read from the
+ * partials but derived from the conv's finished weight gradient dW -- with a = relu(bn(x)) and dy = mask * (W^T dz),
+ * sum_p dy*bn(x) = sum_o W[o][c]*dW[o][c], and bn(x) = gamma*xhat + beta, so
+ * S2 = (sum_o W[o][c]*dW[o][c] - beta[c]*S1) / gamma[c]  (gamma[c] == 0: S2 = 0).  The data-gradient pass then
+ * needs no x at all (eml_dense_conv1x1_bwd_data_multi_f32 with relu_masks). */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
                                   int Cpad, int training, float* dgamma, float* dbeta, float* cA,
                                   float* cB, float* cC, float* sB, float* sC, int s_accumulate,
-                                  int c_lo, int c_hi, eml_stream_t stream);
+                                  int c_lo, int c_hi, const float* beta, const float* W, const float* dW,
+                                  int w_rows, eml_stream_t stream);
 
 /* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).
@@ -224,14 +234,18 @@ int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, 
  * [k_lo, k_hi): G[p][k] += sum_j scale1_j[k]*dam_j[p][k] -- X is read once and G read-modify-written once
  * for both layers (the backward of a dense block is HBM-bound on exactly that traffic).  Per-layer
  * arrays of length n_layers (1 or 2); DZ/Zr are (P,48); partials_j is [grid][Kp_j][2].
- * Zr == NULL (then cA/cB/cC are ignored): DZ_j already holds dz_j (dz_out of eml_dense_conv1x1_bwd_weight_f32). */
+ * Zr == NULL (then cA/cB/cC are ignored): DZ_j already holds dz_j (dz_out of eml_dense_conv1x1_bwd_weight_f32).
+ * relu_masks != NULL (per layer: the relu_mask the forward wrote): the ReLU mask comes from those bits and X / mean /
+ * istd are NOT read (they may be NULL) -- a third of the pass's bytes; partials then carry S1 only (S2 slot = 0; BN1's
+ * S2 comes from the weight gradient, see eml_dense_bn_bwd_finalize_f32). */
 int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
                                          const float* const* cA, const float* const* cB,
                                          const float* const* cC, const float* const* Wd,
                                          const float* const* scale1, const float* const* shift1,
                                          double* const* partials, const int* Kp, const float* X, int ldx,
                                          const float* mean, const float* istd, long P, int k_lo,
-                                         int k_hi, float* G, int ldg, int grid, eml_stream_t stream);
+                                         int k_hi, float* G, int ldg, int grid,
+                                         const unsigned long long* const* relu_masks, eml_stream_t stream);
 
 /* Narrow data pass (autograd of DenseNet.py:50-55 restricted to 12 channels): the data gradient of a dense layer
  * over the 12 output channels [k_lo, k_lo+12) of the layer below it, added to what G holds there and written as the

@@ -58,7 +58,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_spade_modulate_fwd_f32(one, 16, one, 16, one, 16, 4, 16, ctypes.c_float(0.2), None) == -1   # gb needs 2C
     assert L.eml_spade_modulate_bwd_f32(one, 6, one, 6, one, 12, one, 6, one, 12, 4, 6, ctypes.c_float(1.0), None) == -1
     assert L.eml_dense_conv1x1_bwd_data_multi_f32(3, None, None, None, None, None, None, None, None, None, None, one, 224,
-                                                  one, one, 10, 0, 16, one, 224, 512, None) == -1
+                                                  one, one, 10, 0, 16, one, 224, 512, None, None) == -1
     # round-2 entry points: fused SphereConv (channel counts must tile), BatchNorm fold, narrow dgrad
     assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 48, 64, None) == -1     # C % 32
     assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 96, None) == -1     # O % 64

@@ -120,9 +120,20 @@ def test_conv1x1_fwd(lib, pool, Cin, Cout, B, H, W):
     ldo = r16(Cout)
     out = torch.zeros(P, ldo, device=DEV)
     part = torch.zeros(nch * G * 96, dtype=torch.float64, device=DEV)
+    mask = None if pool else torch.zeros(((P + 255) // 256) * 16 * (Kp // 16) * 4, dtype=torch.int64, device=DEV)
     lib.check(L.eml_dense_conv1x1_fwd_f32(p(X), ld, P, H, W, pool, Kp, p(sc), p(sh), p(Wp), Cout, p(out), ldo, p(part),
-                                          G, st), "conv1x1")
+                                          G, p(mask), st), "conv1x1")
     a = (X[:, :Cin].double() * sc[:Cin].double() + sh[:Cin].double()).clamp_min(0)
+    if mask is not None:
+        # relu_mask: word (pixel group pg, K-step j, t), bit r + 16*q <-> pixel 16*pg + r, channel 16*j + 4*q + t
+        act = torch.zeros(((P + 255) // 256) * 256, Kp, dtype=torch.bool, device=DEV)
+        act[:P, :Cin] = torch.addcmul(sh[:Cin], X[:, :Cin], sc[:Cin]) > 0     # f32 fma, like the kernel's bn_relu4
+        bits = act.view(-1, 16, Kp // 16, 4, 4).permute(0, 2, 4, 3, 1).reshape(-1, 64)   # (pg, j, t, q*16 + r)
+        got = ((mask.view(-1, 1) >> torch.arange(64, device=DEV)) & 1).bool()
+        npg = (P + 15) // 16                                                # pixel groups past P hold clamped duplicates
+        differ = (got.view(-1, (Kp // 16) * 4, 64)[:P // 16] != bits.view(-1, (Kp // 16) * 4, 64)[:P // 16])
+        assert int(differ.sum()) <= 2, int(differ.sum())                    # (an fma within 1 ulp of 0 may round the other way)
+        assert npg <= mask.numel() // ((Kp // 16) * 4)
     if pool:
         a = nhwc(F.avg_pool2d(nchw(a, B, H, W), 2, 2))
     want = a @ Wt.double().t()
@@ -252,7 +263,7 @@ def test_bn_bwd_finalize(lib):
     cA, cB, cC = (torch.full((Cpad,), 3.0, device=DEV) for _ in range(3))
     sB, sC = torch.ones(Cpad, device=DEV), torch.ones(Cpad, device=DEV)
     lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg), p(db),
-                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, 0, Cpad, st), "finalize")
+                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, 0, Cpad, None, None, None, 0, st), "finalize")
     S = part.view(R, C, 2).sum(0)
     S1, S2 = S[:, 0], S[:, 1]
     ga, is_, mu = gamma.double(), istd.double(), mean.double()
@@ -267,7 +278,8 @@ def test_bn_bwd_finalize(lib):
     cA2, sB2 = torch.full((Cpad,), 3.0, device=DEV), torch.ones(Cpad, device=DEV)
     dg2 = torch.full((C,), 7.0, device=DEV)
     lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg2), p(db),
-                                              p(cA2), p(cB), p(cC), p(sB2), p(sC), 1, 40, 52, st), "finalize range")
+                                              p(cA2), p(cB), p(cC), p(sB2), p(sC), 1, 40, 52, None, None, None, 0, st),
+              "finalize range")
     close(dg2[40:52], S2[40:52], what="dgamma range")
     assert bool((dg2[:40] == 7.0).all()) and bool((dg2[52:] == 7.0).all())
     assert bool((cA2[:40] == 3.0).all()) and bool((sB2[52:] == 1.0).all())
@@ -424,7 +436,7 @@ def test_conv1x1_bwd_data_two_layers_per_pass(lib, Cin_a, B, H, W):
         lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
             len(layers), *args, arr("Wd"), arr("s1"), arr("t1"),
             arr("part"), (ctypes.c_int * len(layers))(*[y["Kp"] for y in layers]), p(X), ld, p(mean), p(istd), P, k_lo,
-            k_hi, p(Gd), ld, G, st), "multi")
+            k_hi, p(Gd), ld, G, None, st), "multi")
 
     G0 = rnd(P, ld)
     Gd = G0.clone()
@@ -485,7 +497,7 @@ def test_conv1x1_bwd_narrow_and_raw_dz_passes(lib, Cin_a, B, H, W):
     arr = lambda key: (ctypes.c_void_p * 2)(*[y[key].data_ptr() for y in layers])
     lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
         2, arr("dz"), None, None, None, None, arr("Wd"), arr("s1"), arr("t1"), arr("part"),
-        (ctypes.c_int * 2)(Kpa, Kpb), p(X), ld, p(mean), p(istd), P, 0, Cin_b, p(Gd), ld, G, st), "multi raw")
+        (ctypes.c_int * 2)(Kpa, Kpb), p(X), ld, p(mean), p(istd), P, 0, Cin_b, p(Gd), ld, G, None, st), "multi raw")
     want = G0.double()
     want[:, :Cin_b] += A["s1"][:Cin_b].double() * A["dam"][:, :Cin_b] + Bl["s1"][:Cin_b].double() * Bl["dam"]
     close(Gd, want, what="fused G (raw dz)", rtol=1e-4)
@@ -498,3 +510,81 @@ def test_conv1x1_bwd_narrow_and_raw_dz_passes(lib, Cin_a, B, H, W):
                                               p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st) == -1
     assert L.eml_dense_conv1x1_bwd_narrow_f32(p(A["dz"]), p(A["W"]), Cin_a, Cin_a - 2, p(X), ld, p(A["s1"]), p(A["t1"]), p(mean),
                                               p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st) == -1
+
+
+@pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 16, 32), (330, 1, 16, 16), (162, 3, 16, 16), (174, 2, 9, 7)])
+def test_conv1x1_bwd_masked_pass_and_bn1_from_weight_gradient(lib, Cin_a, B, H, W):
+    """The X-free data-gradient pass: the forward kernel's ReLU bits replace relu(bn1(x)) > 0, the pass accumulates S1
+    only, and BN1's S2 = sum dy*xhat is recovered from the conv's weight gradient:
+    S2 = (sum_o W[o][c]*dW[o][c] - beta*S1) / gamma -- all against f64 torch on the same inputs."""
+    import ctypes
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    Cin_b = Cin_a - 12
+    Kpa, Kpb = r16(Cin_a), r16(Cin_b)
+    ld = Kpa + 16
+    P = B * H * W
+    X = rnd(P, ld)
+    mu_t = X[:, :Cin_a].double().mean(0)
+    var_t = X[:, :Cin_a].double().var(0, unbiased=False)
+    mean, istd = torch.zeros(ld, device=DEV), torch.ones(ld, device=DEV)
+    mean[:Cin_a], istd[:Cin_a] = mu_t.float(), (var_t + 1e-5).rsqrt().float()
+    xh = (X.double() - mean.double()) * istd.double()
+
+    def layer(Cin, Kp):
+        gamma, beta = torch.rand(Cin, device=DEV) + 0.5, rnd(Cin, scale=0.3)
+        s1, t1 = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
+        s1[:Cin] = gamma * istd[:Cin]
+        t1[:Cin] = beta - mean[:Cin] * s1[:Cin]
+        d = dict(dz=rnd(P, 48), s1=s1, t1=t1, gamma=gamma, beta=beta, W=rnd(48, Cin, scale=0.15),
+                 Wd=torch.empty(Kp * 48, device=DEV), Wp=torch.empty(Kp * 48, device=DEV),
+                 part=torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV), Kp=Kp, Cin=Cin,
+                 mask=torch.zeros(((P + 255) // 256) * 16 * (Kp // 16) * 4, dtype=torch.int64, device=DEV))
+        lib.check(L.eml_dense_permute_w1_bwd_f32(p(d["W"]), 48, Cin, Kp, 48, p(d["Wd"]), st), "permute bwd")
+        lib.check(L.eml_dense_permute_w1_f32(p(d["W"]), 48, Cin, Kp, p(d["Wp"]), st), "permute fwd")
+        z, fp = torch.empty(P, 48, device=DEV), torch.zeros(G * 96, dtype=torch.float64, device=DEV)
+        lib.check(L.eml_dense_conv1x1_fwd_f32(p(X), ld, P, H, W, 0, Kp, p(s1), p(t1), p(d["Wp"]), 48, p(z), 48, p(fp), G,
+                                              p(d["mask"]), st), "forward (writes the mask)")
+        pre = torch.addcmul(t1[:Cin], X[:, :Cin], s1[:Cin])              # f32, the forward's own expression
+        a = pre.double().clamp_min(0)
+        d["dam"] = torch.where(pre > 0, d["dz"].double() @ d["W"].double(), torch.zeros(P, Cin, device=DEV, dtype=torch.float64))
+        d["dW"] = (d["dz"].double().t() @ a).float().contiguous()      # the conv's weight gradient (48, Cin)
+        return d
+    A, Bl = layer(Cin_a, Kpa), layer(Cin_b, Kpb)
+    layers = [A, Bl]
+    arr = lambda key: (ctypes.c_void_p * 2)(*[y[key].data_ptr() for y in layers])
+    G0 = rnd(P, ld)
+    Gd = G0.clone()
+    lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
+        2, arr("dz"), None, None, None, None, arr("Wd"), arr("s1"), arr("t1"), arr("part"),
+        (ctypes.c_int * 2)(Kpa, Kpb), None, ld, None, None, P, 0, Cin_b, p(Gd), ld, G, arr("mask"), st), "multi masked")
+    want = G0.double()
+    want[:, :Cin_b] += A["s1"][:Cin_b].double() * A["dam"][:, :Cin_b] + Bl["s1"][:Cin_b].double() * Bl["dam"]
+    close(Gd, want, what="fused G (masked)", rtol=1e-4)
+    n = float(P)
+    for y, Kp in ((A, Kpa), (Bl, Kpb)):
+        S1, S2z = fold_partials(y["part"], G, Kp)
+        close(S1[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="masked S1", rtol=1e-5, atol=1e-4)
+        assert float(S2z.abs().max()) == 0.0                            # the S2 slots stay zero
+        C = y["Cin"]
+        dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        lib.check(L.eml_dense_bn_bwd_finalize_f32(p(y["part"]), G, 2 * Kp, n, p(y["gamma"]), p(mean), p(istd), C, Kp, 1, p(dg),
+                                                  p(db), None, None, None, None, None, 0, 0, Cin_b, p(y["beta"]), p(y["W"]),
+                                                  p(y["dW"]), 48, st), "finalize from dW")
+        S2 = (y["dam"][:, :Cin_b] * xh[:, :Cin_b]).sum(0)
+        scale = float(S2.abs().max())
+        close(dg[:Cin_b], S2, what="dgamma from the weight gradient", rtol=2e-4, atol=2e-5 * max(scale, 1.0))
+        close(db[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="dbeta", rtol=1e-5, atol=1e-4)
+    # single-layer form
+    Gd1 = G0.clone()
+    A["part"].zero_()
+    one = lambda key: (ctypes.c_void_p * 1)(A[key].data_ptr())
+    lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
+        1, one("dz"), None, None, None, None, one("Wd"), one("s1"), one("t1"), one("part"), (ctypes.c_int * 1)(Kpa), None, ld,
+        None, None, P, 0, Cin_a, p(Gd1), ld, G, one("mask"), st), "single masked")
+    want1 = G0.double()
+    want1[:, :Cin_a] += A["s1"][:Cin_a].double() * A["dam"]
+    close(Gd1, want1, what="single-layer G (masked)", rtol=1e-4)
+    # masks without the materialised dz are refused
+    assert L.eml_dense_conv1x1_bwd_data_multi_f32(
+        1, one("dz"), one("dz"), one("s1"), one("s1"), one("s1"), one("Wd"), one("s1"), one("t1"), one("part"),
+        (ctypes.c_int * 1)(Kpa), None, ld, None, None, P, 0, Cin_a, p(Gd1), ld, G, one("mask"), st) == -1
