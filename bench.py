@@ -79,10 +79,10 @@ def family_bytes(B, crop_hw):
                 # old G in, new G out, 2 x dz in, the two layers' ReLU bit masks in (round 2, late: X is no longer read)
                 by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((2 * k + 96) * 4 + 2 * kp / 8) * P
         ct = c + 192
-        by["eml_dense_pool_act_f32"] += (ct + ct // 4) * 4 * P           # transition: X in, pooled activation A out
+        by["eml_dense_pool_act_f32"] += ((ct + ct // 4) * 4 + ct / 8) * P   # transition: X in, pooled activation A + ReLU bits out
         by["eml_dense_conv1x1_fwd_f32"] += (ct // 4 + ct // 8) * 4 * P   # transition conv on A: A in, pooled out
         by["eml_dense_conv1x1_bwd_weight_f32"] += (ct // 4 + ct // 8) * 4 * P
-        by["eml_dense_conv1x1_bwd_data_f32"] += (2 * ct + ct // 8) * 4 * P   # dY(pooled), X in, G out
+        by["eml_dense_conv1x1_bwd_data_f32"] += ((ct + ct // 8) * 4 + ct / 8) * P   # dY(pooled), ReLU bits in, G out (no X)
         c, h, w = ct // 2, h // 2, w // 2
     return by
 

@@ -66,6 +66,10 @@ class _Workspace:
                 "T": torch.zeros(B * (h // 2) * (w // 2), _r16(cout), **f32),  # raw transition output (kept for backward)
                 # pooled activation mean2x2(relu(bn(X))): operand of the transition conv and of its weight gradient
                 "A": torch.empty(B * (h // 2) * (w // 2), kpt, **f32),
+                # ReLU mask of the transition's BN output, 16 bits per (pooled pixel, channel quad): what the transition's
+                # data gradient reads instead of X (training only)
+                "mask16": (torch.empty(B * (h // 2) * (w // 2) * (kpt // 4), dtype=torch.int16, device=dev)
+                           if keep_all else None),
                 "one": torch.ones(kpt, **f32), "zero": torch.zeros(kpt, **f32),
                 "tmean": torch.zeros(cout, **f32), "tvar": torch.ones(cout, **f32), "tistd": torch.ones(cout, **f32),
                 "scaleL": torch.zeros(cout, **f32), "shiftL": torch.zeros(cout, **f32),
@@ -292,7 +296,8 @@ class HipDenseEncoder:
             Pn = B * (Hb // 2) * (Wb // 2)
             # pool first (it commutes with the 1x1 conv): the conv's output chunks then read A, a quarter of X
             _lib.check(L.eml_dense_pool_act_f32(p(blk["X"]), ld, B, Hb, Wb, kpt, p(tr["scale"]), p(tr["shift"]),
-                                                p(tr["A"]), kpt, st), "eml_dense_pool_act_f32")
+                                                p(tr["A"]), kpt, p(tr["mask16"]) if (keep_all and training) else None,
+                                                st), "eml_dense_pool_act_f32")
             _lib.check(L.eml_dense_conv1x1_fwd_f32(p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, p(tr["one"]),
                                                    p(tr["zero"]), p(tr["Wp"]), cout, p(tr["T"]), tr["Ko"], p(part), G,
                                                    None, st), "eml_dense_conv1x1_fwd_f32(transition)")

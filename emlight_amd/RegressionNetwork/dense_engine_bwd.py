@@ -104,10 +104,10 @@ def run_backward(enc, ws, x, gpooled):
         _lib.check(L.eml_dense_permute_w1_bwd_f32(p(T.conv.weight), cout, ctot, kpt, Ko, p(bw.Wd), st),
                    "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
-            p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.Wd), p(blk["X"]), ld, p(tr["scale"]),
-            p(tr["shift"]), p(blk["mean"]), p(blk["istd"]), Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, st),
-            "eml_dense_conv1x1_bwd_data_f32")
-        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False)
+            p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.Wd), None, ld, p(tr["scale"]),
+            p(tr["shift"]), None, None, Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, p(tr["mask16"]), st),
+            "eml_dense_conv1x1_bwd_data_f32")   # ReLU mask from pool_act's bits: X is not read
+        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False, conv=T.conv)
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
         def conv2_backward(l, slot, n12=False):

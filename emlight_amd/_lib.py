@@ -70,7 +70,8 @@ SIGNATURES = {
                                          _int, _f32p, _int, _f32p, _int, ctypes.c_void_p, _stream]),
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
                                          _int, _stream]),
-    "eml_dense_pool_act_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _int, _stream]),
+    "eml_dense_pool_act_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _int, ctypes.c_void_p,
+                                      _stream]),
     "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),
     # DenseNet-BC encoder, backward
     "eml_dense_conv3x3_bwd_data_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
@@ -88,7 +89,7 @@ SIGNATURES = {
     "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
-                                              _int, _f32p, _int, _int, _f32p, _int, _stream]),
+                                              _int, _f32p, _int, _int, _f32p, _int, ctypes.c_void_p, _stream]),
     "eml_dense_conv1x1_bwd_data_multi_f32": (_int, [_int] + [ctypes.c_void_p] * 10 + [_f32p, _int, _f32p, _f32p,
                                                     ctypes.c_long, _int, _int, _f32p, _int, _int, ctypes.c_void_p,
                                                     _stream]),

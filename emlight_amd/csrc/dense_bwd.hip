@@ -841,13 +841,16 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
 // pixels per wave, two 16-channel tiles per chunk, the chunk's 16 x quads (4 input pixels per pooled pixel) requested
 // before its MFMAs, the next output-channel group's dz / weight fragments requested one step ahead, per-channel
 // vectors in LDS, unconditional operand use, DPP row reductions -- 2 waves per SIMD and no exposed round trips.
-template <int MT, int NCH, bool ACC /* G += instead of G = */>
+// MASKED: the ReLU mask comes from the 16-bit words pool_act_kernel stored (bit 4*sub + g of word [pooled pixel][channel
+// quad]); x, mean, istd are not read and only S1 is accumulated (S2 from the transition conv's weight gradient).
+template <int MT, int NCH, bool ACC /* G += instead of G = */, bool MASKED = false>
 __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
     const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
     const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
     const float* __restrict__ X, int ldx, const float* __restrict__ scale1, const float* __restrict__ shift1,
     const float* __restrict__ mean, const float* __restrict__ istd, int P, int Hin, int Win, int Kp,
-    float* __restrict__ Gd, int ldg, double* __restrict__ partials /*[grid][Kp][2]*/) {
+    float* __restrict__ Gd, int ldg, double* __restrict__ partials /*[grid][Kp][2]*/,
+    const unsigned short* __restrict__ mask16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   double* sacc = reinterpret_cast<double*>(smem);                  // [4 waves][Kp][2]
   float* vec_l = reinterpret_cast<float*>(sacc + (size_t)4 * Kp * 2);  // scale1, shift1, mean, istd [Kp]; cA, cB, cC [Ko]
@@ -858,8 +861,8 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
   for (int e = tid; e < Kp; e += 256) {
     vec_l[e] = scale1[e];
     vec_l[Kp + e] = shift1[e];
-    vec_l[2 * Kp + e] = mean[e];
-    vec_l[3 * Kp + e] = istd[e];
+    vec_l[2 * Kp + e] = MASKED ? 0.f : mean[e];
+    vec_l[3 * Kp + e] = MASKED ? 0.f : istd[e];
   }
   for (int e = tid; e < Ko; e += 256) {
     co_l[e] = cA[e];
@@ -888,18 +891,21 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
     }
     for (int nt0 = 0; nt0 < nnt; nt0 += NCH) {
       // the chunk's x quads (and old G when accumulating): requested now, consumed after the MFMAs
-      float4 xv[MT][NCH][4], gs[ACC ? MT : 1][ACC ? NCH : 1][4];
+      float4 xv[MASKED ? 1 : MT][MASKED ? 1 : NCH][4], gs[ACC ? MT : 1][ACC ? NCH : 1][4];
+      unsigned mk[MT][NCH];
 #pragma unroll
       for (int n = 0; n < NCH; ++n) {
         const int k4 = 16 * min(nt0 + n, nnt - 1) + 4 * kk;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+          if constexpr (MASKED) mk[m][n] = mask16[(size_t)prow[m] * (Kp >> 2) + (k4 >> 2)];
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub) {
             const size_t pi = pin[m] + (sub >> 1) * (size_t)Win + (sub & 1);
-            xv[m][n][sub] = *reinterpret_cast<const float4*>(X + pi * ldx + k4);
+            if constexpr (!MASKED) xv[m][n][sub] = *reinterpret_cast<const float4*>(X + pi * ldx + k4);
             if constexpr (ACC) gs[m][n][sub] = *reinterpret_cast<const float4*>(Gd + pi * ldg + k4);
           }
+        }
       }
       f32x4 acc[MT][NCH];
 #pragma unroll
@@ -963,13 +969,23 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
             const float da2 = 0.25f * acc[m][n][2], da3 = 0.25f * acc[m][n][3];
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-              const float4 x = xv[m][n][sub];
               float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
               if constexpr (ACC) g = gs[m][n][sub];
-              const float d0 = (pv[m] && fmaf(x.x, sk.x, tk.x) > 0.f) ? da0 : 0.f;
-              const float d1 = (pv[m] && fmaf(x.y, sk.y, tk.y) > 0.f) ? da1 : 0.f;
-              const float d2 = (pv[m] && fmaf(x.z, sk.z, tk.z) > 0.f) ? da2 : 0.f;
-              const float d3 = (pv[m] && fmaf(x.w, sk.w, tk.w) > 0.f) ? da3 : 0.f;
+              float d0, d1, d2, d3;
+              float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+              if constexpr (MASKED) {
+                const unsigned b = pv[m] ? mk[m][n] >> (4 * sub) : 0u;
+                d0 = (b & 1u) ? da0 : 0.f;
+                d1 = (b & 2u) ? da1 : 0.f;
+                d2 = (b & 4u) ? da2 : 0.f;
+                d3 = (b & 8u) ? da3 : 0.f;
+              } else {
+                x = xv[m][n][sub];
+                d0 = (pv[m] && fmaf(x.x, sk.x, tk.x) > 0.f) ? da0 : 0.f;
+                d1 = (pv[m] && fmaf(x.y, sk.y, tk.y) > 0.f) ? da1 : 0.f;
+                d2 = (pv[m] && fmaf(x.z, sk.z, tk.z) > 0.f) ? da2 : 0.f;
+                d3 = (pv[m] && fmaf(x.w, sk.w, tk.w) > 0.f) ? da3 : 0.f;
+              }
               g.x = fmaf(sk.x, d0, g.x);
               g.y = fmaf(sk.y, d1, g.y);
               g.z = fmaf(sk.z, d2, g.z);
@@ -982,19 +998,21 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
               l1[1] += d1;
               l1[2] += d2;
               l1[3] += d3;
-              l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
-              l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
-              l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
-              l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
+              if constexpr (!MASKED) {
+                l2[0] = fmaf(d0, (x.x - mu.x) * is.x, l2[0]);
+                l2[1] = fmaf(d1, (x.y - mu.y) * is.y, l2[1]);
+                l2[2] = fmaf(d2, (x.z - mu.z) * is.z, l2[2]);
+                l2[3] = fmaf(d3, (x.w - mu.w) * is.w, l2[3]);
+              }
             }
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             l1[g] = eml::row16_sum(l1[g]);
-            l2[g] = eml::row16_sum(l2[g]);
+            if constexpr (!MASKED) l2[g] = eml::row16_sum(l2[g]);
             if (r == 0) {
               my[2 * (k4 + g)] += (double)l1[g];
-              my[2 * (k4 + g) + 1] += (double)l2[g];
+              if constexpr (!MASKED) my[2 * (k4 + g) + 1] += (double)l2[g];
             }
           }
         }
@@ -1647,11 +1665,13 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
                                               const float* X, int ldx, const float* scale1, const float* shift1,
                                               const float* mean, const float* istd, long P, int Hin, int Win, int pool,
                                               int Kp, float* G, int ldg, int accumulate, double* partials, int grid,
-                                              eml_stream_t stream) {
-  if (!DY || !Zr || !cA || !cB || !cC || !Wd || !X || !scale1 || !shift1 || !mean || !istd || !G || !partials ||
-      P < 1 || grid < 1 || (Kp & 15) || (Ko & 15) || Ko > ld_dy || Ko > ld_z || (ld_dy & 3) || (ld_z & 3) ||
-      (ldx & 3) || (ldg & 3) || Kp > ldx || Kp > ldg)
+                                              const unsigned short* relu_mask16, eml_stream_t stream) {
+  if (!DY || !Zr || !cA || !cB || !cC || !Wd || (!relu_mask16 && (!X || !mean || !istd)) || !scale1 || !shift1 || !G ||
+      !partials || P < 1 || grid < 1 || (Kp & 15) || (Ko & 15) || Ko > ld_dy || Ko > ld_z || (ld_dy & 3) || (ld_z & 3) ||
+      (ldx & 3) || (ldg & 3) || (!relu_mask16 && Kp > ldx) || Kp > ldg)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: bad arguments");
+  if (relu_mask16 && !(pool && Ko != 48))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_f32: relu_mask16 is for the transition form (pool, Ko != 48)");
   const size_t lds = (size_t)4 * Kp * 2 * sizeof(double);
 #define EML_LAUNCH_BWD_DATA(POOLV, RESV, NCHV)                                                                        \
   hipLaunchKernelGGL((conv1x1_bwd_data_kernel<POOLV, RESV, NCHV>), dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, \
@@ -1664,15 +1684,19 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
       EML_LAUNCH_BWD_DATA(true, true, 4);
     } else {  // transitions
       const size_t lds_t = lds + (size_t)(4 * Kp + 3 * Ko) * sizeof(float);
-#define EML_LAUNCH_TRANSITION(ACCV)                                                                                    \
+#define EML_LAUNCH_TRANSITION(ACCV, MSKV)                                                                              \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transition_bwd_data_kernel<2, 2, ACCV>),                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transition_bwd_data_kernel<2, 2, ACCV, MSKV>),            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);                                 \
-    hipLaunchKernelGGL((transition_bwd_data_kernel<2, 2, ACCV>), dim3(grid), dim3(256), lds_t, (hipStream_t)stream, DY, \
-                       ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, (int)P, Hin, Win, Kp, G, \
-                       ldg, partials);                                                                                 \
+    hipLaunchKernelGGL((transition_bwd_data_kernel<2, 2, ACCV, MSKV>), dim3(grid), dim3(256), lds_t,                   \
+                       (hipStream_t)stream, DY, ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, \
+                       (int)P, Hin, Win, Kp, G, ldg, partials, relu_mask16);                                           \
   } while (0)
-      if (accumulate) EML_LAUNCH_TRANSITION(true); else EML_LAUNCH_TRANSITION(false);
+      if (relu_mask16) {
+        if (accumulate) EML_LAUNCH_TRANSITION(true, true); else EML_LAUNCH_TRANSITION(false, true);
+      } else {
+        if (accumulate) EML_LAUNCH_TRANSITION(true, false); else EML_LAUNCH_TRANSITION(false, false);
+      }
 #undef EML_LAUNCH_TRANSITION
     }
   } else {

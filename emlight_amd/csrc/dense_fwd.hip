@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict_
 // of the block buffer -- instead of re-reading and re-pooling the whole block buffer once per chunk.
 __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__ X, int ldx, int B, int Hin, int Win,
                                                        int Kp, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, float* __restrict__ A, int lda) {
+                                                       const float* __restrict__ shift, float* __restrict__ A, int lda,
+                                                       unsigned short* __restrict__ relu_mask16) {
   const int Ho = Hin >> 1, Wo = Win >> 1, nq = Kp >> 2;
   const size_t total = (size_t)B * Ho * Wo * nq;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -707,6 +708,12 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
     a.z = ((v0.z + v1.z) + (v2.z + v3.z)) * 0.25f;
     a.w = ((v0.w + v1.w) + (v2.w + v3.w)) * 0.25f;
     *reinterpret_cast<float4*>(A + pp * lda + 4 * q) = a;
+    if (relu_mask16) {   // bit 4*sub + g <-> window pixel sub (row-major 2x2), channel 4q + g: the transition dgrad's ReLU mask
+      auto nib = [](const float4& v) {
+        return (unsigned)(v.x > 0.f) | ((unsigned)(v.y > 0.f) << 1) | ((unsigned)(v.z > 0.f) << 2) | ((unsigned)(v.w > 0.f) << 3);
+      };
+      relu_mask16[e] = (unsigned short)(nib(v0) | (nib(v1) << 4) | (nib(v2) << 8) | (nib(v3) << 12));
+    }
   }
 }
 
@@ -811,14 +818,15 @@ extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, co
 }
 
 extern "C" int eml_dense_pool_act_f32(const float* X, int ldx, int B, int Hin, int Win, int Kp, const float* scale,
-                                      const float* shift, float* A, int lda, eml_stream_t stream) {
+                                      const float* shift, float* A, int lda, unsigned short* relu_mask16,
+                                      eml_stream_t stream) {
   if (!X || !scale || !shift || !A || B < 1 || Hin < 2 || Win < 2 || (Hin & 1) || (Win & 1) || Kp < 4 || (Kp & 3) ||
       Kp > ldx || Kp > lda || (ldx & 3) || (lda & 3))
     return eml::fail(EML_EINVAL, "eml_dense_pool_act_f32: bad arguments");
   const size_t total = (size_t)B * (Hin / 2) * (Win / 2) * (Kp / 4);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(pool_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, B, Hin, Win, Kp, scale, shift,
-                     A, lda);
+                     A, lda, relu_mask16);
   return eml::check_launch("eml_dense_pool_act_f32");
 }
 

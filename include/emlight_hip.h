@@ -157,9 +157,12 @@ int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* 
 /* Transition operand: A[p'][c] = 2x2 mean of relu(scale[c]*X + shift[c]), p' over (B, Hin/2, Win/2), c < Kp
  * (Kp % 4 == 0; padded channels have scale = shift = 0).  The transition's 1x1 conv and its weight gradient
  * run on A with pool = 0 and a unit BN (scale 1, shift 0) -- replaces torch's avg_pool2d after the conv in
- * DenseNet.py:14-21 (the pool commutes with the 1x1 conv). */
+ * DenseNet.py:14-21 (the pool commutes with the 1x1 conv).
+ * relu_mask16 (may be NULL): [B*Hin/2*Win/2][Kp/4] 16-bit words for the backward, bit 4*sub + g <-> pixel sub of the 2x2
+ * window (row-major), channel 4*q + g: relu(scale*X + shift) > 0. */
 int eml_dense_pool_act_f32(const float* X, int ldx, int B, int Hin, int Win, int Kp, const float* scale,
-                           const float* shift, float* A, int lda, eml_stream_t stream);
+                           const float* shift, float* A, int lda, unsigned short* relu_mask16,
+                           eml_stream_t stream);
 
 /* out (B, C, H/k, W/k) = avg_pool_k(relu(F)) for NHWC F: the head of DenseNet.forward
  * (DenseNet.py:136-137), flattened in the reference's (C,h,w) order for `fc`. */
@@ -222,13 +225,16 @@ int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int 
 
 /* dam[p][k] = relu-mask(scale1*X+shift1) * sum_o dz[p][o] W[o][k]  (pool != 0: spread over the 2x2
  * input pixels, /4) and G[p][k] (+)= scale1[k]*dam[p][k] (accumulate = 0 overwrites);
- * partials [grid][Kp][2] = (sum dam, sum dam*xhat) for the BN1 backward. */
+ * partials [grid][Kp][2] = (sum dam, sum dam*xhat) for the BN1 backward.
+ * relu_mask16 (transition form only; may be NULL): the words eml_dense_pool_act_f32 stored -- then X, mean and istd are
+ * not read (may be NULL) and the partials carry S1 only (S2: eml_dense_bn_bwd_finalize_f32 with the conv's W / dW). */
 int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const float* Zr, int ld_z,
                                    const float* cA, const float* cB, const float* cC, int Ko,
                                    const float* Wd, const float* X, int ldx, const float* scale1,
                                    const float* shift1, const float* mean, const float* istd, long P,
                                    int Hin, int Win, int pool, int Kp, float* G, int ldg,
-                                   int accumulate, double* partials, int grid, eml_stream_t stream);
+                                   int accumulate, double* partials, int grid,
+                                   const unsigned short* relu_mask16, eml_stream_t stream);
 
 /* The same data gradient for 1 or 2 CONSECUTIVE dense layers in one pass over the channel range
  * [k_lo, k_hi): G[p][k] += sum_j scale1_j[k]*dam_j[p][k] -- X is read once and G read-modify-written once

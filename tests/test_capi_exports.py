@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(built_lib):
     rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, one, None, None, one, 2, 0, None)
     assert rc == -1
     # encoder / projector launchers: nulls, odd pooling sizes, misaligned channel counts
-    assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None) == -1
+    assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None, None) == -1
     assert L.eml_dense_conv3x3_bwd_data_f32(one, 224, 24, one, one, one, one, one, 1, 8, 8, one, 512, one, 224, 24, None,
                                             None, None, None) == -1 and b"fused affine" in L.eml_last_error()
     assert L.eml_sphere_im2col_f32(one, one, one, None, 1, 32, 32, 8, None) == -1

@@ -192,11 +192,20 @@ def test_pool_act(lib, B, H, W, C, ld):
     sc, sh = torch.zeros(Kp, device=DEV), torch.zeros(Kp, device=DEV)
     sc[:C], sh[:C] = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.3)
     A = torch.full((B * (H // 2) * (W // 2), Kp), 9.0, device=DEV)
-    lib.check(L.eml_dense_pool_act_f32(p(X), ld, B, H, W, Kp, p(sc), p(sh), p(A), Kp, st), "pool_act")
+    m16 = torch.zeros(B * (H // 2) * (W // 2) * (Kp // 4), dtype=torch.int16, device=DEV)
+    lib.check(L.eml_dense_pool_act_f32(p(X), ld, B, H, W, Kp, p(sc), p(sh), p(A), Kp, p(m16), st), "pool_act")
     act = torch.relu(nchw(X[:, :Kp].double(), B, H, W) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
     want = nhwc(F.avg_pool2d(act, 2))
     close(A, want, what="pooled activation", rtol=1e-6, atol=1e-6)
     assert float(A[:, C:].abs().max()) == 0.0 if Kp > C else True
+    # relu_mask16: word [pooled pixel][quad q], bit 4*sub + g <-> window pixel sub (row-major), channel 4q + g
+    on = (torch.addcmul(sh, X[:, :Kp], sc) > 0).view(B, H // 2, 2, W // 2, 2, Kp // 4, 4)      # f32 fma like the kernel
+    bits = on.permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, 16)                                      # (b, oy, ox, q, dy, dx, g)
+    got = ((m16.view(-1, 1).int() >> torch.arange(16, device=DEV)) & 1).bool()
+    assert int((got != bits).sum()) <= 2
+    A2 = torch.empty_like(A)
+    lib.check(L.eml_dense_pool_act_f32(p(X), ld, B, H, W, Kp, p(sc), p(sh), p(A2), Kp, None, st), "pool_act (no mask)")
+    assert torch.equal(A, A2)
 
 
 # ------------------------------------------------------------------------------------------ backward
@@ -346,13 +355,39 @@ def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
         part = torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV)
         lib.check(L.eml_dense_conv1x1_bwd_data_f32(p(DY), ld_dy, p(Zr), Ko, p(cA), p(cB), p(cC), Ko, p(Wd), p(X), ld,
                                                    p(s1), p(t1), p(mean), p(istd), P, H, W, pool, Kp, p(Gd), ld,
-                                                   accumulate, p(part), G, st), "dgrad")
+                                                   accumulate, p(part), G, None, st), "dgrad")
         want = s1[:Cin].double() * dam + (G0[:, :Cin].double() if accumulate else 0)
         close(Gd[:, :Cin], want, what="G (accumulate=%d)" % accumulate, rtol=1e-4)
         assert torch.equal(Gd[:, Kp:], G0[:, Kp:])
         S1, S2 = fold_partials(part, G, Kp)
         close(S1[:Cin], dam.sum(0), what="S1", rtol=1e-5, atol=1e-4)
         close(S2[:Cin], (dam * xh).sum(0), what="S2", rtol=1e-5, atol=1e-4)
+        if pool and Cout != 48:
+            # the transition's x-free form: ReLU bits from pool_act, S1 only; BN's S2 from the conv's weight gradient
+            A_ = torch.empty(P, Kp, device=DEV)
+            m16 = torch.zeros(P * (Kp // 4), dtype=torch.int16, device=DEV)
+            lib.check(L.eml_dense_pool_act_f32(p(X), ld, B, H, W, Kp, p(s1), p(t1), p(A_), Kp, p(m16), st), "pool_act mask")
+            Gm = G0.clone()
+            part.zero_()
+            lib.check(L.eml_dense_conv1x1_bwd_data_f32(p(DY), ld_dy, p(Zr), Ko, p(cA), p(cB), p(cC), Ko, p(Wd), None, ld,
+                                                       p(s1), p(t1), None, None, P, H, W, pool, Kp, p(Gm), ld,
+                                                       accumulate, p(part), G, p(m16), st), "dgrad (masked)")
+            close(Gm[:, :Cin], want, what="G masked (accumulate=%d)" % accumulate, rtol=1e-4)
+            S1m, S2m = fold_partials(part, G, Kp)
+            close(S1m[:Cin], dam.sum(0), what="S1 masked", rtol=1e-5, atol=1e-4)
+            assert float(S2m.abs().max()) == 0.0
+            # S2 = (sum_o W*dW - beta*S1) / gamma with scale1 = gamma*istd, shift1 = beta - mean*scale1
+            gamma = (s1[:Cin] / istd[:Cin]).contiguous()
+            beta = (t1[:Cin] + mean[:Cin] * s1[:Cin]).contiguous()
+            dg, db = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+            lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), G, 2 * Kp, float(Pin), p(gamma), p(mean), p(istd), Cin, Kp, 1,
+                                                      p(dg), p(db), None, None, None, None, None, 0, 0, Kp, p(beta), p(Wt),
+                                                      p(dW), Cout, st), "finalize from dW")
+            S2w = (dam * xh).sum(0)
+            close(dg, S2w, what="dgamma from dW (transition)", rtol=5e-4, atol=5e-5 * max(float(S2w.abs().max()), 1.0))
+    if not (pool and Cout != 48):
+        assert L.eml_dense_conv1x1_bwd_data_f32(p(DY), ld_dy, p(Zr), Ko, p(cA), p(cB), p(cC), Ko, p(Wd), p(X), ld, p(s1), p(t1),
+                                                p(mean), p(istd), P, H, W, pool, Kp, p(Gd), ld, 1, p(part), G, p(part), st) == -1
 
 
 def test_grad_materialize_and_bn_bwd_stats(lib):
