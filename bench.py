@@ -70,12 +70,13 @@ def family_bytes(B, crop_hw):
             kp = (k + 15) // 16 * 16
             by["eml_dense_conv1x1_fwd_f32"] += ((k + 48) * 4 + kp / 8) * P   # X[:, :k] in, Z out, ReLU bit mask out
             by["eml_dense_conv1x1_bwd_weight_f32"] += (k + 96 + 48) * 4 * P   # X[:, :k], dzn, Z in; dz out (materialised)
+            if l % 2 == 1:   # upper layer of a pair: the narrow pass rides on it (G slice in, compact N12 out)
+                by["eml_dense_conv1x1_bwd_weight_f32"] += (12 + 12) * 4 * P
             by["eml_dense_conv3x3_fwd_f32"] += (48 + 12) * 4 * P         # Z in, 12 new channels out
             # G, X (deferred affine), Z in; dzn, GF out; the lower layer of a pair also reads the compact N12
             by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 12 + 48 + 48 + 12 + (12 if l % 2 == 0 else 0)) * 4 * P
             by["eml_dense_conv3x3_bwd_weight_f32"] += (12 + 48) * 4 * P  # dY, Z in
             if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
-                by["eml_dense_conv1x1_bwd_narrow_f32"] += (48 + 12 + 12) * 4 * P      # dz, X slice in; N12 out
                 # old G in, new G out, 2 x dz in, the two layers' ReLU bit masks in (round 2, late: X is no longer read)
                 by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((2 * k + 96) * 4 + 2 * kp / 8) * P
         ct = c + 192

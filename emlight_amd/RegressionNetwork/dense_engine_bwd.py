@@ -100,7 +100,8 @@ def run_backward(enc, ws, x, gpooled):
         # weight grad on the pooled activation A kept by the forward (unit BN: relu(1*A + 0) == A)
         _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
             p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, ctot, p(tr["one"]), p(tr["zero"]), p(dY), ld_dy, p(tr["T"]),
-            Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, None, st), "eml_dense_conv1x1_bwd_weight_f32")
+            Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, None, None, 0, None, 0, None, None, st),
+            "eml_dense_conv1x1_bwd_weight_f32")
         _lib.check(L.eml_dense_permute_w1_bwd_f32(p(T.conv.weight), cout, ctot, kpt, Ko, p(bw.Wd), st),
                    "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
@@ -110,10 +111,12 @@ def run_backward(enc, ws, x, gpooled):
         finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False, conv=T.conv)
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
-        def conv2_backward(l, slot, n12=False):
+        def conv2_backward(l, slot, n12=False, narrow_lo=None):
             """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad, which
             also materialises dz = cA*dzn + cB*z + cC in place over DZ[slot] for the data-gradient passes.
-            n12: the layer above left the finished gradient of this layer's channels in the compact bw.N12."""
+            n12: the layer above left the finished gradient of this layer's channels in the compact bw.N12.
+            narrow_lo: this is the upper layer of a pair -- its narrow data pass over the lower layer's 12 output channels
+            [narrow_lo, narrow_lo + 12) rides on the weight-gradient kernel's dz tile (-> bw.N12, S1 -> bw.part2[slot])."""
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
             cin, kp, z, dz = lay["Cin"], lay["Kp"], blk["Z"][l], bw.DZ[slot]
@@ -131,7 +134,9 @@ def run_backward(enc, ws, x, gpooled):
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
-                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, p(dz), st), "eml_dense_conv1x1_bwd_weight_f32")
+                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, p(dz),
+                *((p(Lm.conv1.weight), narrow_lo, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot])) if narrow_lo is not None
+                  else (None, 0, None, 0, None, None)), st), "eml_dense_conv1x1_bwd_weight_f32")
             _lib.check(L.eml_dense_permute_w1_bwd_f32(p(Lm.conv1.weight), 48, cin, kp, 48, p(bw.Wd[slot]), st),
                        "eml_dense_permute_w1_bwd_f32")
             return Lm
@@ -167,8 +172,7 @@ def run_backward(enc, ws, x, gpooled):
             if l >= 1:
                 la, lb = l, l - 1
                 cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
-                Lma = conv2_backward(la, 0)
-                narrow(la, Lma, 0, cin_b)                      # narrow pass: layer lb's output channels only -> N12
+                Lma = conv2_backward(la, 0, narrow_lo=cin_b)   # + narrow pass: layer lb's output channels only -> N12
                 bn1_finalize(la, Lma, 0, cin_b, cin_a)
                 Lmb = conv2_backward(lb, 1, n12=True)
                 dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once

@@ -83,7 +83,7 @@ SIGNATURES = {
                                              _f32p, _f32p, _f32p, _int, _stream]),
     "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
                                                 _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
-                                                _f32p, _int, _f32p, _stream]),
+                                                _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_narrow_f32": (_int, [_f32p, _f32p, _int, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
                                                 ctypes.c_long, _f32p, _int, _f32p, _f32p, _int, _int, _stream]),
     "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),

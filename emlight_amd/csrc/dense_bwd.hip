@@ -491,19 +491,43 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 //     so lane i of a 32-channel group loads channels (2i, 2i+1) of its pixel -- 128 contiguous
 //     bytes per pixel -- and feeds them to two accumulator tiles whose row i means channel 2i+t;
 //   * the Kp/32 channel groups are dealt round-robin to the 4 waves (<= 3 each).
-template <bool POOL>
-__global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
+//   * NARROW (dense layers, the upper layer of a backward pair): the dz tile sitting in LDS also feeds the NARROW data
+//     pass -- the finished gradient of the lower layer's 12 output channels [k_lo, k_lo + 12),
+//     N12[p][c] = G[p][k_lo+c] + scale1*mask*(dz[p] . W1[:, k_lo+c]) -- as 12 extra MFMAs per wave and chunk (wave w
+//     owns pixel tile w): what was a separate streaming kernel re-reading dz (48 floats per pixel) and a 12-channel
+//     slice of x is an epilogue on data this kernel already holds (the x slice is the tail of the row it just read).
+struct NarrowArgs {
+  const float* W1;     // [48][Cin] (PyTorch layout)
+  const float* G;      // block gradient, read only
+  float* N12;          // (P, 12) out
+  double* partials;    // [grid][Kp][2]: S1 of channels k_lo .. k_lo+11 (S2 slot = 0: it comes from the weight gradient)
+  int Cin, k_lo, ldg;
+};
+template <bool POOL, bool NARROW = false>
+__global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp, const float* __restrict__ scale1,
     const float* __restrict__ shift1, const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr,
     int ld_z, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n_valid,
     int n_load /* columns (multiple of 4) that may be read without leaving the DY / Zr rows */,
     float* __restrict__ partial /*[grid][Kp][48]*/,
     float* __restrict__ dz_out /* NULL, or (P,48): the rebuilt dz is materialised here for the data-gradient passes
-                                  (may alias DY: every element is read and written by the same thread) */) {
+                                  (may alias DY: every element is read and written by the same thread) */,
+    NarrowArgs na) {
   __shared__ __attribute__((aligned(16))) float dz_l[2][64 * 48];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int ngroups = (Kp + 31) >> 5;
+  // narrow pass: A fragments (rows = the 12 channels, k = o), BN1 affine of this lane's 4 channels, f64 statistics
+  float nsk[4] = {0.f, 0.f, 0.f, 0.f}, ntk[4] = {0.f, 0.f, 0.f, 0.f};
+  double ns1[4] = {0.0, 0.0, 0.0, 0.0};
+  const int kq = min(kk, 2);   // lanes kk = 3 hold MFMA rows 12..15: padding (clamped addresses, masked results)
+  if constexpr (NARROW) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      nsk[g] = kk < 3 ? scale1[na.k_lo + 4 * kq + g] : 0.f;
+      ntk[g] = kk < 3 ? shift1[na.k_lo + 4 * kq + g] : 0.f;
+    }
+  }
 
   float2 s2[3], t2[3];
   int coff[3];
@@ -517,24 +541,45 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
     s2[i] = gv[i] ? *reinterpret_cast<const float2*>(scale1 + ch) : make_float2(0.f, 0.f);
     t2[i] = gv[i] ? *reinterpret_cast<const float2*>(shift1 + ch) : make_float2(0.f, 0.f);
   }
-  // dz staging role: pixel = tid >> 2, columns 4*(q + 4j), j = 0..2
+  // dz staging role: pixel = tid >> 2, columns 4*(q + 4j), j = 0..2.  NARROW: the BN2-backward affine (cA, cB, cC; 0
+  // past n_valid) and the narrow pass's weight fragments live in LDS (read once per chunk): the plain kernel sits at the
+  // 256-register line of two waves per SIMD (180 VGPRs + 72 AGPRs) and the narrow epilogue needs ~40 more.  The plain
+  // variant keeps them in registers -- moved to LDS too it lost 2 ms/step (measured).
   const int spix = tid >> 2, sq = tid & 3;
-  float4 sa[3], sb[3], sc[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = 4 * (sq + 4 * j);
-    float a[4], b[4], c[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool v = col + e < n_valid;
-      a[e] = v ? cA[col + e] : 0.f;
-      b[e] = v ? cB[col + e] : 0.f;
-      c[e] = v ? cC[col + e] : 0.f;
+  __shared__ __attribute__((aligned(16))) float co_l[3 * 48];
+  __shared__ float wn_l[NARROW ? 12 * 64 : 1];
+  float4 sa_r[NARROW ? 1 : 3], sb_r[NARROW ? 1 : 3], sc_r[NARROW ? 1 : 3];   // plain variant: the affine in registers
+  if constexpr (NARROW) {
+    if (tid < 48) {
+      const bool v = tid < n_valid;
+      co_l[tid] = v ? cA[tid] : 0.f;
+      co_l[48 + tid] = v ? cB[tid] : 0.f;
+      co_l[96 + tid] = v ? cC[tid] : 0.f;
     }
-    sa[j] = make_float4(a[0], a[1], a[2], a[3]);
-    sb[j] = make_float4(b[0], b[1], b[2], b[3]);
-    sc[j] = make_float4(c[0], c[1], c[2], c[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = 4 * (sq + 4 * j);
+      float a[4], b[4], c[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool v = col + e < n_valid;
+        a[e] = v ? cA[col + e] : 0.f;
+        b[e] = v ? cB[col + e] : 0.f;
+        c[e] = v ? cC[col + e] : 0.f;
+      }
+      sa_r[j] = make_float4(a[0], a[1], a[2], a[3]);
+      sb_r[j] = make_float4(b[0], b[1], b[2], b[3]);
+      sc_r[j] = make_float4(c[0], c[1], c[2], c[3]);
+    }
   }
+  if constexpr (NARROW) {   // A fragments (rows = the 12 channels, k = o): entry (st, kk, r) = W1[4*st + kk][k_lo + r]
+    for (int e = tid; e < 12 * 64; e += 256) {
+      const int st = e >> 6, l = e & 63, rr = l & 15, k4 = l >> 4;
+      wn_l[e] = rr < 12 ? na.W1[(size_t)(4 * st + k4) * na.Cin + na.k_lo + rr] : 0.f;
+    }
+  }
+  __syncthreads();
   f32x4 acc[3][2][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -568,11 +613,21 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int col = 4 * (sq + 4 * j);
+      float4 sa, sb, sc;
+      if constexpr (NARROW) {
+        sa = *reinterpret_cast<const float4*>(co_l + col);
+        sb = *reinterpret_cast<const float4*>(co_l + 48 + col);
+        sc = *reinterpret_cast<const float4*>(co_l + 96 + col);
+      } else {
+        sa = sa_r[j];
+        sb = sb_r[j];
+        sc = sc_r[j];
+      }
       float4 v;
-      v.x = rpv ? fmaf(sa[j].x, rdy[j].x, fmaf(sb[j].x, rzr[j].x, sc[j].x)) : 0.f;
-      v.y = rpv ? fmaf(sa[j].y, rdy[j].y, fmaf(sb[j].y, rzr[j].y, sc[j].y)) : 0.f;
-      v.z = rpv ? fmaf(sa[j].z, rdy[j].z, fmaf(sb[j].z, rzr[j].z, sc[j].z)) : 0.f;
-      v.w = rpv ? fmaf(sa[j].w, rdy[j].w, fmaf(sb[j].w, rzr[j].w, sc[j].w)) : 0.f;
+      v.x = rpv ? fmaf(sa.x, rdy[j].x, fmaf(sb.x, rzr[j].x, sc.x)) : 0.f;
+      v.y = rpv ? fmaf(sa.y, rdy[j].y, fmaf(sb.y, rzr[j].y, sc.y)) : 0.f;
+      v.z = rpv ? fmaf(sa.z, rdy[j].z, fmaf(sb.z, rzr[j].z, sc.z)) : 0.f;
+      v.w = rpv ? fmaf(sa.w, rdy[j].w, fmaf(sb.w, rzr[j].w, sc.w)) : 0.f;
       *reinterpret_cast<float4*>(dzb + spix * 48 + col) = v;
       if (dz_out && rpv) *reinterpret_cast<float4*>(dz_out + (size_t)rp * 48 + col) = v;
     }
@@ -615,6 +670,19 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
       const float* dzb = dz_l[it & 1];
       stage_load(chunk + gridDim.x);  // next chunk's loads fly during this chunk's MFMAs
+      // narrow pass operands of this wave's pixel tile (x slice: the tail of rows this kernel reads anyway; G slice):
+      // requested now, used after the chunk's MFMAs
+      float2 nx[2], ng[2];
+      const int pn = chunk * 64 + 16 * wave + r;
+      if constexpr (NARROW) {
+        const size_t pc = (size_t)min(pn, P - 1);
+        const float* xs = X + pc * ldx + na.k_lo + 4 * kq;
+        const float* gs = na.G + pc * na.ldg + na.k_lo + 4 * kq;
+        nx[0] = *reinterpret_cast<const float2*>(xs);
+        nx[1] = *reinterpret_cast<const float2*>(xs + 2);
+        ng[0] = *reinterpret_cast<const float2*>(gs);
+        ng[1] = *reinterpret_cast<const float2*>(gs + 2);
+      }
       if constexpr (NGW > 0) {
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
@@ -654,6 +722,21 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (NARROW) {
+        f32x4 an = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 12; ++st) an = mfma16(wn_l[st * 64 + lane], dzb[(16 * wave + r) * 48 + 4 * st + kk], an);
+        const bool nv = pn < P && kk < 3;
+        const float xg[4] = {nx[0].x, nx[0].y, nx[1].x, nx[1].y}, gg[4] = {ng[0].x, ng[0].y, ng[1].x, ng[1].y};
+        float o4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float dam = (nv && fmaf(xg[g], nsk[g], ntk[g]) > 0.f) ? an[g] : 0.f;
+          o4[g] = fmaf(nsk[g], dam, gg[g]);
+          ns1[g] += (double)dam;
+        }
+        if (nv) *reinterpret_cast<float4*>(na.N12 + (size_t)pn * 12 + 4 * kk) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
       stage_write(dz_l[(it + 1) & 1]);
       // LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the x operands of the NEXT chunk's first
       // batch, requested a moment ago -- one exposed HBM round trip per 64-pixel chunk
@@ -680,6 +763,22 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(
           for (int n = 0; n < 3; ++n) out[(size_t)ch * 48 + 16 * n + r] = acc[i][t][n][g];
         }
       }
+  }
+  if constexpr (NARROW) {   // S1 of the 12 narrow channels: over the 16 pixel lanes, then the 4 waves
+    __syncthreads();        // everyone is done with dz_l
+    double* red = reinterpret_cast<double*>(&dz_l[0][0]);   // [4 waves][12]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ns1[g] += shfl_xor_d(ns1[g], o);
+      if (r == 0 && kk < 3) red[wave * 12 + 4 * kk + g] = ns1[g];
+    }
+    __syncthreads();
+    if (tid < 12) {
+      double* dst = na.partials + ((size_t)blockIdx.x * Kp + na.k_lo + tid) * 2;
+      dst[0] = (red[tid] + red[12 + tid]) + (red[24 + tid] + red[36 + tid]);
+      dst[1] = 0.0;
+    }
   }
 }
 
@@ -1622,9 +1721,14 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
                                                 int Cin, const float* scale1, const float* shift1, const float* DY,
                                                 int ld_dy, const float* Zr, int ld_z, const float* cA, const float* cB,
                                                 const float* cC, int Cout, float* partial, float* dW, int grid,
-                                                float* dz_out, eml_stream_t stream) {
+                                                float* dz_out, const float* W1, int k_lo, const float* G, int ldg,
+                                                float* N12, double* partials_n, eml_stream_t stream) {
   if (dz_out && (Cout != 48 || pool))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: dz_out is for dense layers (Cout == 48, no pool)");
+  if (N12 && (Cout != 48 || pool || !W1 || !G || !partials_n || k_lo < 0 || (k_lo & 1) || k_lo + 12 > Cin || (ldg & 1) ||
+              k_lo + 12 > ldg))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: fused narrow pass needs a dense layer, W1, G, partials_n "
+                                 "and an even k_lo with k_lo + 12 <= Cin (k_lo=%d, Cin=%d)", k_lo, Cin);
   if (!X || !scale1 || !shift1 || !DY || !Zr || !cA || !cB || !cC || !partial || !dW || P < 1 || grid < 1 || Kp < 32 ||
       (Kp & 15) || Cin > Kp || Cout < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: bad arguments");
@@ -1634,14 +1738,19 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
     int n_load = ((ld_dy < ld_z ? ld_dy : ld_z) - n0) & ~3;
     if (n_load > 48) n_load = 48;
     if (n_load < nv) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: DY/Zr rows narrower than Cout");
+    const NarrowArgs na{W1, G, N12, partials_n, Cin, k_lo, ldg};
     if (pool)
-      hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)P,
-                         Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0, nv,
-                         n_load, partial, nullptr);
-    else
-      hipLaunchKernelGGL(conv1x1_bwd_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+      hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
                          (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
-                         nv, n_load, partial, dz_out);
+                         nv, n_load, partial, nullptr, na);
+    else if (N12)
+      hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                         (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
+                         nv, n_load, partial, dz_out, na);
+    else
+      hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                         (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
+                         nv, n_load, partial, dz_out, na);
     int rc = eml::check_launch("eml_dense_conv1x1_bwd_weight_f32");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((Cin * 48 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,

@@ -211,13 +211,18 @@ int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, do
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).
  * partial: grid*Kp*48 floats of scratch.
  * dz_out (may be NULL; dense layers only, Cout == 48, pool == 0): the rebuilt dz is also written to this (P,48)
- * buffer for the data-gradient passes; it may alias DY (in place). */
+ * buffer for the data-gradient passes; it may alias DY (in place).
+ * N12 != NULL (dense layers): the narrow data pass of eml_dense_conv1x1_bwd_narrow_f32 rides on the dz tile this
+ * kernel holds in LDS -- N12 (P,12) = G[:, k_lo:k_lo+12] + scale1*relu-mask*(dz W1[:, k_lo:k_lo+12]) with W1 (48,Cin)
+ * the conv's weight (PyTorch layout), G (P, ldg) read only, k_lo even, and partials_n [grid][Kp][2] receiving S1 of
+ * those 12 channels (S2 slot 0: see eml_dense_bn_bwd_finalize_f32). */
 int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, int Win, int pool,
                                      int Kp, int Cin, const float* scale1, const float* shift1,
                                      const float* DY, int ld_dy, const float* Zr, int ld_z,
                                      const float* cA, const float* cB, const float* cC, int Cout,
                                      float* partial, float* dW, int grid, float* dz_out,
-                                     eml_stream_t stream);
+                                     const float* W1, int k_lo, const float* G, int ldg, float* N12,
+                                     double* partials_n, eml_stream_t stream);
 
 /* W (Cout,Cin) -> Wd [Kp/16][Ko/16][4][16][4], the B-fragment order of the data-gradient kernel. */
 int eml_dense_permute_w1_bwd_f32(const float* W, int Cout, int Cin, int Kp, int Ko, float* Wd,

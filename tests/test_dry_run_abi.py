@@ -13,7 +13,7 @@ import torch
 
 class _Recorder:
     def __init__(self, signatures):
-        self.signatures, self.calls = signatures, []
+        self.signatures, self.calls, self.args = signatures, [], []
 
     def __getattr__(self, name):
         if name not in self.signatures:
@@ -28,6 +28,7 @@ class _Recorder:
                 except (TypeError, ctypes.ArgumentError) as e:
                     raise AssertionError("%s: argument %d (%r) does not convert to %s" % (name, k, a, t.__name__)) from e
             self.calls.append(name)
+            self.args.append((name, args))
             return 0
         return call
 
@@ -52,12 +53,14 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     sum(v.sum() for v in out.values()).backward()
     for name in ("eml_dense_conv0_fwd_f32", "eml_dense_conv1x1_fwd_f32", "eml_dense_conv3x3_fwd_f32", "eml_dense_pool_act_f32",
                  "eml_dense_conv3x3_bwd_data_f32", "eml_dense_conv3x3_bwd_weight_f32", "eml_dense_conv1x1_bwd_weight_f32",
-                 "eml_dense_conv1x1_bwd_narrow_f32", "eml_dense_conv1x1_bwd_data_multi_f32", "eml_dense_conv1x1_bwd_data_f32",
+                 "eml_dense_conv1x1_bwd_data_multi_f32", "eml_dense_conv1x1_bwd_data_f32",
                  "eml_dense_bn_bwd_finalize_f32", "eml_dense_grad_materialize_f32", "eml_dense_conv0_bwd_weight_f32",
                  "eml_dense_head_pool_bwd_f32"):
         assert name in recorder.calls, name
-    # the pair schedule: 8 narrow passes and 8 two-layer passes per block of 16 layers
-    assert recorder.calls.count("eml_dense_conv1x1_bwd_narrow_f32") == 24
+    # the pair schedule: 8 narrow passes (riding on the upper layer's weight-gradient launch: its N12 argument, fifth
+    # from the end, is set) and 8 two-layer passes per block of 16 layers
+    narrow = [a for n, a in recorder.args if n == "eml_dense_conv1x1_bwd_weight_f32" and a[-3] is not None]
+    assert len(narrow) == 24 and all(a[-6] % 2 == 0 for a in narrow)
     assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 24
     assert all(p.grad is not None for p in net.parameters())
 
@@ -69,7 +72,8 @@ def test_odd_block_config_uses_the_single_layer_pass(recorder):
     net._hip = HipDenseEncoder(net)
     net._hip._cu = 256
     sum(v.sum() for v in net(torch.rand(1, 3, 32, 32)).values()).backward()
-    assert recorder.calls.count("eml_dense_conv1x1_bwd_narrow_f32") == 2      # pairs (1,0) of block 1 and (2,1) of block 2
+    narrow = [a for n, a in recorder.args if n == "eml_dense_conv1x1_bwd_weight_f32" and a[-3] is not None]
+    assert len(narrow) == 2                                                  # pairs (1,0) of block 1 and (2,1) of block 2
     assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 4  # + the single layers 0 of blocks 2 and 3
 
 

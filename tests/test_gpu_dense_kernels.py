@@ -325,22 +325,43 @@ def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
     partW = torch.empty(G * Kp * 48, device=DEV)
     dW = torch.empty(Cout, Cin, device=DEV)
     lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
-                                                 p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, None, st), "wgrad")
+                                                 p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, None, None, 0, None, 0, None, None, st), "wgrad")
     close(dW, dz.t() @ a, what="dW", rtol=1e-4)
     if not pool and Cout == 48:   # dense layer: dz materialised for the data-gradient passes, separately and in place
         dz_out = torch.full((P, 48), 5.0, device=DEV)
         lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
-                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(dz_out), st), "wgrad+dz")
+                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(dz_out), None, 0, None, 0, None, None, st), "wgrad+dz")
         close(dW, dz.t() @ a, what="dW (dz_out)", rtol=1e-4)
         close(dz_out, dz, what="dz_out", rtol=1e-6, atol=1e-6)
         DYc = DY[:, :48].contiguous()
         lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DYc), 48, p(Zr), Ko,
-                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DYc), st), "wgrad in place")
+                                                     p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DYc), None, 0, None, 0, None, None, st), "wgrad in place")
         close(dW, dz.t() @ a, what="dW (in place)", rtol=1e-4)
         close(DYc, dz, what="dz in place", rtol=1e-6, atol=1e-6)
+        if Cin >= 24:
+            # the narrow data pass riding on the weight-gradient kernel: N12 = G[:, k_lo:k_lo+12] + s1*mask*(dz W[:, k_lo:k_lo+12])
+            k_lo = Cin - 12
+            Gn = rnd(P, ld)
+            N12 = torch.full((P, 12), 3.0, device=DEV)
+            pn = torch.zeros(G * Kp * 2, dtype=torch.float64, device=DEV)
+            dW_n, dz_n = torch.empty(Cout, Cin, device=DEV), torch.empty(P, 48, device=DEV)
+            lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                         p(cA), p(cB), p(cC), Cout, p(partW), p(dW_n), G, p(dz_n), p(Wt), k_lo,
+                                                         p(Gn), ld, p(N12), p(pn), st), "wgrad + narrow")
+            close(dW_n, dz.t() @ a, what="dW (with the narrow pass)", rtol=1e-4)
+            close(dz_n, dz, what="dz_out (with the narrow pass)", rtol=1e-6, atol=1e-6)
+            dam_n = torch.where(pre[:, k_lo:] > 0, dz @ Wt.double()[:, k_lo:], torch.zeros(P, 12, device=DEV, dtype=torch.float64))
+            close(N12, Gn[:, k_lo:Cin].double() + s1[k_lo:Cin].double() * dam_n, what="fused N12", rtol=1e-4)
+            S1n, S2n = fold_partials(pn, G, Kp)
+            close(S1n[k_lo:Cin], dam_n.sum(0), what="fused narrow S1", rtol=1e-5, atol=1e-4)
+            assert float(S2n.abs().max()) == 0.0 and float(S1n[:k_lo].abs().max()) == 0.0
+            # odd k_lo / range past Cin are refused
+            assert L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                      p(cA), p(cB), p(cC), Cout, p(partW), p(dW_n), G, p(dz_n), p(Wt), k_lo + 1,
+                                                      p(Gn), ld, p(N12), p(pn), st) == -1
     else:
         assert L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
-                                                  p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DY), st) == -1
+                                                  p(cA), p(cB), p(cC), Cout, p(partW), p(dW), G, p(DY), None, 0, None, 0, None, None, st) == -1
     # ---- data gradient, accumulate and overwrite modes, + BN1-backward partial sums
     Wd = torch.empty(Kp * Ko, device=DEV)
     lib.check(L.eml_dense_permute_w1_bwd_f32(p(Wt), Cout, Cin, Kp, Ko, p(Wd), st), "permute bwd")
