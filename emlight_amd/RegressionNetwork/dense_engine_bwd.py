@@ -153,15 +153,6 @@ def run_backward(enc, ws, x, gpooled):
                 parr([y["mask"] for y in lays]), st),   # ReLU masks from the forward's bits: X is not read
                 "eml_dense_conv1x1_bwd_data_multi_f32")
 
-        def narrow(l, Lm, slot, k_lo):
-            """Layer l's data gradient over the 12 channels [k_lo, k_lo+12) -> compact bw.N12 (+ BN1 partial sums)."""
-            lay = blk["layers"][l]
-            _lib.check(L.eml_dense_conv1x1_bwd_narrow_f32(
-                p(bw.DZ[slot]), p(Lm.conv1.weight), lay["Cin"], k_lo, p(blk["X"]), ld, p(lay["scale1"]),
-                p(lay["shift1"]), p(blk["mean"]), p(blk["istd"]), P, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot]),
-                lay["Kp"], G, st),
-                "eml_dense_conv1x1_bwd_narrow_f32")
-
         def bn1_finalize(l, Lm, slot, c_lo, c_hi):
             lay = blk["layers"][l]
             finalize(G, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,

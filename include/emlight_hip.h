@@ -262,7 +262,8 @@ int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, c
  * over the 12 output channels [k_lo, k_lo+12) of the layer below it, added to what G holds there and written as the
  * compact tensor N12 (P,12) = G[p][k] + scale1[k] * relu-mask * sum_o DZ[p][o] * W1[o][k]  (DZ = materialised dz
  * (P,48), W1 = conv1.weight (48,Cin)), which eml_dense_conv3x3_bwd_data_f32 then takes as its (G, 12, 0);
- * partials[grid][Kp][2] receives (sum dam, sum dam*xhat) at channels k_lo..k_lo+11 for the BN1 backward. */
+ * partials[grid][Kp][2] receives (sum dam, sum dam*xhat) at channels k_lo..k_lo+11 for the BN1 backward.
+ * (The stand-alone form of the pass; the training engine uses the one riding on eml_dense_conv1x1_bwd_weight_f32.) */
 int eml_dense_conv1x1_bwd_narrow_f32(const float* DZ, const float* W1, int Cin, int k_lo, const float* X,
                                      int ldx, const float* scale1, const float* shift1,
                                      const float* mean, const float* istd, long P, const float* G, int ldg,
