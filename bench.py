@@ -91,11 +91,10 @@ def family_bytes(B, crop_hw):
 # launcher -> (kernel family, which algorithmic FLOP count one pass over its launches performs)
 FAMILIES = {
     "eml_dense_conv1x1_fwd_f32": ("conv1x1_fwd_kernel (BN1+ReLU fused into the MFMA operand load)", 0),
-    "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS and materialised)", 0),
-    "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 2 dense layers per pass + ReLU "
-                                             "mask + BN1-backward accumulate)", 0),
-    "eml_dense_conv1x1_bwd_narrow_f32": ("conv1x1_bwd_narrow_kernel (upper layer's dgrad over the lower layer's 12 channels, "
-                                         "compact output)", 3),
+    "eml_dense_conv1x1_bwd_weight_f32": ("conv1x1_bwd_weight_kernel (wgrad, dz rebuilt in LDS and materialised; the upper "
+                                         "layer of a pair also runs the narrow data pass on that dz tile)", 0),
+    "eml_dense_conv1x1_bwd_data_multi_f32": ("conv1x1_bwd_data_multi_kernel (dgrad of 2 dense layers per pass; ReLU mask "
+                                             "from the forward's bits, no x read; BN1-backward accumulate)", 0),
     "eml_dense_conv1x1_bwd_data_f32": ("transition_bwd_data_kernel (transition dgrad: un-pool, ReLU mask, BN backward accumulate)", 2),
     "eml_dense_pool_act_f32": ("pool_act_kernel (transition operand: 2x2 mean of relu(bn(x)))", 3),
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
