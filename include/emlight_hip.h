@@ -198,7 +198,7 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
  * W != NULL (BN1 of a dense layer, followed by ReLU and the 1x1 conv W [w_rows][C]): S2 is not read from the
  * partials but derived from the conv's finished weight gradient dW -- with a = relu(bn(x)) and dy = mask * (W^T dz),
  * sum_p dy*bn(x) = sum_o W[o][c]*dW[o][c], and bn(x) = gamma*xhat + beta, so
- * S2 = (sum_o W[o][c]*dW[o][c] - beta[c]*S1) / gamma[c]  (gamma[c] == 0: S2 = 0).  The data-gradient pass then
+ * S2 = (sum_o W[o][c]*dW[o][c] - beta[c]*S1) / gamma[c]  (|gamma[c]| < 1e-12: S2 = 0).  The data-gradient pass then
  * needs no x at all (eml_dense_conv1x1_bwd_data_multi_f32 with relu_masks). */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
