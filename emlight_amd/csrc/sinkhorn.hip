@@ -466,7 +466,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   float* pts = smem;
   float* lw2 = pts + 2 * NP;
   float* h2 = lw2 + 2 * NP;
-  float* Mtile = h2 + 4 * NP;              // [2][NR][TS]
+  float* qq = h2 + 4 * NP;                 // [2][NP]: 0.05 * point^2 (the column-only term of the cost), pads zero
+  float* Mtile = qq + 2 * NP;              // [2][NR][TS]
 
   const int b = blockIdx.x >> 1, role = blockIdx.x & 1, tid = threadIdx.x;
   const int gl = tid / kGT, g = 2 * role + gl, t = tid & (kGT - 1);
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
       l = (w > 0.f) ? logf(w) : -100000.0f;
     }
     pts[i] = p;
+    qq[i] = 0.05f * p * p;
     lw2[i] = l * kLog2e;
   }
   for (int i = tid; i < 4 * NP; i += kWG) h2[i] = 0.f;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   const float* Q = pts + (cols_x ? 0 : NP);
   const float* lw2_rows = lw2 + (rows_x ? 0 : NP);
   const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
+  const float* QQ = qq + (cols_x ? 0 : NP);
   for (int k = t; k < N; k += kGT) h2[gl * NP + k] = lw2_cols[k];
 
   const int i = t / LPR, part = t % LPR;
@@ -536,24 +539,26 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
       __builtin_amdgcn_sched_barrier(0);
       const int j0 = tile * TJ + 16 * part;
       const float* mt = Mtile + (size_t)buf * NR * TS + min(i, NR - 1) * TS + 16 * part;
-      // the exponents t_j = h_j - C_ij / eps on register PAIRS (v_pk_mul / v_pk_fma / v_pk_add: two columns per VALU
-      // slot), same arithmetic as cost_ij: ((p*p - 2*(p*q) + q*q) * 0.1 + m) * 0.5
+      // the exponents t_j = h_j - C_ij / eps with C_ij = .05 p^2 - .1 p q + .05 q^2 + .5 m expanded around its column- and
+      // row-only parts:  t_j = [h_j + n*.05 q_j^2] + (-.1 n p_i) q_j + (.5 n) m_ij + n*.05 p_i^2,  n = -log2(e)/eps.  The last
+      // term is constant along the row: it is added to the row's maximum after the sweep (row_shift), so an element costs
+      // three fused multiply-adds on register pairs (v_pk_fma_f32) instead of six operations for cost + exponent
       typedef float v2f __attribute__((ext_vector_type(2)));
       v2f tv[8];
-      const v2f pp = v2f{pi * pi, pi * pi}, pv = v2f{pi, pi}, nn = v2f{nie2, nie2};
+      const v2f nn = v2f{nie2, nie2}, dd = v2f{-0.1f * nie2 * pi, -0.1f * nie2 * pi}, ee = v2f{0.5f * nie2, 0.5f * nie2};
       v2f mA = v2f{-INFINITY, -INFINITY}, mB = mA;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float4 mv = *reinterpret_cast<const float4*>(mt + 4 * u);
-        const float4 qv = *reinterpret_cast<const float4*>(Q + j0 + 4 * u);      // pads of pts / h2 are zero-filled
+        const float4 qv = *reinterpret_cast<const float4*>(Q + j0 + 4 * u);      // pads of pts / qq / h2 are zero-filled
+        const float4 sv = *reinterpret_cast<const float4*>(QQ + j0 + 4 * u);
         const float4 hv = *reinterpret_cast<const float4*>(hsrc + j0 + 4 * u);
         const bool jv = j0 + 4 * u < N;
-        const v2f q0 = v2f{qv.x, qv.y}, q1 = v2f{qv.z, qv.w};
-        const v2f c0 = (((pp - 2.0f * (pv * q0)) + q0 * q0) * 0.1f + v2f{mv.x, mv.y}) * 0.5f;
-        const v2f c1 = (((pp - 2.0f * (pv * q1)) + q1 * q1) * 0.1f + v2f{mv.z, mv.w}) * 0.5f;
+        const v2f a0 = v2f{sv.x, sv.y} * nn + v2f{hv.x, hv.y}, a1 = v2f{sv.z, sv.w} * nn + v2f{hv.z, hv.w};
+        const v2f b0 = dd * v2f{qv.x, qv.y} + a0, b1 = dd * v2f{qv.z, qv.w} + a1;
         const v2f ninf = v2f{-INFINITY, -INFINITY};
-        tv[2 * u + 0] = jv ? c0 * nn + v2f{hv.x, hv.y} : ninf;
-        tv[2 * u + 1] = jv ? c1 * nn + v2f{hv.z, hv.w} : ninf;
+        tv[2 * u + 0] = jv ? ee * v2f{mv.x, mv.y} + b0 : ninf;
+        tv[2 * u + 1] = jv ? ee * v2f{mv.z, mv.w} + b1 : ninf;
         mA = __builtin_elementwise_max(mA, tv[2 * u + 0]);
         mB = __builtin_elementwise_max(mB, tv[2 * u + 1]);
       }
@@ -596,7 +601,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
       sum = s_run * fa + so * fb;
       tq = tq_run * fa + qo * fb;
     }
-    const float sm = -eps * kLn2 * (m + __builtin_amdgcn_logf(sum));
+    const float row_shift = 0.05f * nie2 * pi * pi;   // the row-only term of the exponents, left out of the tiles above
+    const float sm = -eps * kLn2 * ((m + row_shift) + __builtin_amdgcn_logf(sum));
     if (final_sweep) {
       if (owner) {
         fin_out[i] = sm;
@@ -747,7 +753,7 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
   } else if (N <= 512 && (N & 3) == 0) {
     // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
     const int lpr = N <= 256 ? 2 : 1;
-    lds = (size_t)(8 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
+    lds = (size_t)(10 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
     if (lpr == 2) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
