@@ -496,7 +496,12 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   const float* lw2_rows = lw2 + (rows_x ? 0 : NP);
   const float* lw2_cols = lw2 + (cols_x ? 0 : NP);
   const float* QQ = qq + (cols_x ? 0 : NP);
-  for (int k = t; k < N; k += kGT) h2[gl * NP + k] = lw2_cols[k];
+  // the dual vector travels as A_j = h_j + n * .05 q_j^2 (n = -log2(e)/eps of the sweep that READS it): the column-only
+  // term of the exponent is folded in by whoever writes h, once per column and sweep, not once per element
+  {
+    const float k0 = kLog2e / eps_s[0];
+    for (int k = t; k < N; k += kGT) h2[gl * NP + k] = fmaf(-k0, QQ[k], lw2_cols[k]);
+  }
 
   const int i = t / LPR, part = t % LPR;
   const bool owner = part == 0 && i < N;
@@ -542,20 +547,19 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
       // the exponents t_j = h_j - C_ij / eps with C_ij = .05 p^2 - .1 p q + .05 q^2 + .5 m expanded around its column- and
       // row-only parts:  t_j = [h_j + n*.05 q_j^2] + (-.1 n p_i) q_j + (.5 n) m_ij + n*.05 p_i^2,  n = -log2(e)/eps.  The last
       // term is constant along the row: it is added to the row's maximum after the sweep (row_shift), so an element costs
-      // three fused multiply-adds on register pairs (v_pk_fma_f32) instead of six operations for cost + exponent
+      // TWO fused multiply-adds on register pairs (v_pk_fma_f32) -- the bracket arrives ready-made in the dual vector --
+      // instead of six operations for cost + exponent, and three LDS reads (M tile, q, A) instead of four
       typedef float v2f __attribute__((ext_vector_type(2)));
       v2f tv[8];
-      const v2f nn = v2f{nie2, nie2}, dd = v2f{-0.1f * nie2 * pi, -0.1f * nie2 * pi}, ee = v2f{0.5f * nie2, 0.5f * nie2};
+      const v2f dd = v2f{-0.1f * nie2 * pi, -0.1f * nie2 * pi}, ee = v2f{0.5f * nie2, 0.5f * nie2};
       v2f mA = v2f{-INFINITY, -INFINITY}, mB = mA;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float4 mv = *reinterpret_cast<const float4*>(mt + 4 * u);
         const float4 qv = *reinterpret_cast<const float4*>(Q + j0 + 4 * u);      // pads of pts / qq / h2 are zero-filled
-        const float4 sv = *reinterpret_cast<const float4*>(QQ + j0 + 4 * u);
-        const float4 hv = *reinterpret_cast<const float4*>(hsrc + j0 + 4 * u);
+        const float4 hv = *reinterpret_cast<const float4*>(hsrc + j0 + 4 * u);   // A_j (see the h2 initialisation)
         const bool jv = j0 + 4 * u < N;
-        const v2f a0 = v2f{sv.x, sv.y} * nn + v2f{hv.x, hv.y}, a1 = v2f{sv.z, sv.w} * nn + v2f{hv.z, hv.w};
-        const v2f b0 = dd * v2f{qv.x, qv.y} + a0, b1 = dd * v2f{qv.z, qv.w} + a1;
+        const v2f b0 = dd * v2f{qv.x, qv.y} + v2f{hv.x, hv.y}, b1 = dd * v2f{qv.z, qv.w} + v2f{hv.z, hv.w};
         const v2f ninf = v2f{-INFINITY, -INFINITY};
         tv[2 * u + 0] = jv ? ee * v2f{mv.x, mv.y} + b0 : ninf;
         tv[2 * u + 1] = jv ? ee * v2f{mv.z, mv.w} + b1 : ninf;
@@ -610,7 +614,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
       }
     } else {
       pot = (s == 0) ? sm : 0.5f * (pot + sm);
-      if (owner) hdst[i] = fmaf(pot, k_next, lw2_rows[i]);
+      // this row is a COLUMN of the group that reads hdst: fold its .05 p^2 term in with that sweep's n = -k_next
+      if (owner) hdst[i] = fmaf(pot, k_next, lw2_rows[i]) - k_next * (0.05f * pi * pi);
     }
     __syncthreads();
   }
