@@ -15,6 +15,7 @@ emits the (scale, shift) the next consumer applies while loading its MFMA operan
 import os
 import weakref
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -94,6 +95,28 @@ class _Workspace:
     def in_use(self):
         """True while a graph built on this workspace is alive and its backward has not run."""
         return (not self.done) and self.owner is not None and self.owner() is not None
+
+
+class _PermuteTable:
+    """Device array of ``eml_permute_desc`` for ``eml_dense_permute_batch_f32``: every weight re-layout of a pass in ONE
+    launch.  Built once per workspace and rebuilt only when a source or destination pointer moved (``model.to()``,
+    a re-created parameter); ``load_state_dict`` and the optimiser update weights in place."""
+    _DT = np.dtype([("src", "<u8"), ("dst", "<u8"), ("kind", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"), ("Kp", "<i4"),
+                    ("Ko", "<i4"), ("reserved", "<i4")])
+
+    def __init__(self):
+        self.key, self.dev, self.n = None, None, 0
+
+    def launch(self, L, st, items):
+        """items: (weight tensor, destination tensor, kind, Cout, Cin, Kp, Ko)."""
+        key = tuple((w.data_ptr(), d.data_ptr()) for w, d, *_ in items)
+        if key != self.key:
+            host = np.zeros(len(items), dtype=self._DT)
+            for i, (w, d, kind, cout, cin, kp, ko) in enumerate(items):
+                host[i] = (w.data_ptr(), d.data_ptr(), kind, cout, cin, kp, ko, 0)
+            self.dev = torch.from_numpy(host.view(np.uint8).copy()).to(items[0][1].device)
+            self.key, self.n = key, len(items)
+        _lib.check(L.eml_dense_permute_batch_f32(_lib.ptr(self.dev), self.n, st), "eml_dense_permute_batch_f32")
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -251,6 +274,19 @@ class HipDenseEncoder:
         training = m.training
         part = ws.partials
         b0 = ws.blocks[0]
+        # ---- every weight re-layout of the forward (1x1 -> W1p / Wp, 3x3 -> W2p) in one launch
+        if getattr(ws, "fwd_permutes", None) is None:
+            ws.fwd_permutes = _PermuteTable()
+        items = []
+        for bi, blk in enumerate(ws.blocks):
+            mod = getattr(f, "denseblock%d" % (bi + 1))
+            for l, lay in enumerate(blk["layers"]):
+                Lm = getattr(mod, "denselayer%d" % (l + 1))
+                items.append((Lm.conv1.weight, lay["W1p"], 0, 48, lay["Cin"], lay["Kp"], 0))
+                items.append((Lm.conv2.weight, lay["W2p"], 1, 12, 48, 48, 0))
+            T, tr = getattr(f, "transition%d" % (bi + 1)), blk["trans"]
+            items.append((T.conv.weight, tr["Wp"], 0, tr["Cout"], blk["Ctot"], tr["Kp"], 0))
+        ws.fwd_permutes.launch(L, st, items)
         # ---- conv0 -> norm0 -> relu0 (DenseNet.py:88-93)
         _lib.check(L.eml_dense_conv0_fwd_f32(p(x), p(f.conv0.weight), p(ws.Y0), self.c_init, B, H, W, self.c_init,
                                              p(part), G, st), "eml_dense_conv0_fwd_f32")
@@ -271,16 +307,12 @@ class HipDenseEncoder:
                 z = blk["Z"][l if keep_all else 0]
                 self._prepare(L, st, part if pending else None, G3, 32, 12, cin - 12, P, blk["mean"], blk["var"],
                               blk["istd"], Lm.norm1, cin, kp, training, lay["scale1"], lay["shift1"])
-                _lib.check(L.eml_dense_permute_w1_f32(p(Lm.conv1.weight), 48, cin, kp, p(lay["W1p"]), st),
-                           "eml_dense_permute_w1_f32")
                 _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, P, Hb, Wb, 0, kp, p(lay["scale1"]),
                                                        p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), G,
                                                        p(lay["mask"]) if (keep_all and training) else None, st),
                            "eml_dense_conv1x1_fwd_f32")
                 self._prepare(L, st, part, G, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
                               training, lay["scale2"], lay["shift2"])
-                _lib.check(L.eml_dense_permute_w2_f32(p(Lm.conv2.weight), 12, p(lay["W2p"]), st),
-                           "eml_dense_permute_w2_f32")
                 _lib.check(L.eml_dense_conv3x3_fwd_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2p"]),
                                                        p(blk["X"]), ld, cin, B, Hb, Wb, p(part), G3, st),
                            "eml_dense_conv3x3_fwd_f32")
@@ -291,8 +323,6 @@ class HipDenseEncoder:
             ctot, cout, kpt = blk["Ctot"], tr["Cout"], tr["Kp"]
             self._prepare(L, st, part if pending else None, G3, 32, 12, ctot - 12, P, blk["mean"], blk["var"],
                           blk["istd"], T.norm, ctot, kpt, training, tr["scale"], tr["shift"])
-            _lib.check(L.eml_dense_permute_w1_f32(p(T.conv.weight), cout, ctot, kpt, p(tr["Wp"]), st),
-                       "eml_dense_permute_w1_f32")
             Pn = B * (Hb // 2) * (Wb // 2)
             # pool first (it commutes with the 1x1 conv): the conv's output chunks then read A, a quarter of X
             _lib.check(L.eml_dense_pool_act_f32(p(blk["X"]), ld, B, Hb, Wb, kpt, p(tr["scale"]), p(tr["shift"]),

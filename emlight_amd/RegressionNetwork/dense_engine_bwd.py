@@ -26,7 +26,11 @@ class _BwdBuffers:
         # scratch sized from the network (widest block Kp, widest transition Ko) and the largest grid, not for
         # EMLight's default only
         kp, ko, g = enc.kp_max, max(enc.ko_max, 48), enc.grid_max
-        self.Wd = torch.empty(2, kp * ko, **f32)       # permuted conv1 / transition weights for the data gradient
+        # permuted conv1 / transition weights for the data gradient: one buffer per layer (all of them are re-laid out by
+        # ONE launch at the start of the backward)
+        self.Wd = [[torch.empty(lay["Kp"] * 48, **f32) for lay in blk["layers"]] for blk in ws.blocks]
+        self.WdT = [torch.empty(blk["trans"]["Kp"] * blk["trans"]["Ko"], **f32) for blk in ws.blocks]
+        self.permutes = None
         self.coef = torch.zeros(8, max(kp, ko), **f32)  # two (cA,cB,cC) sets for dz, then sB, sC
         self.part2 = torch.zeros(2, g * kp * 2, dtype=torch.float64, device=dev)
         # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
@@ -49,6 +53,20 @@ def run_backward(enc, ws, x, gpooled):
         ws.bwd = _BwdBuffers(enc, ws, dev)
     bw = ws.bwd
     part = ws.partials
+    # ---- every data-gradient weight layout of the backward in one launch
+    if bw.permutes is None:
+        from .dense_engine import _PermuteTable
+        bw.permutes = _PermuteTable()
+    items = []
+    for bi_, blk_ in enumerate(ws.blocks):
+        mod_ = getattr(f, "denseblock%d" % (bi_ + 1))
+        for l_, lay_ in enumerate(blk_["layers"]):
+            items.append((getattr(mod_, "denselayer%d" % (l_ + 1)).conv1.weight, bw.Wd[bi_][l_], 2, 48, lay_["Cin"],
+                          lay_["Kp"], 48))
+        tr_ = blk_["trans"]
+        items.append((getattr(f, "transition%d" % (bi_ + 1)).conv.weight, bw.WdT[bi_], 2, tr_["Cout"], blk_["Ctot"],
+                      tr_["Kp"], tr_["Ko"]))
+    bw.permutes.launch(L, st, items)
     params = enc.param_list()
     grads = {id(q): torch.empty_like(q) for q in params}
     gr = lambda q: p(grads[id(q)])
@@ -102,10 +120,8 @@ def run_backward(enc, ws, x, gpooled):
             p(tr["A"]), kpt, Pn, Hb // 2, Wb // 2, 0, kpt, ctot, p(tr["one"]), p(tr["zero"]), p(dY), ld_dy, p(tr["T"]),
             Ko, p(cA), p(cB), p(cC), cout, p(bw.partW), gr(T.conv.weight), G, None, None, 0, None, 0, None, None, st),
             "eml_dense_conv1x1_bwd_weight_f32")
-        _lib.check(L.eml_dense_permute_w1_bwd_f32(p(T.conv.weight), cout, ctot, kpt, Ko, p(bw.Wd), st),
-                   "eml_dense_permute_w1_bwd_f32")
         _lib.check(L.eml_dense_conv1x1_bwd_data_f32(
-            p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.Wd), None, ld, p(tr["scale"]),
+            p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.WdT[bi]), None, ld, p(tr["scale"]),
             p(tr["shift"]), None, None, Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, p(tr["mask16"]), st),
             "eml_dense_conv1x1_bwd_data_f32")   # ReLU mask from pool_act's bits: X is not read
         finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False, conv=T.conv)
@@ -137,8 +153,6 @@ def run_backward(enc, ws, x, gpooled):
                 p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, p(dz),
                 *((p(Lm.conv1.weight), narrow_lo, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot])) if narrow_lo is not None
                   else (None, 0, None, 0, None, None)), st), "eml_dense_conv1x1_bwd_weight_f32")
-            _lib.check(L.eml_dense_permute_w1_bwd_f32(p(Lm.conv1.weight), 48, cin, kp, 48, p(bw.Wd[slot]), st),
-                       "eml_dense_permute_w1_bwd_f32")
             return Lm
 
         def dgrad(layers, slots, k_lo, k_hi):
@@ -146,7 +160,7 @@ def run_backward(enc, ws, x, gpooled):
             lays = [blk["layers"][l] for l in layers]
             _lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
                 len(layers), parr([bw.DZ[s_] for s_ in slots]), None, None, None, None,   # DZ holds the materialised dz
-                parr([bw.Wd[s_] for s_ in slots]),
+                parr([bw.Wd[bi][l_] for l_ in layers]),
                 parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
                 parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
                 None, ld, None, None, P, k_lo, k_hi, p(Gbuf), ld, G,

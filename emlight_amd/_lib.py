@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 7   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 8   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -66,6 +66,7 @@ SIGNATURES = {
                                         _f32p, _f32p, _stream]),
     "eml_dense_permute_w1_f32": (_int, [_f32p, _int, _int, _int, _f32p, _stream]),
     "eml_dense_permute_w2_f32": (_int, [_f32p, _int, _f32p, _stream]),
+    "eml_dense_permute_batch_f32": (_int, [ctypes.c_void_p, _int, _stream]),
     "eml_dense_conv1x1_fwd_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _f32p, _f32p, _f32p,
                                          _int, _f32p, _int, _f32p, _int, ctypes.c_void_p, _stream]),
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,

@@ -659,6 +659,47 @@ __global__ void permute_w2_kernel(const float* __restrict__ W2, int Cout, float*
   }
 }
 
+// All weight re-layouts of a pass in ONE launch (blockIdx.y = descriptor): the per-layer permutes are 4-5 us kernels, 150 of
+// them per training step, each one a launch boundary between two big kernels.  kind 0: permute_w1 (1x1 forward),
+// 1: permute_w2 (3x3 forward), 2: the data-gradient layout of dense_bwd.hip's permute_w1_bwd_kernel.
+__global__ __launch_bounds__(256) void permute_batch_kernel(const eml_permute_desc* __restrict__ descs) {
+  const eml_permute_desc d = descs[blockIdx.y];
+  const float* __restrict__ W = d.src;
+  float* __restrict__ out = d.dst;
+  const size_t stride = (size_t)gridDim.x * 256, e0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (d.kind == 0) {
+    const int nj = d.Kp >> 4;
+    const size_t total = (size_t)((d.Cout + 47) / 48) * d.Kp * 48;
+    for (size_t e = e0; e < total; e += stride) {
+      const int t = (int)(e & 3);
+      size_t rest = e >> 2;
+      const int o = (int)(rest % 48);
+      rest /= 48;
+      const int kk = (int)(rest & 3);
+      rest >>= 2;
+      const int j = (int)(rest % nj), ch = (int)(rest / nj);
+      const int k = 16 * j + 4 * kk + t, oc = ch * 48 + o;
+      out[e] = (k < d.Cin && oc < d.Cout) ? W[(size_t)oc * d.Cin + k] : 0.f;
+    }
+  } else if (d.kind == 1) {
+    for (size_t e = e0; e < 9 * 3 * 4 * 16 * 4; e += stride) {
+      const int ei = (int)e, t = ei & 3, o = (ei >> 2) & 15, kk = (ei >> 6) & 3;
+      const int rest = ei >> 8, j = rest % 3, tap = rest / 3;
+      out[e] = (o < d.Cout) ? W[((size_t)o * 48 + 16 * j + 4 * kk + t) * 9 + tap] : 0.f;
+    }
+  } else {
+    const int njo = d.Ko >> 4;
+    const size_t total = (size_t)d.Kp * d.Ko;
+    for (size_t e = e0; e < total; e += stride) {
+      const int t = (int)(e & 3), col = (int)((e >> 2) & 15), kk = (int)((e >> 6) & 3);
+      const size_t rest = e >> 8;
+      const int jo = (int)(rest % njo), nt = (int)(rest / njo);
+      const int o = 16 * jo + 4 * kk + t, k = 16 * nt + col;
+      out[e] = (o < d.Cout && k < d.Cin) ? W[(size_t)o * d.Cin + k] : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ head: relu -> avgpool(k) -> (B, C, h, w) flatten
 __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ F, int ldf, int C, int B, int H, int W,
                                                         int k, float* __restrict__ out) {
@@ -760,6 +801,13 @@ extern "C" int eml_dense_permute_w1_f32(const float* W, int Cout, int Cin, int K
   const int nchunks = (Cout + 47) / 48;
   hipLaunchKernelGGL(permute_w1_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, Cout, Cin, Kp, nchunks, Wp);
   return eml::check_launch("eml_dense_permute_w1_f32");
+}
+
+extern "C" int eml_dense_permute_batch_f32(const eml_permute_desc* descs, int n, eml_stream_t stream) {
+  if (!descs || n < 0 || n > 65535) return eml::fail(EML_EINVAL, "eml_dense_permute_batch_f32: bad arguments");
+  if (n == 0) return EML_OK;
+  hipLaunchKernelGGL(permute_batch_kernel, dim3(8, n), dim3(256), 0, (hipStream_t)stream, descs);
+  return eml::check_launch("eml_dense_permute_batch_f32");
 }
 
 extern "C" int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t stream) {

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 7
+#define EML_ABI_VERSION 8
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -135,6 +135,16 @@ int eml_dense_bn_prepare_f32(const double* partials, int G, int pstride, int n_n
  * W [Cout][Cin] (1x1) -> Wp [ceil(Cout/48)][Kp/16][4][48][4];  W2 [Cout<=16][48][3][3] -> W2p [9][3][4][16][4]. */
 int eml_dense_permute_w1_f32(const float* W, int Cout, int Cin, int Kp, float* Wp, eml_stream_t stream);
 int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t stream);
+
+/* All re-layouts of a pass in one launch: descs is a DEVICE array of n descriptors (the caller uploads it once; it stays
+ * valid while the weight and workspace pointers do).  kind 0 = eml_dense_permute_w1_f32 (Cout, Cin, Kp), 1 =
+ * eml_dense_permute_w2_f32 (Cout), 2 = eml_dense_permute_w1_bwd_f32 (Cout, Cin, Kp, Ko); same outputs, bit for bit. */
+typedef struct eml_permute_desc {
+  const float* src;
+  float* dst;
+  int kind, Cout, Cin, Kp, Ko, reserved;
+} eml_permute_desc;
+int eml_dense_permute_batch_f32(const eml_permute_desc* descs, int n, eml_stream_t stream);
 
 /* out[p][o] = sum_k relu(scale_k*X[p][k] + shift_k) * W[o][k]:  BN1 -> ReLU -> conv1 of a dense layer
  * (DenseNet.py:30-37; Cout = 48) and, with pool != 0, a transition BN -> ReLU -> conv -> avgpool2

@@ -183,6 +183,37 @@ def test_head_pool_fwd_bwd(lib):
     close(dF[:, :C], nhwc(f.grad), what="head pool bwd")
 
 
+def test_permute_batch_equals_the_single_permutes(lib):
+    """eml_dense_permute_batch_f32: every re-layout of a pass in one launch, bit for bit the three single kernels."""
+    import ctypes
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("kind", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"), ("Kp", "<i4"),
+                   ("Ko", "<i4"), ("reserved", "<i4")])
+    cases = [(0, 48, 36, 48, 0), (0, 171, 342, 352, 0), (1, 12, 48, 48, 0), (2, 48, 150, 160, 48), (2, 108, 216, 224, 112)]
+    host = np.zeros(len(cases), dtype=dt)
+    keep, want = [], []
+    for i, (kind, cout, cin, kp, ko) in enumerate(cases):
+        if kind == 1:
+            Wt, n = rnd(12, 48, 3, 3), 9 * 3 * 4 * 16 * 4
+        else:
+            Wt, n = rnd(cout, cin), (((cout + 47) // 48) * kp * 48 if kind == 0 else kp * ko)
+        dst, ref = torch.full((n,), 7.0, device=DEV), torch.empty(n, device=DEV)
+        if kind == 0:
+            lib.check(L.eml_dense_permute_w1_f32(p(Wt), cout, cin, kp, p(ref), st), "w1")
+        elif kind == 1:
+            lib.check(L.eml_dense_permute_w2_f32(p(Wt), 12, p(ref), st), "w2")
+        else:
+            lib.check(L.eml_dense_permute_w1_bwd_f32(p(Wt), cout, cin, kp, ko, p(ref), st), "w1 bwd")
+        host[i] = (Wt.data_ptr(), dst.data_ptr(), kind, cout, cin, kp, ko, 0)
+        keep.append((Wt, dst))
+        want.append(ref)
+    table = torch.from_numpy(host.view(np.uint8).copy()).to(DEV)
+    lib.check(L.eml_dense_permute_batch_f32(p(table), len(cases), st), "batch")
+    for (Wt, dst), ref in zip(keep, want):
+        assert torch.equal(dst, ref)
+    assert L.eml_dense_permute_batch_f32(None, 3, st) == -1 and L.eml_dense_permute_batch_f32(p(table), 0, st) == 0
+
+
 @pytest.mark.parametrize("B,H,W,C,ld", [(2, 6, 10, 216, 224), (1, 4, 4, 20, 32)])
 def test_pool_act(lib, B, H, W, C, ld):
     """A = mean2x2(relu(scale*x + shift)): the transition's operand (DenseNet.py:14-21, pool commuted before the conv)."""
