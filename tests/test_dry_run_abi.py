@@ -65,6 +65,28 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     assert all(p.grad is not None for p in net.parameters())
 
 
+def test_permute_table_is_rebuilt_only_when_a_pointer_moves(recorder):
+    """One batched re-layout launch per pass; its device descriptor table follows the weights' data pointers."""
+    import numpy as np
+    from emlight_amd.RegressionNetwork.dense_engine import _PermuteTable
+    tab = _PermuteTable()
+    w, d = torch.zeros(48, 24), torch.zeros(32 * 48)
+    tab.launch(recorder, None, [(w, d, 0, 48, 24, 32, 0)])
+    first = tab.dev
+    tab.launch(recorder, None, [(w, d, 0, 48, 24, 32, 0)])
+    assert tab.dev is first and recorder.calls.count("eml_dense_permute_batch_f32") == 2
+    host = np.frombuffer(first.numpy().tobytes(), dtype=_PermuteTable._DT)
+    assert int(host["src"][0]) == w.data_ptr() and int(host["dst"][0]) == d.data_ptr() and int(host["Kp"][0]) == 32
+    w2 = w.clone()                                   # e.g. model.to(): new storage -> new table
+    tab.launch(recorder, None, [(w2, d, 0, 48, 24, 32, 0)])
+    assert tab.dev is not first
+    # an optimiser step / load_state_dict writes in place: same pointer, same table
+    w2.add_(1.0)
+    second = tab.dev
+    tab.launch(recorder, None, [(w2, d, 0, 48, 24, 32, 0)])
+    assert tab.dev is second
+
+
 def test_odd_block_config_uses_the_single_layer_pass(recorder):
     from emlight_amd.RegressionNetwork.DenseNet import DenseNet
     from emlight_amd.RegressionNetwork.dense_engine import HipDenseEncoder
