@@ -224,6 +224,11 @@ class HipDenseEncoder:
         g = int(os.environ.get(env, 0))
         return min(self.grid_max, g if g > 0 else default)
 
+    def overlap_wgrad(self, dev):
+        """Run the conv3x3 weight gradients (MFMA-bound, off the critical path) on a side stream next to the HBM-bound
+        1x1 chain of the backward.  EML_WGRAD_OVERLAP=0/1 overrides the default."""
+        return torch.device(dev).type == "cuda" and os.environ.get("EML_WGRAD_OVERLAP", "0") == "1"
+
     def _grid3(self, dev):
         """Persistent grid of the conv3x3 kernels: their 512-thread workgroups use ~140 KB of LDS, one fits a CU, and a
         second round of workgroups only repeats the weight-fragment prologue (A/B on one box: #CU beats 2 x #CU by 4 % on

@@ -5,6 +5,9 @@ keeping one gradient buffer G per dense block that mirrors the block's NHWC acti
 buffer; every BatchNorm backward is reduced to a per-channel affine (dx = cA*dy + cB*x + cC)
 and folded into the operand loads of the neighbouring convolution kernels.
 """
+import ctypes
+import os
+
 import torch
 
 from .. import _lib
@@ -14,6 +17,39 @@ def _r16(v):
     return (v + 15) // 16 * 16
 
 
+def _side_stream(dev, prio):
+    """A second HIP stream on `dev`.  torch's pool only hands out priorities <= 0; a LOW-priority stream (prio > 0: the
+    background weight gradients must not take CUs from the critical chain) is created through the HIP runtime torch
+    has already loaded and wrapped as an ExternalStream."""
+    if prio <= 0:
+        return torch.cuda.Stream(device=dev, priority=prio)
+    hip = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(prio))  # 1 = non-blocking
+    if rc != 0:
+        raise RuntimeError("hipStreamCreateWithPriority failed (%d)" % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def _masked_stream(dev, n_cu, keep):
+    """A HIP stream restricted to the CUs i of [0, n_cu) with keep(i) (hipExtStreamCreateWithCUMask): a kernel launched
+    on it only ever occupies that subset, so a persistent grid sized for the subset never waits for a CU that another
+    stream's kernel holds."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cu):
+        if keep(i):
+            mask[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class _BwdBuffers:
     def __init__(self, enc, ws, dev):
         f32 = dict(dtype=torch.float32, device=dev)
@@ -21,7 +57,10 @@ class _BwdBuffers:
         self.GF = torch.zeros(ws.F.shape[0], ws.F.shape[1], **f32)
         maxP = ws.blocks[0]["P"]
         self.DZ = torch.empty(2, maxP, 48, **f32)   # one per layer of a pair
-        self.GF12 = torch.empty(maxP, 12, **f32)    # finished gradient of a layer's 12 output channels (compact)
+        # finished gradient of a layer's 12 output channels (compact); a ring, so that the conv3x3 weight gradient of
+        # layer l may still be reading slot l % R on the side stream while the main stream is R - 1 layers further
+        self.ring = max(1, int(os.environ.get("EML_WGRAD_RING", 4))) if enc.overlap_wgrad(dev) else 1
+        self.GF12 = [torch.empty(maxP, 12, **f32) for _ in range(self.ring)]
         self.N12 = torch.empty(maxP, 12, **f32)     # narrow pass: finished gradient of the lower layer's 12 channels
         # scratch sized from the network (widest block Kp, widest transition Ko) and the largest grid, not for
         # EMLight's default only
@@ -35,9 +74,39 @@ class _BwdBuffers:
         self.part2 = torch.zeros(2, g * kp * 2, dtype=torch.float64, device=dev)
         # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
         self.partW = torch.empty(g * max(kp * 48, 2 * 27 * 256, 4 * 1024), **f32)
+        # side stream of the conv3x3 weight gradients (nothing downstream waits for dW2): own partial buffers per slot
+        self.side = None
+        if enc.overlap_wgrad(dev):
+            # EML_CU_SPLIT=m: the side stream owns the CUs with i % m == m - 1, the main chain of the backward runs on a
+            # stream that owns the rest (experiment: partitioned instead of competing for the same CUs)
+            m = int(os.environ.get("EML_CU_SPLIT", 0))
+            self.main_masked = None
+            if m > 1:
+                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                self.side = _masked_stream(dev, n_cu, lambda i: i % m == m - 1)
+                self.main_masked = _masked_stream(dev, n_cu, lambda i: i % m != m - 1)
+            else:
+                self.side = _side_stream(dev, int(os.environ.get("EML_SIDE_PRIO", 0)))
+            self.partW3 = [torch.empty(g * 2 * 27 * 256, **f32) for _ in range(self.ring)]
+            self.ev_ready = [torch.cuda.Event() for _ in range(self.ring)]
+            self.ev_done = [None] * self.ring
 
 
 def run_backward(enc, ws, x, gpooled):
+    if getattr(ws, "bwd", None) is None:
+        ws.bwd = _BwdBuffers(enc, ws, x.device)
+    masked = getattr(ws.bwd, "main_masked", None)
+    if masked is None:
+        return _run_backward(enc, ws, x, gpooled)
+    cur = torch.cuda.current_stream(x.device)
+    masked.wait_stream(cur)
+    with torch.cuda.stream(masked):
+        out = _run_backward(enc, ws, x, gpooled)
+    cur.wait_stream(masked)
+    return out
+
+
+def _run_backward(enc, ws, x, gpooled):
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
     m = enc.model
     f = m.features
@@ -49,10 +118,14 @@ def run_backward(enc, ws, x, gpooled):
     G = enc._grid(dev)
     G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
     Gb = min(enc.grid_max, 4 * enc._cu)
-    if getattr(ws, "bwd", None) is None:
-        ws.bwd = _BwdBuffers(enc, ws, dev)
     bw = ws.bwd
     part = ws.partials
+    ring = [0]
+    if bw.side is not None:
+        main = torch.cuda.current_stream(dev)
+        st_side = ctypes.c_void_p(bw.side.cuda_stream)
+        G3s = enc._tuned("EML_GRID3_SIDE", G3)
+        bw.side.wait_stream(main)   # the parameter-gradient tensors below are allocated on the main stream
     # ---- every data-gradient weight layout of the backward in one launch
     if bw.permutes is None:
         from .dense_engine import _PermuteTable
@@ -70,7 +143,6 @@ def run_backward(enc, ws, x, gpooled):
     params = enc.param_list()
     grads = {id(q): torch.empty_like(q) for q in params}
     gr = lambda q: p(grads[id(q)])
-    import ctypes
     coefs = [tuple(bw.coef[3 * k + i] for i in range(3)) for k in range(2)]
     cA, cB, cC = coefs[0]
     sB, sC = bw.coef[6], bw.coef[7]
@@ -139,13 +211,29 @@ def run_backward(enc, ws, x, gpooled):
             # the gradient of this layer's 12 output channels is complete: its deferred BN1 affine (sB, sC) is
             # applied inside the conv3x3 dgrad's tile staging, which also leaves the finished gradient in GF12
             gsrc = (p(bw.N12), 12, 0) if n12 else (p(Gbuf), ld, cin)
+            r = ring[0] = (ring[0] + 1) % bw.ring
+            if bw.side is not None and bw.ev_done[r] is not None:
+                main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
                                                         p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3, p(blk["X"]), ld,
-                                                        cin, p(sB), p(sC), p(bw.GF12), st),
+                                                        cin, p(sB), p(sC), p(bw.GF12[r]), st),
                        "eml_dense_conv3x3_bwd_data_f32")
-            _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12), 12, 0, p(z), p(lay["scale2"]), p(lay["shift2"]),
-                                                          B, Hb, Wb, p(bw.partW), gr(Lm.conv2.weight), G3, st),
-                       "eml_dense_conv3x3_bwd_weight_f32")
+            if bw.side is None:
+                _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12[r]), 12, 0, p(z), p(lay["scale2"]),
+                                                              p(lay["shift2"]), B, Hb, Wb, p(bw.partW),
+                                                              gr(Lm.conv2.weight), G3, st),
+                           "eml_dense_conv3x3_bwd_weight_f32")
+            else:
+                # dW2 feeds nothing downstream: MFMA-bound, nearly HBM-idle -> side stream, next to the HBM-bound 1x1 chain
+                bw.ev_ready[r].record(main)
+                bw.side.wait_event(bw.ev_ready[r])
+                _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12[r]), 12, 0, p(z), p(lay["scale2"]),
+                                                              p(lay["shift2"]), B, Hb, Wb, p(bw.partW3[r]),
+                                                              gr(Lm.conv2.weight), G3s, st_side),
+                           "eml_dense_conv3x3_bwd_weight_f32")
+                if bw.ev_done[r] is None:
+                    bw.ev_done[r] = torch.cuda.Event()
+                bw.ev_done[r].record(bw.side)
             finalize(G3, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
@@ -201,4 +289,6 @@ def run_backward(enc, ws, x, gpooled):
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")
+    if bw.side is not None:
+        main.wait_stream(bw.side)   # every dW2 is complete before the gradients leave
     return [grads[id(q)] for q in params]

@@ -54,12 +54,11 @@ class JointTrainer:
         return {"input": predicted_gaussian_map(pred, self.ln, self.pano_hw), "crop": crop128,
                 "warped": batch["warped"], "map": batch["map"]}
 
-    def step(self, batch):
-        """One joint iteration on ``batch`` = regression keys (``crop, distribution, intensity, rgb_ratio, ambient``)
-        + projector keys (``warped`` real HDR panorama (B,3,128,256), ``map`` light mask (B,1,128,256))."""
+    def generator_step(self, batch):
+        """Encoder + generator half of an iteration: one backward of L_reg + sum(G losses), Adam on both.  Returns the
+        projector data dict (its guide map still attached to the encoder's graph) for ``discriminator_step``."""
         enc = self.reg.ddp if self.reg.ddp is not None else self.reg.model
         pm = self.proj.model
-        # ---- encoder + generator step
         pred = enc(batch["crop"])
         l_reg, terms = regression_loss(pred, batch, self.reg.sam_loss, self.ln)
         data = self.projector_inputs(batch, pred)
@@ -69,14 +68,25 @@ class JointTrainer:
         (l_reg + sum(g_losses.values()).mean()).backward()
         self.reg.optimizer.step()
         self.proj.optimizer_G.step()
-        # ---- discriminator step on the same (detached) guide map
+        self.losses = {**terms, **g_losses}
+        self.generated, self.guide = fake, data["input"]
+        return data
+
+    def discriminator_step(self, data):
+        """Discriminator half on the same (detached) guide map, with the generator as ``generator_step`` left it."""
+        pm = self.proj.model
         data_d = dict(data, input=data["input"].detach())
         self.proj.optimizer_D.zero_grad()
         d_losses = pm(data_d, mode="discriminator")
         sum(d_losses.values()).mean().backward()
         self.proj.optimizer_D.step()
-        self.losses = {**terms, **g_losses, **d_losses}
-        self.generated, self.guide = fake, data["input"]
+        self.losses = {**self.losses, **d_losses}
+        return d_losses
+
+    def step(self, batch):
+        """One joint iteration on ``batch`` = regression keys (``crop, distribution, intensity, rgb_ratio, ambient``)
+        + projector keys (``warped`` real HDR panorama (B,3,128,256), ``map`` light mask (B,1,128,256))."""
+        self.discriminator_step(self.generator_step(batch))
         return self.losses
 
 

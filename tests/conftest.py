@@ -9,6 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the oracle's stock-op convolutions (MIOpen) must not spend minutes auto-tuning dozens of one-off shapes on the GPU box
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 
 
 def pytest_configure(config):
@@ -52,3 +54,8 @@ def golden_raster():
 @pytest.fixture(scope="session")
 def golden_densenet():
     return Golden("densenet")
+
+
+@pytest.fixture(scope="session")
+def golden_densenet_cfg2():
+    return Golden("densenet_cfg2")

@@ -399,6 +399,81 @@ def gen_densenet():
     np.savez_compressed(os.path.join(HERE, "densenet.npz"), **out)
 
 
+def gen_densenet_cfg2():
+    """One full training step of the reference at BASELINE's geometry (240x320 crops, 128 anchors, blur .05; cfg2's shapes
+    at B = 2 so the CPU run stays in minutes) -> densenet_cfg2.npz.  The reference class raises at 240x320 (fc is
+    8208-wide, DenseNet.py:125) and hard-codes 96 anchors: as for cfg1 the oracle is the SAME class with fc / fc_dist
+    swapped for matching nn.Linear, everything else -- features, forward, train.py:81-102's loss -- verbatim."""
+    sys.path.insert(0, os.path.join(REF, "RegressionNetwork"))
+    import DenseNet as refnet
+    from oracle.densenet import deterministic_state_dict
+    geomloss, gutils = ref_geomloss()
+    out = {}
+    ln, B, crop = 128, 2, (240, 320)
+
+    def sample(t, k=64):
+        flat = t.detach().reshape(-1)
+        idx = np.linspace(0, flat.numel() - 1, k).astype(np.int64)
+        return flat[idx].numpy(), idx
+
+    torch.manual_seed(0)
+    net = refnet.DenseNet()
+    net.fc = torch.nn.Linear(171 * 7 * 10, 1024)
+    net.fc_dist = torch.nn.Linear(1024, ln)
+    net.load_state_dict(deterministic_state_dict(net.state_dict(), seed=5))
+    net.train()
+    x = torch.from_numpy(rng(40).random((B, 3) + crop, dtype=np.float32))
+    crit = ref_samples_loss(geomloss, gutils, ln, B, .05)
+    g = rng(41)
+    gt = {
+        "distribution": torch.from_numpy(sinkhorn_inputs("sparse", B, ln, 43)[1]),
+        "intensity": torch.from_numpy(g.uniform(.05, 2, (B, 1)).astype(np.float32)),
+        "rgb_ratio": torch.from_numpy(g.uniform(.4, .7, (B, 3)).astype(np.float32)),
+        "ambient": torch.from_numpy(g.uniform(0, .3, (B, 3)).astype(np.float32)),
+    }
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    pred = net(x)
+    l2 = torch.nn.MSELoss()
+    dp, dg = pred["distribution"].view(-1, ln, 1), gt["distribution"].view(-1, ln, 1)
+    terms = [crit(dp, dg).sum() * 1000.0, l2(dp, dg) * 1000.0,
+             l2(pred["intensity"], gt["intensity"]) * 0.1,
+             l2(pred["rgb_ratio"], gt["rgb_ratio"]) * 100.0,
+             l2(pred["ambient"], gt["ambient"]) * 1.0]
+    loss = sum(terms)
+    opt.zero_grad()
+    loss.backward()
+    for k, v in pred.items():
+        out["train/" + k] = v.detach().numpy()
+    for k, v in gt.items():
+        out["train/gt_" + k] = v.numpy()
+    out["train/loss_terms"] = np.array([float(t) for t in terms], dtype=np.float64)
+    named = dict(net.named_parameters())
+    for key in ["features.conv0.weight", "features.norm0.bias",
+                "features.denseblock1.denselayer1.conv1.weight",
+                "features.denseblock1.denselayer2.norm1.weight",
+                "features.denseblock1.denselayer15.conv1.weight",
+                "features.denseblock1.denselayer16.conv2.weight",
+                "features.denseblock2.denselayer8.conv1.weight",
+                "features.denseblock2.denselayer7.norm2.bias",
+                "features.denseblock3.denselayer16.conv1.weight",
+                "features.denseblock3.denselayer1.conv2.weight",
+                "features.transition1.conv.weight", "features.transition2.norm.weight",
+                "features.transition3.conv.weight", "features.last_norm3.weight",
+                "fc.weight", "fc_dist.bias", "fc_rgb_ratio.weight"]:
+        gsmp, gidx = sample(named[key].grad, 48)
+        out["train/grad/" + key] = gsmp
+        out["train/grad_idx/" + key] = gidx
+        out["train/grad_l2/" + key] = np.float64(named[key].grad.double().norm())
+    out["train/running_mean/features.norm0"] = net.features.norm0.running_mean.numpy().copy()
+    out["train/running_var/features.denseblock2.denselayer3.norm2"] = \
+        net.features.denseblock2.denselayer3.norm2.running_var.numpy().copy()
+    out["train/running_var/features.last_norm3"] = net.features.last_norm3.running_var.numpy().copy()
+    opt.step()
+    out["train/post_step/fc_dist.bias"] = net.fc_dist.bias.detach().numpy().copy()
+    print("densenet cfg2-geometry train terms", out["train/loss_terms"])
+    np.savez_compressed(os.path.join(HERE, "densenet_cfg2.npz"), **out)
+
+
 # --------------------------------------------------------------------------- GenProjector
 def projector_inputs(B, seed):
     g = rng(seed, B)
@@ -477,13 +552,15 @@ def gen_projector():
 
 if __name__ == "__main__":
     install_shims()
-    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "projector", "gmloss", "gt_param"]
+    which = sys.argv[1:] or ["sinkhorn", "rasteriser", "densenet", "densenet_cfg2", "projector", "gmloss", "gt_param"]
     if "sinkhorn" in which:
         gen_sinkhorn()
     if "rasteriser" in which:
         gen_rasteriser()
     if "densenet" in which:
         gen_densenet()
+    if "densenet_cfg2" in which:
+        gen_densenet_cfg2()
     if "projector" in which:
         gen_projector()
     if "gmloss" in which:

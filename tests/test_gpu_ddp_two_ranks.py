@@ -87,3 +87,70 @@ def test_two_ranks_projector_syncbn_hip_sphereconv(tmp_path):
     p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
     assert p0[0] == 1.0 and p1[0] == 1.0
     assert p0[1] == 0.0 and p0[2] == 0.0, "projector replicas diverged: %s" % p0
+
+
+def _spade_case(seed=7, B=4, C=16, H=16, W=32):
+    """Inputs + a SPADE module (parameter-free sync BatchNorm, normalization.py:68-115) with seeded weights."""
+    from emlight_amd.GenProjector import networks
+    torch.manual_seed(seed)
+    mod = networks.SPADE("spadesyncbatch3x3", C, 3)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.5
+    x[B // 2:] += 1.5          # the two halves have different statistics: a per-rank norm would be visibly wrong
+    seg = torch.rand(B, 3, 128, 256, generator=g)
+    wy = torch.randn(B, C, H, W, generator=g)
+    return mod, x, seg, wy
+
+
+def _spade_run(mod, x, seg, wy):
+    mod = mod.cuda().train()
+    x = x.cuda().requires_grad_(True)
+    y = mod(x, seg.cuda(), slope=0.2)
+    (y * wy.cuda()).sum().backward()
+    bn = mod.param_free_norm
+    out = {"y": y.detach(), "dx": x.grad, "running_mean": bn.running_mean, "running_var": bn.running_var}
+    out.update({"grad/" + k: p.grad for k, p in mod.named_parameters()})
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def _spade_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world), EML_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    init_distributed()
+    mod, x, seg, wy = _spade_case()
+    h = x.shape[0] // world
+    sl = slice(rank * h, (rank + 1) * h)
+    np.savez(os.path.join(out_dir, "spade%d.npz" % rank), **_spade_run(mod, x[sl], seg[sl], wy[sl]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sync_bn_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
+    """What sync_batchnorm/batchnorm.py:105-145 guarantees: 2 ranks x B/2 samples normalise with the statistics of the
+    WHOLE batch.  SPADE's modulation (the HIP kernels + the (2C+1)-float all-reduce of its sums, forward and backward)
+    on two ranks against ONE process holding both halves: outputs, input gradients, the summed parameter gradients and the
+    running statistics agree to f32 round-off (the sums are f64; a per-rank norm would be off by O(1) here)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_spade_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = _spade_run(*_spade_case())
+    r = [np.load(tmp_path / ("spade%d.npz" % k)) for k in range(2)]
+    for k in ("y", "dx"):
+        got = np.concatenate([r[0][k], r[1][k]], 0)
+        np.testing.assert_allclose(got, want[k], rtol=2e-5, atol=2e-5 * np.abs(want[k]).max(), err_msg=k)
+    for k in ("running_mean", "running_var"):
+        np.testing.assert_allclose(r[0][k], want[k], rtol=1e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_array_equal(r[0][k], r[1][k])
+    for k in [k for k in want if k.startswith("grad/")]:
+        got = r[0][k] + r[1][k]      # DDP would average; the sum of the per-rank gradients is the whole batch's
+        np.testing.assert_allclose(got, want[k], rtol=1e-4, atol=2e-5 * np.abs(want[k]).max(), err_msg=k)
+    # and the statistics really are the whole batch's, not a rank's own
+    mod, x, seg, wy = _spade_case()
+    half = _spade_run(mod, x[:2], seg[:2], wy[:2])
+    assert np.abs(half["y"] - want["y"][:2]).max() > 1e-2

@@ -120,6 +120,43 @@ def test_golden_train_step_reference_geometry(golden_densenet):
                                atol=2e-6)
 
 
+def test_golden_train_step_baseline_geometry(golden_densenet_cfg2):
+    """The backward AT BASELINE's geometry against the reference: one full training step of the reference class at
+    240x320 crops / 128 anchors / blur .05 (B = 2; fc and fc_dist swapped for matching nn.Linear, SURVEY 8c;
+    tests/golden/make_golden.py::gen_densenet_cfg2) through RegressionTrainer.step -- block 1 runs at 240x320, where the
+    192x256 golden step never exercised the kernels' tile boundaries (320 = 10 x 32, 240 = 30 x 8 row tiles; pixel count
+    153 600 per image).  Same quantities and bounds as the reference-geometry step above; 17 sampled gradient tensors."""
+    from emlight_amd.RegressionNetwork.engine import RegressionTrainer
+    g = golden_densenet_cfg2
+    tr = RegressionTrainer(anchors=128, crop_hw=(240, 320), blur=.05, device="cuda:0")
+    ref = oracle.OracleDenseNet(anchors=128, crop_hw=(240, 320))
+    tr.model.load_state_dict(oracle.deterministic_state_dict(ref.state_dict(), seed=5))
+    x = torch.from_numpy(np.random.default_rng([40]).random((2, 3, 240, 320), dtype=np.float32)).cuda()
+    batch = {k: torch.from_numpy(g["train/gt_" + k]).cuda() for k in KEYS}
+    batch["crop"] = x
+    loss, terms = tr.step(batch)
+    for k in KEYS:
+        np.testing.assert_allclose(tr.last_pred[k].detach().cpu().numpy(), g["train/" + k], rtol=0, atol=OUT_ATOL)
+    np.testing.assert_allclose(np.array([float(t.detach()) for t in terms.values()]), g["train/loss_terms"], rtol=1e-4)
+    named = dict(tr.model.named_parameters())
+    worst = []
+    for key in [k[len("train/grad/"):] for k in g.z.files if k.startswith("train/grad/")]:
+        got = named[key].grad.detach().reshape(-1).cpu()[torch.from_numpy(g["train/grad_idx/" + key])].numpy()
+        rms = float(g["train/grad_l2/" + key]) / np.sqrt(named[key].numel())
+        worst.append((float(np.abs(got - g["train/grad/" + key]).max() / rms), key))
+    worst.sort(reverse=True)
+    print("golden train step at 240x320: worst sampled |dgrad| / rms(grad) per tensor:", worst)
+    assert worst[0][0] < GOLDEN_GRAD_MAX, worst[:4]
+    assert np.median([e for e, _ in worst]) < GOLDEN_GRAD_MEDIAN, worst
+    f = tr.model.features
+    np.testing.assert_allclose(f.norm0.running_mean.cpu().numpy(), g["train/running_mean/features.norm0"], atol=1e-6)
+    np.testing.assert_allclose(f.denseblock2.denselayer3.norm2.running_var.cpu().numpy(),
+                               g["train/running_var/features.denseblock2.denselayer3.norm2"], rtol=1e-4)
+    np.testing.assert_allclose(f.last_norm3.running_var.cpu().numpy(), g["train/running_var/features.last_norm3"], rtol=1e-4)
+    np.testing.assert_allclose(tr.model.fc_dist.bias.detach().cpu().numpy(), g["train/post_step/fc_dist.bias"], rtol=0,
+                               atol=2e-6)
+
+
 @pytest.mark.parametrize("crop_hw,B,anchors", [((192, 256), 2, 96), ((64, 96), 2, 32)])
 def test_gradient_error_is_f32_conditioning(crop_hw, B, anchors):
     """Whole-network gradients of the HIP engine (f32) and of the oracle's stock-op graph in f32 are both compared with

@@ -41,26 +41,29 @@ def test_joint_step_small_vs_oracle_composition():
     batch = joint_batch(B, "cuda:0", ln, crop, seed=77)
     batch_cpu = {k: v.cpu() for k, v in batch.items()}
 
-    got = tr.step(batch)
+    # The iteration runs in its two halves (JointTrainer.step == generator_step + discriminator_step).  The D half is
+    # evaluated AFTER Adam's first update of G, which moves every entry by lr * sign(g): two f32 evaluations disagree on
+    # the sign where g ~ 0, so comparing the D half of two independently updated generators measures that, not the D-path
+    # kernels.  The halves are therefore decoupled: after the first half the oracle's UPDATED generator is copied into the
+    # product, and the D half is compared from identical weights at the same bounds as the generator's.
+    data = tr.generator_step(batch)
+    got = dict(tr.losses)
     M = oracle.anchor_cost_matrix(ln)
+    emd = lambda a, b: oracle.samples_loss(a, b, M, blur=.05)
     opt_E = torch.optim.Adam(enc_o.parameters(), lr=1e-4, betas=(0.9, 0.999))
     opt_G, opt_D = pm_o.create_optimizers(opt)
     with oracle.stock_sphere_ops():
-        want = oracle.joint_step(enc_o, pm_o, opt_E, opt_G, opt_D, batch_cpu,
-                                 lambda a, b: oracle.samples_loss(a, b, M, blur=.05), ln)
+        want = oracle.joint_generator_step(enc_o, pm_o, opt_E, opt_G, batch_cpu, emd, ln)
 
     # forward: guide map (HDR map: north_star 1e-2 rel, held to 1e-4 of peak), generated panorama, every loss term
     gm = want["gmap"].detach().numpy()
     np.testing.assert_allclose(tr.guide.detach().cpu().numpy(), gm, rtol=1e-4, atol=1e-4 * np.abs(gm).max())
     fk = want["fake"].detach().numpy()
     np.testing.assert_allclose(tr.generated.detach().cpu().numpy(), fk, rtol=1e-3, atol=2e-3)
-    ref_losses = {**want["terms"], **want["g_losses"], **want["d_losses"]}
+    ref_losses = {**want["terms"], **want["g_losses"]}
     assert set(got) == set(ref_losses)
     for k, v in ref_losses.items():
-        # the D terms are evaluated AFTER Adam's first update of G (+-lr per entry, sign(g) -- entries with g ~ 0 may take
-        # the other sign in two f32 evaluations), so they agree to 1e-3, not to the 1e-4 of the pre-update terms
-        rtol = 2e-3 if k in want["d_losses"] else 1e-4
-        np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=rtol, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=1e-4, atol=1e-6, err_msg=k)
 
     # backward: relative L2 per tensor (element-wise agreement is impossible across two f32 ReLU networks)
     def check(named_got, named_want, max_bound, med_bound, what):
@@ -72,13 +75,21 @@ def test_joint_step_small_vs_oracle_composition():
         assert np.median([e for e, _ in errs]) < med_bound, "%s: median %g" % (what, np.median([e for e, _ in errs]))
     check(dict(tr.reg.model.named_parameters()), dict(enc_o.named_parameters()), 5e-2, 5e-3, "encoder")
     check(dict(tr.proj.model.netG.named_parameters()), dict(pm_o.netG.named_parameters()), 2e-2, 2e-3, "generator")
-    # the 8-channel PatchGANs normalise per instance over as few as 8x16 positions: measured worst 2.1e-2 (scale-2 model0)
-    check(dict(tr.proj.model.netD.named_parameters()), dict(pm_o.netD.named_parameters()), 1e-1, 1e-2, "discriminator")   # after G's update, see above
+
+    # ---- D half from IDENTICAL generator weights (the oracle's post-Adam G, spectral-norm vectors and BN buffers included)
+    tr.proj.model.netG.load_state_dict(pm_o.netG.state_dict())
+    got_d = tr.discriminator_step(data)
+    with oracle.stock_sphere_ops():
+        want_d = oracle.joint_discriminator_step(pm_o, opt_D, want["data"])
+    assert set(got_d) == set(want_d)
+    for k, v in want_d.items():
+        np.testing.assert_allclose(float(got_d[k].detach().mean()), float(v.detach().mean()), rtol=1e-3, atol=1e-6, err_msg=k)
+    check(dict(tr.proj.model.netD.named_parameters()), dict(pm_o.netD.named_parameters()), 2e-2, 2e-3, "discriminator")
 
     # the projector's losses really reach the encoder through the rasteriser: the regression-only gradient differs
     enc_r = oracle.OracleDenseNet(anchors=ln, crop_hw=crop).train()
     enc_r.load_state_dict(sd)
-    l_reg, _ = oracle.regression_loss(enc_r(batch_cpu["crop"]), batch_cpu, lambda a, b: oracle.samples_loss(a, b, M, blur=.05), ln)
+    l_reg, _ = oracle.regression_loss(enc_r(batch_cpu["crop"]), batch_cpu, emd, ln)
     l_reg.backward()
     d = (enc_r.fc_intensity.weight.grad - enc_o.fc_intensity.weight.grad).abs().max()
     assert float(d) > 1e-6 * float(enc_r.fc_intensity.weight.grad.abs().max())
@@ -96,34 +107,47 @@ def test_joint_step_properties_at_cfg4_size():
     dev, ln, crop, B = "cuda:0", 128, (240, 320), 32
     batch = joint_batch(B, dev, ln, crop, seed=5)
 
-    def run(n):
-        torch.manual_seed(3)
-        tr = JointTrainer(networks.default_options(), anchors=ln, crop_hw=crop, blur=.05, device=dev)
-        out = [{k: v.detach().clone() for k, v in tr.step(batch).items()} for _ in range(n)]
-        return tr, out
-    tr, a = run(2)
-    enc_w = tr.reg.model.fc_dist.weight.detach().clone()
-    g_w = tr.proj.model.netG.sphere_conv1.weight.detach().clone()
-    del tr
-    torch.cuda.empty_cache()
-    tr, b = run(2)
-    for it, (la, lb) in enumerate(zip(a, b)):
+    def snapshot(tr):
+        mods = (tr.reg.model, tr.proj.model)
+        opts = (tr.reg.optimizer, tr.proj.optimizer_G, tr.proj.optimizer_D)
+        return [copy.deepcopy(m.state_dict()) for m in mods], [copy.deepcopy(o.state_dict()) for o in opts]
+
+    def restore(tr, snap):
+        for m, sd in zip((tr.reg.model, tr.proj.model), snap[0]):
+            m.load_state_dict(sd)
+        for o, sd in zip((tr.reg.optimizer, tr.proj.optimizer_G, tr.proj.optimizer_D), snap[1]):
+            o.load_state_dict(copy.deepcopy(sd))
+
+    def one(tr):
+        return {k: v.detach().clone() for k, v in tr.step(batch).items()}
+
+    def same(la, lb, what):
+        # GAN / D terms are O(1e-2) differences of O(1) discriminator outputs, hence the absolute part
         for k in la:
             assert torch.isfinite(la[k]).all(), k
-            # iteration 1 is a pure function of the initial weights: tight (GAN / D terms are O(1e-2) differences of
-            # O(1) discriminator outputs, hence the absolute part).  Iteration 2 follows Adam's FIRST update, which moves
-            # every weight by lr * sign(g): entries with g ~ 0 amplify the library calls' summation-order noise, so
-            # only a loose bound is meaningful there.
-            rtol, atol = (1e-3, 2e-4) if it == 0 else (1e-1, 5e-3)
-            torch.testing.assert_close(la[k], lb[k], rtol=rtol, atol=atol,
-                                       msg=lambda m, k=k, it=it: "joint iteration %d must be reproducible (%s): %s" % (it + 1, k, m))
-    # Adam's first steps move every weight by +-lr (1e-4): an entry whose gradient is ~0 may take the other sign in a
-    # rerun (at most 2 * lr per step), everything else agrees far below lr -- so: mean far below lr, max within 4 * lr.
-    # (How many entries flip varies from run to run: the 1728-entry output layer has been seen between 2e-6 and 5.2e-6
-    # mean; 2e-5 = a fifth of lr still means "a few per cent of the entries flipped, the rest identical".)
+            torch.testing.assert_close(la[k], lb[k], rtol=1e-3, atol=2e-4,
+                                       msg=lambda m, k=k: "%s must be reproducible (%s): %s" % (what, k, m))
+    torch.manual_seed(3)
+    tr = JointTrainer(networks.default_options(), anchors=ln, crop_hw=crop, blur=.05, device=dev)
+    s0 = snapshot(tr)
+    a1 = one(tr)
+    # Iteration 2 is compared from ONE post-update state replayed twice: two independently trained copies differ after
+    # Adam's first update by lr * sign(g) wherever g ~ 0 (that is the optimiser's conditioning, not the kernels'), which
+    # would force a 10 % bound; from identical weights + optimiser state the second iteration holds the first's bound.
+    s1 = snapshot(tr)
+    a2 = one(tr)
+    enc_w = tr.reg.model.fc_dist.weight.detach().clone()
+    g_w = tr.proj.model.netG.sphere_conv1.weight.detach().clone()
+    restore(tr, s1)
+    b2 = one(tr)
+    same(a2, b2, "joint iteration 2 (replayed from the state after iteration 1)")
+    # the replayed Adam step lands on the same weights up to the sign of entries with g ~ 0 (at most 2 * lr apart)
     for a_w, b_w in ((enc_w, tr.reg.model.fc_dist.weight.detach()), (g_w, tr.proj.model.netG.sphere_conv1.weight.detach())):
         d = (a_w - b_w).abs()
         assert float(d.mean()) < 2e-5 and float(d.max()) <= 4.1e-4, (float(d.mean()), float(d.max()))
+    restore(tr, s0)
+    same(a1, one(tr), "joint iteration 1 (replayed from the initial state)")
+    del s0, s1
 
     # (2) additivity on the encoder, no optimiser steps
     enc, pm = tr.reg.model, tr.proj.model

@@ -133,6 +133,94 @@ def test_sphere_conv_fused_kernels_vs_stock_ops(B, Cin, Cout, H, W, stride, bias
     assert torch.equal(y2, yh) and torch.equal(xh2.grad, xh.grad) and torch.equal(hip.weight.grad, gw1)
 
 
+# Every distinct SphereConv geometry (B, Cin, Cout, H, W, stride) of the ngf = ndf = 64 projector at BASELINE configs[2]
+# (B = 32; the discriminator sees fake + real = 64): the SPADE blocks' convs and their (gamma | beta) heads (one conv over the
+# concatenated outputs), the 3 -> 128 guide-map convs at every resolution, the output layer, both PatchGAN scales.
+# test_ngf64_shape_list_is_what_the_networks_run holds this list to the shapes the modules really call.
+NGF64_SHAPES = [
+    # generator: head_0 @ 4x8, G_middle_* @ 8x16
+    (32, 3, 128, 4, 8, 1), (32, 128, 2048, 4, 8, 1), (32, 1024, 1024, 4, 8, 1),
+    (32, 3, 128, 8, 16, 1), (32, 128, 2048, 8, 16, 1), (32, 1024, 1024, 8, 16, 1),
+    # up_0 (1024 -> 512) @ 16x32
+    (32, 3, 128, 16, 32, 1), (32, 128, 2048, 16, 32, 1), (32, 128, 1024, 16, 32, 1), (32, 1024, 512, 16, 32, 1),
+    (32, 512, 512, 16, 32, 1),
+    # up_1 (512 -> 256) @ 32x64
+    (32, 3, 128, 32, 64, 1), (32, 128, 1024, 32, 64, 1), (32, 128, 512, 32, 64, 1), (32, 512, 256, 32, 64, 1),
+    (32, 256, 256, 32, 64, 1),
+    # up_2 (256 -> 128) @ 64x128
+    (32, 3, 128, 64, 128, 1), (32, 128, 512, 64, 128, 1), (32, 128, 256, 64, 128, 1), (32, 256, 128, 64, 128, 1),
+    (32, 128, 128, 64, 128, 1),
+    # up_3 (128 -> 64) and the output layer @ 128x256
+    (32, 3, 128, 128, 256, 1), (32, 128, 256, 128, 256, 1), (32, 128, 128, 128, 256, 1), (32, 128, 64, 128, 256, 1),
+    (32, 64, 64, 128, 256, 1), (32, 64, 3, 128, 256, 1),
+    # discriminator, scale 1 (128x256 input) and scale 2 (64x128)
+    (64, 6, 64, 128, 256, 2), (64, 64, 128, 64, 128, 2), (64, 128, 256, 32, 64, 2), (64, 256, 512, 16, 32, 1),
+    (64, 512, 3, 16, 32, 1),
+    (64, 6, 64, 64, 128, 2), (64, 64, 128, 32, 64, 2), (64, 128, 256, 16, 32, 2), (64, 256, 512, 8, 16, 1),
+    (64, 512, 3, 8, 16, 1),
+]
+
+
+def test_ngf64_shape_list_is_what_the_networks_run(monkeypatch):
+    from emlight_amd.GenProjector import networks, spherenet
+    from emlight_amd.GenProjector.data import projector_batch
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    seen = set()
+    real = spherenet.sphere_conv
+
+    def spy(x, weight, bias, stride=1):
+        seen.add((x.shape[0], x.shape[1], weight.shape[0], x.shape[2], x.shape[3], stride))
+        return real(x, weight, bias, stride)
+    monkeypatch.setattr(spherenet, "sphere_conv", spy)
+    torch.manual_seed(0)
+    pm = Pix2PixModel(networks.default_options()).cuda()
+    with torch.no_grad():
+        pm(projector_batch(32, "cuda", seed=1), mode="generator")
+    assert seen == set(NGF64_SHAPES), (sorted(seen - set(NGF64_SHAPES)), sorted(set(NGF64_SHAPES) - seen))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", NGF64_SHAPES)
+def test_sphere_conv_ngf64_layer_shapes_natural_dispatch(B, Cin, Cout, H, W, stride, monkeypatch):
+    """The projector at its REAL size never met the oracle layer by layer: the reference golden is ngf = 8, and the per-shape
+    dispatch rules (fused gather-GEMM kernels vs im2col + library GEMM, ``_SphereConvFn.forward``) pick different kernels
+    at ngf = 64.  Every distinct layer geometry of NGF64_SHAPES, at BASELINE's batch, with the dispatch left alone:
+    output, d/dx, d/dweight, d/dbias against grid_sample + conv2d(stride 3) (sphere_cnn.py:111-124) in torch f32.
+    Bounds: f32 sums over K = 9*Cin (forward), 9*Cout (d/dx), B*H'*W' (d/dweight) terms in two different orders agree to
+    ~sqrt(K) * 6e-8 of the sum's scale -- 1e-4 relative + 1e-4 of the tensor's largest entry covers K up to 1e6."""
+    from emlight_amd import _lib
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    torch.manual_seed(Cin * 7 + Cout + H)
+    hip = SphereConv2D(Cin, Cout, stride=stride, bias=True).cuda()
+    with torch.no_grad():
+        hip.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(B, Cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    xr, xh = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    wr, br = hip.weight.detach().clone().requires_grad_(True), hip.bias.detach().clone().requires_grad_(True)
+    real, seen = _lib.lib(), set()
+
+    class Spy:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+
+            def call(*a):
+                seen.add(name)
+                return fn(*a)
+            return call
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    yh = hip(xh)
+    gy = torch.randn_like(yh)
+    yh.backward(gy)
+    monkeypatch.undo()
+    yr = oracle.sphere_conv(xr, wr, br, stride)
+    assert yh.shape == yr.shape == (B, Cout, H // stride, W // stride)
+    yr.backward(gy)
+    print("dispatch", (B, Cin, Cout, H, W, stride), sorted(n.replace("eml_sphere_", "") for n in seen))
+    for name, a, b in [("y", yh.detach(), yr.detach()), ("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad),
+                       ("db", hip.bias.grad, br.grad)]:
+        s_ = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4 * s_, err_msg=name)
+
+
 def test_sphere_conv_hip_is_deterministic_and_has_no_cpu_path():
     from emlight_amd import _lib
     from emlight_amd.GenProjector.spherenet import SphereConv2D

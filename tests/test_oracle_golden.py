@@ -119,6 +119,39 @@ def test_densenet_cfg1_240x320_128_anchors(golden_densenet):
         np.testing.assert_allclose(p[k].numpy(), g["cfg1/" + k], rtol=0, atol=1e-5)
 
 
+def test_densenet_train_step_baseline_geometry(golden_densenet_cfg2):
+    """One full training step of the reference at BASELINE's geometry (240x320 crops, 128 anchors, blur .05, B = 2;
+    ``make_golden.gen_densenet_cfg2``: the reference class with fc / fc_dist swapped): predictions, the five
+    loss terms, 17 sampled gradient tensors (block 1 at 240x320 included), running statistics, post-Adam bias."""
+    g = golden_densenet_cfg2
+    net = oracle.OracleDenseNet(anchors=128, crop_hw=(240, 320))
+    net.load_state_dict(oracle.deterministic_state_dict(net.state_dict(), seed=5))
+    net.train()
+    x = torch.from_numpy(np.random.default_rng([40]).random((2, 3, 240, 320), dtype=np.float32))
+    gt = {k: torch.from_numpy(g["train/gt_" + k]) for k in ("distribution", "intensity", "rgb_ratio", "ambient")}
+    M = oracle.anchor_cost_matrix(128)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    pred = net(x)
+    loss, terms = oracle.regression_loss(pred, gt, lambda a, b: oracle.samples_loss(a, b, M, blur=.05), 128)
+    opt.zero_grad()
+    loss.backward()
+    for k in ("distribution", "intensity", "rgb_ratio", "ambient"):
+        np.testing.assert_allclose(pred[k].detach().numpy(), g["train/" + k], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(np.array([float(t.detach()) for t in terms.values()]), g["train/loss_terms"], rtol=1e-4)
+    named = dict(net.named_parameters())
+    for key in [k[len("train/grad/"):] for k in g.z.files if k.startswith("train/grad/")]:
+        got = _sample(named[key].grad, g["train/grad_idx/" + key])
+        want = g["train/grad/" + key]
+        l2 = float(g["train/grad_l2/" + key])
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * l2 / np.sqrt(named[key].numel()) + 1e-7, err_msg=key)
+    np.testing.assert_allclose(net.features.norm0.running_mean.numpy(), g["train/running_mean/features.norm0"], atol=1e-6)
+    np.testing.assert_allclose(net.features.denseblock2.denselayer3.norm2.running_var.numpy(),
+                               g["train/running_var/features.denseblock2.denselayer3.norm2"], rtol=1e-4)
+    np.testing.assert_allclose(net.features.last_norm3.running_var.numpy(), g["train/running_var/features.last_norm3"], rtol=1e-4)
+    opt.step()
+    np.testing.assert_allclose(net.fc_dist.bias.detach().numpy(), g["train/post_step/fc_dist.bias"], rtol=0, atol=2e-6)
+
+
 def test_gmloss_geometry_cost_matches_reference():
     """GMLight variant (RegressionNetwork/gmloss): depth-scaled anchors, per-call chord matrix, same Sinkhorn."""
     from tests.conftest import Golden
