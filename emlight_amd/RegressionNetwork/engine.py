@@ -32,8 +32,13 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available():
-        local %= torch.cuda.device_count()  # more ranks than GPUs (tests on a 1-GPU box): share devices
+    if torch.cuda.is_available() and local >= torch.cuda.device_count():
+        # More ranks than GPUs.  RCCL wants one rank per device, so this is an error for a real launch; the 2-rank tests
+        # on a 1-GPU box opt in (gloo transport) and share the device.
+        if os.environ.get("EML_DIST_BACKEND") != "gloo" and os.environ.get("EML_SHARE_GPUS") != "1":
+            raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: one process per GPU (set EML_DIST_BACKEND=gloo "
+                               "or EML_SHARE_GPUS=1 to let ranks share a device in tests)" % (local, torch.cuda.device_count()))
+        local %= torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         # 'nccl' is RCCL on ROCm; EML_DIST_BACKEND=gloo lets two ranks share one GPU in tests
         backend = os.environ.get("EML_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -49,14 +54,21 @@ class RegressionTrainer:
     """Model + Sinkhorn criterion + Adam(1e-4, (.9,.999)) (``train.py:55-61``)."""
 
     def __init__(self, anchors=96, crop_hw=(192, 256), blur=.025, diameter=None, lr=1e-4,
-                 betas=(0.9, 0.999), device="cuda", world=1, bucket_cap_mb=64, model=None, sam_loss=None):
+                 betas=(0.9, 0.999), device="cuda", world=1, bucket_cap_mb=64, model=None, sam_loss=None,
+                 sync_diameter=None):
         """``model`` / ``sam_loss``: pre-built modules to train instead of the HIP ``DenseNet`` / ``SamplesLoss``
-        (the CPU-only distributed tests inject the oracle's stock-op restatements; the product never does)."""
+        (the CPU-only distributed tests inject the oracle's stock-op restatements; the product never does).
+        ``sync_diameter``: derive the Sinkhorn eps-schedule from the range of the GLOBAL batch (2-float all-reduce per
+        step) so that N ranks x B reproduce the single-process run with N*B samples (sinkhorn_divergence.py:9-18);
+        default: on when world > 1 and no fixed ``diameter`` is given."""
+        if sync_diameter is None:
+            sync_diameter = world > 1 and diameter is None
         self.ln = anchors
         self.device = torch.device(device)
         self.model = (DenseNet(anchors=anchors, crop_hw=crop_hw) if model is None else model).to(self.device)
         self.model.train()
-        self.sam_loss = sam_loss or SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors)
+        self.sam_loss = sam_loss or SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors,
+                                                sync_diameter=sync_diameter)
         self.ddp = None
         if world > 1:
             # DenseNet BN stays per-rank (plain nn.BatchNorm2d in the reference); only the

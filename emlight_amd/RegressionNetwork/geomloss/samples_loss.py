@@ -25,16 +25,32 @@ def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
             "work": torch.empty(8, B, N, **f32)}
 
 
-def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False, out=None):
+def global_range(x, y):
+    """(2,) tensor (min, max) of x U y over the batch of EVERY data-parallel rank, without a host sync: the local extrema,
+    then ONE 2-float all-reduce (MIN over (min, -max)).  ``max_diameter`` (sinkhorn_divergence.py:9-18) takes the range
+    over the whole batch, so a rank that only scanned its own shard would derive a different eps-schedule than the
+    single-process run with the global batch.  With one rank this is just the local range."""
+    import torch.distributed as dist
+    lo = torch.minimum(x.detach().amin(), y.detach().amin())
+    hi = torch.maximum(x.detach().amax(), y.detach().amax())
+    r = torch.stack([lo, -hi]).float()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(r, op=dist.ReduceOp.MIN)
+    return torch.stack([r[0], -r[1]])
+
+
+def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False, out=None,
+                 range_lo_hi=None):
     """One call into the HIP library; returns every device-side output (no autograd).  ``out``: buffers from
-    ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches)."""
+    ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches).
+    ``range_lo_hi``: device (2,) tensor from ``global_range`` -- the kernel folds it into its own scan."""
     L = _lib.lib()
     B, N = x.shape
     o = out if out is not None else sinkhorn_outputs(B, N, x.device, need_gx, need_gy)
     _lib.check(L.eml_sinkhorn_fwd_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
         float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
-        _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
+        _lib.ptr(range_lo_hi), _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
         _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
     return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
             "diameter": o["diameter"], "duals": o["work"][:4]}
@@ -45,9 +61,9 @@ class _SinkhornDivergence(torch.autograd.Function):
     extrapolation (``sinkhorn_divergence.py:101-107``), produced by the forward kernel."""
 
     @staticmethod
-    def forward(ctx, x, y, alpha, beta, M, Mt, p, blur, scaling, diameter):
+    def forward(ctx, x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, range_lo_hi=None):
         r = sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter,
-                         ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], range_lo_hi=range_lo_hi)
         ctx.save_for_backward(r["gx"], r["gy"])
         return r["loss"]
 
@@ -65,7 +81,7 @@ class _SinkhornDivergence(torch.autograd.Function):
             _lib.check(L.eml_sinkhorn_bwd_f32(_lib.ptr(gloss), _lib.ptr(gu), _lib.ptr(go), B, N,
                                               _lib.current_stream()), "eml_sinkhorn_bwd_f32")
             out[k] = go
-        return out[0], out[1], None, None, None, None, None, None, None, None
+        return out[0], out[1], None, None, None, None, None, None, None, None, None
 
 
 class SamplesLoss(Module):
@@ -77,7 +93,7 @@ class SamplesLoss(Module):
     """
 
     def __init__(self, loss="sinkhorn", p=2, blur=.05, reach=None, diameter=None, scaling=.5,
-                 batchsize=None, anchors=96, cost_matrix=None):
+                 batchsize=None, anchors=96, cost_matrix=None, sync_diameter=False):
         super().__init__()
         if loss != "sinkhorn":
             raise ValueError("only loss='sinkhorn' exists in EMLight's geomloss fork")
@@ -85,6 +101,9 @@ class SamplesLoss(Module):
             raise NotImplementedError("unbalanced OT (reach) is not on EMLight's path (rho=None)")
         self.loss, self.p, self.blur, self.reach = loss, p, blur, reach
         self.diameter, self.scaling = diameter, scaling
+        # data-parallel training: derive the eps-schedule from the range of the GLOBAL batch (one 2-float all-reduce per
+        # call, no host sync) -- what the single-process reference sees; ignored when ``diameter`` is given
+        self.sync_diameter = bool(sync_diameter)
         self.N = int(anchors) if cost_matrix is None else int(cost_matrix.shape[-1])
         # anchors as the reference builds them: float64 Fibonacci sphere cast to f32 (utils.py:67-69)
         self.register_buffer("anchors", torch.from_numpy(sphere_points(self.N)).float(), persistent=False)
@@ -140,7 +159,8 @@ class SamplesLoss(Module):
         a2 = None if a is None else _lib.require_gpu_tensor(a.reshape(B, self.N), "alpha")
         b2 = None if b is None else _lib.require_gpu_tensor(b.reshape(B, self.N), "beta")
         M, Mt = self.cost_matrix(x2.device)
-        return _SinkhornDivergence.apply(x2, y2, a2, b2, M, Mt, self.p, self.blur, self.scaling, self.diameter)
+        rng = global_range(x2, y2) if (self.sync_diameter and self.diameter is None) else None
+        return _SinkhornDivergence.apply(x2, y2, a2, b2, M, Mt, self.p, self.blur, self.scaling, self.diameter, rng)
 
     def forward_raw(self, x, y, need_gx=True, need_gy=True, out=None):
         """Every device output of one call (loss, unit grads, schedule, duals) -- for parity tests and timing."""
@@ -148,5 +168,6 @@ class SamplesLoss(Module):
         x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
         y2 = _lib.require_gpu_tensor(y.reshape(B, self.N), "y")
         M, Mt = self.cost_matrix(x2.device)
+        rng = global_range(x2, y2) if (self.sync_diameter and self.diameter is None) else None
         return sinkhorn_raw(x2, y2, None, None, M, Mt, self.p, self.blur, self.scaling, self.diameter,
-                            need_gx, need_gy, out)
+                            need_gx, need_gy, out, range_lo_hi=rng)

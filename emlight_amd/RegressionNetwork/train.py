@@ -45,6 +45,9 @@ def main(argv=None):
     ap.add_argument("--crop_hw", type=int, nargs=2, default=(192, 256))
     ap.add_argument("--blur", type=float, default=.025)
     ap.add_argument("--diameter", type=float, default=None)
+    ap.add_argument("--sync_diameter", type=int, choices=(0, 1), default=None,
+                    help="Sinkhorn eps-schedule from the range of the GLOBAL batch (2-float all-reduce per step); default: "
+                         "on under torchrun unless --diameter is given (a single-process run sees the whole batch)")
     ap.add_argument("--epochs", type=int, default=500)
     ap.add_argument("--max_iters", type=int, default=0)
     ap.add_argument("--save_dir", default="./checkpoints")
@@ -55,7 +58,8 @@ def main(argv=None):
     rank, local, world = init_distributed()
     device = "cuda:%d" % local
     tr = RegressionTrainer(anchors=args.anchors, crop_hw=tuple(args.crop_hw), blur=args.blur,
-                           diameter=args.diameter, device=device, world=world)
+                           diameter=args.diameter, device=device, world=world,
+                           sync_diameter=None if args.sync_diameter is None else bool(args.sync_diameter))
     if args.load:
         tr.model.load_state_dict(torch.load(args.load, map_location=device))
         if rank == 0:

@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 8   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 9   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -25,10 +25,10 @@ SIGNATURES = {
     "eml_sg_rasterise_bwd_colors_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
     "eml_emd_anchor_cost_f32": (_int, [_f32p, _f32p, _int, _stream]),
     "eml_sinkhorn_schedule_f32": (_int, [_f32p, _f32p, ctypes.c_long, ctypes.c_double, ctypes.c_double, _int,
-                                         ctypes.c_double, _f32p, _i32p, _f32p, _stream]),
+                                         ctypes.c_double, _f32p, _f32p, _i32p, _f32p, _stream]),
     "eml_sinkhorn_work_floats": (ctypes.c_size_t, [_int, _int]),
     "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_double, ctypes.c_double, _int,
-                                    ctypes.c_double, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
+                                    ctypes.c_double, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                     _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
     # ground-truth parametrisation

@@ -1688,8 +1688,7 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
   if (!G || !Z || !scale2 || !shift2 || !partial || !dW2 || B < 1 || H < 1 || W < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_weight_f32: bad arguments");
   const size_t lds = (size_t)(2 * kHH * kHW * kPSW) * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_weight_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EML_ENSURE_LDS((&conv3x3_bwd_weight_kernel), lds);
   hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(grid), dim3(kBW), lds, (hipStream_t)stream, G, ldg, c0, Z, scale2,
                      shift2, B, H, W, partial);
   int rc = eml::check_launch("eml_dense_conv3x3_bwd_weight_f32");
@@ -1796,8 +1795,7 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
       const size_t lds_t = lds + (size_t)(4 * Kp + 3 * Ko) * sizeof(float);
 #define EML_LAUNCH_TRANSITION(ACCV, MSKV)                                                                              \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transition_bwd_data_kernel<2, 2, ACCV, MSKV>),            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);                                 \
+    EML_ENSURE_LDS((&transition_bwd_data_kernel<2, 2, ACCV, MSKV>), lds_t);                                 \
     hipLaunchKernelGGL((transition_bwd_data_kernel<2, 2, ACCV, MSKV>), dim3(grid), dim3(256), lds_t,                   \
                        (hipStream_t)stream, DY, ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, \
                        (int)P, Hin, Win, Kp, G, ldg, partials, relu_mask16);                                           \
@@ -1856,8 +1854,7 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
   if (lds > 80 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_f32: Kp=%d does not fit LDS", kmax);
 #define EML_LAUNCH_MULTI(NLV, MTV, RAWV, MSKV)                                                                       \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>),   \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    EML_ENSURE_LDS((&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>), lds);                                 \
     hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>), dim3(grid), dim3(256), lds,            \
                        (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax,        \
                        Mk[0], Mk[1]);                                                                               \

@@ -836,13 +836,11 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
     const float* wp = Wp + (size_t)ch * Kp * 48;
     double* pp = partials + (size_t)ch * grid * 96;
     if (pool) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EML_ENSURE_LDS((&conv1x1_fwd_kernel<true>), lds);
       hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
                          Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EML_ENSURE_LDS((&conv1x1_fwd_kernel<false>), lds);
       hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
                          Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, relu_mask);
     }
@@ -858,8 +856,7 @@ extern "C" int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, co
   if (!Z || !scale2 || !shift2 || !W2p || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || c_out0 + 12 > ldx || (c_out0 & 1) || (ldx & 1))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_fwd_f32: bad arguments");
   const size_t lds = (size_t)(2 * kHH * kHW * kPS + 96) * sizeof(float) + 8 * 16 * 2 * sizeof(double);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EML_ENSURE_LDS((&conv3x3_fwd_kernel), lds);
   hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(grid), dim3(kC3Threads), lds, (hipStream_t)stream, Z, scale2, shift2, W2p, X, ldx,
                      c_out0, B, H, W, partials);
   return eml::check_launch("eml_dense_conv3x3_fwd_f32");

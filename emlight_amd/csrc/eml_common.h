@@ -1,8 +1,10 @@
 // Shared helpers for the gfx950 kernels of libemlight_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/emlight_hip.h"
 
@@ -32,6 +34,27 @@ inline int check_launch(const char* what) {
   }
   return EML_OK;
 }
+
+// Kernels that use more than the default 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised.
+// That is a property of (kernel, device), not of a launch: it is set when a launch first needs more than any earlier one
+// did (a grow-only high-water mark per device), not on every enqueue -- a training step made ~250 of these host calls.
+constexpr int kMaxDevices = 64;
+inline void ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<int>* high_water) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& hw = high_water[dev & (kMaxDevices - 1)];
+  if ((int)bytes <= hw.load(std::memory_order_acquire)) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)bytes <= hw.load(std::memory_order_relaxed)) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hw.store((int)bytes, std::memory_order_release);
+}
+#define EML_ENSURE_LDS(kernel_ptr, bytes)                                                     \
+  do {                                                                                        \
+    static std::atomic<int> eml_lds_hw_[eml::kMaxDevices];                                    \
+    eml::ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_ptr), (bytes), eml_lds_hw_); \
+  } while (0)
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -78,12 +78,19 @@ constexpr int kSmemVecs = 2 + 2 + 4 + 2;
 // work (staging) while it is in flight: schedule_scan_begin issues the loads, device_schedule folds them.
 struct ScanHead {
   float4 a, c, a2, c2;
+  float rlo, rhi;   // range of x U y on the OTHER ranks (all-reduced by the caller), or +inf / -inf
 };
 template <int kWG>
 __device__ __forceinline__ ScanHead schedule_scan_begin(const float* __restrict__ x, const float* __restrict__ y, int B,
-                                                        int N, double diameter) {
+                                                        int N, double diameter, const float* __restrict__ range_dev) {
   ScanHead h;
   h.a = h.c = h.a2 = h.c2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  h.rlo = INFINITY;
+  h.rhi = -INFINITY;
+  if (diameter <= 0.0 && range_dev) {   // data-parallel ranks: the diameter is the range over the GLOBAL batch
+    h.rlo = range_dev[0];
+    h.rhi = range_dev[1];
+  }
   const long n4 = ((long)B * N) >> 2;   // hipMalloc'd buffers: 16-B aligned
   if (diameter <= 0.0 && n4 > 0) {
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -119,6 +126,8 @@ __device__ __forceinline__ void device_schedule(const ScanHead& head, const floa
       fold(head.a, head.c);
       fold(head.a2, head.c2);
     }
+    lo = fminf(lo, head.rlo);
+    hi = fmaxf(hi, head.rhi);
     // further trips (B * N > 8 * kWG floats per array): two strides per trip, four loads in flight
     for (long k = tid0 + 2 * kWG; k < n4; k += 2 * kWG) {
       const long k2 = (k + kWG < n4) ? k + kWG : k;
@@ -183,7 +192,7 @@ template <bool kCached>
 __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
     const float* __restrict__ Mt, const float* __restrict__ alpha, const float* __restrict__ beta,
-    double blur, double log_blur, double log_scaling, int p_exp, double diameter, float* __restrict__ eps_out,
+    double blur, double log_blur, double log_scaling, int p_exp, double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work /* (8,B,N): duals a_x,b_y,a_y,b_x then E rows */, int B, int N) {
   constexpr int kGT = kCached ? 512 : 256;  // threads per softmin group
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(kCached ? 1024 : 512) void sinkhorn_loop_kernel(
       }
     }
   }
-  const ScanHead scan_head = schedule_scan_begin<kWG>(x, y, B, N, diameter);   // requested; folded in device_schedule
+  const ScanHead scan_head = schedule_scan_begin<kWG>(x, y, B, N, diameter, range_dev);   // requested; folded in device_schedule
   if constexpr (kCached) {
     // staging runs WHILE the scan is in flight (the M / point loads were issued first, so they land first): points,
     // log-weights, h buffer 0 = log w of each group's columns (sweep 0 reads h = log w, potentials are zero:
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
     const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
     int p_exp,
-    double diameter, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
+    double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
     float* __restrict__ work, int B, int N) {
   constexpr int kGT = 512, kWG = 1024;
   constexpr int NR = 512 / LPR;            // row capacity of a softmin group
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   constexpr int TS = TJ + 4;               // LDS row stride of a tile
   __shared__ float eps_l[EML_MAX_EPS];
   __shared__ int n_eps_l;
-  device_schedule<kWG>(schedule_scan_begin<kWG>(x, y, B, N, diameter), x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter,
+  device_schedule<kWG>(schedule_scan_begin<kWG>(x, y, B, N, diameter, range_dev), x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter,
                        eps_l, &n_eps_l, eps_out, n_eps_out, diameter_out);
   const float* eps_s = eps_l;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(256) void anchor_cost_kernel(const float* __restric
 __global__ __launch_bounds__(1024) void schedule_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ y, long n,
                                                         double blur, double scaling, int p,
-                                                        double diameter, float* __restrict__ eps_out,
+                                                        double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out,
                                                         int* __restrict__ n_eps_out,
                                                         float* __restrict__ diameter_out) {
   __shared__ float red_min[16], red_max[16];
@@ -687,6 +696,10 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const float* __restrict_
     for (int w = 0; w < 16; ++w) {
       lo = fminf(lo, red_min[w]);
       hi = fmaxf(hi, red_max[w]);
+    }
+    if (range_dev) {   // the other ranks' range (all-reduced by the caller)
+      lo = fminf(lo, range_dev[0]);
+      hi = fmaxf(hi, range_dev[1]);
     }
     d = (double)(hi - lo);  // f32 subtraction, then .item(): sinkhorn_divergence.py:15
   }
@@ -722,15 +735,15 @@ extern "C" int eml_emd_anchor_cost_f32(const float* anchors, float* M, int N, em
 }
 
 extern "C" int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blur,
-                                         double scaling, int p, double diameter, float* eps_out,
-                                         int* n_eps_out, float* diameter_out, eml_stream_t stream) {
+                                         double scaling, int p, double diameter, const float* range_lo_hi,
+                                         float* eps_out, int* n_eps_out, float* diameter_out, eml_stream_t stream) {
   if (!eps_out || !n_eps_out || !diameter_out) return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: null output");
   if (diameter <= 0.0 && (!x || !y || n < 1))
     return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: need x, y, n>=1 when diameter is not given");
   if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
     return eml::fail(EML_EINVAL, "eml_sinkhorn_schedule_f32: need blur>0, 0<scaling<1, p>=1");
   hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, n, blur, scaling, p,
-                     diameter, eps_out, n_eps_out, diameter_out);
+                     diameter, range_lo_hi, eps_out, n_eps_out, diameter_out);
   return eml::check_launch("eml_sinkhorn_schedule_f32");
 }
 
@@ -738,8 +751,8 @@ extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)8 * B 
 
 extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                                     const float* alpha, const float* beta, double blur, double scaling, int p,
-                                    double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
-                                    float* loss, float* gx, float* gy, float* work, int B, int N,
+                                    double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
+                                    float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
                                     eml_stream_t stream) {
   if (!x || !y || !M || !Mt || !loss || !work) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
   if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
@@ -751,30 +764,30 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
   size_t lds = (size_t)(kSmemVecs * NP) * sizeof(float);
   if (N <= 4 * kCJ) {
     lds += (size_t)(N * (round_up4(N) + 4) + kJPT) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EML_ENSURE_LDS((&sinkhorn_loop_kernel<true>), lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                       alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
+                       work, B, N);
   } else if (N <= 512 && (N & 3) == 0) {
     // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
     const int lpr = N <= 256 ? 2 : 1;
     lds = (size_t)(10 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
     if (lpr == 2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<2>), lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                         beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
+                       work, B, N);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_tiled_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<1>), lds);
       hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                         beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
+                       work, B, N);
     }
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_loop_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EML_ENSURE_LDS((&sinkhorn_loop_kernel<false>), lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,
-                       alpha, beta, blur, log_blur, log_scaling, p, diameter, eps_out, n_eps_out, diameter_out, work, B, N);
+                       alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
+                       work, B, N);
   }
   int rc = eml::check_launch("eml_sinkhorn_fwd_f32(loop)");
   if (rc) return rc;

@@ -449,13 +449,11 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   const long n_mt = (M + kBM - 1) / kBM, per_xcd = (n_mt + 7) / 8;
   const dim3 grid((unsigned)(8 * per_xcd * (O / bn)));   // 1-D: the kernel maps id -> (XCD band, pixel tile, O-tile)
   if (bn == 128) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<128>), lds);
     hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
                        Y, (int)M, HW, Po, C, O, ke, rowmax);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_fwd_fused_kernel<64>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<64>), lds);
     hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
                        Y, (int)M, HW, Po, C, O, ke, rowmax);
   }
@@ -503,8 +501,7 @@ extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, c
   const dim3 grid(9 * (C / bn), (O + bmo - 1) / bmo, split_k);
 #define EML_LAUNCH_WGRAD(BNV, BMV)                                                                                   \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sphere_conv_wgrad_fused_kernel<BNV, BMV>),              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV>), lds);                                 \
     hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
                        wgt, dY, partial, (int)M, HW, Po, C, O);                                                      \
   } while (0)

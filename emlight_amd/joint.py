@@ -41,11 +41,11 @@ def predicted_gaussian_map(pred, ln, pano_hw=(128, 256)):
 
 class JointTrainer:
     def __init__(self, opt=None, anchors=128, crop_hw=(240, 320), blur=.05, diameter=None, device="cuda", world=1,
-                 pano_hw=(128, 256), encoder=None, sam_loss=None):
+                 pano_hw=(128, 256), encoder=None, sam_loss=None, sync_diameter=None):
         """``encoder`` / ``sam_loss``: see ``RegressionTrainer`` (CPU-only distributed tests inject the oracle's)."""
         self.ln, self.pano_hw, self.world = anchors, tuple(pano_hw), world
         self.reg = RegressionTrainer(anchors=anchors, crop_hw=crop_hw, blur=blur, diameter=diameter, device=device,
-                                     world=world, model=encoder, sam_loss=sam_loss)
+                                     world=world, model=encoder, sam_loss=sam_loss, sync_diameter=sync_diameter)
         self.proj = Trainer(opt or networks.default_options(), device=device, world=world)
         self.losses = {}
 

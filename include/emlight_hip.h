@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 8
+#define EML_ABI_VERSION 9
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -64,14 +64,18 @@ int eml_emd_anchor_cost_f32(const float* anchors, float* M, int N, eml_stream_t 
 
 /* Epsilon schedule on the device (no .item() host sync):
  *   d     = diameter > 0 ? diameter : max(x U y) - min(x U y)        (n values each)
+ *           range_lo_hi (device, 2 floats, may be NULL): (min, max) of x U y over the OTHER data-parallel ranks'
+ *           shards, all-reduced by the caller -- folded into the scan, so that every rank derives the schedule of the
+ *           GLOBAL batch like a single-process run (max_diameter, sinkhorn_divergence.py:9-18, takes the range over the
+ *           whole batch); no host sync either
  *   eps_s = [d^p] + [exp(e) for e in arange(p ln d, p ln blur, p ln scaling)] + [blur^p]
  * evaluated in f64 exactly as numpy does, stored as f32.
  * Replaces max_diameter / scaling_parameters / epsilon_schedule,
  * RegressionNetwork/geomloss/sinkhorn_divergence.py:9-36.
  * Outputs: eps_out[EML_MAX_EPS], *n_eps_out (device int), *diameter_out (device float). */
 int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blur,
-                              double scaling, int p, double diameter, float* eps_out,
-                              int* n_eps_out, float* diameter_out, eml_stream_t stream);
+                              double scaling, int p, double diameter, const float* range_lo_hi,
+                              float* eps_out, int* n_eps_out, float* diameter_out, eml_stream_t stream);
 
 /* Whole debiased Sinkhorn divergence in one call (loop kernel + finishing kernel): the diameter and the
  * epsilon schedule (as eml_sinkhorn_schedule_f32, computed inside the loop kernel), cost build
@@ -85,6 +89,7 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
  *   M, Mt       (N,N)  ground cost and its transpose (may alias when M is symmetric)
  *   alpha, beta (B,N)  weights, or NULL for uniform 1/N
  *   blur, scaling, p, diameter   as SamplesLoss(...); diameter <= 0: range of x U y over the batch
+ *   range_lo_hi (2), device, or NULL   see eml_sinkhorn_schedule_f32 (diameter over the global batch under DDP)
  *   eps_out[EML_MAX_EPS], n_eps_out, diameter_out   device outputs of the schedule, or NULL
  *   loss        (B)
  *   gx, gy      (B,N)  d loss_b / d x_i, d loss_b / d y_j, or NULL
@@ -93,8 +98,8 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
 size_t eml_sinkhorn_work_floats(int B, int N);
 int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                          const float* alpha, const float* beta, double blur, double scaling, int p,
-                         double diameter, float* eps_out, int* n_eps_out, float* diameter_out,
-                         float* loss, float* gx, float* gy, float* work, int B, int N,
+                         double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
+                         float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
                          eml_stream_t stream);
 
 /* Backward of the loss vector: gout[b,i] = gloss[b] * gunit[b,i]  (gunit = gx or gy above). */

@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu(built_lib):
     one = ctypes.c_void_p(16)
     rc = L.eml_sg_rasterise_f32(one, one, one, one, 1, 4, 128, 200, None)
     assert rc == -1 and b"W==2H" in L.eml_last_error()
-    rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, one, None, None, one, 2, 0, None)
+    rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, None, one, None, None, one, 2, 0, None)
     assert rc == -1
     # encoder / projector launchers: nulls, odd pooling sizes, misaligned channel counts
     assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None, None) == -1

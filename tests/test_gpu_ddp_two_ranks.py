@@ -154,3 +154,56 @@ def test_sync_bn_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
     mod, x, seg, wy = _spade_case()
     half = _spade_run(mod, x[:2], seg[:2], wy[:2])
     assert np.abs(half["y"] - want["y"][:2]).max() > 1e-2
+
+
+def _diameter_case():
+    g = torch.Generator().manual_seed(5)
+    B, N = 8, 128
+    x = torch.softmax(torch.randn(B, N, generator=g), 1).view(B, N, 1)
+    y = torch.softmax(3 * torch.randn(B, N, generator=g), 1).view(B, N, 1)
+    y[B // 2:] = torch.softmax(8 * torch.randn(B // 2, N, generator=g), 1).view(B // 2, N, 1)   # rank 1's shard has the peaks
+    return x, y
+
+
+def _diameter_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world), EML_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    init_distributed()
+    x, y = _diameter_case()
+    h = x.shape[0] // world
+    xs, ys = x[rank * h:(rank + 1) * h].cuda(), y[rank * h:(rank + 1) * h].cuda()
+    out = {}
+    for name, sync in (("synced", True), ("local", False)):
+        r = SamplesLoss("sinkhorn", p=2, blur=.05, anchors=x.shape[1], sync_diameter=sync).forward_raw(xs, ys)
+        out[name + "_loss"] = r["loss"].cpu().numpy()
+        out[name + "_eps"] = r["eps_s"][:int(r["n_eps"].item())].cpu().numpy()
+        out[name + "_gx"] = r["gx"].cpu().numpy()
+    np.savez(os.path.join(out_dir, "diam%d.npz" % rank), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sync_diameter_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
+    """The HIP Sinkhorn under data parallelism: with ``sync_diameter`` two ranks x B/2 derive the eps-schedule of the whole
+    batch (bit for bit) and reproduce the one-process loss / gradient of the B samples (sinkhorn_divergence.py:9-18);
+    without it rank 0, whose shard has the smaller range, runs another schedule."""
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_diameter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x, y = _diameter_case()
+    w = SamplesLoss("sinkhorn", p=2, blur=.05, anchors=x.shape[1]).forward_raw(x.cuda(), y.cuda())
+    eps = w["eps_s"][:int(w["n_eps"].item())].cpu().numpy()
+    d = [np.load(tmp_path / ("diam%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        np.testing.assert_array_equal(d[k]["synced_eps"], eps)
+    np.testing.assert_allclose(np.concatenate([d[0]["synced_loss"], d[1]["synced_loss"]]), w["loss"].cpu().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.concatenate([d[0]["synced_gx"], d[1]["synced_gx"]]), w["gx"].cpu().numpy(), rtol=1e-6, atol=1e-10)
+    assert len(d[0]["local_eps"]) != len(eps) or not np.array_equal(d[0]["local_eps"], eps)

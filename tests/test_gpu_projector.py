@@ -211,9 +211,19 @@ def test_sphere_conv_ngf64_layer_shapes_natural_dispatch(B, Cin, Cout, H, W, str
     gy = torch.randn_like(yh)
     yh.backward(gy)
     monkeypatch.undo()
-    yr = oracle.sphere_conv(xr, wr, br, stride)
+    # The stock ops run in batch chunks (samples are independent; parameter gradients accumulate over the chunks): at
+    # B = 32, C = 128, 128x256 the grid_sample output is 4.83 GB and ATen / MIOpen on ROCm address it with 32-bit byte
+    # offsets -- measured on the MI355X: exactly the elements past 2^32 bytes (the last 11.1 % of the batch) come out
+    # wrong in the STOCK forward.  The HIP kernels index with 64-bit pixel offsets and take the whole batch at once.
+    per_sample = Cin * 9 * (H // stride) * (W // stride) * 4
+    bs = max(1, min(B, (1 << 30) // per_sample))
+    ys = []
+    for i in range(0, B, bs):
+        yc = oracle.sphere_conv(xr[i:i + bs], wr, br, stride)
+        yc.backward(gy[i:i + bs])
+        ys.append(yc.detach())
+    yr = torch.cat(ys, 0)
     assert yh.shape == yr.shape == (B, Cout, H // stride, W // stride)
-    yr.backward(gy)
     print("dispatch", (B, Cin, Cout, H, W, stride), sorted(n.replace("eml_sphere_", "") for n in seen))
     for name, a, b in [("y", yh.detach(), yr.detach()), ("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad),
                        ("db", hip.bias.grad, br.grad)]:

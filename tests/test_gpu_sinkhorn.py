@@ -126,7 +126,7 @@ def test_standalone_schedule_launcher_matches_numpy():
         eps = torch.zeros(64, device="cuda")
         n_eps = torch.zeros(1, dtype=torch.int32, device="cuda")
         d = torch.zeros(1, device="cuda")
-        _lib.check(L.eml_sinkhorn_schedule_f32(p(x), p(y), x.numel(), blur, .5, 2, -1.0 if diam is None else diam, p(eps),
+        _lib.check(L.eml_sinkhorn_schedule_f32(p(x), p(y), x.numel(), blur, .5, 2, -1.0 if diam is None else diam, None, p(eps),
                                                p(n_eps), p(d), _lib.current_stream()), "schedule")
         want_d = diam if diam is not None else oracle.max_diameter(x.cpu().view(-1, 96, 1), y.cpu().view(-1, 96, 1))
         want = oracle.epsilon_schedule(2, want_d, blur, .5)
@@ -152,3 +152,28 @@ def test_gmloss_samples_loss_matches_reference_golden():
         np.testing.assert_allclose(loss.detach().cpu().numpy(), g[name + "/loss"], rtol=0, atol=1e-6)
         loss.sum().backward()
         np.testing.assert_allclose(x.grad.cpu().numpy().reshape(B, 128), g[name + "/grad_x"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,n", [(4, 128), (3, 96), (3, 256), (2, 384), (2, 202)])
+def test_global_range_is_folded_into_the_diameter_scan(B, n):
+    """``range_lo_hi`` of the C ABI (the other data-parallel ranks' (min, max), all-reduced by the caller): the kernel's
+    own scan of x U y is widened by it, so the eps-schedule and the loss are those of the GLOBAL batch
+    (sinkhorn_divergence.py:9-18) -- register-resident (128, 96), LDS-tiled (256, 384) and streaming (202) kernels."""
+    from emlight_amd.RegressionNetwork.geomloss.samples_loss import sinkhorn_raw
+    g = torch.Generator().manual_seed(77 + n)
+    x = torch.softmax(torch.randn(B, n, generator=g), 1)
+    y = torch.softmax(3 * torch.randn(B, n, generator=g), 1)
+    lo, hi = float(min(x.min(), y.min())), float(max(x.max(), y.max()))
+    crit = _crit(n, .05)
+    M, Mt = crit.cost_matrix(torch.device("cuda"))
+    Mo = oracle.anchor_cost_matrix(n)
+    for rng in ((lo - 0.05, hi + 0.4), (lo + 0.01, hi - 0.01), (lo - 0.2, hi - 0.01)):   # wider, narrower (no effect), one-sided
+        d = np.float32(max(hi, rng[1])) - np.float32(min(lo, rng[0]))       # f32 subtraction like max_diameter
+        r = sinkhorn_raw(x.cuda(), y.cuda(), None, None, M, Mt, 2, .05, .5, None,
+                         range_lo_hi=torch.tensor(rng, dtype=torch.float32, device="cuda"))
+        want, aux = oracle.samples_loss(x.view(B, n, 1), y.view(B, n, 1), Mo, blur=.05, diameter=float(d), return_aux=True)
+        n_eps = int(r["n_eps"].item())
+        assert n_eps == len(aux["eps_s"])
+        np.testing.assert_allclose(r["eps_s"][:n_eps].cpu().numpy(), np.asarray(aux["eps_s"], np.float32), rtol=2e-7)
+        assert abs(float(r["diameter"].item()) - float(d)) <= 1e-7
+        np.testing.assert_allclose(r["loss"].cpu().numpy(), want.numpy(), rtol=0, atol=LOSS_ATOL)
