@@ -48,6 +48,23 @@ class _Rasterise(torch.autograd.Function):
         return None, None, gcol, None, None
 
 
+def rasterise_raw(dirs, sizes, colors, pano_hw=(128, 256), exhaustive=False, count=False):
+    """``eml_sg_rasterise_ex_f32`` (no autograd): the panorama and, with ``count``, the number of exponentials the launch
+    evaluated.  ``exhaustive``: every light for every pixel, in the reference's order (util.py:239-244) -- what the
+    hierarchically culled default must equal bit for bit (tests); the bench reports both counts."""
+    H, W = pano_hw
+    d = _lib.require_gpu_tensor(dirs, "dirs")
+    s = _lib.require_gpu_tensor(sizes, "sizes")
+    c = _lib.require_gpu_tensor(colors, "colors")
+    B, N = s.shape
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=d.device)
+    n = torch.zeros(1, dtype=torch.int64, device=d.device) if count else None
+    _lib.check(_lib.lib().eml_sg_rasterise_ex_f32(_lib.ptr(d), _lib.ptr(s), _lib.ptr(c), _lib.ptr(out), B, N, int(H), int(W),
+                                                  1 if exhaustive else 0, _lib.ptr(n), _lib.current_stream()),
+               "eml_sg_rasterise_ex_f32")
+    return (out, int(n.item())) if count else out
+
+
 def convert_to_panorama(dirs, sizes, colors, pano_hw=(128, 256)):
     """SG lobes -> equirect panorama ``(B, 3, H, W)``; reference ``util.py:222-245``.
 

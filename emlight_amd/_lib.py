@@ -22,6 +22,7 @@ SIGNATURES = {
     "eml_abi_version": (_int, []),
     "eml_last_error": (ctypes.c_char_p, []),
     "eml_sg_rasterise_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
+    "eml_sg_rasterise_ex_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, ctypes.c_void_p, _stream]),
     "eml_sg_rasterise_bwd_colors_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream]),
     "eml_emd_anchor_cost_f32": (_int, [_f32p, _f32p, _int, _stream]),
     "eml_sinkhorn_schedule_f32": (_int, [_f32p, _f32p, ctypes.c_long, ctypes.c_double, ctypes.c_double, _int,

@@ -7,17 +7,26 @@
 // through LDS (broadcast reads), and writes the panorama exactly once.
 //
 // Roofline: B*N*H*W exp2 evaluations against B*3*H*W*4 output bytes.  At N=128 that is
-// 128 transcendentals per 12 output bytes -> transcendental-(VALU-)bound, not HBM-bound;
-// the wave-uniform cull below removes the lights whose lobe underflows to exactly 0 for
-// all 64 pixels of a wave's 16x4 tile (exp2(t) == 0 for t < -150 in f32), which is
-// bit-identical to adding them.
+// 128 transcendentals per 12 output bytes -> instruction-bound, not HBM-bound -- and most of
+// them are exactly zero: a lobe of size .0025 underflows (exp2(t) == 0 for t < -150 in f32)
+// outside a 42-degree cone.  Round 2 tested every (wave, light) pair for that inside the
+// accumulation loop (two LDS reads, a dot product, a ballot and a loop-carried branch per
+// pair: the loop was bound by the TEST, not by the exponentials).  Now the cull is
+// hierarchical: each wave first builds the list of lights that can reach its 16x8-pixel patch
+// at all -- one cone test per light against the patch's bounding cap (centre direction c,
+// chord radius r: dot(L, p) <= dot(L, c) + |L| r for every pixel p of the patch), 64 lights
+// per instruction, survivors compacted in index order into a wave-private LDS array -- and
+// the accumulation loop then walks only the survivors, branch-free, two pixels per lane.
+// A light that is not on the list contributes exp2(t) == 0 to every pixel of the patch, so
+// the result is bit-identical to evaluating all N lights in order (tests: the exhaustive
+// variant of this kernel, flag EML_SG_EXHAUSTIVE).
 #include "eml_common.h"
 
 namespace {
 
-constexpr int kTileW = 32;  // block tile: 2x2 waves, each wave a 16(w) x 4(h) pixel patch
-constexpr int kTileH = 8;
-constexpr int kChunk = 512;  // lights staged per LDS pass (8 floats each = 16 KiB)
+constexpr int kTileW = 32;   // block tile: 2x2 waves, each wave a 16(w) x 8(h) pixel patch, two rows per lane
+constexpr int kTileH = 16;
+constexpr int kChunk = 128;  // lights staged per LDS pass (8 floats each = 4 KiB, + 4 KiB of survivors per wave)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kCull = -150.0f;  // exp2(-150) underflows below the smallest f32 denormal
 
@@ -26,37 +35,51 @@ struct __attribute__((aligned(16))) Lobe {
   float r, g, b, pad;    // colour
 };
 
-// f32 view vector of pixel (h, w) on the H x 2H grid, evaluated like the reference
-// (util.py:223-233): theta = (h+.5)*f32(pi/H), phi = (w+.5)*f32(pi/H).
-__device__ __forceinline__ void view_vector(int h, int w, float step, float& x, float& y, float& z) {
-  const float th = ((float)h + 0.5f) * step;
-  const float ph = ((float)w + 0.5f) * step;
-  float st, ct, sp, cp;
-  sincosf(th, &st, &ct);
-  sincosf(ph, &sp, &cp);
-  x = st * cp;
-  y = st * sp;
-  z = ct;
-}
-
+template <bool kExhaustive, bool kCount>
 __global__ __launch_bounds__(256) void sg_rasterise_kernel(
     const float* __restrict__ dirs, const float* __restrict__ sizes,
-    const float* __restrict__ colors, float* __restrict__ out, int N, int H, int W, float step) {
+    const float* __restrict__ colors, float* __restrict__ out, int N, int H, int W, float step,
+    unsigned long long* __restrict__ executed) {
   __shared__ Lobe lobes[kChunk];
+  __shared__ Lobe kept[4][kChunk];
+  __shared__ float sin_t[kTileH], cos_t[kTileH], sin_p[kTileW], cos_p[kTileW];
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int w = blockIdx.x * kTileW + (wave & 1) * 16 + (lane & 15);
-  const int h = blockIdx.y * kTileH + (wave >> 1) * 4 + (lane >> 4);
-  float px, py, pz;
-  view_vector(h, w, step, px, py, pz);
+  // f32 view vectors of the tile's pixels on the H x 2H grid, evaluated like the reference (util.py:223-233):
+  // theta = (h+.5)*f32(pi/H), phi = (w+.5)*f32(pi/H), xyz = (sin th cos ph, sin th sin ph, cos th); one sincos per
+  // tile row / column (48 per block) instead of three per lane
+  if (tid < kTileH) sincosf(((float)(blockIdx.y * kTileH + tid) + 0.5f) * step, &sin_t[tid], &cos_t[tid]);
+  else if (tid < kTileH + kTileW)
+    sincosf(((float)(blockIdx.x * kTileW + tid - kTileH) + 0.5f) * step, &sin_p[tid - kTileH], &cos_p[tid - kTileH]);
+  __syncthreads();
+  const int cw = (wave & 1) * 16 + (lane & 15), r0 = (wave >> 1) * 8 + (lane >> 4), r1 = r0 + 4;
+  const int w = blockIdx.x * kTileW + cw;
+  const int h0 = blockIdx.y * kTileH + r0, h1 = h0 + 4;
+  const float p0x = sin_t[r0] * cos_p[cw], p0y = sin_t[r0] * sin_p[cw], p0z = cos_t[r0];
+  const float p1x = sin_t[r1] * cos_p[cw], p1y = sin_t[r1] * sin_p[cw], p1z = cos_t[r1];
+  // bounding cap of the wave's 128 pixels: centre = midpoint of pixels (row 3, col 8) and (row 4, col 7), radius = the
+  // largest chord to any of the pixels (a reduction over the lanes, no geometric argument needed)
+  float cx, cy, cz, rr;
+  {
+    auto lane_of = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    cx = lane_of(p0x, 56) + lane_of(p1x, 7);
+    cy = lane_of(p0y, 56) + lane_of(p1y, 7);
+    cz = lane_of(p0z, 56) + lane_of(p1z, 7);
+    const float inv = rsqrtf(fmaf(cz, cz, fmaf(cy, cy, cx * cx)));
+    cx *= inv, cy *= inv, cz *= inv;
+    const float a0 = p0x - cx, a1 = p0y - cy, a2 = p0z - cz, b0 = p1x - cx, b1 = p1y - cy, b2 = p1z - cz;
+    const float d2 = fmaxf(fmaf(a2, a2, fmaf(a1, a1, a0 * a0)), fmaf(b2, b2, fmaf(b1, b1, b0 * b0)));
+    rr = sqrtf(eml::wave_max_dpp(d2)) * 1.0001f + 1e-6f;
+  }
 
-  float ar = 0.f, ag = 0.f, ab = 0.f;
+  float ar0 = 0.f, ag0 = 0.f, ab0 = 0.f, ar1 = 0.f, ag1 = 0.f, ab1 = 0.f;
+  unsigned long long n_exec = 0;
   for (int base = 0; base < N; base += kChunk) {
     const int cnt = min(kChunk, N - base);
     __syncthreads();
-    for (int i = tid; i < cnt; i += 256) {
-      const size_t li = (size_t)b * N + base + i;
+    if (tid < cnt) {
+      const size_t li = (size_t)b * N + base + tid;
       Lobe L;
       L.dx = dirs[3 * li + 0];
       L.dy = dirs[3 * li + 1];
@@ -66,26 +89,62 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
       L.g = colors[3 * li + 1];
       L.b = colors[3 * li + 2];
       L.pad = 0.f;
-      lobes[i] = L;
+      lobes[tid] = L;
     }
     __syncthreads();
-    for (int i = 0; i < cnt; ++i) {
-      const Lobe L = lobes[i];  // same address on every lane: LDS broadcast
-      const float dot = fmaf(L.dz, pz, fmaf(L.dy, py, L.dx * px));
-      const float t = (dot - 1.0f) * L.k2;
-      if (__builtin_amdgcn_ballot_w64(t > kCull) == 0) continue;  // wave-uniform, exact
-      const float e = __builtin_amdgcn_exp2f(t);
-      ar = fmaf(L.r, e, ar);
-      ag = fmaf(L.g, e, ag);
-      ab = fmaf(L.b, e, ab);
+    int n = cnt;
+    const Lobe* src = lobes;
+    if (!kExhaustive) {
+      n = 0;
+      for (int j = 0; j < cnt; j += 64) {
+        const int li = j + lane;
+        const Lobe L = lobes[min(li, cnt - 1)];
+        const float len = sqrtf(fmaf(L.dz, L.dz, fmaf(L.dy, L.dy, L.dx * L.dx)));
+        // upper bound of dot(L, p) over the patch, with slack far above the f32 rounding of either side
+        const float s = fmaf(L.dz, cz, fmaf(L.dy, cy, L.dx * cx)) + fmaf(len, rr, 1e-5f * (1.0f + len));
+        const bool odd = !(L.k2 > 0.f) || L.k2 > 3.0e38f || !(len < 3.0e38f);   // non-positive / zero sizes, NaNs: never cull
+        const bool keep = li < cnt && (odd || !((s - 1.0f) * L.k2 <= kCull));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) kept[wave][pos] = L;   // ascending light index: the accumulation order of the exhaustive loop
+        n += __builtin_popcountll(m);
+      }
+      src = kept[wave];
+      // the list is wave-private and a wave's LDS operations execute in order: only the compiler needs a fence
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (kCount) n_exec += (unsigned long long)n * 128ull;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+      const Lobe L = src[i];  // same address on every lane: LDS broadcast
+      const float t0 = (fmaf(L.dz, p0z, fmaf(L.dy, p0y, L.dx * p0x)) - 1.0f) * L.k2;
+      const float t1 = (fmaf(L.dz, p1z, fmaf(L.dy, p1y, L.dx * p1x)) - 1.0f) * L.k2;
+      const float e0 = __builtin_amdgcn_exp2f(t0), e1 = __builtin_amdgcn_exp2f(t1);
+      ar0 = fmaf(L.r, e0, ar0);
+      ag0 = fmaf(L.g, e0, ag0);
+      ab0 = fmaf(L.b, e0, ab0);
+      ar1 = fmaf(L.r, e1, ar1);
+      ag1 = fmaf(L.g, e1, ag1);
+      ab1 = fmaf(L.b, e1, ab1);
     }
   }
-  if (h < H && w < W) {
-    const size_t plane = (size_t)H * W;
-    float* o = out + (size_t)b * 3 * plane + (size_t)h * W + w;
-    o[0] = ar;
-    o[plane] = ag;
-    o[2 * plane] = ab;
+  if (kCount && lane == 0 && executed) atomicAdd(executed, n_exec);
+  const size_t plane = (size_t)H * W;
+  if (w < W) {
+    if (h0 < H) {
+      float* o = out + (size_t)b * 3 * plane + (size_t)h0 * W + w;
+      o[0] = ar0;
+      o[plane] = ag0;
+      o[2 * plane] = ab0;
+    }
+    if (h1 < H) {
+      float* o = out + (size_t)b * 3 * plane + (size_t)h1 * W + w;
+      o[0] = ar1;
+      o[plane] = ag1;
+      o[2 * plane] = ab1;
+    }
   }
 }
 
@@ -158,18 +217,34 @@ __global__ __launch_bounds__(256) void sg_rasterise_bwd_colors_kernel(
 
 }  // namespace
 
-extern "C" int eml_sg_rasterise_f32(const float* dirs, const float* sizes, const float* colors,
-                                    float* out, int B, int N, int H, int W, eml_stream_t stream) {
+extern "C" int eml_sg_rasterise_ex_f32(const float* dirs, const float* sizes, const float* colors, float* out, int B,
+                                       int N, int H, int W, int flags, unsigned long long* executed_exp,
+                                       eml_stream_t stream) {
   if (!dirs || !sizes || !colors || !out) return eml::fail(EML_EINVAL, "eml_sg_rasterise_f32: null pointer");
   if (B < 0 || N < 1 || H < 1 || W != 2 * H)
     return eml::fail(EML_EINVAL, "eml_sg_rasterise_f32: need N>=1, H>=1, W==2H (got B=%d N=%d H=%d W=%d)", B, N, H, W);
+  if (flags & ~EML_SG_EXHAUSTIVE) return eml::fail(EML_EINVAL, "eml_sg_rasterise_ex_f32: unknown flags 0x%x", flags);
   if (B == 0) return EML_OK;
   if (B > 65535) return eml::fail(EML_EINVAL, "eml_sg_rasterise_f32: B=%d exceeds grid.z", B);
   const float step = (float)(3.14159265358979323846 / (double)H);
   dim3 grid((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH, B);
-  hipLaunchKernelGGL(sg_rasterise_kernel, grid, dim3(256), 0, (hipStream_t)stream, dirs, sizes, colors,
-                     out, N, H, W, step);
+  const hipStream_t st = (hipStream_t)stream;
+  if (flags & EML_SG_EXHAUSTIVE) {
+    if (executed_exp)
+      hipLaunchKernelGGL((sg_rasterise_kernel<true, true>), grid, dim3(256), 0, st, dirs, sizes, colors, out, N, H, W, step, executed_exp);
+    else
+      hipLaunchKernelGGL((sg_rasterise_kernel<true, false>), grid, dim3(256), 0, st, dirs, sizes, colors, out, N, H, W, step, nullptr);
+  } else if (executed_exp) {
+    hipLaunchKernelGGL((sg_rasterise_kernel<false, true>), grid, dim3(256), 0, st, dirs, sizes, colors, out, N, H, W, step, executed_exp);
+  } else {
+    hipLaunchKernelGGL((sg_rasterise_kernel<false, false>), grid, dim3(256), 0, st, dirs, sizes, colors, out, N, H, W, step, nullptr);
+  }
   return eml::check_launch("eml_sg_rasterise_f32");
+}
+
+extern "C" int eml_sg_rasterise_f32(const float* dirs, const float* sizes, const float* colors,
+                                    float* out, int B, int N, int H, int W, eml_stream_t stream) {
+  return eml_sg_rasterise_ex_f32(dirs, sizes, colors, out, B, N, H, W, 0, nullptr, stream);
 }
 
 extern "C" int eml_sg_rasterise_bwd_colors_f32(const float* dirs, const float* sizes,

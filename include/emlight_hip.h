@@ -50,6 +50,14 @@ const char* eml_last_error(void);
 int eml_sg_rasterise_f32(const float* dirs, const float* sizes, const float* colors,
                          float* out, int B, int N, int H, int W, eml_stream_t stream);
 
+/* The same launch with options (tests and the bench): flags EML_SG_EXHAUSTIVE = evaluate every light for every pixel
+ * (no cull at all: the reference's loop, util.py:239-244, in its order -- the culled kernel must match it bit for bit);
+ * executed_exp (device, may be NULL) += the number of exponentials the launch evaluated (the reference: B*N*H*W). */
+#define EML_SG_EXHAUSTIVE 1
+int eml_sg_rasterise_ex_f32(const float* dirs, const float* sizes, const float* colors, float* out,
+                            int B, int N, int H, int W, int flags, unsigned long long* executed_exp,
+                            eml_stream_t stream);
+
 /* d loss / d colors of the rasteriser (autograd of util.py:239-244 wrt `colors`):
  * gcolors[b,3i+c] = sum_hw gout[b,c,h,w] * exp((dirs_i . xyz_hw - 1) / sizes_i). */
 int eml_sg_rasterise_bwd_colors_f32(const float* dirs, const float* sizes, const float* gout,

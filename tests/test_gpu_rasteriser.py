@@ -70,3 +70,39 @@ def test_empty_batch_and_bad_shapes():
     with pytest.raises(ValueError):
         convert_to_panorama(torch.rand(1, 12, device="cuda"), torch.rand(1, 5, device="cuda"),
                             torch.rand(1, 12, device="cuda"))
+
+
+@pytest.mark.parametrize("B,n,H,kind", [(32, 128, 128, "anchors"), (16, 256, 256, "anchors"), (3, 130, 128, "random"),
+                                        (2, 600, 64, "random"), (2, 128, 128, "odd"), (2, 96, 72, "anchors")])
+def test_hierarchical_cull_is_bit_identical_to_the_exhaustive_loop(B, n, H, kind):
+    """The per-patch light lists (csrc/sg_rasterise.hip) drop only lights whose lobe underflows to exactly 0 on every
+    pixel of a wave's 16x8 patch: the panorama equals the exhaustive evaluation of all N lights per pixel -- the
+    reference's loop, util.py:239-244 -- BIT FOR BIT.  BASELINE's shapes (Fibonacci anchors, size .0025: ~4/5 of the
+    exponentials are never evaluated), random directions with wide and narrow lobes, non-unit directions, zero / negative /
+    huge sizes (never culled), a height that is not a multiple of the 16-row tile."""
+    from emlight_amd.RegressionNetwork.util import rasterise_raw
+    g = np.random.default_rng([5, B, n])
+    if kind == "anchors":
+        dirs = np.tile(oracle.sphere_points(n).reshape(1, 3 * n), (B, 1)).astype(np.float32)
+        sizes = np.full((B, n), 0.0025, np.float32)
+    else:
+        d = g.standard_normal((B, n, 3))
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        sizes = g.uniform(0.0005, 0.3, (B, n)).astype(np.float32)
+        if kind == "odd":
+            d *= g.uniform(0.2, 3.0, (B, n, 1))          # non-unit directions: exp((|L| cos - 1)/s) can exceed 1
+            sizes[:, ::7] = 0.0                           # exp(-inf) = 0, exp(nan) where dot == 1
+            sizes[:, 1::7] = -0.01                        # negative: grows away from the lobe axis
+            sizes[:, 2::7] = 1e30
+        dirs = d.reshape(B, 3 * n).astype(np.float32)
+    colors = g.uniform(0, 3, (B, 3 * n)).astype(np.float32)
+    a = [torch.from_numpy(v).cuda() for v in (dirs, sizes, colors)]
+    fast, n_fast = rasterise_raw(*a, pano_hw=(H, 2 * H), count=True)
+    full, n_full = rasterise_raw(*a, pano_hw=(H, 2 * H), exhaustive=True, count=True)
+    assert torch.equal(fast.view(torch.int32), full.view(torch.int32))   # bit patterns, NaNs included
+    rows = (H + 15) // 16 * 16
+    assert n_full == B * n * rows * 2 * H
+    assert n_fast <= n_full
+    if kind == "anchors":
+        assert n_fast < 0.3 * n_full, (n_fast, n_full)
+    print("executed exponentials: %d of %d (%.1f %%)" % (n_fast, n_full, 100.0 * n_fast / n_full))
