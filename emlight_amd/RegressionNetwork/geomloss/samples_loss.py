@@ -22,7 +22,9 @@ def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
     return {"eps_s": torch.empty(64, **f32), "n_eps": torch.empty(1, dtype=torch.int32, device=dev),
             "diameter": torch.empty(1, **f32), "loss": torch.empty(B, **f32),
             "gx": torch.empty(B, N, **f32) if need_gx else None, "gy": torch.empty(B, N, **f32) if need_gy else None,
-            "work": torch.empty(8, B, N, **f32)}
+            # scratch size from the library (duals, expectation rows, the small-batch kernel's exchange buffer); never less
+            # than the (8,B,N) planes every kernel writes
+            "work": torch.empty(max(int(_lib.lib().eml_sinkhorn_work_floats(B, N)), 8 * B * N), **f32)}
 
 
 def global_range(x, y):
@@ -53,7 +55,7 @@ def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=T
         _lib.ptr(range_lo_hi), _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
         _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
     return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
-            "diameter": o["diameter"], "duals": o["work"][:4]}
+            "diameter": o["diameter"], "duals": o["work"][:4 * B * N].view(4, B, N)}
 
 
 class _SinkhornDivergence(torch.autograd.Function):

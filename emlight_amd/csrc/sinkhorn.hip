@@ -630,6 +630,213 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
   }
 }
 
+// ---- "split" kernel: small batches at N >= 192 (BASELINE configs[4]: 16 samples x 256 anchors per GPU).  With one
+// workgroup pair per sample only 2 * B of the 256 CUs work and a sweep is bound by the exponentials of ONE CU (tiled kernel:
+// 11.3 us per sweep at N = 256).  Here the ROWS of a sample's problem pair are split over S workgroups (S = 8 or 4: 2 * B * S
+// workgroups, one per CU at B = 16): workgroup (b, role, slice) owns R = N / S rows of both problems of its role and ALL N
+// columns.  Its R x N slice of the chord matrix is loaded ONCE into LDS (33 KB at N = 256; no tile streaming), eight lanes
+// share a row and fold N / 8 columns each from registers, and after every sweep the slices exchange the dual vector (N
+// floats per problem) through global memory as 8-byte {epoch, value} granules (cdna_hip_programming.md G16, form R2: the
+// data is the flag -- relaxed agent-scope 8-byte stores and polls, no fences; double-buffered by sweep parity, so a
+// workgroup that runs ahead never overwrites a granule a slower one still waits for; the launcher zeroes the exchange
+// buffer with a memset node in front of the kernel).  Polls are bounded by wall-clock time: a workgroup that never sees its
+// partners (they cannot all be resident -- the launcher sizes S so that they can) gives up after ~2 s and poisons its rows
+// with NaN instead of hanging the GPU.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int kSplitLPR = 8;        // lanes per row
+constexpr long long kSpinTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
+
+template <int CPL /* columns per lane = N / 8 */, int R /* rows per workgroup = N / S */>
+__global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ M,
+    const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
+    int p_exp, double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out,
+    int* __restrict__ n_eps_out, float* __restrict__ diameter_out, float* __restrict__ work,
+    unsigned long long* __restrict__ exch, int B, int S) {
+  constexpr int N = CPL * kSplitLPR, kWG = 16 * R, kGT = 8 * R, LDM = N + 32;   // LDM = 32 mod 64: two rows cover all banks
+  static_assert(CPL % 4 == 0 && N % 64 == 0 && kWG <= 1024, "split kernel geometry");
+  __shared__ float eps_l[EML_MAX_EPS];
+  __shared__ int n_eps_l;
+  __shared__ int failed_l;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* pts = smem;               // [2][N] x, y
+  float* lw2 = pts + 2 * N;        // [2][N] log2(e) * log-weights
+  float* qq = lw2 + 2 * N;         // [2][N] .05 * point^2
+  float* h2 = qq + 2 * N;          // [2 parity][2 problems][N]
+  float* Ml = h2 + 4 * N;          // [R][LDM]
+  const int tid = threadIdx.x;
+  const int slice = blockIdx.x % S, br = blockIdx.x / S, b = br >> 1, role = br & 1;
+  const int r0 = slice * R;
+  const ScanHead scan_head = schedule_scan_begin<kWG>(x, y, B, N, diameter, range_dev);
+  // this workgroup's rows of the chord matrix: requested before anything waits, committed below
+  constexpr int kM4 = R * N / 4 / kWG;     // float4 per thread: R * N / (64 R) = N / 64
+  float4 mreg[kM4];
+#pragma unroll
+  for (int k = 0; k < kM4; ++k) {
+    const int e = tid + k * kWG, row = e / (N / 4), c4 = e % (N / 4);
+    mreg[k] = *reinterpret_cast<const float4*>(M + (size_t)(r0 + row) * N + 4 * c4);
+  }
+  if (tid == 0) failed_l = 0;
+  const float unif = 1.0f / (float)N;
+  for (int i = tid; i < 2 * N; i += kWG) {
+    const int which = i / N, k = i - which * N;
+    const float p = (which == 0 ? x : y)[(size_t)b * N + k];
+    const float* wp = which == 0 ? alpha : beta;
+    const float w = wp ? wp[(size_t)b * N + k] : unif;
+    pts[i] = p;
+    qq[i] = 0.05f * p * p;
+    lw2[i] = ((w > 0.f) ? logf(w) : -100000.0f) * kLog2e;   // sinkhorn_divergence.py:47-50
+  }
+#pragma unroll
+  for (int k = 0; k < kM4; ++k) {
+    const int e = tid + k * kWG, row = e / (N / 4), c4 = e % (N / 4);
+    *reinterpret_cast<float4*>(Ml + row * LDM + 4 * c4) = mreg[k];
+  }
+  device_schedule<kWG>(scan_head, x, y, B, N, blur, log_blur, log_scaling, p_exp, diameter, eps_l, &n_eps_l,
+                       (slice == 0) ? eps_out : nullptr, (slice == 0) ? n_eps_out : nullptr,
+                       (slice == 0) ? diameter_out : nullptr);   // ends with a barrier: LDS staging above is visible
+  const float* eps_s = eps_l;
+  const int n_eps = n_eps_l;
+
+  const int gl = tid / kGT, g = 2 * role + gl, t = tid - gl * kGT;
+  const bool rows_x = (g == 0 || g == 3), cols_x = (g == 0 || g == 2);
+  const int consumer_l = role ? (1 - gl) : gl;
+  const float* P = pts + (rows_x ? 0 : N);
+  const float* Q = pts + (cols_x ? 0 : N);
+  const float* lw2_rows = lw2 + (rows_x ? 0 : N);
+  const float* lw2_cols = lw2 + (cols_x ? 0 : N);
+  const float* QQ = qq + (cols_x ? 0 : N);
+  {   // sweep 0 reads A_j = log w_j - k0 * .05 q_j^2 (potentials are zero: sinkhorn_divergence.py:82-85)
+    const float k0 = kLog2e / eps_s[0];
+    for (int k = t; k < N; k += kGT) h2[gl * N + k] = fmaf(-k0, QQ[k], lw2_cols[k]);
+  }
+  __syncthreads();
+
+  const int il = t / kSplitLPR, part = t % kSplitLPR, i = r0 + il;
+  const bool owner = part == 0;
+  const float pi = P[i];
+  const float* mrow = Ml + il * LDM;
+  const size_t plane = (size_t)B * N;
+  float* fin_out = work + (size_t)g * plane + (size_t)b * N;
+  float* e_out = work + (size_t)(4 + g) * plane + (size_t)b * N;
+  gu64* xg = (gu64*)exch;   // [2 parity][B][2 roles][2 problems][N]
+  const size_t xpar = (size_t)B * 4 * N, xbase = (size_t)br * 2 * N;
+  float pot = 0.f;
+  for (int s = 0; s < n_eps + 2; ++s) {
+    const bool final_sweep = (s == n_eps + 1);
+    const float eps = eps_s[(s == 0) ? 0 : min(s - 1, n_eps - 1)];
+    const float eps_next = eps_s[min(s, n_eps - 1)];
+    const float nie2 = -kLog2e / eps, k_next = kLog2e / eps_next;
+    const float* hsrc = h2 + (s & 1) * 2 * N + gl * N;
+    // exponents t_j = [A_j + (-.1 n p_i) q_j] + (.5 n) m_ij (+ the row-only term, added to the maximum afterwards), as in the
+    // tiled kernel; lane `part` owns the float4 column chunks part, part + 8, ...: the 8 lanes of a row read 32 consecutive
+    // floats per step and two rows (LDM = 32 mod 64) cover all 64 banks
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // CPL <= 48: the exponents stay in registers between the max pass and the exp pass; wider rows (N = 448, 512 at
+    // 896 / 1024 threads = 128 VGPRs per lane) recompute them from LDS instead of spilling 64 of them to scratch
+    constexpr bool kKeep = CPL <= 48;
+    constexpr int kUnroll = kKeep ? CPL / 4 : 4;
+    v2f tv[kKeep ? CPL / 2 : 2];
+    const v2f dd = v2f{-0.1f * nie2 * pi, -0.1f * nie2 * pi}, ee = v2f{0.5f * nie2, 0.5f * nie2};
+    auto expo = [&](int u, v2f& a, v2f& c) {
+      const int j = 4 * (part + kSplitLPR * u);
+      const float4 mv = *reinterpret_cast<const float4*>(mrow + j);
+      const float4 qv = *reinterpret_cast<const float4*>(Q + j);
+      const float4 hv = *reinterpret_cast<const float4*>(hsrc + j);
+      a = ee * v2f{mv.x, mv.y} + (dd * v2f{qv.x, qv.y} + v2f{hv.x, hv.y});
+      c = ee * v2f{mv.z, mv.w} + (dd * v2f{qv.z, qv.w} + v2f{hv.z, hv.w});
+    };
+    v2f mA = v2f{-INFINITY, -INFINITY}, mB = mA;
+#pragma unroll kUnroll
+    for (int u = 0; u < CPL / 4; ++u) {
+      v2f a, c;
+      expo(u, a, c);
+      if constexpr (kKeep) {
+        tv[2 * u + 0] = a;
+        tv[2 * u + 1] = c;
+      }
+      mA = __builtin_elementwise_max(mA, a);
+      mB = __builtin_elementwise_max(mB, c);
+    }
+    float m = fmaxf(fmaxf(mA.x, mA.y), fmaxf(mB.x, mB.y));
+    m = fmaxf(m, eml::lane_xor1(m));
+    m = fmaxf(m, eml::lane_xor2(m));
+    m = fmaxf(m, eml::dpp_mov<0x141>(m));   // row_half_mirror: the other quad of this row's 8 lanes
+    const v2f mm = v2f{m, m};
+    float sA = 0.f, sB = 0.f, qA = 0.f, qB = 0.f;
+#pragma unroll kUnroll
+    for (int u = 0; u < CPL / 4; ++u) {
+      v2f a, c;
+      if constexpr (kKeep) {
+        a = tv[2 * u + 0];
+        c = tv[2 * u + 1];
+      } else {
+        expo(u, a, c);
+      }
+      const v2f d0 = a - mm, d1 = c - mm;
+      const float e0 = __builtin_amdgcn_exp2f(d0.x), e1 = __builtin_amdgcn_exp2f(d0.y);
+      const float e2 = __builtin_amdgcn_exp2f(d1.x), e3 = __builtin_amdgcn_exp2f(d1.y);
+      sA += e0 + e2;
+      sB += e1 + e3;
+      if (final_sweep) {   // expectation of the column points under the row's softmax: the analytic gradient
+        const float4 qv = *reinterpret_cast<const float4*>(Q + 4 * (part + kSplitLPR * u));
+        qA = fmaf(e0, qv.x, fmaf(e2, qv.z, qA));
+        qB = fmaf(e1, qv.y, fmaf(e3, qv.w, qB));
+      }
+    }
+    float sum = sA + sB, tq = qA + qB;
+    sum += eml::lane_xor1(sum);
+    sum += eml::lane_xor2(sum);
+    sum += eml::dpp_mov<0x141>(sum);
+    const float row_shift = 0.05f * nie2 * pi * pi;
+    const float sm = -eps * kLn2 * ((m + row_shift) + __builtin_amdgcn_logf(sum));
+    if (final_sweep) {
+      tq += eml::lane_xor1(tq);
+      tq += eml::lane_xor2(tq);
+      tq += eml::dpp_mov<0x141>(tq);
+      if (owner) {
+        const bool bad = failed_l != 0;
+        fin_out[i] = bad ? NAN : sm;
+        e_out[i] = bad ? NAN : tq / sum;
+      }
+      break;
+    }
+    pot = (s == 0) ? sm : 0.5f * (pot + sm);
+    // ---- exchange: this row is COLUMN i of the problem that reads it next sweep (its .05 p^2 term folded in with that
+    // sweep's n = -k_next); every workgroup of the (sample, role) then collects all 2 * N granules of the new parity
+    const unsigned epoch = (unsigned)(s + 1);
+    gu64* xw = xg + ((s + 1) & 1) * xpar + xbase;
+    if (owner) {
+      const float hv = fmaf(pot, k_next, lw2_rows[i]) - k_next * (0.05f * pi * pi);
+      __hip_atomic_store(xw + consumer_l * N + i, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, hv),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float* hdst = h2 + ((s + 1) & 1) * 2 * N;
+    for (int k = tid; k < 2 * N; k += kWG) {
+      long long t0 = 0;
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(xw + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == epoch) {
+          hdst[k] = __builtin_bit_cast(float, (unsigned)v);
+          break;
+        }
+        if ((++spins & 1023u) == 0) {   // bounded by wall-clock time, checked rarely
+          const long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > kSpinTicks) {
+            failed_l = 1;
+            hdst[k] = 0.f;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // loss_b = <alpha, b_x - a_x> + <beta, a_y - b_y>  (sinkhorn_divergence.py:65-69) and the
 // analytic backward of the last extrapolation: the gradient reaches x only through the final
 // xx / xy softmins and only through the cost's first argument (utils.py:88), and since the
@@ -747,7 +954,24 @@ extern "C" int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n,
   return eml::check_launch("eml_sinkhorn_schedule_f32");
 }
 
-extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)8 * B * N; }
+// (8,B,N) floats of duals / expectation rows + the split kernel's exchange buffer: [2 parity][B][2 roles][2 problems][N]
+// 8-byte granules = 16*B*N floats
+extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)24 * B * N; }
+
+namespace {
+int device_cu_count() {
+  static std::atomic<int> cached[eml::kMaxDevices];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& c = cached[dev & (eml::kMaxDevices - 1)];
+  int n = c.load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
+    c.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+}  // namespace
 
 extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                                     const float* alpha, const float* beta, double blur, double scaling, int p,
@@ -768,6 +992,31 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
                        alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
                        work, B, N);
+  } else if (N <= 512 && (N & 63) == 0 && N >= 192 && (2 * B * 8 <= device_cu_count() || (N <= 256 && 2 * B * 4 <= device_cu_count()))) {
+    // small batch: the rows of every problem pair split over S workgroups (one per CU, all resident), duals exchanged
+    // through global memory after every sweep (see the kernel).  S = 8 when 16 * B workgroups fit the CUs, else 4.
+    const int S = (2 * B * 8 <= device_cu_count()) ? 8 : 4;
+    const int R = N / S;
+    unsigned long long* exch = reinterpret_cast<unsigned long long*>(work + (size_t)8 * B * N);
+    hipError_t me = hipMemsetAsync(exch, 0, (size_t)16 * B * N * sizeof(float), (hipStream_t)stream);
+    if (me != hipSuccess) return eml::fail(EML_ELAUNCH, "eml_sinkhorn_fwd_f32: memset of the exchange buffer: %s", hipGetErrorString(me));
+    lds = (size_t)(10 * N + R * (N + 32)) * sizeof(float);
+#define EML_LAUNCH_SPLIT(CPLV, RV)                                                                                     \
+  do {                                                                                                                 \
+    EML_ENSURE_LDS((&sinkhorn_loop_split_kernel<CPLV, RV>), lds);                                                      \
+    hipLaunchKernelGGL((sinkhorn_loop_split_kernel<CPLV, RV>), dim3(2 * B * S), dim3(16 * RV), lds, (hipStream_t)stream, \
+                       x, y, M, alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, \
+                       diameter_out, work, exch, B, S);                                                                \
+  } while (0)
+    if (N == 256 && S == 8) EML_LAUNCH_SPLIT(32, 32);
+    else if (N == 256) EML_LAUNCH_SPLIT(32, 64);
+    else if (N == 192 && S == 8) EML_LAUNCH_SPLIT(24, 24);
+    else if (N == 192) EML_LAUNCH_SPLIT(24, 48);
+    else if (N == 320) EML_LAUNCH_SPLIT(40, 40);
+    else if (N == 384) EML_LAUNCH_SPLIT(48, 48);
+    else if (N == 448) EML_LAUNCH_SPLIT(56, 56);
+    else EML_LAUNCH_SPLIT(64, 64);
+#undef EML_LAUNCH_SPLIT
   } else if (N <= 512 && (N & 3) == 0) {
     // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
     const int lpr = N <= 256 ? 2 : 1;

@@ -101,8 +101,10 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
  *   eps_out[EML_MAX_EPS], n_eps_out, diameter_out   device outputs of the schedule, or NULL
  *   loss        (B)
  *   gx, gy      (B,N)  d loss_b / d x_i, d loss_b / d y_j, or NULL
- *   work        (8,B,N) caller-owned scratch, eml_sinkhorn_work_floats(B,N) floats; on return
- *                      planes 0..3 hold the final duals a_x, b_y, a_y, b_x */
+ *   work        caller-owned scratch of eml_sinkhorn_work_floats(B,N) floats (16-byte aligned); on return its first
+ *                      (4,B,N) floats hold the final duals a_x, b_y, a_y, b_x (the next (4,B,N) the expectation rows of
+ *                      the gradient; the rest is the inter-workgroup exchange buffer of the small-batch kernel, zeroed
+ *                      by the call itself) */
 size_t eml_sinkhorn_work_floats(int B, int N);
 int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                          const float* alpha, const float* beta, double blur, double scaling, int p,

@@ -36,7 +36,7 @@ def test_loader_and_abi_version(built_lib):
     L = built_lib.lib()
     header = open(os.path.join(ROOT, "include", "emlight_hip.h")).read()
     assert L.eml_abi_version() == built_lib.ABI_VERSION == int(re.search(r"#define EML_ABI_VERSION (\d+)", header).group(1))
-    assert L.eml_sinkhorn_work_floats(3, 5) == 8 * 3 * 5
+    assert L.eml_sinkhorn_work_floats(3, 5) == 24 * 3 * 5   # (8,B,N) planes + the 16*B*N-float exchange buffer
 
 
 def test_argument_validation_without_gpu(built_lib):

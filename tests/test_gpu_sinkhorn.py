@@ -46,11 +46,15 @@ def test_golden_cases(golden_sinkhorn, case):
 
 
 @pytest.mark.parametrize("B,n,blur", [(64, 128, .05), (7, 96, .025), (5, 33, .05), (3, 64, .05), (2, 8, .05), (3, 200, .05), (16, 256, .05),
-                                      (4, 132, .05), (3, 384, .05), (2, 512, .025), (2, 202, .05), (2, 516, .05)])
+                                      (4, 132, .05), (3, 384, .05), (2, 512, .025), (2, 202, .05), (2, 516, .05),
+                                      (24, 256, .05), (40, 256, .05), (20, 384, .05), (3, 192, .05), (3, 320, .025), (2, 448, .05)])
 def test_autograd_vs_oracle(B, n, blur):
     """Seeded inputs at BASELINE cfg2/cfg5 shapes + ragged N; loss, d/dx and d/dy through autograd.  N <= 128: register-
-    resident costs (N = 128, 64, 8 divide the workgroup size: the strided chord-matrix staging; 96, 33: the general one); 132 / 200 / 256 (two lanes per row) and 384 / 512 (one lane per row): the LDS-tiled kernel; 202 / 516
-    (N % 4 != 0 or N > 512): the streaming kernel."""
+    resident costs (N = 128, 64, 8 divide the workgroup size: the strided chord-matrix staging; 96, 33: the general one);
+    N % 64 == 0 in [192, 512] at small batch: the SPLIT kernel, rows of a sample over 8 workgroups with the duals exchanged
+    through global memory every sweep ((16, 256) = cfg5's per-GPU shape, (3, 192/320/384), (2, 448/512)), over 4 at
+    (24, 256); 132 / 200 and the larger batches (40, 256) (two lanes per row), (20, 384) (one lane per row): the LDS-tiled
+    kernel; 202 / 516 (N % 4 != 0 or N > 512): the streaming kernel."""
     g = torch.Generator().manual_seed(1234)
     x_c = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
     y_c = torch.softmax(3 * torch.randn(B, n, generator=g), 1).view(B, n, 1)
