@@ -129,10 +129,13 @@ class SPADEResnetBlock(nn.Module):
     def forward(self, x, seg):
         stats = None
         n0 = self.norm_0.param_free_norm
-        if self.learned_shortcut and isinstance(n0, nn.BatchNorm2d) and x.shape[1] % 4 == 0 and x.is_cuda:
-            # norm_0 and norm_s normalise the same x with parameter-free BatchNorms: one reduction serves both
-            stats = spherenet.spade_batch_stats(x, n0)
-            spherenet.adopt_batch_stats(self.norm_s.param_free_norm, n0)
+        ns = self.norm_s.param_free_norm if self.learned_shortcut else None
+        if (self.learned_shortcut and isinstance(n0, nn.BatchNorm2d) and n0.training and ns.training and ns.eps == n0.eps
+                and x.shape[1] % 4 == 0 and x.is_cuda):
+            # training: norm_0 and norm_s normalise the same x with parameter-free BatchNorms -- one reduction serves both,
+            # and each norm's running buffers are updated from it with its own momentum.  (In eval every norm uses its OWN
+            # running statistics: a checkpoint may hold different buffers for the two.)
+            stats = spherenet.spade_batch_stats(x, n0, also=(ns,))
         x_s = self.conv_s(self.norm_s(x, seg, stats=stats)) if self.learned_shortcut else x
         dx = self.conv_0(self.norm_0(x, seg, slope=2e-1, stats=stats))   # leaky_relu(norm(.), 0.2), fused into the modulation
         dx = self.conv_1(self.norm_1(dx, seg, slope=2e-1))

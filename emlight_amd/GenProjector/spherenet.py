@@ -324,10 +324,12 @@ def _reduce_sums(partials, rows, C):
     return sums
 
 
-def spade_batch_stats(x, bn):
+def spade_batch_stats(x, bn, also=()):
     """(mean, istd) of SPADE's parameter-free BatchNorm for input ``x`` (normalization.py:101-104): batch statistics in
     training (one read of x, f64 accumulation; running statistics of ``bn`` updated like nn.BatchNorm2d), running
-    statistics in eval.  Not differentiable: the statistics' gradient is part of ``spade_norm_modulate``'s backward."""
+    statistics in eval.  Not differentiable: the statistics' gradient is part of ``spade_norm_modulate``'s backward.
+    ``also``: further parameter-free BatchNorms over the SAME x (SPADEResnetBlock's norm_s next to norm_0): their running
+    buffers are updated from the same sums, each with its own momentum and its own previous values."""
     from .. import _lib
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
     _require_gpu_f32(x, "SPADE input")
@@ -347,17 +349,14 @@ def spade_batch_stats(x, bn):
         _lib.check(L.eml_bn_finalize_f32(p(sums), C, float(bn.eps), float(mom), p(mean), p(istd), p(bn.running_mean),
                                          p(bn.running_var), st), "eml_bn_finalize_f32")
         bn.num_batches_tracked += 1
+        for other in also:
+            if other.training:
+                m2, i2 = torch.empty_like(mean), torch.empty_like(istd)
+                mom2 = other.momentum if other.momentum is not None else 0.1
+                _lib.check(L.eml_bn_finalize_f32(p(sums), C, float(other.eps), float(mom2), p(m2), p(i2),
+                                                 p(other.running_mean), p(other.running_var), st), "eml_bn_finalize_f32")
+                other.num_batches_tracked += 1
     return mean, istd
-
-
-def adopt_batch_stats(bn, src):
-    """A second norm over the SAME input (SPADEResnetBlock's norm_s next to norm_0): same statistics, so its running
-    buffers follow ``src``'s update instead of a second reduction over x."""
-    if bn.training:
-        with torch.no_grad():
-            bn.running_mean.copy_(src.running_mean)
-            bn.running_var.copy_(src.running_var)
-            bn.num_batches_tracked += 1
 
 
 class _SpadeNormModulateFn(torch.autograd.Function):

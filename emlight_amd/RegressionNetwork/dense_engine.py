@@ -109,7 +109,7 @@ class _PermuteTable:
 
     def launch(self, L, st, items):
         """items: (weight tensor, destination tensor, kind, Cout, Cin, Kp, Ko)."""
-        key = tuple((w.data_ptr(), d.data_ptr()) for w, d, *_ in items)
+        key = tuple((w.data_ptr(), d.data_ptr(), cout, cin) for w, d, _, cout, cin, *_ in items)
         if key != self.key:
             host = np.zeros(len(items), dtype=self._DT)
             for i, (w, d, kind, cout, cin, kp, ko) in enumerate(items):
@@ -136,10 +136,14 @@ class _EncoderFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         ws = ctx.ws
         if ws.owner is None or ws.owner() is not ctx:
-            raise RuntimeError("HIP DenseNet: the activations of this forward were overwritten (backward called twice "
-                               "on the same graph? retain_graph is not supported)")
+            raise RuntimeError("HIP DenseNet: the activations of this forward are gone -- backward() was already run on "
+                               "this graph (the workspace is released after the first backward; retain_graph / double "
+                               "backward are not supported)")
         grads = ctx.enc.run_backward(ws, x, gpooled.contiguous())
-        ws.done = True
+        # the buffers go back to the pool: a second backward on this graph (retain_graph=True) raises above instead of
+        # reading activations a later forward may have overwritten
+        ws.done, ws.owner = True, None
+        ctx.enc.trim_pool(ws)
         return (None, None) + tuple(grads)
 
 
@@ -210,8 +214,11 @@ class HipDenseEncoder:
             raise ValueError("expected (B,3,H,W) input")
         div = 2 ** len(self.block_layers)
         if H % div or W % div or (H // div) < self.avgpool or (W // div) < self.avgpool:
-            raise ValueError("crop %dx%d: each of the %d transitions halves the map (even sizes required) and the head "
-                             "pools %dx%d" % (H, W, len(self.block_layers), self.avgpool, self.avgpool))
+            raise ValueError("crop %dx%d: each of the %d transitions halves the map and the HIP kernels need even maps "
+                             "(H, W divisible by %d), then the head pools %dx%d.  Deviation from the reference: its "
+                             "AvgPool2d(2) floors odd maps, so e.g. 100x132 trains there; crop to a multiple of %d "
+                             "(EMLight's 192x256 and 240x320 are)." % (H, W, len(self.block_layers), div, self.avgpool,
+                                                                       self.avgpool, div))
         return _EncoderFn.apply(self, x, *self.param_list())
 
     def _grid(self, dev):
@@ -248,9 +255,27 @@ class HipDenseEncoder:
         for ws in pool:
             if not ws.in_use():
                 return ws
+        if pool:
+            import warnings
+            warnings.warn("HIP DenseNet: a %s grad-enabled forward of shape %s is alive before the previous one ran its "
+                          "backward: allocating another full activation workspace (GBs at training sizes; idle extras are "
+                          "freed after a backward)" % ("second" if len(pool) == 1 else "%d-th" % (len(pool) + 1),
+                                                       (B, H, W)), stacklevel=3)
         ws = _Workspace(self, B, H, W, dev, keep_all)
         pool.append(ws)
         return ws
+
+    POOL_KEEP = 2   # idle workspaces (with their backward buffers) kept per shape after a backward
+
+    def trim_pool(self, ws):
+        """After a backward: drop idle workspaces beyond POOL_KEEP so a one-off double forward (or a burst of accumulated,
+        un-backwarded losses) does not leave N full activation sets resident for the rest of training."""
+        for key, pool in self._ws.items():
+            if ws in pool:
+                idle = [w for w in pool if not w.in_use()]
+                for extra in idle[self.POOL_KEEP:]:
+                    pool.remove(extra)
+                return
 
     # ------------------------------------------------------------------ forward
     def _prepare(self, L, st, partials, G, pstride, n_new, c_new0, count, mean, var, istd, bn, C, Cpad, training,
