@@ -326,8 +326,81 @@ def run_timed(step_fn, steps, warmup, world, device):
 
 
 G_FWD_GFLOP, D_PAIR_GFLOP = 154.1, 4.71   # SPADE generator forward / discriminator forward on a fake+real pair
+# VGG19 to relu5_1 at 128x256, algorithmic conv FLOPs per image forward (2*Cout*Cin*9*H*W over the 13 convolutions):
+# 0.113 + 2.416 + 2 * (1.208 + 2.416) ... = 23.6; the G step runs it on fake and on real and takes the data gradient
+# through fake (loss.py:108-114, pix2pix_model.py:119-120)
+VGG_FWD_GFLOP = sum(2.0 * co * ci * 9 * (128 >> lvl) * (256 >> lvl) for lvl, ci, co in
+                    [(0, 3, 64), (0, 64, 64), (1, 64, 128), (1, 128, 128), (2, 128, 256), (2, 256, 256), (2, 256, 256),
+                     (2, 256, 256), (3, 256, 512), (3, 512, 512), (3, 512, 512), (3, 512, 512), (4, 512, 512)]) / 1e9
 # G step: G fwd + bwd (3x) and D fwd/bwd-data on the pair (2x); D step: G fwd (no grad) + D fwd/bwd (3x)
 PROJECTOR_STEP_GFLOP = 3 * G_FWD_GFLOP + 2 * D_PAIR_GFLOP + G_FWD_GFLOP + 3 * D_PAIR_GFLOP
+VGG_STEP_GFLOP = 3 * VGG_FWD_GFLOP
+
+
+# projector launchers -> (label, FLOP count of one call from its arguments, or None for the streaming kernels)
+PROJECTOR_FAMILIES = {
+    "eml_sphere_conv_fwd_fused_f32": ("sphere_conv_fwd_fused_kernel (taps gathered into the LDS operand of an f32-MFMA implicit "
+                                      "GEMM: SphereConv2D forward; VGG19's 3x3 convolutions use it with a planar tap table)",
+                                      lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),     # B * Po * 9C * O
+    "eml_sphere_conv_dgrad_fused_f32": ("sphere_conv_fwd_fused_kernel on the transposed tap table (input gradient)",
+                                        lambda a: 2.0 * a[7] * a[8] * 9 * a[10] * a[11]),  # B * HW * 9C * O
+    "eml_sphere_conv_wgrad_fused_f32": ("sphere_conv_wgrad_fused_kernel (weight gradient, split-K over pixels)",
+                                        lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),
+    "eml_sphere_im2col_f32": ("sphere_im2col_kernel (gather for the layers that keep the library GEMM)", None),
+    "eml_sphere_col2im_f32": ("sphere_col2im_kernel (transpose gather of the unfused input gradient)", None),
+    "eml_spade_norm_modulate_fwd_f32": ("spade_norm_modulate_fwd_kernel (BN + modulation + LeakyReLU)", None),
+    "eml_spade_norm_modulate_bwd_f32": ("spade_norm_modulate_bwd_kernel", None),
+    "eml_bn_stats_f32": ("bn_stats_kernel (SPADE batch statistics)", None),
+    "eml_bn_bwd_apply_f32": ("bn_bwd_apply_kernel", None),
+}
+
+
+def time_projector_families(trainer, data, steps):
+    """Per-family GPU time of one projector step (HIP events around every launcher call, on the stream it launches on),
+    sorted by time; `other` = the step's remaining GPU time (library GEMMs of the unfused layers, ATen glue, Adam)."""
+    from emlight_amd import _lib
+    L = _lib.lib()
+    events = {k: [] for k in PROJECTOR_FAMILIES}
+    flops = {k: 0.0 for k in PROJECTOR_FAMILIES}
+    orig = {k: getattr(L, k) for k in PROJECTOR_FAMILIES}
+
+    def timed(name):
+        fn, fl = orig[name], PROJECTOR_FAMILIES[name][1]
+
+        def call(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            events[name].append((e0, e1))
+            if fl is not None:
+                flops[name] += fl(a)
+            return rc
+        return call
+    for k in PROJECTOR_FAMILIES:
+        setattr(L, k, timed(k))
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        torch.cuda.synchronize()
+        t0.record()
+        for _ in range(steps):
+            trainer.step(data)
+        t1.record()
+        torch.cuda.synchronize()
+    finally:
+        for k in PROJECTOR_FAMILIES:
+            setattr(L, k, orig[k])
+    total = t0.elapsed_time(t1) / steps
+    rows, acc = [], 0.0
+    for k, (label, fl) in PROJECTOR_FAMILIES.items():
+        ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
+        acc += ms
+        rows.append({"kernel": label, "launches_per_step": len(events[k]) // steps, "ms_per_step": round(ms, 3),
+                     "tflops": round(flops[k] / steps / (ms * 1e-3) / 1e12, 2) if (fl is not None and ms > 0) else None})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    rows.append({"kernel": "other (library GEMMs of the unfused layers, ATen elementwise / pooling / norms, Adam)",
+                 "launches_per_step": None, "ms_per_step": round(total - acc, 3), "tflops": None})
+    return rows
 
 
 def _free_gpu():
@@ -346,22 +419,51 @@ def leg_projector(args, rank, world, dev, steps, warmup):
     from emlight_amd.GenProjector.model_trainer import Trainer
     from emlight_amd.GenProjector.data import projector_batch
     B = args.projector_batch
-    tr = Trainer(default_options(), device=dev, world=world)
+    import warnings
     data = projector_batch(B, dev, ln=args.anchors, seed=1234 + rank)
-    dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
-    value = B * world * steps / dt
-    tf = PROJECTOR_STEP_GFLOP * value / world / 1e3
-    out = {"metric": "training images/sec (projector step: SPADE generator + PatchGAN discriminator, G step + D step)",
+
+    def run(no_vgg):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # "random VGG features": stated in the JSON instead
+            tr = Trainer(default_options(no_vgg_loss=no_vgg), device=dev, world=world)
+        dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
+        fams = time_projector_families(tr, data, 1) if (not no_vgg and rank == 0) else None
+        peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+        del tr
+        _free_gpu()
+        return dt, peak, fams
+    # headline: the reference's step, VGG perceptual term included (pix2pix_model.py:119-120) -- torchvision's weights are
+    # not obtainable offline, so the feature stack holds seeded random weights: same work, not the reference's loss value
+    dt, peak, fams = run(False)
+    dt0, _, _ = run(True)
+    value, value0 = B * world * steps / dt, B * world * steps / dt0
+    gflop = PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
+    tf = gflop * value / world / 1e3
+    out = {"metric": "training images/sec (projector step: SPADE generator + PatchGAN discriminator + VGG19 perceptual "
+                     "term, G step + D step)",
            "value": round(value, 2), "unit": "images/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 3),
            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "per_gpu_batch": B,
-                      "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64},
-           "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
-           "roofline": {"kernel": "whole step", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D step) + "
-                                "5*%.2f (D) GFLOP, VGG / feature-matching terms excluded" % (G_FWD_GFLOP, D_PAIR_GFLOP)}}
-    del tr, data
+                      "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
+                      "vgg": "VGG19 to relu5_1 on fake and real, seeded random weights (pretrained ones are not obtainable "
+                             "offline; injectable via opt.vgg_weights)"},
+           "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
+                           "frac_of_f32_mfma_peak": round(PROJECTOR_STEP_GFLOP * value0 / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                           "note": "the round-1/2 configuration (no_vgg_loss=True): a step lighter than the reference's"},
+           "peak_hbm_GB": peak,
+           "step_frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+           "step_note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D step) + 5*%.2f (D) "
+                        "+ 3*%.1f (VGG19: fake, real, data gradient) = %.1f GFLOP" % (G_FWD_GFLOP, D_PAIR_GFLOP, VGG_FWD_GFLOP, gflop)}
+    if fams:
+        dom = fams[0]
+        out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round((dom["tflops"] or 0.0) / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
+                           "note": "dominant kernel family of the projector step by HIP-event time on the launch stream (one "
+                                   "instrumented step); achieved = the algorithmic conv FLOPs of exactly those launches "
+                                   "(2*M*K*N from the launcher arguments) / their summed duration"}
+        out["kernel_families"] = fams
+    del data
     _free_gpu()
     return out
 
@@ -372,11 +474,25 @@ def leg_joint(args, rank, world, dev, steps, warmup):
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     from emlight_amd.joint import JointTrainer, joint_batch
     B, crop_hw = args.joint_batch, tuple(args.crop_hw)
-    tr = JointTrainer(anchors=args.anchors, crop_hw=crop_hw, blur=args.blur, device=dev, world=world)
+    import warnings
+    from emlight_amd.GenProjector.networks import default_options
     batch = joint_batch(B, dev, args.anchors, crop_hw, seed=1234 + rank)
-    dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
-    value = B * world * steps / dt
-    gflop = (STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0) + PROJECTOR_STEP_GFLOP
+
+    def run(no_vgg):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tr = JointTrainer(default_options(no_vgg_loss=no_vgg), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
+                              device=dev, world=world)
+        dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
+        peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+        del tr
+        _free_gpu()
+        return dt, peak
+    dt, peak = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
+    dt0, _ = run(True)
+    value, value0 = B * world * steps / dt, B * world * steps / dt0
+    enc_gflop = STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
+    gflop = enc_gflop + PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
     tf = gflop * value / world / 1e3
     out = {"metric": "training images/sec (joint step: DenseNet -> SG rasteriser -> SPADE generator + PatchGAN, "
                      "encoder+G step and D step)",
@@ -384,13 +500,17 @@ def leg_joint(args, rank, world, dev, steps, warmup):
            "ms_per_step": round(dt / steps * 1e3, 3),
            "config": {"workload": "joint regression+projector train step, BASELINE configs[3] (256 over 8 GPUs)",
                       "per_gpu_batch": B, "global_batch": B * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
-                      "pano_hw": [128, 256], "ngf": 64, "ndf": 64},
-           "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                      "pano_hw": [128, 256], "ngf": 64, "ndf": 64, "vgg": "VGG19 perceptual term on, seeded random weights"},
+           "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
+                           "frac_of_f32_mfma_peak": round((enc_gflop + PROJECTOR_STEP_GFLOP) * value0 / world / 1e3
+                                                          / F32_MFMA_PEAK_TFLOPS, 4)},
+           "peak_hbm_GB": peak,
            "roofline": {"kernel": "whole step", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "note": "algorithmic conv FLOPs per image = %.1f (encoder train step) + %.1f (projector G+D step) "
-                                "GFLOP" % (STEP_GFLOP_240x320, PROJECTOR_STEP_GFLOP)}}
-    del tr, batch
+                        "note": "algorithmic conv FLOPs per image = %.1f (encoder train step) + %.1f (projector G+D step) + "
+                                "%.1f (VGG19 on fake, real, data gradient) GFLOP; per-kernel figures: the `projector` and "
+                                "regression legs" % (enc_gflop, PROJECTOR_STEP_GFLOP, VGG_STEP_GFLOP)}}
+    del batch
     _free_gpu()
     return out
 

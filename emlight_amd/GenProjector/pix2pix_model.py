@@ -3,9 +3,10 @@
 ``forward(data, mode)`` with ``mode in {'generator', 'discriminator', 'inference'}`` and the data dict keys
 ``input`` (Gaussian map, B,3,128,256), ``crop`` (B,3,128,128), ``warped`` (real HDR panorama), ``map`` (light mask).
 Loss terms as ``pix2pix_model.py:92-141``: hinge GAN, mask-weighted feature matching (x50 off the lights),
-cosine x5, VGG x5.  The VGG term needs torchvision's pretrained VGG19 weights, which cannot be obtained
-offline (parity unpinned); it is included only when ``opt.no_vgg_loss`` is False and a
-``vgg_features`` callable is supplied.
+cosine x5, VGG x5.  The VGG term (``vgg.py``) needs torchvision's pretrained VGG19 weights, which cannot be obtained
+offline (parity of the VALUE unpinned): with ``opt.no_vgg_loss`` False the feature stack is built from
+``opt.vgg_weights`` (a torchvision ``vgg19`` state dict) or, when absent, from seeded random weights -- the step then does
+the reference's work.  A ``vgg_features`` callable may be passed instead.
 """
 import torch
 import torch.nn.functional as F
@@ -19,13 +20,17 @@ class Pix2PixModel(torch.nn.Module):
         self.opt = opt
         self.netG = networks.define_G(opt)
         self.netD = networks.define_D(opt) if opt.isTrain else None
-        self.vgg_features = vgg_features
         if opt.isTrain:
             self.criterionGAN = networks.GANLoss(opt.gan_mode)
             self.criterionFeat = torch.nn.L1Loss()
             if not opt.no_vgg_loss and vgg_features is None:
-                raise RuntimeError("VGG perceptual loss requested but no pretrained VGG19 is available offline "
-                                   "(pass vgg_features=..., or set opt.no_vgg_loss=True)")
+                # the reference always adds the term (pix2pix_model.py:119-120); torchvision's ImageNet weights cannot be
+                # obtained offline, so they are injectable: opt.vgg_weights = path of a torchvision vgg19 state dict,
+                # otherwise a seeded random stack that does the same work (vgg.py)
+                from .vgg import VGG19Features
+                path = getattr(opt, "vgg_weights", None)
+                vgg_features = VGG19Features(torch.load(path, map_location="cpu") if path else None)
+        self.vgg_features = vgg_features
 
     def forward(self, data, mode):
         dev = next(self.netG.parameters()).device
@@ -71,9 +76,8 @@ class Pix2PixModel(torch.nn.Module):
                     feat = feat + self.criterionFeat(wf, wr.detach()) / num_D
             losses["GAN_Feat"] = feat
         if not self.opt.no_vgg_loss:
-            weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
-            xf, yf = self.vgg_features(fake), self.vgg_features(real)
-            losses["VGG"] = sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(weights, xf, yf)) * 5
+            from .vgg import vgg_loss
+            losses["VGG"] = vgg_loss(self.vgg_features, fake, real) * 5
         cos = torch.nn.CosineSimilarity(dim=1, eps=1e-20)
         losses["COS"] = (1 - cos(fake, real)).mean() * 5
         return losses, fake

@@ -62,17 +62,32 @@ class SphereGeometry:
     """Per (H, W, stride, device): the bilinear tap table of the sampling grid and its CSR transpose
     (``eml_sphere_tap_table_f32``; the transpose is what turns grid_sample's atomicAdd backward into a gather)."""
 
-    def __init__(self, h, w, stride, device):
+    def __init__(self, h, w, stride, device, kind="sphere"):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-        grid = sphere_sampling_grid(h, w, stride).to(device).contiguous()
         self.h, self.w = h, w
-        self.ho, self.wo = grid.shape[1] // 3, grid.shape[2] // 3
-        n = self.ho * self.wo * 9
-        self.idx = torch.empty(n, 4, dtype=torch.int32, device=device)
-        self.wgt = torch.empty(n, 4, dtype=torch.float32, device=device)
-        _lib.check(L.eml_sphere_tap_table_f32(p(grid), h, w, self.ho, self.wo, p(self.idx), p(self.wgt), st),
-                   "eml_sphere_tap_table_f32")
+        if kind == "planar":
+            # an ordinary 3x3 convolution with zero padding 1 (the VGG19 feature stack of the perceptual loss,
+            # architecture.py:92-125) as the degenerate case of the same gather: tap (a, b) of output pixel (r, c) is input
+            # pixel (r*stride + a - 1, c*stride + b - 1) with weight 1 on the first corner, nothing on the other three
+            self.ho, self.wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+            n = self.ho * self.wo * 9
+            r = torch.arange(self.ho, device=device).view(-1, 1, 1, 1) * stride + torch.arange(3, device=device).view(1, 1, 3, 1) - 1
+            c = torch.arange(self.wo, device=device).view(1, -1, 1, 1) * stride + torch.arange(3, device=device).view(1, 1, 1, 3) - 1
+            ok = ((r >= 0) & (r < h) & (c >= 0) & (c < w)).reshape(n)
+            src = (r * w + c).reshape(n)
+            self.idx = torch.full((n, 4), -1, dtype=torch.int32, device=device)
+            self.wgt = torch.zeros(n, 4, dtype=torch.float32, device=device)
+            self.idx[:, 0] = torch.where(ok, src, torch.full_like(src, -1)).to(torch.int32)
+            self.wgt[:, 0] = ok.float()
+        else:
+            grid = sphere_sampling_grid(h, w, stride).to(device).contiguous()
+            self.ho, self.wo = grid.shape[1] // 3, grid.shape[2] // 3
+            n = self.ho * self.wo * 9
+            self.idx = torch.empty(n, 4, dtype=torch.int32, device=device)
+            self.wgt = torch.empty(n, 4, dtype=torch.float32, device=device)
+            _lib.check(L.eml_sphere_tap_table_f32(p(grid), h, w, self.ho, self.wo, p(self.idx), p(self.wgt), st),
+                       "eml_sphere_tap_table_f32")
         dst = self.idx.view(-1).long()
         keep = dst >= 0
         src = torch.arange(n, device=device).repeat_interleave(4)[keep]
@@ -117,10 +132,10 @@ class SphereGeometry:
 _GEOMETRY = {}
 
 
-def sphere_geometry(h, w, stride, device):
-    key = (h, w, stride, str(device))
+def sphere_geometry(h, w, stride, device, kind="sphere"):
+    key = (h, w, stride, str(device), kind)
     if key not in _GEOMETRY:
-        _GEOMETRY[key] = SphereGeometry(h, w, stride, device)
+        _GEOMETRY[key] = SphereGeometry(h, w, stride, device, kind)
     return _GEOMETRY[key]
 
 
@@ -146,12 +161,12 @@ class _SphereConvFn(torch.autograd.Function):
         return a9
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride):
+    def forward(ctx, x, weight, bias, stride, kind="sphere"):
         from .. import _lib
         _require_gpu_f32(x, "SphereConv2D input")
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         B, C, H, W = x.shape
-        geo = sphere_geometry(H, W, stride, x.device)
+        geo = sphere_geometry(H, W, stride, x.device, kind)
         po = geo.ho * geo.wo
         xr = x.permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C); a view when x is channels-last
         O = weight.shape[0]
@@ -245,13 +260,19 @@ class _SphereConvFn(torch.autograd.Function):
                     _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
                                                        H * W, po, C, st), "eml_sphere_col2im_f32")
             gx = gxr.permute(0, 3, 1, 2)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def sphere_conv(x, weight, bias, stride=1):
     """``conv2d(grid_sample(x, grid(H, W, stride)), weight, bias, stride=3)`` on the MI355X (the one execution path;
     tests swap this attribute for the oracle's stock-op restatement when they need a CPU run)."""
     return _SphereConvFn.apply(x, weight, bias, stride)
+
+
+def planar_conv3x3(x, weight, bias, stride=1):
+    """``F.conv2d(x, weight, bias, stride, padding=1)`` for a 3x3 kernel through the same gather + f32-MFMA kernels as
+    SphereConv2D (the tap table of an ordinary convolution; used by the VGG19 feature stack of the perceptual loss)."""
+    return _SphereConvFn.apply(x, weight, bias, stride, "planar")
 
 
 def _rows_view(t):

@@ -35,10 +35,15 @@ def main(argv=None):
     ap.add_argument("--print_freq", type=int, default=100, help="in samples, like the reference")
     ap.add_argument("--continue_train", action="store_true", help="resume from <which_epoch>_net_{G,D}.pth and iter.txt")
     ap.add_argument("--which_epoch", default="latest")
+    ap.add_argument("--no_vgg_loss", action="store_true",
+                    help="drop the VGG perceptual term (the reference always adds it, pix2pix_model.py:119-120)")
+    ap.add_argument("--vgg_weights", default=None,
+                    help="torchvision vgg19 state dict (.pth); without it the term runs on seeded random features")
     args = ap.parse_args(argv)
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local
-    opt = networks.default_options(ngf=args.ngf, ndf=args.ndf, lr=args.lr, no_TTUR=args.no_TTUR)
+    opt = networks.default_options(ngf=args.ngf, ndf=args.ndf, lr=args.lr, no_TTUR=args.no_TTUR,
+                                   no_vgg_loss=args.no_vgg_loss, vgg_weights=args.vgg_weights)
     tr = Trainer(opt, device=dev, world=world)
     save_dir = os.path.join(args.checkpoints_dir, args.name)
     if rank == 0:

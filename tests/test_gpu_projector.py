@@ -341,3 +341,92 @@ def test_sphere_conv_properties_at_full_size():
     lhs = float((y1.detach().double() * gy.double()).sum())
     rhs = float((x.detach().double() * gx.double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+# ------------------------------------------------------------------------------------------ VGG19 perceptual term
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", [(2, 3, 64, 16, 32, 1), (2, 64, 64, 32, 64, 1), (1, 128, 256, 16, 32, 1),
+                                                   (32, 64, 128, 64, 128, 1), (2, 64, 64, 17, 30, 2), (1, 512, 512, 8, 16, 1)])
+def test_planar_conv3x3_vs_conv2d(B, Cin, Cout, H, W, stride):
+    """An ordinary zero-padded 3x3 convolution through the SphereConv gather-GEMM kernels (planar tap table) against
+    F.conv2d(padding=1): output, d/dx, d/dweight, d/dbias; unfused (3 input channels, small layers) and fused dispatch."""
+    from emlight_amd.GenProjector.spherenet import planar_conv3x3
+    torch.manual_seed(Cin + Cout)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / np.sqrt(9 * Cin)).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda").requires_grad_(True)
+    x = torch.randn(B, Cin, H, W, device="cuda")
+    xr, xh = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yh = planar_conv3x3(xh, w, b, stride)
+    yr = torch.nn.functional.conv2d(xr, wr, br, stride=stride, padding=1)
+    assert yh.shape == yr.shape
+    gy = torch.randn_like(yr)
+    yh.backward(gy)
+    yr.backward(gy)
+    for name, a, c in [("y", yh.detach(), yr.detach()), ("dx", xh.grad, xr.grad), ("dW", w.grad, wr.grad), ("db", b.grad, br.grad)]:
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c.abs().max()), err_msg=name)
+
+
+def test_vgg19_features_and_loss_vs_stock_ops():
+    """The perceptual term's arithmetic (architecture.py:92-125, loss.py:102-114) with INJECTED weights: a torchvision-style
+    ``vgg19`` state dict (seeded here; the ImageNet one cannot be obtained offline) is loaded into VGG19Features and into a
+    stock nn.Sequential with torchvision's layer indices; the five feature maps, the loss and d loss / d fake agree."""
+    from emlight_amd.GenProjector.vgg import VGG19Features, vgg_loss, _CFG
+    torch.manual_seed(3)
+    layers, sd = {}, {}
+    for item in _CFG:
+        if item != "M":
+            idx, ci, co = item
+            conv = torch.nn.Conv2d(ci, co, 3, padding=1)
+            torch.nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+            torch.nn.init.uniform_(conv.bias, -0.1, 0.1)
+            layers[idx] = conv
+            sd["features.%d.weight" % idx], sd["features.%d.bias" % idx] = conv.weight.detach().clone(), conv.bias.detach().clone()
+    sd["classifier.0.weight"] = torch.zeros(4, 4)          # torchvision's dict also carries the classifier: ignored
+    seq = []
+    for i in range(30):
+        seq.append(layers[i] if i in layers else (torch.nn.MaxPool2d(2, 2) if i in (4, 9, 18, 27) else torch.nn.ReLU()))
+    stock = torch.nn.Sequential(*seq).cuda()
+
+    def stock_feats(x):
+        out = []
+        for i, m in enumerate(stock):
+            x = m(x)
+            if i in (1, 6, 11, 20, 29):
+                out.append(x)
+        return out
+    vgg = VGG19Features(state_dict=sd).cuda()
+    assert vgg.pretrained and not any(q.requires_grad for q in vgg.parameters())
+    B = 2
+    fake = (torch.rand(B, 3, 128, 256, device="cuda") * 3).requires_grad_(True)
+    fake_r = fake.detach().clone().requires_grad_(True)
+    real = torch.rand(B, 3, 128, 256, device="cuda") * 3
+    got, want = vgg(fake), stock_feats(fake_r)
+    assert [tuple(t.shape) for t in got] == [(B, 64, 128, 256), (B, 128, 64, 128), (B, 256, 32, 64), (B, 512, 16, 32), (B, 512, 8, 16)]
+    for a, c in zip(got, want):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c.abs().max()))
+    l_h = vgg_loss(vgg, fake, real) * 5
+    w5 = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+    with torch.no_grad():
+        fr = stock_feats(real)
+    l_r = sum(w * torch.nn.functional.l1_loss(a, c) for w, a, c in zip(w5, stock_feats(fake_r), fr)) * 5
+    np.testing.assert_allclose(float(l_h), float(l_r), rtol=1e-4)
+    l_h.backward()
+    l_r.backward()
+    # L1's sign(.) flips where two f32 evaluations of a feature difference straddle zero: relative L2, not element-wise
+    d = (fake.grad - fake_r.grad).double()
+    assert float(d.norm() / fake_r.grad.double().norm()) < 2e-3
+    with pytest.warns(UserWarning, match="RANDOM features"):
+        VGG19Features()
+
+
+def test_generator_step_includes_the_vgg_term():
+    from emlight_amd.GenProjector import data, networks
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    torch.manual_seed(0)
+    with pytest.warns(UserWarning, match="RANDOM features"):
+        tr = Trainer(networks.default_options(ngf=4, ndf=4, no_vgg_loss=False), device="cuda")
+    tr.step(data.projector_batch(2, "cuda", seed=3))
+    losses = tr.get_latest_losses()
+    assert set(losses) == {"GAN", "GAN_Feat", "VGG", "COS", "D_Fake", "D_real"}
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values()) and float(losses["VGG"]) > 0
+    assert not any("vgg" in k for k in tr.model.netG.state_dict())    # checkpoints hold G and D only, like the reference's

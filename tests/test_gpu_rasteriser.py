@@ -100,8 +100,8 @@ def test_hierarchical_cull_is_bit_identical_to_the_exhaustive_loop(B, n, H, kind
     fast, n_fast = rasterise_raw(*a, pano_hw=(H, 2 * H), count=True)
     full, n_full = rasterise_raw(*a, pano_hw=(H, 2 * H), exhaustive=True, count=True)
     assert torch.equal(fast.view(torch.int32), full.view(torch.int32))   # bit patterns, NaNs included
-    rows = (H + 15) // 16 * 16
-    assert n_full == B * n * rows * 2 * H
+    rows, cols = (H + 15) // 16 * 16, (2 * H + 31) // 32 * 32   # whole 32x16 tiles: edge lanes compute and discard
+    assert n_full == B * n * rows * cols
     assert n_fast <= n_full
     if kind == "anchors":
         assert n_fast < 0.3 * n_full, (n_fast, n_full)
