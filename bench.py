@@ -109,10 +109,15 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
     from emlight_amd import _lib
     L = _lib.lib()
     events = {k: [] for k in FAMILIES}
+    dispatches = {k: 0 for k in FAMILIES}
     orig = {k: getattr(L, k) for k in FAMILIES}
+    # kernel dispatches of the family's MAIN kernel per launcher call: the 1x1 launchers run one dispatch per 48-wide
+    # output chunk (a transition's 108 / 150 / 171 output channels = 3 / 4 / 4 dispatches); Cout is argument 10 / 17
+    chunks = {"eml_dense_conv1x1_fwd_f32": lambda a: (a[10] + 47) // 48,
+              "eml_dense_conv1x1_bwd_weight_f32": lambda a: (a[17] + 47) // 48}
 
     def timed(name):
-        fn = orig[name]
+        fn, nd = orig[name], chunks.get(name)
 
         def call(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -120,6 +125,7 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
             rc = fn(*a)
             e1.record()
             events[name].append((e0, e1))
+            dispatches[name] += nd(a) if nd else 1
             return rc
         return call
     for k in FAMILIES:
@@ -144,8 +150,9 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
     for k, (label, which) in FAMILIES.items():
         ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
         n = len(events[k]) // steps
-        rows.append({"kernel": label, "launches_per_step": n, "ms_per_step": round(ms, 3),
-                     "avg_launch_ms": round(ms / max(n, 1), 4),
+        nd = dispatches[k] // steps
+        rows.append({"kernel": label, "launches_per_step": n, "dispatches_per_step": nd, "ms_per_step": round(ms, 3),
+                     "avg_launch_ms": round(ms / max(n, 1), 4), "avg_dispatch_ms": round(ms / max(nd, 1), 4),
                      "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 and flops[which] else None,
                      "algorithmic_GB_per_step": round(nbytes[k] / 1e9, 2),
                      "algorithmic_GBps": round(nbytes[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
@@ -626,6 +633,14 @@ def main():
                                "traffic": traffic, "traffic_source": source,
                                "algorithmic_bytes_per_launch": round(dom["algorithmic_GB_per_step"] * 1e9 /
                                                                      max(dom["launches_per_step"], 1)),
+                               # like for like with `traffic` (a mean over KERNEL DISPATCHES: a transition's launcher call
+                               # is 3-4 dispatches of the family's kernel)
+                               "algorithmic_bytes_per_dispatch": round(dom["algorithmic_GB_per_step"] * 1e9 /
+                                                                       max(dom["dispatches_per_step"], 1)),
+                               "traffic_over_algorithmic": (round(traffic / (dom["algorithmic_GB_per_step"] * 1e9 /
+                                                                             max(dom["dispatches_per_step"], 1)), 3)
+                                                            if traffic else None),
+                               "dispatches_per_step": dom["dispatches_per_step"],
                                "other_roof_frac": round(min(f_hbm, f_mfma), 4),
                                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
                                "note": "achieved = algorithmic bytes (or conv FLOPs) of the family's launches / their "
