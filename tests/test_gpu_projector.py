@@ -410,11 +410,17 @@ def test_vgg19_features_and_loss_vs_stock_ops():
         fr = stock_feats(real)
     l_r = sum(w * torch.nn.functional.l1_loss(a, c) for w, a, c in zip(w5, stock_feats(fake_r), fr)) * 5
     np.testing.assert_allclose(float(l_h), float(l_r), rtol=1e-4)
+    # the data gradient of the whole stack, first through a LINEAR functional of the five maps (no sign(.) in it: tight) ...
+    proj = [torch.randn_like(c) for c in want]
+    gh, = torch.autograd.grad(sum(w * (a * q).mean() for w, a, q in zip(w5, got, proj)), fake, retain_graph=True)
+    gr, = torch.autograd.grad(sum(w * (c * q).mean() for w, c, q in zip(w5, want, proj)), fake_r, retain_graph=True)
+    assert float((gh - gr).double().norm() / gr.double().norm()) < 3e-3   # ReLU / max-pool ties flip in ~1e-6 of the units
+    # ... then through the L1 loss itself: sign(a - b) flips wherever two f32 evaluations of a feature difference straddle
+    # zero (a fraction f of the elements moves the gradient by ~2 sqrt(f) in relative L2), so: relative L2, loose
     l_h.backward()
     l_r.backward()
-    # L1's sign(.) flips where two f32 evaluations of a feature difference straddle zero: relative L2, not element-wise
     d = (fake.grad - fake_r.grad).double()
-    assert float(d.norm() / fake_r.grad.double().norm()) < 2e-3
+    assert float(d.norm() / fake_r.grad.double().norm()) < 2e-2
     with pytest.warns(UserWarning, match="RANDOM features"):
         VGG19Features()
 
