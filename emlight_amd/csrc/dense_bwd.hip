@@ -943,7 +943,11 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_data_kernel(
 // vectors in LDS, unconditional operand use, DPP row reductions -- 2 waves per SIMD and no exposed round trips.
 // MASKED: the ReLU mask comes from the 16-bit words pool_act_kernel stored (bit 4*sub + g of word [pooled pixel][channel
 // quad]); x, mean, istd are not read and only S1 is accumulated (S2 from the transition conv's weight gradient).
-template <int MT, int NCH, bool ACC /* G += instead of G = */, bool MASKED = false>
+// NJO > 0 (= Ko / 16, round 3): the dz fragments of the tile's 32 pooled pixels (dz = cA*dY + cB*T + cC, Ko channels) are
+// built ONCE per tile and stay in registers across the channel chunks, like the dense-layer pass does -- the streaming
+// form (NJO = 0) re-read the dY and T rows and re-applied the affine for every one of the Kp/32 chunks (7 times per
+// tile at transition 1: 6 KB of L2 -> L1 traffic per pooled pixel against 3.5 KB of output).
+template <int MT, int NCH, bool ACC /* G += instead of G = */, bool MASKED = false, int NJO = 0>
 __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
     const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA,
     const float* __restrict__ cB, const float* __restrict__ cC, int Ko, const float* __restrict__ Wd,
@@ -989,6 +993,25 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
       const int oy = rem / Wo, ox = rem - oy * Wo;
       pin[m] = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;   // top-left input pixel of the pooling window
     }
+    float4 dzr[NJO > 0 ? NJO : 1][MT];
+    if constexpr (NJO > 0) {
+#pragma unroll
+      for (int jo = 0; jo < NJO; ++jo) {
+        const int ch = 16 * jo + 4 * kk;
+        const float4 a4 = *reinterpret_cast<const float4*>(co_l + ch);
+        const float4 b4 = *reinterpret_cast<const float4*>(co_l + Ko + ch);
+        const float4 c4 = *reinterpret_cast<const float4*>(co_l + 2 * Ko + ch);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4 y4 = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
+          const float4 z4 = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+          dzr[jo][m].x = fmaf(a4.x, y4.x, fmaf(b4.x, z4.x, c4.x));
+          dzr[jo][m].y = fmaf(a4.y, y4.y, fmaf(b4.y, z4.y, c4.y));
+          dzr[jo][m].z = fmaf(a4.z, y4.z, fmaf(b4.z, z4.z, c4.z));
+          dzr[jo][m].w = fmaf(a4.w, y4.w, fmaf(b4.w, z4.w, c4.w));
+        }
+      }
+    }
     for (int nt0 = 0; nt0 < nnt; nt0 += NCH) {
       // the chunk's x quads (and old G when accumulating): requested now, consumed after the MFMAs
       float4 xv[MASKED ? 1 : MT][MASKED ? 1 : NCH][4], gs[ACC ? MT : 1][ACC ? NCH : 1][4];
@@ -1016,10 +1039,12 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
       float4 ry[MT], rz[MT], wq[NCH];
       auto load_group = [&](int jo) {
         const int ch = 16 * jo + 4 * kk;
+        if constexpr (NJO == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          ry[m] = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
-          rz[m] = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+          for (int m = 0; m < MT; ++m) {
+            ry[m] = *reinterpret_cast<const float4*>(DY + prow[m] * ld_dy + ch);
+            rz[m] = *reinterpret_cast<const float4*>(Zr + prow[m] * ld_z + ch);
+          }
         }
 #pragma unroll
         for (int n = 0; n < NCH; ++n) {
@@ -1028,19 +1053,8 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
         }
       };
       load_group(0);
-      for (int jo = 0; jo < njo; ++jo) {
-        const int ch = 16 * jo + 4 * kk;
-        const float4 a4 = *reinterpret_cast<const float4*>(co_l + ch);
-        const float4 b4 = *reinterpret_cast<const float4*>(co_l + Ko + ch);
-        const float4 c4 = *reinterpret_cast<const float4*>(co_l + 2 * Ko + ch);
-        float4 dz[MT], wc[NCH];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          dz[m].x = fmaf(a4.x, ry[m].x, fmaf(b4.x, rz[m].x, c4.x));
-          dz[m].y = fmaf(a4.y, ry[m].y, fmaf(b4.y, rz[m].y, c4.y));
-          dz[m].z = fmaf(a4.z, ry[m].z, fmaf(b4.z, rz[m].z, c4.z));
-          dz[m].w = fmaf(a4.w, ry[m].w, fmaf(b4.w, rz[m].w, c4.w));
-        }
+      auto group_step = [&](int jo, const float4 (&dz)[MT]) {
+        float4 wc[NCH];
 #pragma unroll
         for (int n = 0; n < NCH; ++n) wc[n] = wq[n];
         load_group(min(jo + 1, njo - 1));
@@ -1051,6 +1065,26 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
           for (int n = 0; n < NCH; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][n] = mfma16(f4c(wc[n], t), f4c(dz[m], t), acc[m][n]);
+      };
+      if constexpr (NJO > 0) {
+#pragma unroll
+        for (int jo = 0; jo < NJO; ++jo) group_step(jo, dzr[jo]);
+      } else {
+        for (int jo = 0; jo < njo; ++jo) {
+          const int ch = 16 * jo + 4 * kk;
+          const float4 a4 = *reinterpret_cast<const float4*>(co_l + ch);
+          const float4 b4 = *reinterpret_cast<const float4*>(co_l + Ko + ch);
+          const float4 c4 = *reinterpret_cast<const float4*>(co_l + 2 * Ko + ch);
+          float4 dz[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            dz[m].x = fmaf(a4.x, ry[m].x, fmaf(b4.x, rz[m].x, c4.x));
+            dz[m].y = fmaf(a4.y, ry[m].y, fmaf(b4.y, rz[m].y, c4.y));
+            dz[m].z = fmaf(a4.z, ry[m].z, fmaf(b4.z, rz[m].z, c4.z));
+            dz[m].w = fmaf(a4.w, ry[m].w, fmaf(b4.w, rz[m].w, c4.w));
+          }
+          group_step(jo, dz);
+        }
       }
       // epilogue: lane owns channels k4..k4+3 of the 4 input pixels under each of its MT pooled pixels
 #pragma unroll
@@ -1800,12 +1834,25 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
                        (hipStream_t)stream, DY, ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, \
                        (int)P, Hin, Win, Kp, G, ldg, partials, relu_mask16);                                           \
   } while (0)
-      if (relu_mask16) {
+      // EMLight's three transitions (108 / 150 / 171 output channels: Ko = 112 / 160 / 176) with the forward's ReLU bits:
+      // dz fragments resident in registers for the tile (NJO = Ko / 16)
+#define EML_LAUNCH_TRANSITION_RES(NJOV)                                                                                \
+  do {                                                                                                                \
+    EML_ENSURE_LDS((&transition_bwd_data_kernel<2, 2, false, true, NJOV>), lds_t);                                     \
+    hipLaunchKernelGGL((transition_bwd_data_kernel<2, 2, false, true, NJOV>), dim3(grid), dim3(256), lds_t,            \
+                       (hipStream_t)stream, DY, ld_dy, Zr, ld_z, cA, cB, cC, Ko, Wd, X, ldx, scale1, shift1, mean, istd, \
+                       (int)P, Hin, Win, Kp, G, ldg, partials, relu_mask16);                                           \
+  } while (0)
+      if (relu_mask16 && !accumulate && Ko == 112) EML_LAUNCH_TRANSITION_RES(7);
+      else if (relu_mask16 && !accumulate && Ko == 160) EML_LAUNCH_TRANSITION_RES(10);
+      else if (relu_mask16 && !accumulate && Ko == 176) EML_LAUNCH_TRANSITION_RES(11);
+      else if (relu_mask16) {
         if (accumulate) EML_LAUNCH_TRANSITION(true, true); else EML_LAUNCH_TRANSITION(false, true);
       } else {
         if (accumulate) EML_LAUNCH_TRANSITION(true, false); else EML_LAUNCH_TRANSITION(false, false);
       }
 #undef EML_LAUNCH_TRANSITION
+#undef EML_LAUNCH_TRANSITION_RES
     }
   } else {
     if (Ko == 48) EML_LAUNCH_BWD_DATA(false, true, 2); else EML_LAUNCH_BWD_DATA(false, false, 4);
