@@ -74,6 +74,19 @@ class _BwdBuffers:
         self.part2 = torch.zeros(2, g * kp * 2, dtype=torch.float64, device=dev)
         # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
         self.partW = torch.empty(g * max(kp * 48, 2 * 27 * 256, 4 * 1024), **f32)
+        # BN1 / transition-norm dgamma: channels whose weight-gradient identity is ill-conditioned (small |gamma|) are flagged
+        # by the finalize kernel and recomputed directly (eml_dense_bn_dgamma_direct_f32).  The fallback launches are
+        # skipped while the previous backward reported no flagged channel (a 4-byte async copy per step, no host sync).
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cond = [[torch.zeros(lay["Kp"], **i32) for lay in blk["layers"]] for blk in ws.blocks]
+        self.condT = [torch.zeros(blk["trans"]["Kp"], **i32) for blk in ws.blocks]
+        self.any_ill = torch.zeros(1, **i32)
+        self.ill_host = torch.zeros(1, dtype=torch.int32)
+        if torch.device(dev).type == "cuda":
+            self.ill_host = self.ill_host.pin_memory()
+        self.ill_event, self.ill_known = None, False
+        self.dg_grid = 128
+        self.dg_scratch = torch.empty(self.dg_grid * kp, dtype=torch.float64, device=dev)
         # side stream of the conv3x3 weight gradients (nothing downstream waits for dW2): own partial buffers per slot
         self.side = None
         if enc.overlap_wgrad(dev):
@@ -147,7 +160,27 @@ def _run_backward(enc, ws, x, gpooled):
     cA, cB, cC = coefs[0]
     sB, sC = bw.coef[6], bw.coef[7]
 
-    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=0, s_acc=None, src=None, c_lo=0, c_hi=None, conv=None):
+    # ---- ill-conditioned dgamma channels: launch the direct recomputation unless the previous backward saw none
+    mode = os.environ.get("EML_DGAMMA_DIRECT", "auto")
+    if mode == "never":
+        direct = False
+    elif mode == "always" or not bw.ill_known or bw.ill_event is None:
+        direct = True
+    else:
+        direct = not (bw.ill_event.query() and int(bw.ill_host[0]) == 0)
+    bw.any_ill.zero_()
+
+    def dgamma_direct(blk, X_ld, Pin, Hin, Win, pool, DY, ld_dy, Zr, ld_z, co, Cout, conv, Cin, scale1, shift1, cond, bn):
+        if not direct:
+            return
+        a, b, c = co if co is not None else (None, None, None)
+        _lib.check(L.eml_dense_bn_dgamma_direct_f32(
+            p(blk["X"]), X_ld, Pin, Hin, Win, pool, p(DY), ld_dy, p(Zr), ld_z, p(a), p(b), p(c), Cout, p(conv.weight), Cin,
+            p(scale1), p(shift1), p(blk["mean"]), p(blk["istd"]), p(cond), p(bw.dg_scratch), gr(bn.weight), bw.dg_grid, st),
+            "eml_dense_bn_dgamma_direct_f32")
+
+    def finalize(R, pstride, count, bn, mean, istd, C, Cpad, coef=0, s_acc=None, src=None, c_lo=0, c_hi=None, conv=None,
+                 cond=None):
         """dgamma/dbeta of `bn` for channels [c_lo, c_hi); coef: write the dz affine into coefficient set
         `coef` (None: skip); s_acc: fold (cB,cC) into sB/sC (True: add, False: overwrite).
         conv: the 1x1 conv that follows bn + ReLU -- S2 then comes from its finished weight gradient
@@ -158,7 +191,8 @@ def _run_backward(enc, ws, x, gpooled):
             p(part if src is None else src), R, pstride, float(count), p(bn.weight), p(mean), p(istd), C, Cpad, 1,
             gr(bn.weight), gr(bn.bias), p(a), p(b), p(c),
             p(sB) if s_acc is not None else None, p(sC) if s_acc is not None else None, int(bool(s_acc)),
-            c_lo, Cpad if c_hi is None else c_hi, *wargs, st), "eml_dense_bn_bwd_finalize_f32")
+            c_lo, Cpad if c_hi is None else c_hi, *wargs, p(cond), p(bw.any_ill) if cond is not None else None, st),
+            "eml_dense_bn_bwd_finalize_f32")
 
     def parr(tensors):
         return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -196,7 +230,10 @@ def _run_backward(enc, ws, x, gpooled):
             p(dY), ld_dy, p(tr["T"]), Ko, p(cA), p(cB), p(cC), Ko, p(bw.WdT[bi]), None, ld, p(tr["scale"]),
             p(tr["shift"]), None, None, Pn, Hb, Wb, 1, kpt, p(Gbuf), ld, 0, p(part), G, p(tr["mask16"]), st),
             "eml_dense_conv1x1_bwd_data_f32")   # ReLU mask from pool_act's bits: X is not read
-        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False, conv=T.conv)
+        finalize(G, 2 * kpt, P, T.norm, blk["mean"], blk["istd"], ctot, kpt, coef=None, s_acc=False, conv=T.conv,
+                 cond=bw.condT[bi])
+        dgamma_direct(blk, ld, P, Hb, Wb, 1, dY, ld_dy, tr["T"], Ko, coefs[0], cout, T.conv, ctot, tr["scale"], tr["shift"],
+                      bw.condT[bi], T.norm)   # before the dense layers reuse coefficient set 0
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
         def conv2_backward(l, slot, n12=False, narrow_lo=None):
@@ -258,7 +295,13 @@ def _run_backward(enc, ws, x, gpooled):
         def bn1_finalize(l, Lm, slot, c_lo, c_hi):
             lay = blk["layers"][l]
             finalize(G, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,
-                     s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi, conv=Lm.conv1)
+                     s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi, conv=Lm.conv1, cond=bw.cond[bi][l])
+
+        def bn1_direct(l, Lm, slot):
+            """after the layer's last bn1_finalize, while DZ[slot] still holds its materialised dz"""
+            lay = blk["layers"][l]
+            dgamma_direct(blk, ld, P, Hb, Wb, 0, bw.DZ[slot], 48, None, 0, None, 48, Lm.conv1, lay["Cin"], lay["scale1"],
+                          lay["shift1"], bw.cond[bi][l], Lm.norm1)
 
         l = len(blk["layers"]) - 1
         while l >= 0:
@@ -271,11 +314,14 @@ def _run_backward(enc, ws, x, gpooled):
                 dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once
                 bn1_finalize(la, Lma, 0, 0, cin_b)
                 bn1_finalize(lb, Lmb, 1, 0, blk["layers"][lb]["Kp"])
+                bn1_direct(la, Lma, 0)
+                bn1_direct(lb, Lmb, 1)
                 l -= 2
             else:
                 Lm0 = conv2_backward(l, 0)
                 dgrad([l], [0], 0, blk["layers"][l]["Cin"])
                 bn1_finalize(l, Lm0, 0, 0, blk["layers"][l]["Kp"])
+                bn1_direct(l, Lm0, 0)
                 l -= 1
         c0b = blk["C0"]
         materialize(Gbuf, blk, 0, c0b)  # block input channels: every layer has contributed
@@ -289,6 +335,12 @@ def _run_backward(enc, ws, x, gpooled):
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")
+    if dev.type == "cuda":   # tell the NEXT backward whether any channel was flagged (no sync: read one step later)
+        bw.ill_host.copy_(bw.any_ill, non_blocking=True)
+        if bw.ill_event is None:
+            bw.ill_event = torch.cuda.Event()
+        bw.ill_event.record()
+        bw.ill_known = True
     if bw.side is not None:
         main.wait_stream(bw.side)   # every dW2 is complete before the gradients leave
     return [grads[id(q)] for q in params]

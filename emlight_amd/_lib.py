@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 9   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 10   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -82,7 +82,10 @@ SIGNATURES = {
                                                 _f32p, _int, _stream]),
     "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,
                                              _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
-                                             _f32p, _f32p, _f32p, _int, _stream]),
+                                             _f32p, _f32p, _f32p, _int, _i32p, _i32p, _stream]),
+    "eml_dense_bn_dgamma_direct_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _f32p, _int, _f32p, _int,
+                                              _f32p, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p, _i32p,
+                                              _f32p, _f32p, _int, _stream]),
     "eml_dense_conv1x1_bwd_weight_f32": (_int, [_f32p, _int, ctypes.c_long, _int, _int, _int, _int, _int, _f32p,
                                                 _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p,
                                                 _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _stream]),

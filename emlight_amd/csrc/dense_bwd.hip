@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ mean, const float* __restrict__ istd, int C, int Cpad, int training,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
     float* __restrict__ cC, float* __restrict__ sB, float* __restrict__ sC, int s_accumulate, int c_lo, int c_hi,
-    const float* __restrict__ beta, const float* __restrict__ Wc, const float* __restrict__ dWc, int w_rows) {
+    const float* __restrict__ beta, const float* __restrict__ Wc, const float* __restrict__ dWc, int w_rows,
+    int* __restrict__ cond /* [C] or NULL */, int* __restrict__ any_cond /* 1 int or NULL */) {
   // one wavefront per channel; lanes stride over the R partial rows; only channels [c_lo, c_hi) are touched
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = c_lo + blockIdx.x * 4 + wave;
@@ -420,8 +421,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     }
     if (Wc) {
       // |gamma| below 1e-12: bn(x) carries no xhat at f32 resolution and the quotient would only amplify rounding noise
-      const double ga0 = gamma[c];
-      S2 = fabs(ga0) >= 1e-12 ? (Q - (double)beta[c] * S1) / ga0 : 0.0;
+      const double ga0 = gamma[c], bs = (double)beta[c] * S1, num = Q - bs;
+      S2 = fabs(ga0) >= 1e-12 ? num / ga0 : 0.0;
+      // Conditioning of the quotient: Q and beta*S1 come from f32 sums (relative error ~1e-6 each); when they cancel to
+      // less than 1e-3 of their magnitude (small |gamma| -- routine in trained DenseNets) fewer than ~3 digits of
+      // dgamma = S2 survive.  Such channels are FLAGGED; eml_dense_bn_dgamma_direct_f32 then recomputes their S2 as the
+      // direct f64 sum of dy * xhat (the coefficients cB, cC below only need gamma * S2 = num, which is well conditioned
+      // in absolute terms, so they keep the value derived here).
+      if (cond && lane == 0) {
+        const int ill = !(fabs(num) > 1e-3 * (fabs(Q) + fabs(bs))) && (fabs(Q) + fabs(bs)) > 0.0;
+        cond[c] = ill;
+        if (ill && any_cond) *any_cond = 1;   // benign race: every writer stores 1
+      }
     }
     if (lane == 0) {
       dgamma[c] = (float)S2;
@@ -1695,6 +1706,79 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
 
 }  // namespace
 
+// =============================================================================== BN1 dgamma, direct (ill-conditioned channels)
+// For the channels bn_bwd_finalize_kernel flagged: S2[c] = sum_p dy[p][c] * xhat[p][c] accumulated per element in f64, with
+// dy = relu-mask * (sum_o W[o][c] dz[p][o]) (pool: the pooled pixel's dz spread over its 2x2 window, / 4) -- the definition
+// the x-free passes replaced by the weight-gradient identity.  A rare path (no flag: both kernels return at once): one
+// flagged channel at a time, every thread striding over the block's pixel range; partial [grid][Cin] doubles.
+__global__ __launch_bounds__(256) void bn_dgamma_direct_partial_kernel(
+    const float* __restrict__ X, int ldx, long P, int Hin, int Win, int pool, const float* __restrict__ DY, int ld_dy,
+    const float* __restrict__ Zr, int ld_z, const float* __restrict__ cA, const float* __restrict__ cB,
+    const float* __restrict__ cC, int Cout, const float* __restrict__ W, int Cin, const float* __restrict__ scale1,
+    const float* __restrict__ shift1, const float* __restrict__ mean, const float* __restrict__ istd,
+    const int* __restrict__ cond, double* __restrict__ partial) {
+  __shared__ int list[384];
+  __shared__ int cnt;
+  __shared__ float wcol[192], co[3][192];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  for (int c = tid; c < Cin; c += 256)
+    if (cond[c]) list[atomicAdd(&cnt, 1)] = c;   // order irrelevant: every channel's sum is its own
+  __syncthreads();
+  const int n = cnt;
+  if (n == 0) return;
+  for (int o = tid; o < Cout; o += 256) {
+    co[0][o] = Zr ? cA[o] : 1.f;
+    co[1][o] = Zr ? cB[o] : 0.f;
+    co[2][o] = Zr ? cC[o] : 0.f;
+  }
+  const long per = (P + gridDim.x - 1) / gridDim.x, p_lo = (long)blockIdx.x * per, p_hi = min(P, p_lo + per);
+  const int Ho = Hin >> 1, Wo = Win >> 1;
+  for (int li = 0; li < n; ++li) {
+    const int c = list[li];
+    __syncthreads();
+    for (int o = tid; o < Cout; o += 256) wcol[o] = W[(size_t)o * Cin + c];
+    __syncthreads();
+    const float s1 = scale1[c], t1 = shift1[c];
+    const double mu = mean[c], is = istd[c];
+    double acc = 0.0;
+    for (long p = p_lo + tid; p < p_hi; p += 256) {
+      const float x = X[(size_t)p * ldx + c];
+      if (fmaf(x, s1, t1) > 0.f) {
+        long pp = p;
+        if (pool) {
+          const long b = p / ((long)Hin * Win), rem = p - b * (long)Hin * Win;
+          const int y = (int)(rem / Win), xx = (int)(rem - (long)y * Win);
+          pp = (b * Ho + (y >> 1)) * Wo + (xx >> 1);
+        }
+        const float* dy = DY + (size_t)pp * ld_dy;
+        const float* zr = Zr ? Zr + (size_t)pp * ld_z : dy;
+        double d = 0.0;
+        for (int o = 0; o < Cout; ++o) d += (double)wcol[o] * (double)fmaf(co[0][o], dy[o], fmaf(co[1][o], zr[o], co[2][o]));
+        if (pool) d *= 0.25;
+        acc += d * (((double)x - mu) * is);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_d(acc, o);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)blockIdx.x * Cin + c] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_dgamma_direct_reduce_kernel(const double* __restrict__ partial, int R, int Cin,
+                                                                      const int* __restrict__ cond,
+                                                                      float* __restrict__ dgamma) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cin || !cond[c]) return;
+  double s = 0.0;
+  for (int g = 0; g < R; ++g) s += partial[(size_t)g * Cin + c];
+  dgamma[c] = (float)s;
+}
+
 // =============================================================================== C ABI
 extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                               const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
@@ -1737,7 +1821,7 @@ extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int 
                                              int training, float* dgamma, float* dbeta, float* cA, float* cB,
                                              float* cC, float* sB, float* sC, int s_accumulate, int c_lo,
                                              int c_hi, const float* beta, const float* W, const float* dW, int w_rows,
-                                             eml_stream_t stream) {
+                                             int* cond, int* any_cond, eml_stream_t stream) {
   if (!partials || !gamma || !mean || !istd || !dgamma || !dbeta || C < 1 || Cpad < C || R < 1 ||
       (cA && (!cB || !cC)) || (sB && !sC) || c_lo < 0 || c_hi <= c_lo)
     return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_finalize_f32: bad arguments");
@@ -1746,8 +1830,26 @@ extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int 
   if (c_hi > Cpad) c_hi = Cpad;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c_hi - c_lo + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials,
                      R, pstride, count, gamma, mean, istd, C, Cpad, training, dgamma, dbeta, cA, cB, cC, sB, sC,
-                     s_accumulate, c_lo, c_hi, beta, W, dW, w_rows);
+                     s_accumulate, c_lo, c_hi, beta, W, dW, w_rows, W ? cond : nullptr, W ? any_cond : nullptr);
   return eml::check_launch("eml_dense_bn_bwd_finalize_f32");
+}
+
+extern "C" int eml_dense_bn_dgamma_direct_f32(const float* X, int ldx, long P, int Hin, int Win, int pool, const float* DY,
+                                              int ld_dy, const float* Zr, int ld_z, const float* cA, const float* cB,
+                                              const float* cC, int Cout, const float* W, int Cin, const float* scale1,
+                                              const float* shift1, const float* mean, const float* istd, const int* cond,
+                                              double* scratch, float* dgamma, int grid, eml_stream_t stream) {
+  if (!X || !DY || !W || !scale1 || !shift1 || !mean || !istd || !cond || !scratch || !dgamma || P < 1 || grid < 1 ||
+      Cin < 1 || Cin > 384 || Cout < 1 || Cout > 192 || Cin > ldx || Cout > ld_dy || (Zr && (!cA || !cB || !cC || Cout > ld_z)) ||
+      (pool && ((Hin | Win) & 1)))
+    return eml::fail(EML_EINVAL, "eml_dense_bn_dgamma_direct_f32: bad arguments (Cin <= 384, Cout <= 192, even maps when pooled)");
+  hipLaunchKernelGGL(bn_dgamma_direct_partial_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx, P, Hin, Win,
+                     pool, DY, ld_dy, Zr, ld_z, cA, cB, cC, Cout, W, Cin, scale1, shift1, mean, istd, cond, scratch);
+  int rc = eml::check_launch("eml_dense_bn_dgamma_direct_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_dgamma_direct_reduce_kernel, dim3((Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch,
+                     grid, Cin, cond, dgamma);
+  return eml::check_launch("eml_dense_bn_dgamma_direct_f32(reduce)");
 }
 
 // partial: [grid*2][Kp][48] floats of scratch; dW: [Cout][Cin] (PyTorch layout), all chunks.

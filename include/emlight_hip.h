@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 9
+#define EML_ABI_VERSION 10
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -224,13 +224,29 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
  * partials but derived from the conv's finished weight gradient dW -- with a = relu(bn(x)) and dy = mask * (W^T dz),
  * sum_p dy*bn(x) = sum_o W[o][c]*dW[o][c], and bn(x) = gamma*xhat + beta, so
  * S2 = (sum_o W[o][c]*dW[o][c] - beta[c]*S1) / gamma[c]  (|gamma[c]| < 1e-12: S2 = 0).  The data-gradient pass then
- * needs no x at all (eml_dense_conv1x1_bwd_data_multi_f32 with relu_masks). */
+ * needs no x at all (eml_dense_conv1x1_bwd_data_multi_f32 with relu_masks).
+ * cond (C ints, may be NULL; W != NULL only): cond[c] = 1 where the two f32-derived terms cancel to less than 1e-3 of
+ * their magnitude (small |gamma|: fewer than ~3 digits of dgamma survive the quotient), else 0; *any_cond (may be NULL)
+ * is set to 1 if any channel was flagged.  eml_dense_bn_dgamma_direct_f32 recomputes the flagged channels. */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
                                   int Cpad, int training, float* dgamma, float* dbeta, float* cA,
                                   float* cB, float* cC, float* sB, float* sC, int s_accumulate,
                                   int c_lo, int c_hi, const float* beta, const float* W, const float* dW,
-                                  int w_rows, eml_stream_t stream);
+                                  int w_rows, int* cond, int* any_cond, eml_stream_t stream);
+
+/* dgamma of the channels flagged in cond, from the definition: dgamma[c] = sum_p dy[p][c] * xhat[p][c] accumulated per
+ * element in f64, dy = relu-mask(scale1*X + shift1) * sum_o W[o][c] dz[p][o], dz = cA*DY + cB*Zr + cC (Zr == NULL: DY
+ * already holds dz), pool != 0: dz lives on the 2x2-pooled grid and is spread over the window (/4) -- the BatchNorm
+ * backward of nn.BatchNorm2d before a ReLU + 1x1 conv (DenseNet.py:29-37, :17-20) without the weight-gradient identity.
+ * Unflagged channels are not touched; with no flag at all both kernels return immediately.  P = input pixels,
+ * W (Cout, Cin), Cin <= 384, Cout <= 192, scratch = grid*Cin doubles. */
+int eml_dense_bn_dgamma_direct_f32(const float* X, int ldx, long P, int Hin, int Win, int pool,
+                                   const float* DY, int ld_dy, const float* Zr, int ld_z, const float* cA,
+                                   const float* cB, const float* cC, int Cout, const float* W, int Cin,
+                                   const float* scale1, const float* shift1, const float* mean,
+                                   const float* istd, const int* cond, double* scratch, float* dgamma,
+                                   int grid, eml_stream_t stream);
 
 /* dW (Cout,Cin) = sum_p dz[p] (x) relu(scale1*X[p] + shift1) with dz = cA*DY + cB*Zr + cC rebuilt
  * in the operand load (pool != 0: transition, 2x2 mean of the activation).

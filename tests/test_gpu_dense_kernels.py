@@ -303,7 +303,7 @@ def test_bn_bwd_finalize(lib):
     cA, cB, cC = (torch.full((Cpad,), 3.0, device=DEV) for _ in range(3))
     sB, sC = torch.ones(Cpad, device=DEV), torch.ones(Cpad, device=DEV)
     lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg), p(db),
-                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, 0, Cpad, None, None, None, 0, st), "finalize")
+                                              p(cA), p(cB), p(cC), p(sB), p(sC), 1, 0, Cpad, None, None, None, 0, None, None, st), "finalize")
     S = part.view(R, C, 2).sum(0)
     S1, S2 = S[:, 0], S[:, 1]
     ga, is_, mu = gamma.double(), istd.double(), mean.double()
@@ -318,7 +318,7 @@ def test_bn_bwd_finalize(lib):
     cA2, sB2 = torch.full((Cpad,), 3.0, device=DEV), torch.ones(Cpad, device=DEV)
     dg2 = torch.full((C,), 7.0, device=DEV)
     lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), R, 2 * C, n, p(gamma), p(mean), p(istd), C, Cpad, 1, p(dg2), p(db),
-                                              p(cA2), p(cB), p(cC), p(sB2), p(sC), 1, 40, 52, None, None, None, 0, st),
+                                              p(cA2), p(cB), p(cC), p(sB2), p(sC), 1, 40, 52, None, None, None, 0, None, None, st),
               "finalize range")
     close(dg2[40:52], S2[40:52], what="dgamma range")
     assert bool((dg2[:40] == 7.0).all()) and bool((dg2[52:] == 7.0).all())
@@ -434,7 +434,7 @@ def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
             dg, db = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
             lib.check(L.eml_dense_bn_bwd_finalize_f32(p(part), G, 2 * Kp, float(Pin), p(gamma), p(mean), p(istd), Cin, Kp, 1,
                                                       p(dg), p(db), None, None, None, None, None, 0, 0, Kp, p(beta), p(Wt),
-                                                      p(dW), Cout, st), "finalize from dW")
+                                                      p(dW), Cout, None, None, st), "finalize from dW")
             S2w = (dam * xh).sum(0)
             close(dg, S2w, what="dgamma from dW (transition)", rtol=5e-4, atol=5e-5 * max(float(S2w.abs().max()), 1.0))
     if not (pool and Cout != 48):
@@ -656,7 +656,7 @@ def test_conv1x1_bwd_masked_pass_and_bn1_from_weight_gradient(lib, Cin_a, B, H, 
         dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         lib.check(L.eml_dense_bn_bwd_finalize_f32(p(y["part"]), G, 2 * Kp, n, p(y["gamma"]), p(mean), p(istd), C, Kp, 1, p(dg),
                                                   p(db), None, None, None, None, None, 0, 0, Cin_b, p(y["beta"]), p(y["W"]),
-                                                  p(y["dW"]), 48, st), "finalize from dW")
+                                                  p(y["dW"]), 48, None, None, st), "finalize from dW")
         S2 = (y["dam"][:, :Cin_b] * xh[:, :Cin_b]).sum(0)
         scale = float(S2.abs().max())
         close(dg[:Cin_b], S2, what="dgamma from the weight gradient", rtol=2e-4, atol=2e-5 * max(scale, 1.0))
