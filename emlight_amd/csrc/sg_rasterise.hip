@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
     rr = sqrtf(eml::wave_max_dpp(d2)) * 1.0001f + 1e-6f;
   }
 
-  float ar0 = 0.f, ag0 = 0.f, ab0 = 0.f, ar1 = 0.f, ag1 = 0.f, ab1 = 0.f;
+  // the lane's two pixels travel as register pairs: every step of the lobe evaluation is ONE packed instruction
+  // (v_pk_mul / v_pk_fma / v_pk_add_f32) for both -- component-wise IEEE fma, bit-identical to the scalar chain
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f px = v2f{p0x, p1x}, py = v2f{p0y, p1y}, pz = v2f{p0z, p1z};
+  v2f ar = v2f{0.f, 0.f}, ag = ar, ab = ar;
   unsigned long long n_exec = 0;
   for (int base = 0; base < N; base += kChunk) {
     const int cnt = min(kChunk, N - base);
@@ -119,15 +123,13 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
 #pragma unroll 2
     for (int i = 0; i < n; ++i) {
       const Lobe L = src[i];  // same address on every lane: LDS broadcast
-      const float t0 = (fmaf(L.dz, p0z, fmaf(L.dy, p0y, L.dx * p0x)) - 1.0f) * L.k2;
-      const float t1 = (fmaf(L.dz, p1z, fmaf(L.dy, p1y, L.dx * p1x)) - 1.0f) * L.k2;
-      const float e0 = __builtin_amdgcn_exp2f(t0), e1 = __builtin_amdgcn_exp2f(t1);
-      ar0 = fmaf(L.r, e0, ar0);
-      ag0 = fmaf(L.g, e0, ag0);
-      ab0 = fmaf(L.b, e0, ab0);
-      ar1 = fmaf(L.r, e1, ar1);
-      ag1 = fmaf(L.g, e1, ag1);
-      ab1 = fmaf(L.b, e1, ab1);
+      const v2f dx = v2f{L.dx, L.dx}, dy = v2f{L.dy, L.dy}, dz = v2f{L.dz, L.dz}, k2 = v2f{L.k2, L.k2};
+      const v2f dot = __builtin_elementwise_fma(dz, pz, __builtin_elementwise_fma(dy, py, dx * px));
+      const v2f t = (dot - v2f{1.0f, 1.0f}) * k2;
+      const v2f e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+      ar = __builtin_elementwise_fma(v2f{L.r, L.r}, e, ar);
+      ag = __builtin_elementwise_fma(v2f{L.g, L.g}, e, ag);
+      ab = __builtin_elementwise_fma(v2f{L.b, L.b}, e, ab);
     }
   }
   if (kCount && lane == 0 && executed) atomicAdd(executed, n_exec);
@@ -135,15 +137,15 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
   if (w < W) {
     if (h0 < H) {
       float* o = out + (size_t)b * 3 * plane + (size_t)h0 * W + w;
-      o[0] = ar0;
-      o[plane] = ag0;
-      o[2 * plane] = ab0;
+      o[0] = ar.x;
+      o[plane] = ag.x;
+      o[2 * plane] = ab.x;
     }
     if (h1 < H) {
       float* o = out + (size_t)b * 3 * plane + (size_t)h1 * W + w;
-      o[0] = ar1;
-      o[plane] = ag1;
-      o[2 * plane] = ab1;
+      o[0] = ar.y;
+      o[plane] = ag.y;
+      o[2 * plane] = ab.y;
     }
   }
 }
