@@ -225,9 +225,10 @@ int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const floa
  * sum_p dy*bn(x) = sum_o W[o][c]*dW[o][c], and bn(x) = gamma*xhat + beta, so
  * S2 = (sum_o W[o][c]*dW[o][c] - beta[c]*S1) / gamma[c]  (|gamma[c]| < 1e-12: S2 = 0).  The data-gradient pass then
  * needs no x at all (eml_dense_conv1x1_bwd_data_multi_f32 with relu_masks).
- * cond (C ints, may be NULL; W != NULL only): cond[c] = 1 where the two f32-derived terms cancel to less than 1e-3 of
- * their magnitude (small |gamma|: fewer than ~3 digits of dgamma survive the quotient), else 0; *any_cond (may be NULL)
- * is set to 1 if any channel was flagged.  eml_dense_bn_dgamma_direct_f32 recomputes the flagged channels. */
+ * cond (C ints, may be NULL; W != NULL only): cond[c] = 1 where |gamma[c]| < 1e-3 * |beta[c]| or gamma[c] == 0 -- the
+ * quotient then amplifies the f32 summation noise of the shared beta * sum dy term to more than ~0.1 % of dgamma -- else
+ * 0; *any_cond (may be NULL) is set to 1 if any channel was flagged.  eml_dense_bn_dgamma_direct_f32 recomputes the
+ * flagged channels. */
 int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
                                   const float* gamma, const float* mean, const float* istd, int C,
                                   int Cpad, int training, float* dgamma, float* dbeta, float* cA,
