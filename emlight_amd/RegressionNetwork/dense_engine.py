@@ -300,6 +300,7 @@ class HipDenseEncoder:
         ws = self.workspace(B, H, W, dev, keep_all)
         G = self._grid(dev)
         G3 = self._grid3(dev)
+        Gf = self._tuned("EML_GRID_FWD1", G)   # per-family knob for A/B runs (default: the common 2 x #CU)
         Gb = min(self.grid_max, 4 * (self._cu or 256))
         training = m.training
         part = ws.partials
@@ -338,10 +339,10 @@ class HipDenseEncoder:
                 self._prepare(L, st, part if pending else None, G3, 32, 12, cin - 12, P, blk["mean"], blk["var"],
                               blk["istd"], Lm.norm1, cin, kp, training, lay["scale1"], lay["shift1"])
                 _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, P, Hb, Wb, 0, kp, p(lay["scale1"]),
-                                                       p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), G,
+                                                       p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), Gf,
                                                        p(lay["mask"]) if (keep_all and training) else None, st),
                            "eml_dense_conv1x1_fwd_f32")
-                self._prepare(L, st, part, G, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
+                self._prepare(L, st, part, Gf, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
                               training, lay["scale2"], lay["shift2"])
                 _lib.check(L.eml_dense_conv3x3_fwd_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2p"]),
                                                        p(blk["X"]), ld, cin, B, Hb, Wb, p(part), G3, st),

@@ -130,6 +130,8 @@ def _run_backward(enc, ws, x, gpooled):
     B, _, H, W = x.shape
     G = enc._grid(dev)
     G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
+    Gw = enc._tuned("EML_GRID_WGRAD1", G)   # per-family knobs for A/B runs (default: the common 2 x #CU)
+    Gd = enc._tuned("EML_GRID_DGRAD", G)
     Gb = min(enc.grid_max, 4 * enc._cu)
     bw = ws.bwd
     part = ws.partials
@@ -275,7 +277,7 @@ def _run_backward(enc, ws, x, gpooled):
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
-                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), G, p(dz),
+                p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), Gw, p(dz),
                 *((p(Lm.conv1.weight), narrow_lo, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot])) if narrow_lo is not None
                   else (None, 0, None, 0, None, None)), st), "eml_dense_conv1x1_bwd_weight_f32")
             return Lm
@@ -288,13 +290,14 @@ def _run_backward(enc, ws, x, gpooled):
                 parr([bw.Wd[bi][l_] for l_ in layers]),
                 parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
                 parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
-                None, ld, None, None, P, k_lo, k_hi, p(Gbuf), ld, G,
+                None, ld, None, None, P, k_lo, k_hi, p(Gbuf), ld, Gd,
                 parr([y["mask"] for y in lays]), st),   # ReLU masks from the forward's bits: X is not read
                 "eml_dense_conv1x1_bwd_data_multi_f32")
 
-        def bn1_finalize(l, Lm, slot, c_lo, c_hi):
+        def bn1_finalize(l, Lm, slot, c_lo, c_hi, rows=None):
+            """rows: the grid of the kernel that wrote this channel range's partials (wide pass: Gd; narrow pass: Gw)"""
             lay = blk["layers"][l]
-            finalize(G, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,
+            finalize(Gd if rows is None else rows, 2 * lay["Kp"], P, Lm.norm1, blk["mean"], blk["istd"], lay["Cin"], lay["Kp"], coef=None,
                      s_acc=True, src=bw.part2[slot], c_lo=c_lo, c_hi=c_hi, conv=Lm.conv1, cond=bw.cond[bi][l])
 
         def bn1_direct(l, Lm, slot):
@@ -309,7 +312,7 @@ def _run_backward(enc, ws, x, gpooled):
                 la, lb = l, l - 1
                 cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
                 Lma = conv2_backward(la, 0, narrow_lo=cin_b)   # + narrow pass: layer lb's output channels only -> N12
-                bn1_finalize(la, Lma, 0, cin_b, cin_a)
+                bn1_finalize(la, Lma, 0, cin_b, cin_a, rows=Gw)
                 Lmb = conv2_backward(lb, 1, n12=True)
                 dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once
                 bn1_finalize(la, Lma, 0, 0, cin_b)
