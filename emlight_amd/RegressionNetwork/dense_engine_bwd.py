@@ -81,10 +81,11 @@ class _BwdBuffers:
         self.cond = [[torch.zeros(lay["Kp"], **i32) for lay in blk["layers"]] for blk in ws.blocks]
         self.condT = [torch.zeros(blk["trans"]["Kp"], **i32) for blk in ws.blocks]
         self.any_ill = torch.zeros(1, **i32)
-        self.ill_host = torch.zeros(1, dtype=torch.int32)
-        if torch.device(dev).type == "cuda":
-            self.ill_host = self.ill_host.pin_memory()
-        self.ill_event, self.ill_known = None, False
+        # reports of the last backwards: (event, pinned host int).  The host runs a step or more ahead of the GPU, so the
+        # report of the PREVIOUS backward is usually not in yet; the newest COMPLETED one decides (the flags depend on the
+        # parameters only and drift with the learning rate: a report a few steps old is as good)
+        self.ill_ring = [None] * 8
+        self.ill_step = 0
         self.dg_grid = 128
         self.dg_scratch = torch.empty(self.dg_grid * kp, dtype=torch.float64, device=dev)
         # side stream of the conv3x3 weight gradients (nothing downstream waits for dW2): own partial buffers per slot
@@ -166,10 +167,15 @@ def _run_backward(enc, ws, x, gpooled):
     mode = os.environ.get("EML_DGAMMA_DIRECT", "auto")
     if mode == "never":
         direct = False
-    elif mode == "always" or not bw.ill_known or bw.ill_event is None:
+    elif mode == "always":
         direct = True
     else:
-        direct = not (bw.ill_event.query() and int(bw.ill_host[0]) == 0)
+        direct = True   # nothing known yet (first backwards of this workspace): run the fallback
+        for back in range(1, len(bw.ill_ring) + 1):
+            rep = bw.ill_ring[(bw.ill_step - back) % len(bw.ill_ring)] if bw.ill_step - back >= 0 else None
+            if rep is not None and rep[0].query():
+                direct = int(rep[1][0]) != 0
+                break
     bw.any_ill.zero_()
 
     def dgamma_direct(blk, X_ld, Pin, Hin, Win, pool, DY, ld_dy, Zr, ld_z, co, Cout, conv, Cin, scale1, shift1, cond, bn):
@@ -338,12 +344,14 @@ def _run_backward(enc, ws, x, gpooled):
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")
-    if dev.type == "cuda":   # tell the NEXT backward whether any channel was flagged (no sync: read one step later)
-        bw.ill_host.copy_(bw.any_ill, non_blocking=True)
-        if bw.ill_event is None:
-            bw.ill_event = torch.cuda.Event()
-        bw.ill_event.record()
-        bw.ill_known = True
+    if dev.type == "cuda":   # report whether any channel was flagged (no sync: later backwards read it once it has landed)
+        slot = bw.ill_step % len(bw.ill_ring)
+        if bw.ill_ring[slot] is None:
+            bw.ill_ring[slot] = (torch.cuda.Event(), torch.zeros(1, dtype=torch.int32).pin_memory())
+        ev, host = bw.ill_ring[slot]
+        host.copy_(bw.any_ill, non_blocking=True)
+        ev.record()
+    bw.ill_step += 1
     if bw.side is not None:
         main.wait_stream(bw.side)   # every dW2 is complete before the gradients leave
     return [grads[id(q)] for q in params]

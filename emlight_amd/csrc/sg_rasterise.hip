@@ -49,6 +49,22 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
   // f32 view vectors of the tile's pixels on the H x 2H grid, evaluated like the reference (util.py:223-233):
   // theta = (h+.5)*f32(pi/H), phi = (w+.5)*f32(pi/H), xyz = (sin th cos ph, sin th sin ph, cos th); one sincos per
   // tile row / column (48 per block) instead of three per lane
+  // the first chunk of lights is REQUESTED before anything else: its global-memory latency hides behind the sincos below
+  // (later chunks are requested while the previous one is being accumulated)
+  Lobe pre;
+  auto preload = [&](int base) {
+    const int li_ = min(base + tid, N - 1);
+    const size_t li = (size_t)b * N + li_;
+    pre.dx = dirs[3 * li + 0];
+    pre.dy = dirs[3 * li + 1];
+    pre.dz = dirs[3 * li + 2];
+    pre.k2 = sizes[li];          // divided when it is committed to LDS
+    pre.r = colors[3 * li + 0];
+    pre.g = colors[3 * li + 1];
+    pre.b = colors[3 * li + 2];
+    pre.pad = 0.f;
+  };
+  if (tid < kChunk) preload(0);
   if (tid < kTileH) sincosf(((float)(blockIdx.y * kTileH + tid) + 0.5f) * step, &sin_t[tid], &cos_t[tid]);
   else if (tid < kTileH + kTileW)
     sincosf(((float)(blockIdx.x * kTileW + tid - kTileH) + 0.5f) * step, &sin_p[tid - kTileH], &cos_p[tid - kTileH]);
@@ -81,21 +97,14 @@ __global__ __launch_bounds__(256) void sg_rasterise_kernel(
   unsigned long long n_exec = 0;
   for (int base = 0; base < N; base += kChunk) {
     const int cnt = min(kChunk, N - base);
-    __syncthreads();
+    if (base > 0) __syncthreads();   // the previous chunk's lobes / survivor lists are no longer read
     if (tid < cnt) {
-      const size_t li = (size_t)b * N + base + tid;
-      Lobe L;
-      L.dx = dirs[3 * li + 0];
-      L.dy = dirs[3 * li + 1];
-      L.dz = dirs[3 * li + 2];
-      L.k2 = kLog2e / sizes[li];
-      L.r = colors[3 * li + 0];
-      L.g = colors[3 * li + 1];
-      L.b = colors[3 * li + 2];
-      L.pad = 0.f;
+      Lobe L = pre;
+      L.k2 = kLog2e / pre.k2;
       lobes[tid] = L;
     }
     __syncthreads();
+    if (base + kChunk < N && tid < kChunk) preload(base + kChunk);
     int n = cnt;
     const Lobe* src = lobes;
     if (!kExhaustive) {
