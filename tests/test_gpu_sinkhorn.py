@@ -76,9 +76,10 @@ def test_autograd_vs_oracle(B, n, blur):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(want).max())
 
 
-def test_weighted_four_argument_form_and_zero_weights():
-    """(alpha, x, beta, y) form incl. zero-mass anchors (log-weight -1e5, sinkhorn_divergence.py:47-50)."""
-    B, n = 3, 96
+@pytest.mark.parametrize("B,n", [(3, 96), (3, 256), (40, 256), (2, 384), (2, 202)])
+def test_weighted_four_argument_form_and_zero_weights(B, n):
+    """(alpha, x, beta, y) form incl. zero-mass anchors (log-weight -1e5, sinkhorn_divergence.py:47-50) on every loop kernel:
+    register-resident (96), split (3 x 256, 2 x 384), LDS-tiled (40 x 256), streaming (202)."""
     g = torch.Generator().manual_seed(5)
     x = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
     y = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
