@@ -66,6 +66,7 @@ class SphereGeometry:
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         self.h, self.w = h, w
+        self.idx1 = self.wgt1 = None
         if kind == "planar":
             # an ordinary 3x3 convolution with zero padding 1 (the VGG19 feature stack of the perceptual loss,
             # architecture.py:92-125) as the degenerate case of the same gather: tap (a, b) of output pixel (r, c) is input
@@ -80,6 +81,8 @@ class SphereGeometry:
             self.wgt = torch.zeros(n, 4, dtype=torch.float32, device=device)
             self.idx[:, 0] = torch.where(ok, src, torch.full_like(src, -1)).to(torch.int32)
             self.wgt[:, 0] = ok.float()
+            # single-entry tables for the fused kernels (ke = 1): a quarter of the gather loads, no bilinear combine
+            self.idx1, self.wgt1 = self.idx[:, 0].contiguous(), self.wgt[:, 0].contiguous()
         else:
             grid = sphere_sampling_grid(h, w, stride).to(device).contiguous()
             self.ho, self.wo = grid.shape[1] // 3, grid.shape[2] // 3
@@ -125,6 +128,8 @@ class SphereGeometry:
                 tidx[key, rank] = pix.to(torch.int32)
                 twgt[key, rank] = wk
                 rowmax = counts.view(hw, 9).max(1).values.to(torch.uint8).contiguous()
+                if kmax <= 1 and self.idx1 is not None:   # an ordinary convolution: one source per (pixel, tap)
+                    tidx, twgt, ke = tidx[:, :1], twgt[:, :1], 1
                 self._transposed = (tidx.contiguous(), twgt.contiguous(), rowmax, ke)
         return self._transposed if self._transposed[0] is not None else None
 
@@ -188,9 +193,10 @@ class _SphereConvFn(torch.autograd.Function):
         a9 = None
         if ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
-            _lib.check(L.eml_sphere_conv_fwd_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+            tab = (geo.idx1, geo.wgt1, 1) if geo.idx1 is not None else (geo.idx, geo.wgt, 4)
+            _lib.check(L.eml_sphere_conv_fwd_fused_f32(p(xr), p(tab[0]), p(tab[1]), p(w2.contiguous()),
                                                        p(bias.contiguous()) if bias is not None else None, p(y), B,
-                                                       H * W, po, C, O, st), "eml_sphere_conv_fwd_fused_f32")
+                                                       H * W, po, C, O, tab[2], st), "eml_sphere_conv_fwd_fused_f32")
         else:
             a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
             y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()

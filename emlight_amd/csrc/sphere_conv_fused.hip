@@ -67,7 +67,10 @@ __device__ __forceinline__ float4 combine(const float4 (&v)[4], const float4& w)
 // tap: almost always 4, up to 8 in the few rows next to the poles).  `ke` = table entries per (pixel, tap): 4, or 8 with
 // `rowmax` (per destination pixel: its largest entry count) telling a tile whether any of its pixels needs the second
 // group of four at all (block-uniform; those tiles fetch it at commit time).
-template <int BN>
+// ONE: tables with a single entry per (pixel, tap) (ke == 1) -- an ordinary zero-padded 3x3 convolution seen as a gather
+// (the VGG19 stack of the perceptual loss): 4 operand loads per chunk instead of 16, a scale instead of the bilinear
+// combine; everything else is the same kernel.
+template <int BN, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
@@ -107,10 +110,17 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   const int cpt = C / kBK;            // chunks per tap
   const int nchunks = 9 * cpt;
 
+  constexpr int NA = ONE ? 4 : 16;    // gathered float4 per thread and chunk
+  constexpr int NP = NA + 4;          // + the dense operand's four
   auto load_tap = [&](int tap) {
     Tap t;
-    t.id = *reinterpret_cast<const int4*>(idp + ke * tap);
-    t.w = *reinterpret_cast<const float4*>(wgp + ke * tap);
+    if constexpr (ONE) {
+      t.id = make_int4(idp[tap], -1, -1, -1);
+      t.w = make_float4(wgp[tap], 0.f, 0.f, 0.f);
+    } else {
+      t.id = *reinterpret_cast<const int4*>(idp + ke * tap);
+      t.w = *reinterpret_cast<const float4*>(wgp + ke * tap);
+    }
     return t;
   };
   float4 av[4][4];          // in-flight operands of the next chunk: A[corner][j] ...
@@ -121,28 +131,36 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   // staging was removed altogether).
   auto load_piece = [&](int piece, int chunk, const Tap& t) {
     const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
-    if (piece < 16) {
+    if (piece < NA) {
       const int k = piece >> 2, j = piece & 3;
       const int id = k == 0 ? t.id.x : k == 1 ? t.id.y : k == 2 ? t.id.z : t.id.w;
       const float* src = xb + (size_t)max(id, 0) * C + c0;   // out-of-bounds corners carry weight 0
       av[k][j] = *reinterpret_cast<const float4*>(src + 4 * j);
     } else {
-      const float* ws = wrow + tap * C + c0 + 4 * (piece - 16);
+      const float* ws = wrow + tap * C + c0 + 4 * (piece - NA);
       const float4 v = *reinterpret_cast<const float4*>(ws);
-      if (piece == 16) bv0 = v; else if (piece == 17) bv1 = v; else if (piece == 18) bv2 = v; else bv3 = v;
+      if (piece == NA) bv0 = v; else if (piece == NA + 1) bv1 = v; else if (piece == NA + 2) bv2 = v; else bv3 = v;
     }
   };
   auto load_chunk = [&](int chunk, const Tap& t) {
 #pragma unroll
-    for (int piece = 0; piece < 20; ++piece) load_piece(piece, chunk, t);
+    for (int piece = 0; piece < NP; ++piece) load_piece(piece, chunk, t);
+  };
+  auto gathered = [&](const Tap& t, int j) {
+    if constexpr (ONE) {
+      const float4 v = av[0][j];
+      return make_float4(v.x * t.w.x, v.y * t.w.x, v.z * t.w.x, v.w * t.w.x);
+    } else {
+      const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
+      return combine(v, t.w);
+    }
   };
   // commit = bilinear combine + LDS store of the staged operands.  Tiles without pole rows (ng2 == false, 97 % of
   // them) commit piecewise from INSIDE the second K-half's MFMA stream (commit_a / commit_b); the rare ng2 tiles
   // commit after it, fetching slots 4..7 of the transposed table with the latency exposed.
   auto commit_a = [&](int buf, const Tap& t, int j) {
     float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
-    const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
-    *reinterpret_cast<float4*>(ad + 4 * j) = combine(v, t.w);
+    *reinterpret_cast<float4*>(ad + 4 * j) = gathered(t, j);
   };
   auto commit_b = [&](int buf, int j) {
     if (BN == 128 || stage_b) {   // BN = 128: every thread stages a weight row (no branch in the MFMA stream)
@@ -154,11 +172,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     float* ad = As + (size_t)buf * kBM * kLdF + sp * kLdF + 16 * half;
     float4 out[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 v[4] = {av[0][j], av[1][j], av[2][j], av[3][j]};
-      out[j] = combine(v, t.w);
-    }
-    if (ng2) {   // entries 4..7 of this (pixel, tap)
+    for (int j = 0; j < 4; ++j) out[j] = gathered(t, j);
+    if (!ONE && ng2) {   // entries 4..7 of this (pixel, tap)
       const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * kBK;
       const int4 id2 = *reinterpret_cast<const int4*>(idp + ke * tap + 4);
       const float4 w2 = *reinterpret_cast<const float4*>(wgp + ke * tap + 4);
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
       constexpr int kHalf = 4 * NI * 4;       // MFMAs per K-half: 64 (BN = 128) or 32 (BN = 64)
       // first half: one operand load per kEvery MFMAs; second half: the 8 commit pieces from its middle on.  (Tried:
       // all loads within the first 2/3 of the half and commits only in the last quarter -- no change, 109 vs 112 TF/s.)
-      constexpr int kEvery = kHalf / 20;
+      constexpr int kEvery = kHalf / NP;
       constexpr int kCommit0 = kHalf / 2;
       constexpr int kCommitEvery = kHalf / 16;
 #pragma unroll
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
             for (int mi = 0; mi < 4; ++mi) {
               acc[ni][mi] = mfma16(f4c(bf[ni], t), f4c(af[mi], t), acc[ni][mi]);
               const int cnt = (t * NI + ni) * 4 + mi;          // MFMA index within this K-half
-              if (h == 0 && cnt % kEvery == kEvery - 1 && cnt / kEvery < 20) {
+              if (h == 0 && cnt % kEvery == kEvery - 1 && cnt / kEvery < NP) {
                 load_piece(cnt / kEvery, nxc, t_use);
                 __builtin_amdgcn_sched_barrier(0);             // keep the request here (the scheduler would sink it)
               }
@@ -448,25 +463,29 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   const size_t lds = (size_t)(2 * kBM * kLdF + 2 * bn * kLdF) * sizeof(float);
   const long n_mt = (M + kBM - 1) / kBM, per_xcd = (n_mt + 7) / 8;
   const dim3 grid((unsigned)(8 * per_xcd * (O / bn)));   // 1-D: the kernel maps id -> (XCD band, pixel tile, O-tile)
-  if (bn == 128) {
-    EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<128>), lds);
-    hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
-                       Y, (int)M, HW, Po, C, O, ke, rowmax);
+#define EML_LAUNCH_GG(BNV, ONEV)                                                                                     \
+  do {                                                                                                              \
+    EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<BNV, ONEV>), lds);                                                \
+    hipLaunchKernelGGL((sphere_conv_fwd_fused_kernel<BNV, ONEV>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
+                       wgt, W2, bias, Y, (int)M, HW, Po, C, O, ke, rowmax);                                         \
+  } while (0)
+  if (ke == 1) {
+    if (bn == 128) EML_LAUNCH_GG(128, true); else EML_LAUNCH_GG(64, true);
   } else {
-    EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<64>), lds);
-    hipLaunchKernelGGL(sphere_conv_fwd_fused_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, X, idx, wgt, W2, bias,
-                       Y, (int)M, HW, Po, C, O, ke, rowmax);
+    if (bn == 128) EML_LAUNCH_GG(128, false); else EML_LAUNCH_GG(64, false);
   }
+#undef EML_LAUNCH_GG
   return eml::check_launch(what);
 }
 }  // namespace
 
 extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                              const float* bias, float* Y, int B, int HW, int Po, int C, int O,
-                                             eml_stream_t stream) {
+                                             int ke, eml_stream_t stream) {
   if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
-  return launch_gather_gemm("eml_sphere_conv_fwd_fused_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, 4, nullptr, stream);
+  if (ke != 4 && ke != 1) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: ke must be 4 (bilinear taps) or 1");
+  return launch_gather_gemm("eml_sphere_conv_fwd_fused_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr, stream);
 }
 
 // dX (B*HW, C) = gather-GEMM over the transposed tap table: tidx / twgt (HW*9*ke) = for input pixel q and tap t the
@@ -475,8 +494,8 @@ extern "C" int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx,
                                                const unsigned char* rowmax, int ke, const float* W2t, float* dX, int B,
                                                int HW, int Po, int C, int O, eml_stream_t stream) {
   if (!dY || !tidx || !twgt || !W2t || !dX || B < 0 || HW < 1 || Po < 1 || O < 32 || (O % 32) || C < 64 || (C % 64) ||
-      (ke != 4 && ke != 8) || (ke == 8 && !rowmax))
-    return eml::fail(EML_EINVAL, "eml_sphere_conv_dgrad_fused_f32: need O %% 32 == 0, C %% 64 == 0, ke in {4, 8} (C=%d, O=%d)",
+      (ke != 4 && ke != 8 && ke != 1) || (ke == 8 && !rowmax))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_dgrad_fused_f32: need O %% 32 == 0, C %% 64 == 0, ke in {1, 4, 8} (C=%d, O=%d)",
                      C, O);
   // roles swap: the rows gathered are dY's (Po per sample, O wide), the destination pixels are the HW input pixels
   return launch_gather_gemm("eml_sphere_conv_dgrad_fused_f32", dY, tidx, twgt, W2t, nullptr, dX, B, Po, HW, O, C, ke, rowmax,

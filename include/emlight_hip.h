@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 10
+#define EML_ABI_VERSION 11
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -360,13 +360,17 @@ int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, cons
  * bias (O) or NULL, Y (B*Po, O).  Forward: C % 32 == 0, O % 64 == 0.
  * Weight gradient dW2 (O, 9C) = sum_m dY[m] (x) Ag[m]: C % 64 == 0, O >= 64, O % 16 == 0; split_k workgroups share the
  * pixel axis, partial = eml_sphere_conv_wgrad_partial_floats(C, O, split_k) floats of scratch (deterministic sum). */
+/* ke = table entries per (pixel, tap): 4 = the bilinear corners of the tap table; 1 = a single (index, weight) pair
+ * (idx / wgt then hold Po*9 entries) -- an ordinary zero-padded 3x3 convolution written as a gather, used by the VGG19
+ * feature stack of the perceptual loss (architecture.py:92-125): a quarter of the operand loads, no bilinear combine. */
 int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
-                                  const float* bias, float* Y, int B, int HW, int Po, int C, int O,
+                                  const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
                                   eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the
- * largest slot count over its taps, so that only tiles with pole rows fetch slots 4..7.  W2t (C, 9*O) = weight.permute(1,2,3,0).
+ * largest slot count over its taps, so that only tiles with pole rows fetch slots 4..7; ke = 1: one entry per (pixel, tap), as
+ * in the forward.  W2t (C, 9*O) = weight.permute(1,2,3,0).
  * O % 32 == 0, C % 64 == 0.  Deterministic (a gather, no atomics); neither dA9 nor its col2im pass exist. */
 int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const float* twgt, const unsigned char* rowmax,
                                     int ke, const float* W2t, float* dX, int B, int HW, int Po, int C, int O,

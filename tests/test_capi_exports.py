@@ -60,10 +60,11 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_dense_conv1x1_bwd_data_multi_f32(3, None, None, None, None, None, None, None, None, None, None, one, 224,
                                                   one, one, 10, 0, 16, one, 224, 512, None, None) == -1
     # round-2 entry points: fused SphereConv (channel counts must tile), BatchNorm fold, narrow dgrad
-    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 48, 64, None) == -1     # C % 32
-    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 96, None) == -1     # O % 64
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 48, 64, 4, None) == -1     # C % 32
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 96, 4, None) == -1     # O % 64
     assert b"C %" in L.eml_last_error()
-    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, None) == 0      # empty batch
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, 4, None) == 0      # empty batch
+    assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 2, None) == -1     # ke in {1, 4}
     assert L.eml_sphere_conv_wgrad_fused_f32(one, one, one, one, one, one, 1, 32, 32, 32, 64, 4, None) == -1  # C % 64
     assert L.eml_sphere_conv_wgrad_partial_floats(128, 256, 7) == 7 * 256 * 9 * 128
     assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 8, one, one, 1, 32, 32, 64, 64, None) == -1   # ke = 8 needs rowmax
