@@ -96,18 +96,15 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
   if (mt * kBM >= M) return;   // padding of the last band (whole workgroup, before any barrier)
   const int m0 = mt * kBM, o0 = ot * BN;
 
-  // staging roles: A -- pixel sp, 16 channels (half); B -- output channel sp (sp < BN), 16 channels.  Lane mapping: the 16
-  // lanes of a ds_write_b128 phase hold 16 DIFFERENT rows of the same half -- row offsets 36 * p mod 64 are 16 distinct
-  // multiples of 4, so the phase covers all 64 banks.  (Round 2 had sp = tid / 2, half = tid % 2: rows p and p + 4 of the
-  // other half landed on the same banks -- a 2-way conflict on every commit, a third of the kernel's LDS cycles.)
-  const int sp = ((tid >> 5) << 4) | (tid & 15), half = (tid >> 4) & 1;
+  // staging roles: A -- pixel sp = tid / 2, 16 channels (half); B -- output channel sp (threads < 2*BN), 16 channels
+  const int sp = tid >> 1, half = tid & 1;
   const int ms = min(m0 + sp, M - 1);
   const int sb = ms / Po, spix = ms - sb * Po;
   const float* xb = X + (size_t)sb * HW * C + 16 * half;
   const int* idp = idx + (size_t)spix * 9 * ke;
   const float* wgp = wgt + (size_t)spix * 9 * ke;
   const bool ng2 = (ke == 8) && __syncthreads_or(rowmax ? rowmax[spix] > 4 : 1);   // block-uniform
-  const bool stage_b = sp < BN;   // BN = 64: waves 0, 1
+  const bool stage_b = tid < 2 * BN;
   const float* wrow = W2 + (size_t)(o0 + min(sp, BN - 1)) * 9 * C + 16 * half;
 
   const int cpt = C / kBK;            // chunks per tap
