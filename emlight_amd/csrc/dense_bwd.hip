@@ -1246,24 +1246,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
   load_w(0, nt_lo, wq[0]);
   int wsel = 0;  // register set holding the weights of the step about to run (compile-time after unrolling for NL = 2)
 
-  // RAW (the product's form): the dz fragments of the NEXT tile are requested during the current tile's last channel
-  // chunk.  Loaded at the top of a tile they were an exposed HBM round trip in front of its first MFMA (SQ counters, round 3:
-  // 57 % of this kernel's wave-cycles at s_waitcnt).  Unconditional loads from clamped pixels, pinned with sched_barrier.
-  float4 dzn[RAW ? NL : 1][3][RAW ? MT : 1];
-  auto load_dz_next = [&](int tile_) {
-    if constexpr (RAW) {
-      const int p0n = tile_ * TP + wave * 16 * MT;
-#pragma unroll
-      for (int j = 0; j < NL; ++j)
-#pragma unroll
-        for (int jo = 0; jo < 3; ++jo)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            dzn[j][jo][m] = *reinterpret_cast<const float4*>(Ls[j].DZ + (size_t)min(p0n + 16 * m + r, P - 1) * 48 + 16 * jo + 4 * kk);
-    }
-  };
-  load_dz_next(min((int)blockIdx.x, ntiles - 1));
-
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int p0 = tile * TP + wave * 16 * MT;
     long prow[MT];
@@ -1285,7 +1267,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
         const int ch = 16 * jo + 4 * kk;
         if constexpr (RAW) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) dz[j][jo][m] = dzn[j][jo][m];   // requested a tile ago
+          for (int m = 0; m < MT; ++m) dz[j][jo][m] = *reinterpret_cast<const float4*>(Ls[j].DZ + prow[m] * 48 + ch);
         } else {
           const float4 a4 = *reinterpret_cast<const float4*>(Ls[j].cA + ch);
           const float4 b4 = *reinterpret_cast<const float4*>(Ls[j].cB + ch);
@@ -1317,10 +1299,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
         }
       }
       const int nt_next = nt0 + NCH < nt_hi ? nt0 + NCH : nt_lo;  // the next tile starts at nt_lo again
-      if (RAW && nt0 + NCH >= nt_hi) {   // block-uniform: last chunk of this tile -> request the next tile's dz
-        load_dz_next(min(tile + (int)gridDim.x, ntiles - 1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int nnt = Ls[j].Kp >> 4;
