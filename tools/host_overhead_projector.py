@@ -11,13 +11,18 @@ which = sys.argv[1] if len(sys.argv) > 1 else "projector"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 if which == "joint":
     from emlight_amd.joint import JointTrainer, joint_batch
-    tr = JointTrainer(device="cuda:0")
+    from emlight_amd.GenProjector.networks import default_options
+    import warnings
+    warnings.simplefilter("ignore")
+    tr = JointTrainer(default_options(no_vgg_loss=False), device="cuda:0")
     data = joint_batch(B, "cuda:0")
 else:
     from emlight_amd.GenProjector.data import projector_batch
     from emlight_amd.GenProjector.model_trainer import Trainer
     from emlight_amd.GenProjector.networks import default_options
-    tr = Trainer(default_options(), device="cuda:0")
+    import warnings
+    warnings.simplefilter("ignore")
+    tr = Trainer(default_options(no_vgg_loss=False), device="cuda:0")   # the reference's step: VGG term on
     data = projector_batch(B, "cuda:0")
 for _ in range(3):
     tr.step(data)
