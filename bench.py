@@ -434,7 +434,8 @@ def leg_projector(args, rank, world, dev, steps, warmup):
             warnings.simplefilter("ignore")   # "random VGG features": stated in the JSON instead
             tr = Trainer(default_options(no_vgg_loss=no_vgg), device=dev, world=world)
         dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
-        fams = time_projector_families(tr, data, 1) if (not no_vgg and rank == 0) else None
+        # EVERY rank runs the instrumented step (it contains DDP's all-reduces and SPADE's statistics all-reduce); rank 0 reports
+        fams = time_projector_families(tr, data, 1) if not no_vgg else None
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
@@ -461,7 +462,7 @@ def leg_projector(args, rank, world, dev, steps, warmup):
            "step_frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
            "step_note": "algorithmic conv FLOPs per image = 4*%.1f (G: fwd+bwd in the G step, fwd in the D step) + 5*%.2f (D) "
                         "+ 3*%.1f (VGG19: fake, real, data gradient) = %.1f GFLOP" % (G_FWD_GFLOP, D_PAIR_GFLOP, VGG_FWD_GFLOP, gflop)}
-    if fams:
+    if fams and rank == 0:
         dom = fams[0]
         out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round((dom["tflops"] or 0.0) / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
