@@ -207,3 +207,26 @@ def test_sync_diameter_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
     np.testing.assert_allclose(np.concatenate([d[0]["synced_loss"], d[1]["synced_loss"]]), w["loss"].cpu().numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(np.concatenate([d[0]["synced_gx"], d[1]["synced_gx"]]), w["gx"].cpu().numpy(), rtol=1e-6, atol=1e-10)
     assert len(d[0]["local_eps"]) != len(eps) or not np.array_equal(d[0]["local_eps"], eps)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_runs_every_leg_without_deadlock():
+    """`bench.py --gpus 2` end to end on the test box's one GPU (gloo transport, EML_SHARE_GPUS=1), small batches: every leg
+    of the line -- the regression step with its live kernel-family timing, the projector leg with its instrumented step
+    (which contains DDP's and SPADE's all-reduces: every rank has to run it), the joint leg -- completes on both ranks and
+    rank 0 prints ONE N = 2 line.  (Round 3 found and fixed a rank-0-only instrumented step that would have hung N > 1.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, EML_DIST_BACKEND="gloo", EML_SHARE_GPUS="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--projector_batch", "2", "--joint_batch", "2", "--no_cpu_baseline"],
+                       env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 8
+    assert j["value"] > 0 and j["projector"]["value"] > 0 and j["joint"]["value"] > 0
+    assert j["projector"]["config"]["global_batch"] == 4 and "kernel_families" in j["projector"] and "roofline" in j
