@@ -74,6 +74,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_bn_bwd_apply_f32(one, 8, one, 8, 0, 8, one, one, None, one, 8, None) == 0                       # no rows
     assert L.eml_dense_conv1x1_bwd_narrow_f32(one, one, 48, 37, one, 64, one, one, one, one, 10, one, 64, one, one, 48, 4,
                                               None) == -1                                                       # odd channel offset
+    # round-3 entry points
+    assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 1, 4, 128, 256, 6, None, None) == -1 and b"flags" in L.eml_last_error()
+    assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 0, 4, 128, 256, 1, None, None) == 0                    # empty batch
+    assert L.eml_dense_bn_dgamma_direct_f32(one, 224, 100, 10, 10, 0, one, 48, None, 0, None, None, None, 48, one, 400,
+                                            one, one, one, one, one, one, one, 64, None) == -1                  # Cin <= 384
+    assert L.eml_dense_bn_dgamma_direct_f32(one, 224, 100, 9, 10, 1, one, 112, one, 112, one, one, one, 108, one, 216,
+                                            one, one, one, one, one, one, one, 64, None) == -1                  # pooled: even maps
+    assert L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, 1.5, 2, -1.0, None, None, None, None, one, None, None,
+                                  one, 2, 96, None) == -1                                                       # 0 < scaling < 1
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 1, one, one, 0, 32, 32, 64, 64, None) == 0     # ke = 1, empty batch
 
 
 def test_product_path_has_no_cpu_fallback():
