@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
   float* sl = wl + (size_t)Kp * 48; // [Kp]
   float* tl = sl + Kp;              // [Kp]
   double* red = reinterpret_cast<double*>(tl + Kp);  // [4][48][2]
+  // ReLU ballot words of the tile being computed, staged per wave: [4 waves][4 pixel groups][Kp/16][4] (round 3).  A
+  // global store per K-step sat in the middle of the operand-load stream: vmcnt counts in order, so every step's wait
+  // for its x operands (the ISA shows s_waitcnt vmcnt(0) at the top of the step) also waited for the PREVIOUS step's mask
+  // store to reach memory.  Through LDS (lgkmcnt) the loop holds loads only; the words leave once per tile, as one
+  // contiguous 128*Kp/16-byte run per wave.
+  unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(red + 4 * 48 * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
 
@@ -120,11 +126,18 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
   // MFMAs of K-step j (unconditional loads, clamped rows).  Issued inside its own K-step, every 16-channel step
   // exposed an HBM round trip (ISA: global_load; s_waitcnt vmcnt; v_mfma).
   float4 xn[4];
+#ifdef EML_FWD_PF2   // experiment build (tools/exp_build.sh pf2 -DEML_FWD_PF2): operands requested TWO K-steps ahead
+  float4 xn2[4];
+#endif
   int tile = blockIdx.x;
   if constexpr (!POOL) {
     if (tile < ntiles) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(row_ptr(tile, m));
+#ifdef EML_FWD_PF2
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xn2[m] = *reinterpret_cast<const float4*>(row_ptr(tile, m) + 16);
+#endif
     }
   }
   for (; tile < ntiles; tile += gridDim.x) {
@@ -163,9 +176,18 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
         float4 xc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) xc[m] = xn[m];
+#ifdef EML_FWD_PF2
+        const int j2 = j + 2;   // wave-uniform: step j + 2 of this tile, or step j + 2 - nj (0 or 1) of the next one
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          xn[m] = xn2[m];
+          xn2[m] = *reinterpret_cast<const float4*>(j2 < nj ? rp[m] + 16 * j2 : rpn[m] + 16 * (j2 - nj));
+        }
+#else
         const bool last = j + 1 == nj;  // wave-uniform
 #pragma unroll
         for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(last ? rpn[m] : rp[m] + 16 * (j + 1));
+#endif
         __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
@@ -183,8 +205,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
               const unsigned long long w = __ballot(f4c(a[m], t) > 0.f);
               mine = (lane == 4 * m + t) ? w : mine;
             }
-          if (lane < 16)
-            relu_mask[((size_t)(tile * 16 + wave * 4 + (lane >> 2)) * nj + j) * 4 + (lane & 3)] = mine;
+          if (lane < 16) mask_l[((wave * 4 + (lane >> 2)) * nj + j) * 4 + (lane & 3)] = mine;
         }
       }
       float4 bw[3];
@@ -203,6 +224,15 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
     } else {
 #pragma unroll 2
       for (int j = 0; j < nj; ++j) kstep(j);
+    }
+    if constexpr (!POOL) {
+      if (relu_mask) {   // this wave's words of the tile: one contiguous run (wave-private LDS, in-order: compiler fence only)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long* dst = relu_mask + (size_t)(tile * 16 + wave * 4) * nj * 4;
+        for (int e = lane; e < 16 * nj; e += 64) dst[e] = mask_l[wave * 16 * nj + e];
+      }
     }
     // epilogue: D rows = channels 16n + 4kk + g, column = pixel 16m + r
 #pragma unroll
@@ -828,7 +858,8 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
   if (relu_mask && (pool || Cout > 48))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: relu_mask is for dense layers (no pool, Cout <= 48)");
   if (pool && ((Hin & 1) || (Win & 1))) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: pool needs even H, W");
-  const size_t lds = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double);
+  const size_t lds = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double) +
+                     (relu_mask ? (size_t)4 * 16 * (Kp / 16) * sizeof(unsigned long long) : 0);
   if (lds > 160 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: Kp=%d does not fit LDS", Kp);
   const int nchunks = (Cout + 47) / 48;
   for (int ch = 0; ch < nchunks; ++ch) {
