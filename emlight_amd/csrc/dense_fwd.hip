@@ -126,18 +126,11 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
   // MFMAs of K-step j (unconditional loads, clamped rows).  Issued inside its own K-step, every 16-channel step
   // exposed an HBM round trip (ISA: global_load; s_waitcnt vmcnt; v_mfma).
   float4 xn[4];
-#ifdef EML_FWD_PF2   // experiment build (tools/exp_build.sh pf2 -DEML_FWD_PF2): operands requested TWO K-steps ahead
-  float4 xn2[4];
-#endif
   int tile = blockIdx.x;
   if constexpr (!POOL) {
     if (tile < ntiles) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(row_ptr(tile, m));
-#ifdef EML_FWD_PF2
-#pragma unroll
-      for (int m = 0; m < 4; ++m) xn2[m] = *reinterpret_cast<const float4*>(row_ptr(tile, m) + 16);
-#endif
     }
   }
   for (; tile < ntiles; tile += gridDim.x) {
@@ -176,18 +169,9 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
         float4 xc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) xc[m] = xn[m];
-#ifdef EML_FWD_PF2
-        const int j2 = j + 2;   // wave-uniform: step j + 2 of this tile, or step j + 2 - nj (0 or 1) of the next one
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          xn[m] = xn2[m];
-          xn2[m] = *reinterpret_cast<const float4*>(j2 < nj ? rp[m] + 16 * j2 : rpn[m] + 16 * (j2 - nj));
-        }
-#else
         const bool last = j + 1 == nj;  // wave-uniform
 #pragma unroll
         for (int m = 0; m < 4; ++m) xn[m] = *reinterpret_cast<const float4*>(last ? rpn[m] : rp[m] + 16 * (j + 1));
-#endif
         __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
