@@ -362,17 +362,32 @@ PROJECTOR_FAMILIES = {
 }
 
 
-def time_projector_families(trainer, data, steps):
-    """Per-family GPU time of one projector step (HIP events around every launcher call, on the stream it launches on),
-    sorted by time; `other` = the step's remaining GPU time (library GEMMs of the unfused layers, ATen glue, Adam)."""
+# encoder launchers as they appear in the JOINT step's table: (label, FLOP count of one call from its arguments)
+ENCODER_FAMILIES = {
+    "eml_dense_conv1x1_fwd_f32": ("encoder conv1x1_fwd_kernel", lambda a: 2.0 * a[2] * a[6] * a[10]),                  # P * Kp * Cout
+    "eml_dense_conv1x1_bwd_weight_f32": ("encoder conv1x1_bwd_weight_kernel", lambda a: 2.0 * a[2] * a[7] * a[17]),  # P * Cin * Cout
+    "eml_dense_conv1x1_bwd_data_multi_f32": ("encoder conv1x1_bwd_data_multi_kernel (two layers per pass)",
+                                             lambda a: 2.0 * a[0] * a[15] * (a[17] - a[16]) * 48),      # layers * P * channels * 48
+    "eml_dense_conv1x1_bwd_data_f32": ("encoder transition_bwd_data_kernel", lambda a: 2.0 * a[15] * a[19] * a[7]),  # P * Kp * Ko
+    "eml_dense_conv3x3_fwd_f32": ("encoder conv3x3_fwd_kernel", lambda a: 2.0 * a[7] * a[8] * a[9] * 9 * 48 * 12),
+    "eml_dense_conv3x3_bwd_data_f32": ("encoder conv3x3_bwd_data_kernel", lambda a: 2.0 * a[8] * a[9] * a[10] * 9 * 48 * 12),
+    "eml_dense_conv3x3_bwd_weight_f32": ("encoder conv3x3_bwd_weight_kernel", lambda a: 2.0 * a[6] * a[7] * a[8] * 9 * 48 * 12),
+}
+
+
+def time_projector_families(trainer, data, steps, families=None, other_label=None):
+    """Per-family GPU time of one projector (or joint) step (HIP events around every launcher call, on the stream it
+    launches on), sorted by time; `other` = the step's remaining GPU time (library GEMMs of the unfused layers, ATen glue,
+    Adam).  `families`: launcher -> (label, flops-of-a-call or None); default: the projector's."""
     from emlight_amd import _lib
     L = _lib.lib()
-    events = {k: [] for k in PROJECTOR_FAMILIES}
-    flops = {k: 0.0 for k in PROJECTOR_FAMILIES}
-    orig = {k: getattr(L, k) for k in PROJECTOR_FAMILIES}
+    FAM = families or PROJECTOR_FAMILIES
+    events = {k: [] for k in FAM}
+    flops = {k: 0.0 for k in FAM}
+    orig = {k: getattr(L, k) for k in FAM}
 
     def timed(name):
-        fn, fl = orig[name], PROJECTOR_FAMILIES[name][1]
+        fn, fl = orig[name], FAM[name][1]
 
         def call(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,7 +399,7 @@ def time_projector_families(trainer, data, steps):
                 flops[name] += fl(a)
             return rc
         return call
-    for k in PROJECTOR_FAMILIES:
+    for k in FAM:
         setattr(L, k, timed(k))
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
@@ -395,17 +410,17 @@ def time_projector_families(trainer, data, steps):
         t1.record()
         torch.cuda.synchronize()
     finally:
-        for k in PROJECTOR_FAMILIES:
+        for k in FAM:
             setattr(L, k, orig[k])
     total = t0.elapsed_time(t1) / steps
     rows, acc = [], 0.0
-    for k, (label, fl) in PROJECTOR_FAMILIES.items():
+    for k, (label, fl) in FAM.items():
         ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
         acc += ms
         rows.append({"kernel": label, "launches_per_step": len(events[k]) // steps, "ms_per_step": round(ms, 3),
                      "tflops": round(flops[k] / steps / (ms * 1e-3) / 1e12, 2) if (fl is not None and ms > 0) else None})
     rows.sort(key=lambda r: -r["ms_per_step"])
-    rows.append({"kernel": "other (library GEMMs of the unfused layers, ATen elementwise / pooling / norms, Adam)",
+    rows.append({"kernel": other_label or "other (library GEMMs of the unfused layers, ATen elementwise / pooling / norms, Adam)",
                  "launches_per_step": None, "ms_per_step": round(total - acc, 3), "tflops": None})
     return rows
 
@@ -492,12 +507,16 @@ def leg_joint(args, rank, world, dev, steps, warmup):
             tr = JointTrainer(default_options(no_vgg_loss=no_vgg), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
                               device=dev, world=world)
         dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
+        # every rank runs the instrumented iteration (collectives inside); rank 0 reports
+        fams = None if no_vgg else time_projector_families(
+            tr, batch, 1, {**ENCODER_FAMILIES, **PROJECTOR_FAMILIES},
+            "other (encoder BN / pooling / head passes, Sinkhorn, rasteriser, library GEMMs of the unfused layers, ATen glue, Adam)")
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
-        return dt, peak
-    dt, peak = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
-    dt0, _ = run(True)
+        return dt, peak, fams
+    dt, peak, fams = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
+    dt0, _, _ = run(True)
     value, value0 = B * world * steps / dt, B * world * steps / dt0
     enc_gflop = STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
     gflop = enc_gflop + PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
@@ -518,6 +537,8 @@ def leg_joint(args, rank, world, dev, steps, warmup):
                         "note": "algorithmic conv FLOPs per image = %.1f (encoder train step) + %.1f (projector G+D step) + "
                                 "%.1f (VGG19 on fake, real, data gradient) GFLOP; per-kernel figures: the `projector` and "
                                 "regression legs" % (enc_gflop, PROJECTOR_STEP_GFLOP, VGG_STEP_GFLOP)}}
+    if fams and rank == 0:
+        out["kernel_families"] = fams
     del batch
     _free_gpu()
     return out
