@@ -71,8 +71,8 @@ __device__ __forceinline__ void block_stats_store(double (&s)[NT], double (&q)[N
 // ------------------------------------------------------------------------------ conv1x1
 // out[p][n0 + o] (o < n_valid <= 48) for output pixels p < P.  POOL: the A operand is the
 // 2x2 average of relu(bn(x)) (avg-pool commutes with the 1x1 conv: transition, DenseNet.py:14-21).
-template <bool POOL>
-__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
+template <bool POOL, bool MASK = false /* emit the ReLU ballot words (relu_mask != NULL, dense layers in training) */>
+__global__ __launch_bounds__(256, 2) void conv1x1_fwd_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ Wp,
     float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials,
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
         __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
-        if (relu_mask) {
+        if constexpr (MASK) {
           // ReLU mask of this K-step as wave ballots: word (pixel group, K-step, t), bit r + 16*kk <-> pixel 16*pg + r,
           // channel 16*j + 4*kk + t -- the lane layout of the data-gradient kernel, which then needs neither X nor
           // BN1's affine to know where relu(bn1(x)) was active.  Lane i < 16 stores word (m = i / 4, t = i % 4).
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(
       for (int j = 0; j < nj; ++j) kstep(j);
     }
     if constexpr (!POOL) {
-      if (relu_mask) {   // this wave's words of the tile: one contiguous run (wave-private LDS, in-order: compiler fence only)
+      if constexpr (MASK) {   // this wave's words of the tile: one contiguous run (wave-private LDS, in-order: compiler fence only)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -851,13 +851,17 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
     const float* wp = Wp + (size_t)ch * Kp * 48;
     double* pp = partials + (size_t)ch * grid * 96;
     if (pool) {
-      EML_ENSURE_LDS((&conv1x1_fwd_kernel<true>), lds);
-      hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
+      EML_ENSURE_LDS((&conv1x1_fwd_kernel<true, false>), lds);
+      hipLaunchKernelGGL((conv1x1_fwd_kernel<true, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
                          Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
-    } else {
-      EML_ENSURE_LDS((&conv1x1_fwd_kernel<false>), lds);
-      hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
+    } else if (relu_mask) {
+      EML_ENSURE_LDS((&conv1x1_fwd_kernel<false, true>), lds);
+      hipLaunchKernelGGL((conv1x1_fwd_kernel<false, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
                          Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, relu_mask);
+    } else {
+      EML_ENSURE_LDS((&conv1x1_fwd_kernel<false, false>), lds);
+      hipLaunchKernelGGL((conv1x1_fwd_kernel<false, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
+                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
     }
     int rc = eml::check_launch("eml_dense_conv1x1_fwd_f32");
     if (rc) return rc;
