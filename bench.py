@@ -346,9 +346,10 @@ VGG_STEP_GFLOP = 3 * VGG_FWD_GFLOP
 
 # projector launchers -> (label, FLOP count of one call from its arguments, or None for the streaming kernels)
 PROJECTOR_FAMILIES = {
-    "eml_sphere_conv_fwd_fused_f32": ("sphere_conv_fwd_fused_kernel (taps gathered into the LDS operand of an f32-MFMA implicit "
-                                      "GEMM: SphereConv2D forward; VGG19's 3x3 convolutions use it with a planar tap table)",
-                                      lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),     # B * Po * 9C * O
+    "eml_sphere_conv_fwd_fused_ex_f32": ("sphere_conv_fwd_fused_kernel (taps gathered into the LDS operand of an f32-MFMA implicit "
+                                         "GEMM: SphereConv2D forward, residual sum / ReLU in the epilogue; VGG19's 3x3 "
+                                         "convolutions use it with a planar tap table)",
+                                         lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),     # B * Po * 9C * O
     "eml_sphere_conv_dgrad_fused_f32": ("sphere_conv_fwd_fused_kernel on the transposed tap table (input gradient)",
                                         lambda a: 2.0 * a[7] * a[8] * 9 * a[10] * a[11]),  # B * HW * 9C * O
     "eml_sphere_conv_wgrad_fused_f32": ("sphere_conv_wgrad_fused_kernel (weight gradient, split-K over pixels)",
@@ -359,6 +360,8 @@ PROJECTOR_FAMILIES = {
     "eml_spade_norm_modulate_bwd_f32": ("spade_norm_modulate_bwd_kernel", None),
     "eml_bn_stats_f32": ("bn_stats_kernel (SPADE batch statistics)", None),
     "eml_bn_bwd_apply_f32": ("bn_bwd_apply_kernel", None),
+    "eml_instance_norm_act_fwd_f32": ("instance_norm_*_kernel<fwd> (InstanceNorm + LeakyReLU of the discriminator / encoder)", None),
+    "eml_instance_norm_act_bwd_f32": ("instance_norm_*_kernel<bwd>", None),
 }
 
 

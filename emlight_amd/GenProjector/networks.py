@@ -126,7 +126,9 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
-    def forward(self, x, seg):
+    def forward(self, x, seg, out_slope=1.0):
+        """``out_slope``: a LeakyReLU the caller applies to the block's output (``generator.py:84`` before the last
+        convolution), folded -- like the residual sum itself -- into ``conv_1``'s epilogue."""
         stats = None
         n0 = self.norm_0.param_free_norm
         ns = self.norm_s.param_free_norm if self.learned_shortcut else None
@@ -138,8 +140,16 @@ class SPADEResnetBlock(nn.Module):
             stats = spherenet.spade_batch_stats(x, n0, also=(ns,))
         x_s = self.conv_s(self.norm_s(x, seg, stats=stats)) if self.learned_shortcut else x
         dx = self.conv_0(self.norm_0(x, seg, slope=2e-1, stats=stats))   # leaky_relu(norm(.), 0.2), fused into the modulation
-        dx = self.conv_1(self.norm_1(dx, seg, slope=2e-1))
-        return x_s + dx
+        return self.conv_1(self.norm_1(dx, seg, slope=2e-1), residual=x_s, act_slope=out_slope)   # act(x_s + dx)
+
+
+def _norm_act(stage, x, slope):
+    """``leaky_relu(stage(x), slope)`` for a ``nonspade_norm`` stage: Sequential(conv, InstanceNorm2d) runs its norm and the
+    activation as one HIP launch; a bare convolution (norm 'none') just gets the activation."""
+    mods = list(stage.children()) if isinstance(stage, nn.Sequential) else []
+    if len(mods) == 2 and isinstance(mods[1], nn.InstanceNorm2d):
+        return spherenet.instance_norm_act(mods[0](x), mods[1], slope)
+    return F.leaky_relu(stage(x), slope)
 
 
 class ConvEncoder(nn.Module):
@@ -159,10 +169,10 @@ class ConvEncoder(nn.Module):
 
     def forward(self, x):
         x = F.interpolate(x, size=(128, 128), mode="bilinear")
-        x = self.layer1(x)
-        for layer in (self.layer2, self.layer3, self.layer4, self.layer5):
-            x = layer(self.actvn(x))
-        return self.fc(self.actvn(x).view(x.size(0), -1))
+        # every layer = conv -> InstanceNorm, each followed by the LeakyReLU (generator.py:113-122): norm + activation fused
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5):
+            x = _norm_act(layer, x, self.actvn.negative_slope)
+        return self.fc(x.reshape(x.size(0), -1))
 
 
 class SPADEGenerator(nn.Module):
@@ -199,9 +209,10 @@ class SPADEGenerator(nn.Module):
         x = self.up(x)
         x = self.G_middle_0(x, guide)
         x = self.G_middle_1(x, guide)
-        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+        for blk in (self.up_0, self.up_1, self.up_2):
             x = blk(self.up(x), guide)
-        x = self.sphere_conv1(F.leaky_relu(x, 2e-1))
+        x = self.up_3(self.up(x), guide, out_slope=2e-1)    # = F.leaky_relu(up_3(...), 2e-1) of generator.py:84
+        x = self.sphere_conv1(x)
         return (torch.tanh(x) + 1) * 25
 
 
@@ -225,7 +236,11 @@ class NLayerDiscriminator(nn.Module):
     def forward(self, input):
         results = [input]
         for sub in self.children():
-            results.append(sub(results[-1]))
+            mods = list(sub.children())
+            if len(mods) == 2 and isinstance(mods[1], nn.LeakyReLU) and isinstance(mods[0], nn.Sequential):
+                results.append(_norm_act(mods[0], results[-1], mods[1].negative_slope))   # conv -> norm + LeakyReLU, one launch
+            else:
+                results.append(sub(results[-1]))
         return results[1:] if not self.opt.no_ganFeat_loss else results[-1]
 
 

@@ -46,8 +46,11 @@ class Pix2PixModel(torch.nn.Module):
 
     def create_optimizers(self, opt):
         G_lr, D_lr = (opt.lr, opt.lr) if opt.no_TTUR else (opt.lr / 2, opt.lr * 2)
-        return (torch.optim.Adam(self.netG.parameters(), lr=G_lr, betas=(opt.beta1, opt.beta2)),
-                torch.optim.Adam(self.netD.parameters(), lr=D_lr, betas=(opt.beta1, opt.beta2)))
+        # same update rule as the reference's torch.optim.Adam; on the GPU as ONE fused launch per optimizer instead of the
+        # ~10 foreach passes over G's 385 MB of parameters and moments
+        fused = all(q.is_cuda for q in self.parameters())
+        return (torch.optim.Adam(self.netG.parameters(), lr=G_lr, betas=(opt.beta1, opt.beta2), fused=fused),
+                torch.optim.Adam(self.netD.parameters(), lr=D_lr, betas=(opt.beta1, opt.beta2), fused=fused))
 
     def generate_fake(self, inp, crop):
         return self.netG(inp, crop)
@@ -71,9 +74,11 @@ class Pix2PixModel(torch.nn.Module):
                 for j in range(len(pred_fake[i]) - 1):
                     h, w = pred_fake[i][j].shape[2:]
                     mask = F.interpolate(mask, size=(h, w))  # the reference re-interpolates the running mask
-                    wf = pred_fake[i][j] * mask + pred_fake[i][j] * (1 - mask) * 50
-                    wr = pred_real[i][j] * mask + pred_real[i][j] * (1 - mask) * 50
-                    feat = feat + self.criterionFeat(wf, wr.detach()) / num_D
+                    # reference: L1(f*m + f*(1-m)*50, r*m + r*(1-m)*50) -- both sides carry the same per-pixel weight
+                    # m + 50(1-m) = 50 - 49m, so the term is mean(|(f - r) * (50 - 49m)|): 3 passes over the feature pair
+                    # instead of 11 (and as many fewer in the backward); differs from the literal form by f32 rounding only
+                    wgt = 50.0 - 49.0 * mask
+                    feat = feat + ((pred_fake[i][j] - pred_real[i][j].detach()) * wgt).abs().mean() / num_D
             losses["GAN_Feat"] = feat
         if not self.opt.no_vgg_loss:
             from .vgg import vgg_loss

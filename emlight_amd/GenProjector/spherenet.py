@@ -166,7 +166,9 @@ class _SphereConvFn(torch.autograd.Function):
         return a9
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, kind="sphere"):
+    def forward(ctx, x, weight, bias, stride, kind="sphere", residual=None, slope=1.0):
+        """``residual`` (B, O, H', W') and ``slope``: the consumer's epilogue folded in, ``leaky_relu(conv + bias + residual,
+        slope)`` (slope 1 = none, 0 = ReLU) -- the ``x_s + dx`` of a SPADEResnetBlock (architecture.py:60), VGG's ReLUs."""
         from .. import _lib
         _require_gpu_f32(x, "SphereConv2D input")
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
@@ -191,18 +193,32 @@ class _SphereConvFn(torch.autograd.Function):
         ctx.fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
                            (B * po >= 32768 or lim == 0))
         a9 = None
+        slope = float(slope)
+        res = None
+        if residual is not None:
+            if residual.shape != (B, O, geo.ho, geo.wo):
+                raise ValueError("SphereConv2D residual %s does not match the output (%d, %d, %d, %d)"
+                                 % (tuple(residual.shape), B, O, geo.ho, geo.wo))
+            res = residual.permute(0, 2, 3, 1).contiguous().view(B * po, O)    # a view when it is channels-last
         if ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
             tab = (geo.idx1, geo.wgt1, 1) if geo.idx1 is not None else (geo.idx, geo.wgt, 4)
-            _lib.check(L.eml_sphere_conv_fwd_fused_f32(p(xr), p(tab[0]), p(tab[1]), p(w2.contiguous()),
-                                                       p(bias.contiguous()) if bias is not None else None, p(y), B,
-                                                       H * W, po, C, O, tab[2], st), "eml_sphere_conv_fwd_fused_f32")
+            _lib.check(L.eml_sphere_conv_fwd_fused_ex_f32(p(xr), p(tab[0]), p(tab[1]), p(w2.contiguous()),
+                                                          p(bias.contiguous()) if bias is not None else None, p(y), B,
+                                                          H * W, po, C, O, tab[2], p(res) if res is not None else None,
+                                                          slope, st), "eml_sphere_conv_fwd_fused_ex_f32")
         else:
             a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
             y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
+            if res is not None:
+                y += res
+            if slope != 1.0:
+                y = torch.relu_(y) if slope == 0.0 else nn.functional.leaky_relu_(y, slope)
         # the library weight gradient needs A9 again: keep it (9x the input) or rebuild it from x; the fused one never does
         ctx.keep = (a9 is not None and not ctx.fused_wgrad and SphereConv2D.keep_operand and weight.requires_grad)
-        ctx.save_for_backward(a9 if ctx.keep else xr, weight)
+        ctx.slope = slope
+        # an activation's derivative is taken from the OUTPUT's sign (valid for slope >= 0; the entry point rejects others)
+        ctx.save_for_backward(a9 if ctx.keep else xr, weight, *((y,) if slope != 1.0 else ()))
         ctx.geo, ctx.has_bias, ctx.shape = geo, bias is not None, (B, C, H, W, O)
         return y.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
 
@@ -210,12 +226,18 @@ class _SphereConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-        xr, weight = ctx.saved_tensors
+        xr, weight = ctx.saved_tensors[:2]
         geo = ctx.geo
         B, C, H, W, O = ctx.shape
         po = geo.ho * geo.wo
         gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
-        gx = gw = gb = None
+        if ctx.slope != 1.0:
+            y = ctx.saved_tensors[2]
+            gyr = (torch.ops.aten.threshold_backward(gyr, y, 0.0) if ctx.slope == 0.0
+                   else torch.ops.aten.leaky_relu_backward(gyr, y, ctx.slope, True))
+        gx = gw = gb = gres = None
+        if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5]:
+            gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gyr.sum(0)
         if ctx.needs_input_grad[1]:
@@ -266,19 +288,23 @@ class _SphereConvFn(torch.autograd.Function):
                     _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
                                                        H * W, po, C, st), "eml_sphere_col2im_f32")
             gx = gxr.permute(0, 3, 1, 2)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, gres, None
 
 
-def sphere_conv(x, weight, bias, stride=1):
+def sphere_conv(x, weight, bias, stride=1, residual=None, act_slope=1.0):
     """``conv2d(grid_sample(x, grid(H, W, stride)), weight, bias, stride=3)`` on the MI355X (the one execution path;
-    tests swap this attribute for the oracle's stock-op restatement when they need a CPU run)."""
-    return _SphereConvFn.apply(x, weight, bias, stride)
+    tests swap this attribute for the oracle's stock-op restatement when they need a CPU run).  ``residual`` / ``act_slope``:
+    ``leaky_relu(conv + residual, act_slope)`` in the producing kernel's epilogue (defaults: the plain convolution)."""
+    if residual is None and act_slope == 1.0:
+        return _SphereConvFn.apply(x, weight, bias, stride)
+    return _SphereConvFn.apply(x, weight, bias, stride, "sphere", residual, act_slope)
 
 
-def planar_conv3x3(x, weight, bias, stride=1):
+def planar_conv3x3(x, weight, bias, stride=1, act_slope=1.0):
     """``F.conv2d(x, weight, bias, stride, padding=1)`` for a 3x3 kernel through the same gather + f32-MFMA kernels as
-    SphereConv2D (the tap table of an ordinary convolution; used by the VGG19 feature stack of the perceptual loss)."""
-    return _SphereConvFn.apply(x, weight, bias, stride, "planar")
+    SphereConv2D (the tap table of an ordinary convolution; used by the VGG19 feature stack of the perceptual loss).
+    ``act_slope`` = 0: the ReLU that follows every VGG convolution, applied in the epilogue."""
+    return _SphereConvFn.apply(x, weight, bias, stride, "planar", None, act_slope)
 
 
 def _rows_view(t):
@@ -445,6 +471,50 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
 
 
+class _InstanceNormActFn(torch.autograd.Function):
+    """``leaky_relu(instance_norm(x), slope)`` for ``nn.InstanceNorm2d(affine=False)`` (no running statistics): one HIP launch
+    each way (``csrc/instance_norm.hip``) on a channels-last or an NCHW tensor, statistics in f64."""
+
+    @staticmethod
+    def forward(ctx, x, eps, slope):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        _require_gpu_f32(x, "InstanceNorm input")
+        B, C, H, W = x.shape
+        cl = (not x.is_contiguous()) and C % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+        if not cl:
+            x = x.contiguous()
+        y = torch.empty_like(x)      # preserves the layout
+        stats = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.eml_instance_norm_act_fwd_f32(p(x), p(y), p(stats), B, H * W, C, int(cl), float(eps), float(slope), st),
+                   "eml_instance_norm_act_fwd_f32")
+        ctx.save_for_backward(x, stats)
+        ctx.cl, ctx.slope = cl, float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        x, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last) if ctx.cl else gy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(L.eml_instance_norm_act_bwd_f32(p(gy), p(x), p(stats), p(dx), B, H * W, C, int(ctx.cl), ctx.slope, st),
+                   "eml_instance_norm_act_bwd_f32")
+        return dx, None, None
+
+
+def instance_norm_act(x, norm, slope=1.0):
+    """``leaky_relu(norm(x), slope)`` for a parameter-free ``nn.InstanceNorm2d`` (normalization.py:44-45 + the LeakyReLU that
+    follows it in the discriminator / encoder); any other norm module runs as it is, followed by the stock activation."""
+    if (isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] * x.shape[3] > 1):
+        return _InstanceNormActFn.apply(x, norm.eps, slope)
+    y = norm(x)
+    return y if slope == 1.0 else nn.functional.leaky_relu(y, slope)
+
+
 class SphereConv2D(nn.Module):
     """3x3 spherical convolution, same parameters (``weight`` (out,in,3,3), ``bias``) and init as the
     reference (``sphere_cnn.py:87-109``).  Runs on the MI355X only (``sphere_conv`` above); the reference's two
@@ -470,5 +540,7 @@ class SphereConv2D(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def forward(self, x):
-        return sphere_conv(x, self.weight, self.bias, self.stride)
+    def forward(self, x, residual=None, act_slope=1.0):
+        if residual is None and act_slope == 1.0:
+            return sphere_conv(x, self.weight, self.bias, self.stride)
+        return sphere_conv(x, self.weight, self.bias, self.stride, residual, act_slope)

@@ -36,8 +36,8 @@ class PlanarConv3x3(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # torchvision's VGG initialisation
 
-    def forward(self, x):
-        return spherenet.planar_conv3x3(x, self.weight, self.bias, 1)
+    def forward(self, x, act_slope=1.0):
+        return spherenet.planar_conv3x3(x, self.weight, self.bias, 1, act_slope)
 
 
 class VGG19Features(nn.Module):
@@ -74,7 +74,7 @@ class VGG19Features(nn.Module):
                 idx += 1
                 continue
             idx = item[0]
-            x = torch.relu(self.features[str(idx)](x))
+            x = self.features[str(idx)](x, act_slope=0.0)   # conv + the ReLU that follows it (epilogue of the MFMA kernel)
             idx += 1                      # the ReLU after conv `idx`
             if idx in _SLICE_ENDS:
                 out.append(x)

@@ -76,7 +76,8 @@ class RegressionTrainer:
             self.ddp = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas,
+                                          fused=self.device.type == "cuda")   # one launch instead of the foreach passes
 
     def step(self, batch):
         net = self.ddp if self.ddp is not None else self.model

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
     int HW /* source pixels per sample */, int Po /* destination pixels per sample */, int C, int O, int ke,
-    const unsigned char* __restrict__ rowmax) {
+    const unsigned char* __restrict__ rowmax, const float* __restrict__ res /*[M][O] added before the activation, or NULL*/,
+    float slope /* leaky-ReLU slope of the epilogue: 1 = none, 0 = ReLU */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][kBM][kLdF]
   float* Bs = smem + 2 * kBM * kLdF;      // [2][BN][kLdF]
@@ -276,9 +277,16 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int m = m0 + 64 * wm + 16 * mi + r;
-      if (m < M)
-        *reinterpret_cast<float4*>(Y + (size_t)m * O + o) =
-            make_float4(acc[ni][mi][0] + bq.x, acc[ni][mi][1] + bq.y, acc[ni][mi][2] + bq.z, acc[ni][mi][3] + bq.w);
+      if (m < M) {
+        float4 v = make_float4(acc[ni][mi][0] + bq.x, acc[ni][mi][1] + bq.y, acc[ni][mi][2] + bq.z, acc[ni][mi][3] + bq.w);
+        if (res) {   // residual sum of a ResNet block (x_s + conv_1(.)): the lane that writes an element reads it, Y may alias res
+          const float4 q = *reinterpret_cast<const float4*>(res + (size_t)m * O + o);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(Y + (size_t)m * O + o) = v;
+      }
     }
   }
 }
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 namespace {
 int launch_gather_gemm(const char* what, const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
                        float* Y, int B, int HW, int Po, int C, int O, int ke, const unsigned char* rowmax,
-                       eml_stream_t stream) {
+                       const float* res, float slope, eml_stream_t stream) {
   if (B == 0) return EML_OK;
   const long M = (long)B * Po;
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
@@ -467,7 +475,7 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   do {                                                                                                              \
     EML_ENSURE_LDS((&sphere_conv_fwd_fused_kernel<BNV, ONEV>), lds);                                                \
     hipLaunchKernelGGL((sphere_conv_fwd_fused_kernel<BNV, ONEV>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
-                       wgt, W2, bias, Y, (int)M, HW, Po, C, O, ke, rowmax);                                         \
+                       wgt, W2, bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope);                             \
   } while (0)
   if (ke == 1) {
     if (bn == 128) EML_LAUNCH_GG(128, true); else EML_LAUNCH_GG(64, true);
@@ -485,7 +493,22 @@ extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, con
   if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
   if (ke != 4 && ke != 1) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_f32: ke must be 4 (bilinear taps) or 1");
-  return launch_gather_gemm("eml_sphere_conv_fwd_fused_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr, stream);
+  return launch_gather_gemm("eml_sphere_conv_fwd_fused_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr, nullptr,
+                            1.f, stream);
+}
+
+// The same product with the epilogue of its consumer folded in: Y = act(conv + bias + residual), act = leaky ReLU of slope
+// `act_slope` (1 = none, 0 = ReLU; in [0, 1]).  `residual` (B*Po, O) or NULL; Y may alias it.
+extern "C" int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                                const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
+                                                const float* residual, float act_slope, eml_stream_t stream) {
+  if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
+  if (ke != 4 && ke != 1) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: ke must be 4 (bilinear taps) or 1");
+  if (!(act_slope >= 0.f && act_slope <= 1.f))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: act_slope %g outside [0, 1]", (double)act_slope);
+  return launch_gather_gemm("eml_sphere_conv_fwd_fused_ex_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr,
+                            residual, act_slope, stream);
 }
 
 // dX (B*HW, C) = gather-GEMM over the transposed tap table: tidx / twgt (HW*9*ke) = for input pixel q and tap t the
@@ -499,7 +522,7 @@ extern "C" int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx,
                      C, O);
   // roles swap: the rows gathered are dY's (Po per sample, O wide), the destination pixels are the HW input pixels
   return launch_gather_gemm("eml_sphere_conv_dgrad_fused_f32", dY, tidx, twgt, W2t, nullptr, dX, B, Po, HW, O, C, ke, rowmax,
-                            stream);
+                            nullptr, 1.f, stream);
 }
 
 extern "C" size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k) {

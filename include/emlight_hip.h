@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 11
+#define EML_ABI_VERSION 12
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -366,6 +366,13 @@ int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, cons
 int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                   const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
                                   eml_stream_t stream);
+/* The same product with its consumer's epilogue folded in: Y = leaky_relu(conv + bias + residual, act_slope).  residual
+ * (B*Po, O) or NULL -- the `x_s + dx` of SPADEResnetBlock (architecture.py:60); Y may alias it.  act_slope in [0, 1]: 1 = none,
+ * 0 = ReLU (VGG19's nn.ReLU after every convolution, architecture.py:92-125), 0.2 = the LeakyReLU before the generator's last
+ * convolution (generator.py:84).  eml_sphere_conv_fwd_fused_f32 is this entry with (NULL, 1). */
+int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                     const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
+                                     const float* residual, float act_slope, eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the
@@ -416,6 +423,18 @@ int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, 
 int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
                          const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
                          eml_stream_t stream);
+
+/* nn.InstanceNorm2d(affine=False) + the LeakyReLU that follows it in the PatchGAN discriminator and the crop encoder
+ * (normalization.py:44-45 'instance'; discriminator.py:84-98; generator.py:113-122): y = leaky_relu((x - mean) * istd, slope),
+ * mean / biased variance per (sample, channel) over the HW pixels (f64 accumulation), istd = 1/sqrt(var + eps).
+ * x, y, gy, dx: dense (B, HW, C) pixel-major tensors when channels_last != 0 (C % 4 == 0), dense (B, C, HW) otherwise.
+ * stats (B, C, 2) f32 = (mean, istd), written by the forward and read by the backward:
+ *   g' = gy * (xhat > 0 ? 1 : slope),  dx = istd * (g' - mean_HW(g') - xhat * mean_HW(g' * xhat)).
+ * slope in [0, 1] (1 = no activation).  One launch each way; replaces ATen's copy + batch_norm_* + leaky_relu chains. */
+int eml_instance_norm_act_fwd_f32(const float* x, float* y, float* stats, int B, int HW, int C, int channels_last,
+                                  float eps, float slope, eml_stream_t stream);
+int eml_instance_norm_act_bwd_f32(const float* gy, const float* x, const float* stats, float* dx, int B, int HW, int C,
+                                  int channels_last, float slope, eml_stream_t stream);
 
 /* ---------------------------------------------------------------- ground-truth parametrisation (data preparation)
  * representation/distribution_representation.py:65-120 (`extract_mesh`), the inverse of the rasteriser.

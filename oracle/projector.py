@@ -56,11 +56,18 @@ def sampling_grid(h, w, stride=1):
     return torch.from_numpy(grid.reshape(1, 3 * len(rr), 3 * len(cc), 2)).float()
 
 
-def sphere_conv(x, weight, bias, stride=1):
+def sphere_conv(x, weight, bias, stride=1, residual=None, act_slope=1.0):
     """``SphereConv2D.forward`` (``sphere_cnn.py:111-124``): grid_sample (bilinear, torch >= 1.3 defaults:
-    ``align_corners=False``, zero padding) then a stride-3 3x3 convolution."""
+    ``align_corners=False``, zero padding) then a stride-3 3x3 convolution.  ``residual`` / ``act_slope``: the product folds
+    the ops that FOLLOW some convolutions into their kernel; here they are the reference's own separate ops --
+    ``x_s + dx`` (``architecture.py:60``) and ``F.leaky_relu(., 2e-1)`` (``generator.py:84``) / ``nn.ReLU`` (``normalization.py:92``)."""
     grid = sampling_grid(x.shape[2], x.shape[3], stride).to(x.device).expand(x.shape[0], -1, -1, -1)
-    return F.conv2d(F.grid_sample(x, grid, mode="bilinear", align_corners=False), weight, bias, stride=3)
+    y = F.conv2d(F.grid_sample(x, grid, mode="bilinear", align_corners=False), weight, bias, stride=3)
+    if residual is not None:
+        y = residual + y
+    if act_slope != 1.0:
+        y = F.relu(y) if act_slope == 0.0 else F.leaky_relu(y, act_slope)
+    return y
 
 
 def spade_modulate(normalized, actv, conv_gamma, conv_beta, slope=1.0):

@@ -75,6 +75,14 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_dense_conv1x1_bwd_narrow_f32(one, one, 48, 37, one, 64, one, one, one, one, 10, one, 64, one, one, 48, 4,
                                               None) == -1                                                       # odd channel offset
     # round-3 entry points
+    f = ctypes.c_float
+    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 4, None, f(1.5), None) == -1
+    assert b"act_slope" in L.eml_last_error()
+    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, 1, one, f(0.0), None) == 0   # empty
+    assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 6, 1, f(1e-5), f(0.2), None) == -1    # pixel-major: C % 4
+    assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 8, 1, f(1e-5), f(-0.2), None) == -1 and b"slope" in L.eml_last_error()
+    assert L.eml_instance_norm_act_fwd_f32(one, one, one, 0, 16, 8, 0, f(1e-5), f(0.2), None) == 0      # empty batch
+    assert L.eml_instance_norm_act_bwd_f32(one, one, one, None, 1, 16, 8, 0, f(0.2), None) == -1        # null dx
     assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 1, 4, 128, 256, 6, None, None) == -1 and b"flags" in L.eml_last_error()
     assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 0, 4, 128, 256, 1, None, None) == 0                    # empty batch
     assert L.eml_dense_bn_dgamma_direct_f32(one, 224, 100, 10, 10, 0, one, 48, None, 0, None, None, None, 48, one, 400,

@@ -114,7 +114,7 @@ def test_sphere_conv_fused_kernels_vs_stock_ops(B, Cin, Cout, H, W, stride, bias
     gy = torch.randn_like(yr)
     yr.backward(gy)
     yh.backward(gy)
-    assert "eml_sphere_conv_fwd_fused_f32" in seen
+    assert "eml_sphere_conv_fwd_fused_ex_f32" in seen
     # the fused input gradient: stride-1 layers with Cout % 32 == 0 and Cin % 64 == 0 (else dY W2 + col2im)
     assert ("eml_sphere_conv_dgrad_fused_f32" in seen) == (stride == 1 and Cin % 64 == 0)
     assert ("eml_sphere_col2im_f32" in seen) != ("eml_sphere_conv_dgrad_fused_f32" in seen)
@@ -168,9 +168,9 @@ def test_ngf64_shape_list_is_what_the_networks_run(monkeypatch):
     seen = set()
     real = spherenet.sphere_conv
 
-    def spy(x, weight, bias, stride=1):
+    def spy(x, weight, bias, stride=1, *more):
         seen.add((x.shape[0], x.shape[1], weight.shape[0], x.shape[2], x.shape[3], stride))
-        return real(x, weight, bias, stride)
+        return real(x, weight, bias, stride, *more)
     monkeypatch.setattr(spherenet, "sphere_conv", spy)
     torch.manual_seed(0)
     pm = Pix2PixModel(networks.default_options()).cuda()
@@ -439,3 +439,78 @@ def test_generator_step_includes_the_vgg_term():
     assert set(losses) == {"GAN", "GAN_Feat", "VGG", "COS", "D_Fake", "D_real"}
     assert all(bool(torch.isfinite(v).all()) for v in losses.values()) and float(losses["VGG"]) > 0
     assert not any("vgg" in k for k in tr.model.netG.state_dict())    # checkpoints hold G and D only, like the reference's
+
+
+# ------------------------------------------------------------------------- epilogues folded into the convolution, InstanceNorm
+@pytest.mark.parametrize("B,Cin,Cout,H,W,slope,with_res", [(2, 64, 64, 16, 32, 0.2, True), (2, 128, 128, 32, 64, 1.0, True),
+                                                           (1, 64, 128, 16, 32, 0.0, False), (2, 6, 8, 8, 16, 0.2, True),
+                                                           (2, 3, 16, 8, 16, 0.0, False)])
+def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, slope, with_res):
+    """``leaky_relu(conv(x) + residual, slope)`` in the kernel's epilogue (fused kernel: first three shapes with
+    ``fused_min_bytes = 0``; library-GEMM path: the small ones) against the separate stock ops of the reference
+    (architecture.py:60, generator.py:84): value and d/dx, d/dW, d/db, d/dresidual."""
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    torch.manual_seed(Cin + Cout)
+    conv = SphereConv2D(Cin, Cout).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(B, Cin, H, W, device="cuda")
+    res = torch.randn(B, Cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last) if with_res else None
+    leaves = []
+    outs = []
+    saved = SphereConv2D.fused_min_bytes
+    SphereConv2D.fused_min_bytes = 0
+    try:
+        for fn in ("hip", "stock"):
+            xi = x.clone().requires_grad_(True)
+            ri = res.clone().requires_grad_(True) if with_res else None
+            for q in conv.parameters():
+                q.grad = None
+            if fn == "hip":
+                y = conv(xi, residual=ri, act_slope=slope)
+            else:
+                y = oracle.sphere_conv(xi, conv.weight, conv.bias, 1, ri, slope)
+            gy = torch.randn(y.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
+            y.backward(gy)
+            outs.append(y.detach())
+            leaves.append([xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone()] + ([ri.grad] if with_res else []))
+    finally:
+        SphereConv2D.fused_min_bytes = saved
+    scale = float(outs[1].abs().max())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), outs[1].cpu().numpy(), rtol=1e-4, atol=3e-5 * scale)
+    if slope == 0.0:
+        assert float(outs[0].min()) >= 0.0
+    for name, a, b in zip(("dx", "dW", "db", "dres"), leaves[0], leaves[1]):
+        # an output within rounding of 0 may take the other branch of the activation: compare in RMS, not element-wise
+        err = float((a - b).norm() / b.norm().clamp_min(1e-20))
+        assert err < 2e-3, (name, err)
+
+
+@pytest.mark.parametrize("B,C,H,W,cl,slope", [(4, 128, 32, 64, True, 0.2), (3, 36, 8, 16, True, 0.2), (2, 512, 8, 16, True, 1.0),
+                                              (4, 64, 64, 64, False, 0.2), (2, 512, 4, 4, False, 0.2), (2, 6, 5, 7, False, 0.0)])
+def test_instance_norm_act_vs_stock_ops(B, C, H, W, cl, slope):
+    """``leaky_relu(InstanceNorm2d(affine=False)(x), slope)`` as one HIP launch each way (channels-last and NCHW) against
+    ATen in f64: value and input gradient (normalization.py:44-45, discriminator.py:84-98)."""
+    from emlight_amd.GenProjector.spherenet import instance_norm_act
+    torch.manual_seed(C)
+    x = (torch.randn(B, C, H, W, device="cuda") * 3 + 1.5)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    norm = torch.nn.InstanceNorm2d(C, affine=False)
+    xh = x.clone().requires_grad_(True)
+    if cl:
+        xh.data = xh.data.contiguous(memory_format=torch.channels_last)
+    yh = instance_norm_act(xh, norm, slope)
+    assert yh.shape == x.shape and yh.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+    xr = x.double().contiguous().requires_grad_(True)
+    yr = norm(xr)
+    yr = yr if slope == 1.0 else torch.nn.functional.leaky_relu(yr, slope)
+    gy = torch.randn_like(x)
+    yh.backward(gy)
+    yr.backward(gy.double())
+    np.testing.assert_allclose(yh.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    err = float((xh.grad.double() - xr.grad).norm() / xr.grad.norm())
+    assert err < 1e-4, err
+    # not the HIP kernel: a norm with running statistics or an affine one falls back to the module itself
+    aff = torch.nn.InstanceNorm2d(C, affine=True).cuda()
+    torch.testing.assert_close(instance_norm_act(x, aff, 0.2), torch.nn.functional.leaky_relu(aff(x), 0.2))
