@@ -360,6 +360,8 @@ PROJECTOR_FAMILIES = {
     "eml_spade_norm_modulate_bwd_f32": ("spade_norm_modulate_bwd_kernel", None),
     "eml_bn_stats_f32": ("bn_stats_kernel (SPADE batch statistics)", None),
     "eml_bn_bwd_apply_f32": ("bn_bwd_apply_kernel", None),
+    "eml_sphere_conv_small_fwd_f32": ("sphere_conv_small_fwd_kernel (3 -> 64/128 input layers + ReLU, one pass)", None),
+    "eml_sphere_conv_small_wgrad_f32": ("sphere_conv_small_wgrad_kernel (their dW, db and ReLU backward, one pass)", None),
     "eml_instance_norm_act_fwd_f32": ("instance_norm_*_kernel<fwd> (InstanceNorm + LeakyReLU of the discriminator / encoder)", None),
     "eml_instance_norm_act_bwd_f32": ("instance_norm_*_kernel<bwd>", None),
 }

@@ -21,17 +21,13 @@ class Trainer:
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
             self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
             self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)
-            # the model calls generate_fake / discriminate: route those through the DDP wrappers
+            # the model calls generate_fake / the discriminator step's D: route those through the DDP wrappers (the
+            # generator step calls the bare D with its parameters held out of the graph: nothing to reduce)
             self.model.generate_fake = lambda inp, crop: self._ddpG(inp, crop)
-            self.model.discriminate = self._discriminate_ddp
+            object.__setattr__(self.model, "netD_train", self._ddpD)
         self.optimizer_G, self.optimizer_D = self.model.create_optimizers(opt)
         self.old_lr = opt.lr
         self.g_losses, self.d_losses, self.generated = {}, {}, None
-
-    def _discriminate_ddp(self, inp, fake, real):
-        both = torch.cat([torch.cat([inp, fake], dim=1), torch.cat([inp, real], dim=1)], dim=0)
-        out = self._ddpD(both)
-        return ([[t[:t.size(0) // 2] for t in p] for p in out], [[t[t.size(0) // 2:] for t in p] for p in out])
 
     def run_generator_one_step(self, data):
         self.optimizer_G.zero_grad()

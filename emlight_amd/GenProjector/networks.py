@@ -101,7 +101,8 @@ class SPADE(nn.Module):
         """``slope`` != 1 folds the LeakyReLU that follows this norm in SPADEResnetBlock (architecture.py:56-57) in;
         ``stats``: (mean, istd) of this x when a sibling norm already reduced it (norm_0 / norm_s share their input)."""
         segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
-        actv = self.mlp_shared(segmap)
+        conv, act = self.mlp_shared[0], self.mlp_shared[1]
+        actv = conv(segmap, act_slope=0.0) if isinstance(act, nn.ReLU) else act(conv(segmap))   # ReLU in the conv's epilogue
         return spherenet.spade_norm_modulate(x, self.param_free_norm, actv, self.mlp_gamma, self.mlp_beta, slope, stats)
 
 
@@ -239,6 +240,8 @@ class NLayerDiscriminator(nn.Module):
             mods = list(sub.children())
             if len(mods) == 2 and isinstance(mods[1], nn.LeakyReLU) and isinstance(mods[0], nn.Sequential):
                 results.append(_norm_act(mods[0], results[-1], mods[1].negative_slope))   # conv -> norm + LeakyReLU, one launch
+            elif len(mods) == 2 and isinstance(mods[1], nn.LeakyReLU) and isinstance(mods[0], SphereConv2D):
+                results.append(mods[0](results[-1], act_slope=mods[1].negative_slope))    # LeakyReLU in the conv's epilogue
             else:
                 results.append(sub(results[-1]))
         return results[1:] if not self.opt.no_ganFeat_loss else results[-1]

@@ -31,6 +31,9 @@ class Pix2PixModel(torch.nn.Module):
                 path = getattr(opt, "vgg_weights", None)
                 vgg_features = VGG19Features(torch.load(path, map_location="cpu") if path else None)
         self.vgg_features = vgg_features
+        # D as it is called in the discriminator step (the trainer swaps in its DistributedDataParallel wrapper); kept out of
+        # the module tree so that state_dict keys stay the reference's
+        object.__setattr__(self, "netD_train", self.netD)
 
     def forward(self, data, mode):
         dev = next(self.netG.parameters()).device
@@ -55,9 +58,22 @@ class Pix2PixModel(torch.nn.Module):
     def generate_fake(self, inp, crop):
         return self.netG(inp, crop)
 
-    def discriminate(self, inp, fake, real):
+    def discriminate(self, inp, fake, real, for_generator=False):
+        """``for_generator``: the generator step uses D as a fixed critic.  The reference's backward also fills D's ``.grad``
+        there, but nothing ever reads it (``optimizer_D.zero_grad()`` opens the D step, model_trainer.py:44-46): D's parameters
+        are held out of that graph -- no weight gradients, no spectral-norm backward, and under DDP no all-reduce of them."""
         both = torch.cat([torch.cat([inp, fake], dim=1), torch.cat([inp, real], dim=1)], dim=0)
-        out = self.netD(both)
+        if for_generator:
+            held = [q for q in self.netD.parameters() if q.requires_grad]
+            for q in held:
+                q.requires_grad_(False)
+            try:
+                out = self.netD(both)
+            finally:
+                for q in held:
+                    q.requires_grad_(True)
+        else:
+            out = self.netD_train(both)
         fake_p = [[t[:t.size(0) // 2] for t in p] for p in out]
         real_p = [[t[t.size(0) // 2:] for t in p] for p in out]
         return fake_p, real_p
@@ -65,7 +81,7 @@ class Pix2PixModel(torch.nn.Module):
     def compute_generator_loss(self, inp, crop, real, mask):
         losses = {}
         fake = self.generate_fake(inp, crop)
-        pred_fake, pred_real = self.discriminate(inp, fake, real)
+        pred_fake, pred_real = self.discriminate(inp, fake, real, for_generator=True)
         losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False)
         if not self.opt.no_ganFeat_loss:
             num_D = len(pred_fake)

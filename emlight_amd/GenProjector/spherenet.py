@@ -200,7 +200,18 @@ class _SphereConvFn(torch.autograd.Function):
                 raise ValueError("SphereConv2D residual %s does not match the output (%d, %d, %d, %d)"
                                  % (tuple(residual.shape), B, O, geo.ho, geo.wo))
             res = residual.permute(0, 2, 3, 1).contiguous().view(B * po, O)    # a view when it is channels-last
-        if ctx.fused_fwd:
+        # few-channel input layers (SPADE's mlp_shared 3 -> 128, the discriminator's 6 -> 64, VGG's 3 -> 64): bound by the
+        # write of their output -- one pass each way with the activation (and its backward, and the bias gradient) folded in
+        # (C = 3 only: the 6 -> 64 first stage of the discriminator always needs its input gradient, and with it the general
+        # backward measured faster than these kernels' -- tools/small_conv_bench.py)
+        ctx.small = bool(B > 0 and res is None and C == 3 and L.eml_sphere_conv_small_supported(C, O))
+        if ctx.small:
+            ctx.fused_fwd = ctx.fused_wgrad = False
+            y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
+            _lib.check(L.eml_sphere_conv_small_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+                                                       p(bias.contiguous()) if bias is not None else None, p(y), B, H * W,
+                                                       po, C, O, slope, st), "eml_sphere_conv_small_fwd_f32")
+        elif ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
             tab = (geo.idx1, geo.wgt1, 1) if geo.idx1 is not None else (geo.idx, geo.wgt, 4)
             _lib.check(L.eml_sphere_conv_fwd_fused_ex_f32(p(xr), p(tab[0]), p(tab[1]), p(w2.contiguous()),
@@ -231,16 +242,32 @@ class _SphereConvFn(torch.autograd.Function):
         B, C, H, W, O = ctx.shape
         po = geo.ho * geo.wo
         gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
-        if ctx.slope != 1.0:
-            y = ctx.saved_tensors[2]
+        y = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
+        gx = gw = gb = gres = None
+        # (when the input gradient is wanted too -- the discriminator's first stage -- the masked dY has to be formed for it
+        # anyway and the general weight-gradient path on it measured faster: tools/small_conv_bench.py)
+        small_w = ctx.small and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+        if small_w:
+            # dW2, the bias gradient and the activation's backward in one pass over (dY, Y)
+            part = torch.empty(L.eml_sphere_conv_small_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
+            gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
+            gb_ = torch.empty(O, dtype=torch.float32, device=gy.device) if ctx.has_bias else None
+            _lib.check(L.eml_sphere_conv_small_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(y) if y is not None else None,
+                                                         ctx.slope, p(part), p(gw2), p(gb_) if gb_ is not None else None, B,
+                                                         H * W, po, C, O, st), "eml_sphere_conv_small_wgrad_f32")
+            gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+            gb = gb_ if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            del part
+        need_masked = (ctx.needs_input_grad[0] or (len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5])
+                       or (not small_w and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]))))
+        if y is not None and need_masked:
             gyr = (torch.ops.aten.threshold_backward(gyr, y, 0.0) if ctx.slope == 0.0
                    else torch.ops.aten.leaky_relu_backward(gyr, y, ctx.slope, True))
-        gx = gw = gb = gres = None
         if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5]:
             gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not small_w:
             gb = gyr.sum(0)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not small_w:
             if ctx.fused_wgrad and B:
                 bn = 128 if C % 128 == 0 else 64
                 bmo = 128 if (O % 128 == 0 or O > 192) else 64

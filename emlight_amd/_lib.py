@@ -43,6 +43,12 @@ SIGNATURES = {
                                              _stream]),
     "eml_sphere_conv_fwd_fused_ex_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                                                 _f32p, ctypes.c_float, _stream]),
+    "eml_sphere_conv_small_supported": (_int, [_int, _int]),
+    "eml_sphere_conv_small_fwd_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,
+                                             ctypes.c_float, _stream]),
+    "eml_sphere_conv_small_wgrad_partial_floats": (ctypes.c_size_t, [_int, _int, _int, _int]),
+    "eml_sphere_conv_small_wgrad_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p, _int,
+                                               _int, _int, _int, _int, _stream]),
     "eml_instance_norm_act_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, ctypes.c_float,
                                              _stream]),
     "eml_instance_norm_act_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _stream]),

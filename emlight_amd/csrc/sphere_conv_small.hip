@@ -1,0 +1,287 @@
+// SphereConv2D (and the ordinary 3x3 convolution written as a gather) for the few-channel INPUT layers of the GenProjector:
+// SPADE's mlp_shared 3 -> 128 + ReLU on the guide map (normalization.py:92-96, 28 of them per generator pass), the
+// discriminator's first stage 6 -> 64 + LeakyReLU (discriminator.py:80-82), VGG19's conv1_1 3 -> 64 + ReLU.
+//
+// These layers are HBM-bound on their OUTPUT: K = 9 * Cin = 27 or 54, so per pixel they write O floats for O * 2K flops.
+// On the general path they were im2col (a 9x operand) + library GEMM + a separate activation pass, and in the backward an
+// activation-backward pass, a bias-gradient reduction and a split-K batched GEMM -- 3 and 5 traversals of the (pixels, O)
+// tensor.  Here: one traversal each way.
+//   forward : wave = 32 pixels x all O channels; the K <= 56 interpolated taps of a pixel are built in registers straight from
+//             the tap table (x is a few MB: L2 resident), W2 lives in registers (56 VGPRs), f32 MFMA 16x16x4 with the channels
+//             on the rows so that a lane's 4 results are 4 consecutive channels of one pixel (16-byte stores);
+//             bias + leaky ReLU in the epilogue.
+//   wgrad   : dW2[o][k] = sum_m g'[m][o] * A[m][k] with g' = dY * act'(Y) formed in registers from 16-byte loads of dY and Y
+//             (the pixel axis is the MFMA's K dimension, so WHICH pixel a lane feeds is free: lanes take 4 consecutive channels
+//             of "their" pixel and the four components go to four interleaved row tiles).  The padding column k = 9*Cin of A
+//             is set to 1: its column of the result IS the bias gradient.  Per-wave partials are summed through LDS per
+//             workgroup, then by a deterministic second kernel.
+#include <algorithm>
+
+#include "eml_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// interpolated tap value A[m][k] (k = tap * CIN + c), grid_sampler's corner order; out-of-range corners (index -1) contribute
+// nothing.  All loads are UNCONDITIONAL (clamped address, the value selected afterwards): under `if (id >= 0)` each corner
+// became its own basic block -- load, wait, add -- and a wave's 14 taps x 4 corners ran as 56 serial L2 round trips.
+template <int CIN>
+__device__ __forceinline__ float tap_value(const float* __restrict__ xb, const int* __restrict__ idx,
+                                           const float* __restrict__ wgt, int p, int k) {
+  const int tap = k / CIN, c = k - tap * CIN;
+  const int4 id = *reinterpret_cast<const int4*>(idx + ((size_t)p * 9 + tap) * 4);
+  const float4 w = *reinterpret_cast<const float4*>(wgt + ((size_t)p * 9 + tap) * 4);
+  const float x0 = xb[(size_t)max(id.x, 0) * CIN + c], x1 = xb[(size_t)max(id.y, 0) * CIN + c];
+  const float x2 = xb[(size_t)max(id.z, 0) * CIN + c], x3 = xb[(size_t)max(id.w, 0) * CIN + c];
+  float v = (id.x >= 0 ? x0 : 0.f) * w.x;
+  v += (id.y >= 0 ? x1 : 0.f) * w.y;
+  v += (id.z >= 0 ? x2 : 0.f) * w.z;
+  v += (id.w >= 0 ? x3 : 0.f) * w.w;
+  return v;
+}
+
+template <int CIN, int O>
+__global__ __launch_bounds__(256, 2) void sphere_conv_small_fwd_kernel(const float* __restrict__ X, const int* __restrict__ idx,
+                                                                    const float* __restrict__ wgt,
+                                                                    const float* __restrict__ W2 /*[O][9*CIN]*/,
+                                                                    const float* __restrict__ bias, float* __restrict__ Y,
+                                                                    int M, int HW, int Po, float slope) {
+  constexpr int K = 9 * CIN, KS = (K + 3) / 4, MT = O / 16;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float wreg[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + g;
+      wreg[mt][s] = k < K ? W2[(size_t)(16 * mt + r) * K + k] : 0.f;
+    }
+  float4 bq[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    bq[mt] = bias ? *reinterpret_cast<const float4*>(bias + 16 * mt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ntiles = (M + 31) / 32;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const int m0 = t * 32;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int m = m0 + 16 * nt + r;
+      const bool ok = m < M;
+      const int b = ok ? m / Po : 0, p = ok ? m - b * Po : 0;
+      const float* xb = X + (size_t)b * HW * CIN;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + g;
+        const float v = tap_value<CIN>(xb, idx, wgt, p, min(k, K - 1));   // padding lanes gather a valid address too
+        av[nt][s] = (ok && k < K) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = mfma16(wreg[mt][s], av[0][s], acc[mt][0]);
+        acc[mt][1] = mfma16(wreg[mt][s], av[1][s], acc[mt][1]);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int m = m0 + 16 * nt + r;
+      if (m < M) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float4 v = make_float4(acc[mt][nt][0] + bq[mt].x, acc[mt][nt][1] + bq[mt].y, acc[mt][nt][2] + bq[mt].z,
+                                 acc[mt][nt][3] + bq[mt].w);
+          v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+          v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+          *reinterpret_cast<float4*>(Y + (size_t)m * O + 16 * mt + 4 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+// partial[blockIdx.x][O][KP]  (KP = 4 * ceil((9*CIN + 1) / 16) * 4 columns: k < 9*CIN = dW2, k = 9*CIN = the bias gradient)
+template <int CIN, int O>
+__global__ __launch_bounds__(256, 2) void sphere_conv_small_wgrad_kernel(const float* __restrict__ X, const int* __restrict__ idx,
+                                                                      const float* __restrict__ wgt,
+                                                                      const float* __restrict__ dY, const float* __restrict__ Yact,
+                                                                      float* __restrict__ partial, int M, int HW, int Po,
+                                                                      float slope) {
+  constexpr int K = 9 * CIN, NT = (K + 1 + 15) / 16, KP = 16 * NT, NG = O / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3][O * KP] wave partials of waves 1..3
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+  f32x4 acc[NG][4][NT];   // [64-channel group][component t of the float4][column tile]: row r <-> channel 64G + 4r + t
+#pragma unroll
+  for (int G = 0; G < NG; ++G)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[G][t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // 4 pixels per MFMA k-step; U k-steps per iteration so that U sets of gathers are in flight before the first MFMA needs one
+  constexpr int U = 2;
+  const int nsteps = (M + 4 * U - 1) / (4 * U);
+  for (int st = wave; st < nsteps; st += nwaves) {
+    float bv[U][NT];
+    float4 gq[U][NG];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = (st * U + u) * 4 + g;        // this lane's pixel of the k-step
+      const bool ok = m < M;
+      const int b = ok ? m / Po : 0, p = ok ? m - b * Po : 0;
+      const float* xb = X + (size_t)b * HW * CIN;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int k = 16 * nt + r;
+        const float v = tap_value<CIN>(xb, idx, wgt, p, min(k, K - 1));
+        bv[u][nt] = !ok ? 0.f : k < K ? v : k == K ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int G = 0; G < NG; ++G) {
+        const size_t off = (size_t)(ok ? m : 0) * O + 64 * G + 4 * r;
+        float4 q = *reinterpret_cast<const float4*>(dY + off);
+        if (Yact) {   // wave-uniform
+          const float4 yq = *reinterpret_cast<const float4*>(Yact + off);
+          q.x = yq.x > 0.f ? q.x : q.x * slope; q.y = yq.y > 0.f ? q.y : q.y * slope;
+          q.z = yq.z > 0.f ? q.z : q.z * slope; q.w = yq.w > 0.f ? q.w : q.w * slope;
+        }
+        gq[u][G] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[G][0][nt] = mfma16(gq[u][G].x, bv[u][nt], acc[G][0][nt]);
+          acc[G][1][nt] = mfma16(gq[u][G].y, bv[u][nt], acc[G][1][nt]);
+          acc[G][2][nt] = mfma16(gq[u][G].z, bv[u][nt], acc[G][2][nt]);
+          acc[G][3][nt] = mfma16(gq[u][G].w, bv[u][nt], acc[G][3][nt]);
+        }
+  }
+  // D element i of tile (G, t, nt): row 4g + i <-> channel 64G + 4(4g + i) + t, column 16nt + r
+  if (wv > 0) {
+    float* dst = smem + (size_t)(wv - 1) * O * KP;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[(64 * G + 4 * (4 * g + i) + t) * KP + 16 * nt + r] = acc[G][t][nt][i];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* out = partial + (size_t)blockIdx.x * O * KP;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = (64 * G + 4 * (4 * g + i) + t) * KP + 16 * nt + r;
+            out[e] = ((acc[G][t][nt][i] + smem[e]) + smem[O * KP + e]) + smem[2 * O * KP + e];
+          }
+  }
+}
+
+// dW2[o][k] (k < K) and db[o] (column K) = fixed-order sum of the workgroup partials
+__global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ partial, int S, int O, int K, int KP,
+                                                                 float* __restrict__ dW2, float* __restrict__ db) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= O * KP) return;
+  const int o = e / KP, k = e - o * KP;
+  if (k > K) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += partial[(size_t)z * O * KP + e];
+  if (k < K) dW2[(size_t)o * K + k] = s;
+  else if (db) db[o] = s;
+}
+
+constexpr int kSmallGrid = 512;   // persistent workgroups of the weight gradient (= its partial count)
+
+template <int CIN, int O>
+void launch_small_wgrad(const float* X, const int* idx, const float* wgt, const float* dY, const float* Yact, float* partial,
+                        float* dW2, float* db, int M, int HW, int Po, float slope, int grid, hipStream_t st) {
+  constexpr int K = 9 * CIN, NT = (K + 1 + 15) / 16, KP = 16 * NT;
+  const size_t lds = (size_t)3 * O * KP * sizeof(float);
+  EML_ENSURE_LDS((&sphere_conv_small_wgrad_kernel<CIN, O>), lds);
+  hipLaunchKernelGGL((sphere_conv_small_wgrad_kernel<CIN, O>), dim3(grid), dim3(256), lds, st, X, idx, wgt, dY, Yact, partial, M,
+                     HW, Po, slope);
+  hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3((O * KP + 255) / 256), dim3(256), 0, st, partial, grid, O, K, KP, dW2, db);
+}
+
+int small_kp(int C) { return 16 * ((9 * C + 1 + 15) / 16); }
+bool small_supported(int C, int O) { return (C == 3 && (O == 64 || O == 128)) || (C == 6 && O == 64); }
+int small_wgrad_grid(long M) { return (int)std::min<long>(kSmallGrid, std::max<long>(1, (M + 1023) / 1024)); }
+
+}  // namespace
+
+extern "C" int eml_sphere_conv_small_supported(int C, int O) { return small_supported(C, O) ? 1 : 0; }
+
+extern "C" int eml_sphere_conv_small_fwd_f32(const float* X, const int* idx, const float* wgt, const float* W2,
+                                             const float* bias, float* Y, int B, int HW, int Po, int C, int O,
+                                             float act_slope, eml_stream_t stream) {
+  if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: null pointer or empty shape");
+  if (!small_supported(C, O))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128), (6, 64)}", C, O);
+  if (!(act_slope >= 0.f && act_slope <= 1.f))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: act_slope %g outside [0, 1]", (double)act_slope);
+  const long M = (long)B * Po;
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: too many pixels");
+  if (M == 0) return EML_OK;
+  const int grid = (int)std::min<long>(1024, (M + 127) / 128);   // persistent: W2 is loaded into registers once per wave
+  hipStream_t st = (hipStream_t)stream;
+#define EML_SMALL_FWD(CV, OV)                                                                                              \
+  hipLaunchKernelGGL((sphere_conv_small_fwd_kernel<CV, OV>), dim3(grid), dim3(256), 0, st, X, idx, wgt, W2, bias, Y, (int)M, HW, \
+                     Po, act_slope)
+  if (C == 3 && O == 128) EML_SMALL_FWD(3, 128);
+  else if (C == 3) EML_SMALL_FWD(3, 64);
+  else EML_SMALL_FWD(6, 64);
+#undef EML_SMALL_FWD
+  return eml::check_launch("eml_sphere_conv_small_fwd_f32");
+}
+
+extern "C" size_t eml_sphere_conv_small_wgrad_partial_floats(int B, int Po, int C, int O) {
+  if (!small_supported(C, O) || B < 1 || Po < 1) return 0;
+  return (size_t)small_wgrad_grid((long)B * Po) * O * small_kp(C);
+}
+
+extern "C" int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY,
+                                               const float* Yact, float act_slope, float* partial, float* dW2, float* db,
+                                               int B, int HW, int Po, int C, int O, eml_stream_t stream) {
+  if (!X || !idx || !wgt || !dY || !partial || !dW2 || B < 0 || HW < 1 || Po < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: null pointer or empty shape");
+  if (!small_supported(C, O))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128), (6, 64)}", C, O);
+  if (!(act_slope >= 0.f && act_slope <= 1.f) || (act_slope != 1.f && !Yact))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: act_slope %g needs Yact and a slope in [0, 1]", (double)act_slope);
+  const long M = (long)B * Po;
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: too many pixels");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    (void)hipMemsetAsync(dW2, 0, (size_t)O * 9 * C * sizeof(float), st);
+    if (db) (void)hipMemsetAsync(db, 0, (size_t)O * sizeof(float), st);
+    return eml::check_launch("eml_sphere_conv_small_wgrad_f32");
+  }
+  const int grid = small_wgrad_grid(M);
+  const float* ya = act_slope != 1.f ? Yact : nullptr;
+  if (C == 3 && O == 128) launch_small_wgrad<3, 128>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
+  else if (C == 3) launch_small_wgrad<3, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
+  else launch_small_wgrad<6, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
+  return eml::check_launch("eml_sphere_conv_small_wgrad_f32");
+}

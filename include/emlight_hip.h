@@ -373,6 +373,20 @@ int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* w
 int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                      const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
                                      const float* residual, float act_slope, eml_stream_t stream);
+/* The few-channel input layers -- SPADE's mlp_shared 3 -> 128 + ReLU (normalization.py:92-96), the discriminator's first
+ * stage 6 -> 64 + LeakyReLU (discriminator.py:80-82), VGG19's conv1_1 3 -> 64 + ReLU -- are bound by the write of their
+ * output: one pass each way.  (C, O) in {(3, 64), (3, 128), (6, 64)} (eml_sphere_conv_small_supported); idx / wgt = the
+ * 4-entry tap table; X (B, HW, C), W2 (O, 9C), Y (B*Po, O) = leaky_relu(conv + bias, act_slope).
+ * Weight gradient: dW2 (O, 9C) = sum_m g'[m] (x) A[m] and db (O, or NULL) = sum_m g'[m], g' = dY * (Yact > 0 ? 1 : act_slope)
+ * (Yact = the forward's output; NULL with act_slope = 1); partial = eml_sphere_conv_small_wgrad_partial_floats floats of
+ * scratch (per-workgroup partial sums, reduced in a fixed order: deterministic). */
+int eml_sphere_conv_small_supported(int C, int O);
+int eml_sphere_conv_small_fwd_f32(const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
+                                  float* Y, int B, int HW, int Po, int C, int O, float act_slope, eml_stream_t stream);
+size_t eml_sphere_conv_small_wgrad_partial_floats(int B, int Po, int C, int O);
+int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY, const float* Yact,
+                                    float act_slope, float* partial, float* dW2, float* db, int B, int HW, int Po, int C,
+                                    int O, eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the

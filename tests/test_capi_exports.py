@@ -79,6 +79,12 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 4, None, f(1.5), None) == -1
     assert b"act_slope" in L.eml_last_error()
     assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, 1, one, f(0.0), None) == 0   # empty
+    assert L.eml_sphere_conv_small_supported(3, 128) == 1 and L.eml_sphere_conv_small_supported(6, 128) == 0
+    assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 1, 32, 32, 4, 128, f(0.0), None) == -1 and b"(C, O)" in L.eml_last_error()
+    assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 0, 32, 32, 3, 128, f(0.0), None) == 0       # empty batch
+    assert L.eml_sphere_conv_small_wgrad_partial_floats(32, 32768, 3, 128) == 512 * 128 * 32
+    assert L.eml_sphere_conv_small_wgrad_partial_floats(1, 100, 6, 64) == 64 * 64
+    assert L.eml_sphere_conv_small_wgrad_f32(one, one, one, one, None, f(0.0), one, one, None, 1, 32, 32, 3, 128, None) == -1   # ReLU needs Yact
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 6, 1, f(1e-5), f(0.2), None) == -1    # pixel-major: C % 4
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 8, 1, f(1e-5), f(-0.2), None) == -1 and b"slope" in L.eml_last_error()
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 0, 16, 8, 0, f(1e-5), f(0.2), None) == 0      # empty batch

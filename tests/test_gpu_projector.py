@@ -442,20 +442,26 @@ def test_generator_step_includes_the_vgg_term():
 
 
 # ------------------------------------------------------------------------- epilogues folded into the convolution, InstanceNorm
-@pytest.mark.parametrize("B,Cin,Cout,H,W,slope,with_res", [(2, 64, 64, 16, 32, 0.2, True), (2, 128, 128, 32, 64, 1.0, True),
-                                                           (1, 64, 128, 16, 32, 0.0, False), (2, 6, 8, 8, 16, 0.2, True),
-                                                           (2, 3, 16, 8, 16, 0.0, False)])
-def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, slope, with_res):
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,slope,with_res", [
+    (2, 64, 64, 16, 32, 1, 0.2, True), (2, 128, 128, 32, 64, 1, 1.0, True), (1, 64, 128, 16, 32, 1, 0.0, False),   # fused kernel
+    (2, 6, 8, 8, 16, 1, 0.2, True), (2, 3, 16, 8, 16, 1, 0.0, False),                                               # library GEMM
+    (2, 3, 128, 16, 32, 1, 0.0, False), (3, 6, 64, 16, 32, 2, 0.2, False), (2, 3, 64, 8, 16, 1, 0.0, False),        # few-channel kernels
+    (1, 3, 128, 5, 6, 1, 1.0, False), (2, 3, 128, 64, 128, 1, 0.0, False)])
+def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, stride, slope, with_res):
     """``leaky_relu(conv(x) + residual, slope)`` in the kernel's epilogue (fused kernel: first three shapes with
-    ``fused_min_bytes = 0``; library-GEMM path: the small ones) against the separate stock ops of the reference
-    (architecture.py:60, generator.py:84): value and d/dx, d/dW, d/db, d/dresidual."""
+    ``fused_min_bytes = 0``; library-GEMM path; the few-channel input-layer kernels of ``csrc/sphere_conv_small.hip``, whose
+    weight gradient also folds the activation's backward and the bias gradient) against the separate stock ops of the
+    reference (architecture.py:60, generator.py:84, normalization.py:92-96): value and d/dx, d/dW, d/db, d/dresidual."""
+    from emlight_amd import _lib
     from emlight_amd.GenProjector.spherenet import SphereConv2D
     torch.manual_seed(Cin + Cout)
-    conv = SphereConv2D(Cin, Cout).cuda()
+    conv = SphereConv2D(Cin, Cout, stride=stride).cuda()
+    assert bool(_lib.lib().eml_sphere_conv_small_supported(Cin, Cout)) == ((Cin, Cout) in ((3, 64), (3, 128), (6, 64)))
     with torch.no_grad():
         conv.bias.uniform_(-0.5, 0.5)
     x = torch.randn(B, Cin, H, W, device="cuda")
-    res = torch.randn(B, Cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last) if with_res else None
+    res = (torch.randn(B, Cout, H // stride, W // stride, device="cuda").contiguous(memory_format=torch.channels_last)
+           if with_res else None)
     leaves = []
     outs = []
     saved = SphereConv2D.fused_min_bytes
@@ -469,7 +475,7 @@ def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, slope,
             if fn == "hip":
                 y = conv(xi, residual=ri, act_slope=slope)
             else:
-                y = oracle.sphere_conv(xi, conv.weight, conv.bias, 1, ri, slope)
+                y = oracle.sphere_conv(xi, conv.weight, conv.bias, stride, ri, slope)
             gy = torch.randn(y.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
             y.backward(gy)
             outs.append(y.detach())

@@ -140,3 +140,26 @@ def test_iteration_counter_and_resume(tmp_path):
     for net_a, net_b in ((a.model.netG, b.model.netG), (a.model.netD, b.model.netD)):
         for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
             assert ka == kb and torch.equal(va, vb), ka
+
+
+def test_generator_step_leaves_the_discriminator_out_of_its_graph():
+    """The G step uses D as a fixed critic: G's gradients are those of the literal formulation (D's parameters in the graph,
+    their ``.grad`` filled and then discarded by ``optimizer_D.zero_grad()``, model_trainer.py:34-46), D's ``.grad`` stays
+    empty, and the D step that follows still trains every D parameter."""
+    inp, crop, warped, mask = (torch.from_numpy(a) for a in projector_inputs(1, 5))
+    data = {"input": inp, "crop": crop, "warped": warped, "map": mask}
+    grads = []
+    for literal in (False, True):
+        m = _model()
+        if literal:   # the reference's graph: D's parameters take part
+            m.discriminate = lambda a, b, c, for_generator=False, _d=type(m).discriminate, _m=m: _d(_m, a, b, c, False)
+        losses, _ = m(data, "generator")
+        sum(losses.values()).mean().backward()
+        grads.append({k: q.grad.clone() for k, q in m.netG.named_parameters()})
+        d_grads = [q.grad for q in m.netD.parameters()]
+        assert all(q.requires_grad for q in m.netD.parameters())
+        assert all(gr is not None for gr in d_grads) if literal else all(gr is None for gr in d_grads)
+    for k in grads[0]:
+        torch.testing.assert_close(grads[0][k], grads[1][k], rtol=1e-6, atol=1e-9, msg=k)
+    sum(m.__class__.forward(m, data, "discriminator").values()).mean().backward()
+    assert all(q.grad is not None for q in m.netD.parameters())
