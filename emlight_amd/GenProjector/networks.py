@@ -58,7 +58,7 @@ def nonspade_norm(norm_type):
     def wrap(layer):
         sub = norm_type
         if sub.startswith("spectral"):
-            layer = spectral_norm(layer)
+            layer = spherenet.fused_spectral_norm(layer) if isinstance(layer, SphereConv2D) else spectral_norm(layer)
             sub = sub[len("spectral"):]
         if sub in ("none", ""):
             return layer
@@ -118,9 +118,10 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.conv_s = SphereConv2D(fin, fout)
         if "spectral" in opt.norm_G:
-            self.conv_0, self.conv_1 = spectral_norm(self.conv_0), spectral_norm(self.conv_1)
+            sn = spherenet.fused_spectral_norm
+            self.conv_0, self.conv_1 = sn(self.conv_0), sn(self.conv_1)
             if self.learned_shortcut:
-                self.conv_s = spectral_norm(self.conv_s)
+                self.conv_s = sn(self.conv_s)
         cfg = opt.norm_G.replace("spectral", "")
         self.norm_0 = SPADE(cfg, fin, opt.semantic_nc)
         self.norm_1 = SPADE(cfg, fmiddle, opt.semantic_nc)

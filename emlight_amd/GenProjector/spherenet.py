@@ -255,7 +255,7 @@ class _SphereConvFn(torch.autograd.Function):
             _lib.check(L.eml_sphere_conv_small_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(y) if y is not None else None,
                                                          ctx.slope, p(part), p(gw2), p(gb_) if gb_ is not None else None, B,
                                                          H * W, po, C, O, st), "eml_sphere_conv_small_wgrad_f32")
-            gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+            gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
             gb = gb_ if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             del part
         need_masked = (ctx.needs_input_grad[0] or (len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5])
@@ -278,7 +278,7 @@ class _SphereConvFn(torch.autograd.Function):
                 gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
                 _lib.check(L.eml_sphere_conv_wgrad_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B,
                                                              H * W, po, C, O, split, st), "eml_sphere_conv_wgrad_fused_f32")
-                gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+                gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
                 del part
             else:
                 a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
@@ -297,7 +297,8 @@ class _SphereConvFn(torch.autograd.Function):
                 else:
                     # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
                     gw2 = a9.t() @ gyr
-                gw = gw2.view(3, 3, C, O).permute(3, 2, 0, 1).contiguous()
+                # (O, tap, c) in memory like the fused kernels' result: the one copy this gradient needs either way
+                gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
                 del a9
         if ctx.needs_input_grad[0]:
             gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
@@ -496,6 +497,74 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     gamma, beta = torch.split(gb, C, dim=1)
     out = bn(x) * (1 + gamma) + beta
     return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
+
+
+class _SpectralW2Fn(torch.autograd.Function):
+    """``weight_orig / sigma`` of ``torch.nn.utils.spectral_norm`` (one power iteration on the ``weight_u`` / ``weight_v``
+    buffers in training mode, sigma = u . (W v), u and v constants of the backward) delivered directly in the (O, tap, c)
+    memory order of the gather-GEMM kernels: ``csrc/spectral.hip``, 4 launches forward and 2 backward."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, iterate, eps):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        O, C = w.shape[0], w.shape[1]
+        w = w.contiguous()
+        w2 = torch.empty(O, 9 * C, dtype=torch.float32, device=w.device)
+        sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+        uv = torch.empty(O + 9 * C, dtype=torch.float32, device=w.device)
+        scratch = torch.empty(L.eml_spectral_norm_scratch_floats(O, C), dtype=torch.float32, device=w.device)
+        _lib.check(L.eml_spectral_norm_w2_f32(p(w), p(u), p(v), int(bool(iterate)), float(eps), p(w2), p(sigma), p(uv),
+                                              p(scratch), O, C, st), "eml_spectral_norm_w2_f32")
+        ctx.save_for_backward(w2, uv, sigma)
+        ctx.shape = (O, C)
+        return w2
+
+    @staticmethod
+    def backward(ctx, gw2):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        w2, uv, sigma = ctx.saved_tensors
+        O, C = ctx.shape
+        gw2 = gw2.contiguous()
+        partial = torch.empty(256, dtype=torch.float64, device=gw2.device)
+        dw = torch.empty(O, C, 3, 3, dtype=torch.float32, device=gw2.device)
+        _lib.check(L.eml_spectral_norm_w2_bwd_f32(p(gw2), p(w2), p(uv[:O]), p(uv[O:]), p(sigma), p(partial), p(dw), O, C, st),
+                   "eml_spectral_norm_w2_bwd_f32")
+        return dw, None, None, None, None
+
+
+class _FusedSpectralNormHook:
+    """Forward-pre-hook that stands in for torch's ``SpectralNorm`` hook on a SphereConv2D (same parameters and buffers --
+    ``weight_orig``, ``weight_u``, ``weight_v`` -- hence the same state_dict): on the GPU the normalised weight comes from
+    ``_SpectralW2Fn`` as a (O, C, 3, 3) VIEW of its (O, tap, c) result, which ``_SphereConvFn`` uses without another copy;
+    anywhere else (CPU tests on stock ops) torch's own hook runs."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def __call__(self, module, inputs):
+        sn = self.inner
+        w = getattr(module, sn.name + "_orig")
+        if (w.is_cuda and w.dtype == torch.float32 and sn.dim == 0 and sn.n_power_iterations == 1 and w.dim() == 4
+                and tuple(w.shape[2:]) == (3, 3)):
+            u, v = getattr(module, sn.name + "_u"), getattr(module, sn.name + "_v")
+            O, C = w.shape[0], w.shape[1]
+            w2 = _SpectralW2Fn.apply(w, u, v, module.training, sn.eps)
+            setattr(module, sn.name, w2.view(O, 3, 3, C).permute(0, 3, 1, 2))
+        else:
+            sn(module, inputs)
+
+
+def fused_spectral_norm(module):
+    """``torch.nn.utils.spectral_norm(module)`` whose per-forward work runs as the HIP kernels above when the weight is a
+    3x3 convolution's on the GPU (normalization.py:24-33, architecture.py:41-45)."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    module = torch.nn.utils.spectral_norm(module)
+    for key, hook in list(module._forward_pre_hooks.items()):
+        if isinstance(hook, SpectralNorm):
+            module._forward_pre_hooks[key] = _FusedSpectralNormHook(hook)
+    return module
 
 
 class _InstanceNormActFn(torch.autograd.Function):

@@ -1,0 +1,196 @@
+// Spectral normalisation of a 3x3 convolution weight, fused with the re-layout the gather-GEMM kernels want
+// (reference: models/networks/normalization.py:24-33 'spectral' -> torch.nn.utils.spectral_norm on every SphereConv2D of the
+// generator's ResNet blocks and of the discriminator; architecture.py:41-45).
+//
+// torch's hook runs, per wrapped convolution and per forward: two gemv, two norms, two divisions, a dot, the division of
+// the weight by sigma, clones of u and v -- and the SphereConv then copies the result into its (O, tap, c) operand layout:
+// a dozen launches of 4-10 us for 29 convolutions, twice per iteration, and as many again in the backward.  Here:
+//   forward   t = W^T u (partials over row slices) -> v = t / max(|t|, eps) -> s = W v -> u = s / max(|s|, eps),
+//             sigma = u . s, W2[o][tap*C + c] = W[o][c*9 + tap] / sigma                              (4 launches)
+//   backward  dW[o][c*9 + tap] = (dW2[o][tap*C + c] - <dW2, W2> u[o] v[c*9 + tap]) / sigma          (2 launches)
+// W (O, K = 9C) is the parameter in its natural (o, c, kh, kw) order; u (O), v (K) are the module's buffers, updated in place
+// when `iterate` (training mode, one power iteration as the reference's default), read-only otherwise.  u, v are constants
+// of the backward (torch detaches them): d sigma / dW = u v^T.
+#include <algorithm>
+
+#include "eml_common.h"
+
+namespace {
+
+constexpr int kMaxSlices = 16;
+
+__device__ __forceinline__ double block_sum(double v, double* red /*[16]*/) {
+  for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+// t_part[slice][k] = sum_{o in slice} W[o][k] * u[o]
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                      float* __restrict__ t_part, int O, int K, int rows_per_slice) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int o0 = blockIdx.y * rows_per_slice, o1 = min(O, o0 + rows_per_slice);
+  float a0 = 0.f, a1 = 0.f;
+  int o = o0;
+  for (; o + 1 < o1; o += 2) {
+    a0 = fmaf(W[(size_t)o * K + k], u[o], a0);
+    a1 = fmaf(W[(size_t)(o + 1) * K + k], u[o + 1], a1);
+  }
+  if (o < o1) a0 = fmaf(W[(size_t)o * K + k], u[o], a0);
+  t_part[(size_t)blockIdx.y * K + k] = a0 + a1;
+}
+
+// v = t / max(|t|_2, eps), t = sum of the slices (one workgroup)
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ t_part, int S, int K, float eps,
+                                                            float* __restrict__ v) {
+  __shared__ double red[16];
+  double q = 0.;
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += t_part[(size_t)s * K + k];
+    v[k] = t;
+    q += (double)t * t;
+  }
+  const double n2 = block_sum(q, red);
+  const float inv = 1.f / fmaxf((float)sqrt(n2), eps);
+  for (int k = threadIdx.x; k < K; k += 1024) v[k] *= inv;   // each thread rescales what it wrote
+}
+
+// s[o] = sum_k W[o][k] v[k]: one wave per row
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                     float* __restrict__ s, int O, int K) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* row = W + (size_t)o * K;
+  float a = 0.f;
+  if ((K & 3) == 0) {
+    for (int k = 4 * lane; k < K; k += 256) {
+      const float4 w = *reinterpret_cast<const float4*>(row + k), x = *reinterpret_cast<const float4*>(v + k);
+      a = fmaf(w.x, x.x, a); a = fmaf(w.y, x.y, a); a = fmaf(w.z, x.z, a); a = fmaf(w.w, x.w, a);
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) a = fmaf(row[k], v[k], a);
+  }
+  a = eml::wave_sum(a);
+  if (lane == 0) s[o] = a;
+}
+
+// one workgroup per output row: sigma (every workgroup recomputes it from the O-vector s), u (workgroup 0), and the row of
+// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma through LDS (coalesced on both sides; stride 9 is odd: no bank conflicts)
+__global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                        float* __restrict__ u, const float* __restrict__ v, int iterate, float eps,
+                                                        float* __restrict__ W2, float* __restrict__ sigma_out,
+                                                        float* __restrict__ u_used, int O, int C) {
+  extern __shared__ __attribute__((aligned(16))) float row[];   // [9C]
+  __shared__ double red[16];
+  const int K = 9 * C, o = blockIdx.x;
+  double q = 0.;
+  for (int i = threadIdx.x; i < O; i += 256) q += iterate ? (double)s[i] * s[i] : (double)s[i] * u[i];
+  const double tot = block_sum(q, red);
+  float sigma, unorm = 1.f;
+  if (iterate) {
+    unorm = 1.f / fmaxf((float)sqrt(tot), eps);       // u = s / max(|s|, eps)
+    sigma = (float)(tot * (double)unorm);             // u . (W v) = |s|^2 / max(|s|, eps)
+  } else {
+    sigma = (float)tot;
+  }
+  if (o == 0) {
+    for (int i = threadIdx.x; i < O; i += 256) {
+      const float ui = iterate ? s[i] * unorm : u[i];
+      if (iterate) u[i] = ui;
+      u_used[i] = ui;
+    }
+    for (int i = threadIdx.x; i < K; i += 256) u_used[O + i] = v[i];   // the backward's constants: (u | v) as used here
+    if (threadIdx.x == 0) *sigma_out = sigma;
+  }
+  const float inv = 1.f / sigma;
+  for (int i = threadIdx.x; i < K; i += 256) row[i] = W[(size_t)o * K + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < K; j += 256) {
+    const int tap = j / C, c = j - tap * C;
+    W2[(size_t)o * K + j] = row[c * 9 + tap] * inv;
+  }
+}
+
+// partial[b] = sum over this workgroup's elements of dW2 * W2
+__global__ __launch_bounds__(256) void sn_inner_kernel(const float* __restrict__ dW2, const float* __restrict__ W2, size_t n,
+                                                       double* __restrict__ partial) {
+  __shared__ double red[16];
+  double q = 0.;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q += (double)dW2[i] * W2[i];
+  const double tot = block_sum(q, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dW2, const double* __restrict__ partial,
+                                                           int P, const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma, float* __restrict__ dW, int O,
+                                                           int C) {
+  extern __shared__ __attribute__((aligned(16))) float row[];   // [9C]: dW2's row, (tap, c) order
+  const int K = 9 * C, o = blockIdx.x;
+  double inner = 0.;
+  for (int i = 0; i < P; ++i) inner += partial[i];   // fixed order, same in every workgroup
+  const float inv = 1.f / *sigma;
+  const float coef = (float)inner * u[o];
+  for (int j = threadIdx.x; j < K; j += 256) row[j] = dW2[(size_t)o * K + j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const int c = i / 9, tap = i - 9 * c;
+    dW[(size_t)o * K + i] = (row[tap * C + c] - coef * v[i]) * inv;
+  }
+}
+
+constexpr int kInnerGrid = 256;
+
+}  // namespace
+
+extern "C" size_t eml_spectral_norm_scratch_floats(int O, int C) {
+  if (O < 1 || C < 1) return 0;
+  return (size_t)kMaxSlices * 9 * C + O;   // t partials + s
+}
+
+extern "C" int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, float eps, float* W2, float* sigma,
+                                        float* uv_used /*[O + 9C]*/, float* scratch, int O, int C, eml_stream_t stream) {
+  if (!W || !u || !v || !W2 || !sigma || !uv_used || !scratch || O < 1 || C < 1)
+    return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: null pointer or empty shape");
+  if (!(eps > 0.f)) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: eps must be positive");
+  const int K = 9 * C;
+  if ((size_t)K * sizeof(float) > 160 * 1024) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: C = %d too wide", C);
+  hipStream_t st = (hipStream_t)stream;
+  float* t_part = scratch;
+  float* s = scratch + (size_t)kMaxSlices * K;
+  if (iterate) {
+    const int slices = std::max(1, std::min(kMaxSlices, O / 32));
+    const int rps = (O + slices - 1) / slices;
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((K + 255) / 256, slices), dim3(256), 0, st, W, u, t_part, O, K, rps);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t_part, slices, K, eps, v);
+  }
+  hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, v, s, O, K);
+  const size_t lds = (size_t)K * sizeof(float);
+  EML_ENSURE_LDS((&sn_finish_kernel), lds);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(O), dim3(256), lds, st, W, s, u, v, iterate ? 1 : 0, eps, W2, sigma, uv_used, O, C);
+  return eml::check_launch("eml_spectral_norm_w2_f32");
+}
+
+extern "C" int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, const float* u_used, const float* v,
+                                            const float* sigma, double* partial /*[256]*/, float* dW, int O, int C,
+                                            eml_stream_t stream) {
+  if (!dW2 || !W2 || !u_used || !v || !sigma || !partial || !dW || O < 1 || C < 1)
+    return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_bwd_f32: null pointer or empty shape");
+  const int K = 9 * C;
+  if ((size_t)K * sizeof(float) > 160 * 1024) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_bwd_f32: C = %d too wide", C);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)O * K;
+  const int grid = (int)std::min<size_t>(kInnerGrid, (n + 4095) / 4096);
+  hipLaunchKernelGGL(sn_inner_kernel, dim3(grid), dim3(256), 0, st, dW2, W2, n, partial);
+  const size_t lds = (size_t)K * sizeof(float);
+  EML_ENSURE_LDS((&sn_bwd_apply_kernel), lds);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(O), dim3(256), lds, st, dW2, partial, grid, u_used, v, sigma, dW, O, C);
+  return eml::check_launch("eml_spectral_norm_w2_bwd_f32");
+}

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 12
+#define EML_ABI_VERSION 13
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -437,6 +437,20 @@ int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, 
 int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
                          const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
                          eml_stream_t stream);
+
+/* torch.nn.utils.spectral_norm of a 3x3 convolution weight (normalization.py:24-33, architecture.py:41-45), fused with
+ * the (O, tap, c) re-layout of the gather-GEMM kernels.  W (O, C, 3, 3) = weight_orig; u (O), v (9C) = the module's
+ * weight_u / weight_v buffers.  iterate != 0 (training): one power iteration in place, v = normalize(W^T u),
+ * u = normalize(W v) with normalize(x) = x / max(|x|_2, eps); then sigma = u . (W v) and W2[o][tap*C + c] = W[o][c][tap] / sigma.
+ * uv_used (O + 9C) receives the (u | v) the result was formed with -- the constants of the backward:
+ *   dW[o][c][tap] = (dW2[o][tap*C + c] - <dW2, W2> u[o] v[c*9 + tap]) / sigma.
+ * scratch = eml_spectral_norm_scratch_floats(O, C) floats; partial = 256 doubles.  4 launches forward, 2 backward, in place
+ * of the dozen-plus of the stock hook and the separate re-layout copy. */
+size_t eml_spectral_norm_scratch_floats(int O, int C);
+int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, float eps, float* W2, float* sigma,
+                             float* uv_used, float* scratch, int O, int C, eml_stream_t stream);
+int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, const float* u_used, const float* v_used,
+                                 const float* sigma, double* partial, float* dW, int O, int C, eml_stream_t stream);
 
 /* nn.InstanceNorm2d(affine=False) + the LeakyReLU that follows it in the PatchGAN discriminator and the crop encoder
  * (normalization.py:44-45 'instance'; discriminator.py:84-98; generator.py:113-122): y = leaky_relu((x - mean) * istd, slope),

@@ -89,6 +89,10 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 8, 1, f(1e-5), f(-0.2), None) == -1 and b"slope" in L.eml_last_error()
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 0, 16, 8, 0, f(1e-5), f(0.2), None) == 0      # empty batch
     assert L.eml_instance_norm_act_bwd_f32(one, one, one, None, 1, 16, 8, 0, f(0.2), None) == -1        # null dx
+    assert L.eml_spectral_norm_scratch_floats(1024, 128) == 16 * 9 * 128 + 1024
+    assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(0.0), one, one, one, one, 8, 4, None) == -1 and b"eps" in L.eml_last_error()
+    assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(1e-12), one, one, one, one, 8, 8192, None) == -1   # row does not fit LDS
+    assert L.eml_spectral_norm_w2_bwd_f32(one, one, one, one, one, None, one, 8, 4, None) == -1          # null partial
     assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 1, 4, 128, 256, 6, None, None) == -1 and b"flags" in L.eml_last_error()
     assert L.eml_sg_rasterise_ex_f32(one, one, one, one, 0, 4, 128, 256, 1, None, None) == 0                    # empty batch
     assert L.eml_dense_bn_dgamma_direct_f32(one, 224, 100, 10, 10, 0, one, 48, None, 0, None, None, None, 48, one, 400,

@@ -520,3 +520,43 @@ def test_instance_norm_act_vs_stock_ops(B, C, H, W, cl, slope):
     # not the HIP kernel: a norm with running statistics or an affine one falls back to the module itself
     aff = torch.nn.InstanceNorm2d(C, affine=True).cuda()
     torch.testing.assert_close(instance_norm_act(x, aff, 0.2), torch.nn.functional.leaky_relu(aff(x), 0.2))
+
+
+@pytest.mark.parametrize("O,C", [(64, 32), (128, 1024), (1024, 128), (3, 64), (40, 6)])
+def test_fused_spectral_norm_vs_torch_hook(O, C):
+    """``csrc/spectral.hip`` against ``torch.nn.utils.spectral_norm`` on the same weight_orig / u / v: the normalised weight,
+    the updated power-iteration buffers, the gradient w.r.t. weight_orig (u, v constants), a second training forward, and
+    eval mode (no iteration) -- and the state_dict keys of the wrapped module are torch's."""
+    import copy
+    from emlight_amd.GenProjector.spherenet import SphereConv2D, fused_spectral_norm
+    torch.manual_seed(O + C)
+    base = SphereConv2D(C, O).cuda()
+    with torch.no_grad():
+        base.weight.normal_(0, 0.05)
+    ref = torch.nn.utils.spectral_norm(copy.deepcopy(base))
+    hip = fused_spectral_norm(copy.deepcopy(base))
+    hip.load_state_dict(ref.state_dict())
+    assert set(hip.state_dict()) == set(ref.state_dict()) == {"weight_orig", "weight_u", "weight_v", "bias"}
+    pre_ref = next(iter(ref._forward_pre_hooks.values()))
+    pre_hip = next(iter(hip._forward_pre_hooks.values()))
+    gw = torch.randn(O, C, 3, 3, device="cuda")
+    for mode in ("train", "train", "eval"):
+        ref.train(mode == "train")
+        hip.train(mode == "train")
+        for m in (ref, hip):
+            m.weight_orig.grad = None
+        pre_ref(ref, None)
+        pre_hip(hip, None)
+        assert hip.weight.shape == ref.weight.shape == (O, C, 3, 3)
+        s = float(ref.weight.abs().max())
+        np.testing.assert_allclose(hip.weight.detach().cpu().numpy(), ref.weight.detach().cpu().numpy(), rtol=2e-5, atol=2e-6 * s)
+        for name in ("weight_u", "weight_v"):
+            np.testing.assert_allclose(getattr(hip, name).cpu().numpy(), getattr(ref, name).cpu().numpy(), rtol=1e-4, atol=1e-6)
+        (ref.weight * gw).sum().backward()
+        (hip.weight * gw).sum().backward()
+        gs = float(ref.weight_orig.grad.abs().max())
+        np.testing.assert_allclose(hip.weight_orig.grad.cpu().numpy(), ref.weight_orig.grad.cpu().numpy(), rtol=1e-4,
+                                   atol=1e-5 * gs)
+    # the (O, C, 3, 3) weight the hook hands to the convolution is a view of the kernels' (O, tap, c) operand: no re-layout copy
+    w2 = hip.weight.permute(0, 2, 3, 1)
+    assert w2.is_contiguous()
