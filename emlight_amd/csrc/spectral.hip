@@ -46,27 +46,33 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ 
   t_part[(size_t)blockIdx.y * K + k] = a0 + a1;
 }
 
-// v = t / max(|t|_2, eps), t = sum of the slices (one workgroup)
-__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ t_part, int S, int K, float eps,
-                                                            float* __restrict__ v) {
+// t = sum of the slices, and this workgroup's share of |t|^2 (the norm is finished by its consumers: 36 values at most)
+__global__ __launch_bounds__(256) void sn_fold_t_kernel(const float* __restrict__ t_part, int S, int K, float* __restrict__ t,
+                                                        double* __restrict__ tnorm_part) {
   __shared__ double red[16];
-  double q = 0.;
-  for (int k = threadIdx.x; k < K; k += 1024) {
-    float t = 0.f;
-    for (int s = 0; s < S; ++s) t += t_part[(size_t)s * K + k];
-    v[k] = t;
-    q += (double)t * t;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  float a = 0.f;
+  if (k < K) {
+    for (int s = 0; s < S; ++s) a += t_part[(size_t)s * K + k];
+    t[k] = a;
   }
-  const double n2 = block_sum(q, red);
-  const float inv = 1.f / fmaxf((float)sqrt(n2), eps);
-  for (int k = threadIdx.x; k < K; k += 1024) v[k] *= inv;   // each thread rescales what it wrote
+  const double tot = block_sum((double)a * a, red);
+  if (threadIdx.x == 0) tnorm_part[blockIdx.x] = tot;
 }
 
-// s[o] = sum_k W[o][k] v[k]: one wave per row
+__device__ __forceinline__ float inv_norm(const double* __restrict__ part, int n, float eps) {
+  double q = 0.;
+  for (int i = 0; i < n; ++i) q += part[i];   // fixed order: every caller gets the same bits
+  return 1.f / fmaxf((float)sqrt(q), eps);
+}
+
+// s[o] = sum_k W[o][k] v[k], v = t * vscale (vscale = 1 / max(|t|, eps) from the partials when tnorm_part != NULL): one wave per row
 __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                     const double* __restrict__ tnorm_part, int np, float eps,
                                                      float* __restrict__ s, int O, int K) {
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= O) return;
+  const float vscale = tnorm_part ? inv_norm(tnorm_part, np, eps) : 1.f;
   const float* row = W + (size_t)o * K;
   float a = 0.f;
   if ((K & 3) == 0) {
@@ -77,14 +83,16 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W
   } else {
     for (int k = lane; k < K; k += 64) a = fmaf(row[k], v[k], a);
   }
-  a = eml::wave_sum(a);
+  a = eml::wave_sum(a) * vscale;
   if (lane == 0) s[o] = a;
 }
 
 // one workgroup per output row: sigma (every workgroup recomputes it from the O-vector s), u (workgroup 0), and the row of
 // W2[o][tap*C + c] = W[o][c*9 + tap] / sigma through LDS (coalesced on both sides; stride 9 is odd: no bank conflicts)
 __global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ W, const float* __restrict__ s,
-                                                        float* __restrict__ u, const float* __restrict__ v, int iterate, float eps,
+                                                        float* __restrict__ u, float* __restrict__ v,
+                                                        const float* __restrict__ t, const double* __restrict__ tnorm_part,
+                                                        int np, int iterate, float eps,
                                                         float* __restrict__ W2, float* __restrict__ sigma_out,
                                                         float* __restrict__ u_used, int O, int C) {
   extern __shared__ __attribute__((aligned(16))) float row[];   // [9C]
@@ -106,7 +114,12 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict_
       if (iterate) u[i] = ui;
       u_used[i] = ui;
     }
-    for (int i = threadIdx.x; i < K; i += 256) u_used[O + i] = v[i];   // the backward's constants: (u | v) as used here
+    const float vscale = iterate ? inv_norm(tnorm_part, np, eps) : 1.f;
+    for (int i = threadIdx.x; i < K; i += 256) {   // the backward's constants: (u | v) as used here
+      const float vi = iterate ? t[i] * vscale : v[i];
+      if (iterate) v[i] = vi;
+      u_used[O + i] = vi;
+    }
     if (threadIdx.x == 0) *sigma_out = sigma;
   }
   const float inv = 1.f / sigma;
@@ -152,7 +165,7 @@ constexpr int kInnerGrid = 256;
 
 extern "C" size_t eml_spectral_norm_scratch_floats(int O, int C) {
   if (O < 1 || C < 1) return 0;
-  return (size_t)kMaxSlices * 9 * C + O;   // t partials + s
+  return (size_t)(kMaxSlices + 1) * 9 * C + O + 2 * ((9 * C + 255) / 256 + 1);   // t partials, t, s, |t|^2 partials (doubles)
 }
 
 extern "C" int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, float eps, float* W2, float* sigma,
@@ -164,17 +177,24 @@ extern "C" int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int 
   if ((size_t)K * sizeof(float) > 160 * 1024) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: C = %d too wide", C);
   hipStream_t st = (hipStream_t)stream;
   float* t_part = scratch;
-  float* s = scratch + (size_t)kMaxSlices * K;
+  float* t = scratch + (size_t)kMaxSlices * K;
+  float* s = t + K;
+  // the doubles sit behind the floats, 8-byte aligned
+  double* tnorm_part = reinterpret_cast<double*>(scratch + (((size_t)(kMaxSlices + 1) * K + O + 1) & ~(size_t)1));
+  const int np = (K + 255) / 256;
   if (iterate) {
     const int slices = std::max(1, std::min(kMaxSlices, O / 32));
     const int rps = (O + slices - 1) / slices;
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((K + 255) / 256, slices), dim3(256), 0, st, W, u, t_part, O, K, rps);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t_part, slices, K, eps, v);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(np, slices), dim3(256), 0, st, W, u, t_part, O, K, rps);
+    hipLaunchKernelGGL(sn_fold_t_kernel, dim3(np), dim3(256), 0, st, t_part, slices, K, t, tnorm_part);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, t, tnorm_part, np, eps, s, O, K);
+  } else {
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, v, nullptr, 0, eps, s, O, K);
   }
-  hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, v, s, O, K);
   const size_t lds = (size_t)K * sizeof(float);
   EML_ENSURE_LDS((&sn_finish_kernel), lds);
-  hipLaunchKernelGGL(sn_finish_kernel, dim3(O), dim3(256), lds, st, W, s, u, v, iterate ? 1 : 0, eps, W2, sigma, uv_used, O, C);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(O), dim3(256), lds, st, W, s, u, v, t, tnorm_part, np, iterate ? 1 : 0, eps, W2, sigma,
+                     uv_used, O, C);
   return eml::check_launch("eml_spectral_norm_w2_f32");
 }
 

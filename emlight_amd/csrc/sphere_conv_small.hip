@@ -198,17 +198,26 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_small_wgrad_kernel(const f
   }
 }
 
-// dW2[o][k] (k < K) and db[o] (column K) = fixed-order sum of the workgroup partials
+// dW2[o][k] (k < K) and db[o] (column K) = fixed-order sum of the workgroup partials.  Block = 16 elements x 16 partial lanes
+// (a 16-thread-wide reduction per element would leave 16 workgroups summing 512 partials each: 36 us)
 __global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ partial, int S, int O, int K, int KP,
                                                                  float* __restrict__ dW2, float* __restrict__ db) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= O * KP) return;
-  const int o = e / KP, k = e - o * KP;
-  if (k > K) return;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float s = 0.f;
-  for (int z = 0; z < S; ++z) s += partial[(size_t)z * O * KP + e];
-  if (k < K) dW2[(size_t)o * K + k] = s;
-  else if (db) db[o] = s;
+  if (e < O * KP)
+    for (int z = zl; z < S; z += 16) s += partial[(size_t)z * O * KP + e];
+  red[zl][el] = s;
+  __syncthreads();
+  if (zl == 0 && e < O * KP) {
+    float tot = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) tot += red[z][el];
+    const int o = e / KP, k = e - o * KP;
+    if (k < K) dW2[(size_t)o * K + k] = tot;
+    else if (k == K && db) db[o] = tot;
+  }
 }
 
 constexpr int kSmallGrid = 512;   // persistent workgroups of the weight gradient (= its partial count)
@@ -221,7 +230,7 @@ void launch_small_wgrad(const float* X, const int* idx, const float* wgt, const 
   EML_ENSURE_LDS((&sphere_conv_small_wgrad_kernel<CIN, O>), lds);
   hipLaunchKernelGGL((sphere_conv_small_wgrad_kernel<CIN, O>), dim3(grid), dim3(256), lds, st, X, idx, wgt, dY, Yact, partial, M,
                      HW, Po, slope);
-  hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3((O * KP + 255) / 256), dim3(256), 0, st, partial, grid, O, K, KP, dW2, db);
+  hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3((O * KP + 15) / 16), dim3(256), 0, st, partial, grid, O, K, KP, dW2, db);
 }
 
 int small_kp(int C) { return 16 * ((9 * C + 1 + 15) / 16); }

@@ -89,7 +89,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 8, 1, f(1e-5), f(-0.2), None) == -1 and b"slope" in L.eml_last_error()
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 0, 16, 8, 0, f(1e-5), f(0.2), None) == 0      # empty batch
     assert L.eml_instance_norm_act_bwd_f32(one, one, one, None, 1, 16, 8, 0, f(0.2), None) == -1        # null dx
-    assert L.eml_spectral_norm_scratch_floats(1024, 128) == 16 * 9 * 128 + 1024
+    assert L.eml_spectral_norm_scratch_floats(1024, 128) == 17 * 9 * 128 + 1024 + 2 * (5 + 1)   # t partials, t, s, 5 norm partials (f64)
     assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(0.0), one, one, one, one, 8, 4, None) == -1 and b"eps" in L.eml_last_error()
     assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(1e-12), one, one, one, one, 8, 8192, None) == -1   # row does not fit LDS
     assert L.eml_spectral_norm_w2_bwd_f32(one, one, one, one, one, None, one, 8, 4, None) == -1          # null partial
