@@ -71,8 +71,11 @@ __device__ __forceinline__ void block_stats_store(double (&s)[NT], double (&q)[N
 // ------------------------------------------------------------------------------ conv1x1
 // out[p][n0 + o] (o < n_valid <= 48) for output pixels p < P.  POOL: the A operand is the
 // 2x2 average of relu(bn(x)) (avg-pool commutes with the 1x1 conv: transition, DenseNet.py:14-21).
+#ifndef EML_FWD_MIN_WG   // experiment builds only (tools/exp_build.sh): workgroups per CU the register allocation is capped for
+#define EML_FWD_MIN_WG 2
+#endif
 template <bool POOL, bool MASK = false /* emit the ReLU ballot words (relu_mask != NULL, dense layers in training) */>
-__global__ __launch_bounds__(256, 2) void conv1x1_fwd_kernel(
+__global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ Wp,
     float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials,
