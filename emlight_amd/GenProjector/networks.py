@@ -97,13 +97,16 @@ class SPADE(nn.Module):
         self.mlp_gamma = SphereConv2D(nhidden, norm_nc)
         self.mlp_beta = SphereConv2D(nhidden, norm_nc)
 
-    def forward(self, x, segmap, slope=1.0, stats=None):
+    def forward(self, x, segmap, slope=1.0, stats=None, up2=False):
         """``slope`` != 1 folds the LeakyReLU that follows this norm in SPADEResnetBlock (architecture.py:56-57) in;
-        ``stats``: (mean, istd) of this x when a sibling norm already reduced it (norm_0 / norm_s share their input)."""
-        segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
+        ``stats``: (mean, istd) of this x when a sibling norm already reduced it (norm_0 / norm_s share their input);
+        ``up2``: ``x`` stands for its nearest x2 upsample (the generator's ``self.up``), which is never materialised."""
+        size = (2 * x.size(2), 2 * x.size(3)) if up2 else x.size()[2:]
+        segmap = F.interpolate(segmap, size=size, mode="nearest")
         conv, act = self.mlp_shared[0], self.mlp_shared[1]
         actv = conv(segmap, act_slope=0.0) if isinstance(act, nn.ReLU) else act(conv(segmap))   # ReLU in the conv's epilogue
-        return spherenet.spade_norm_modulate(x, self.param_free_norm, actv, self.mlp_gamma, self.mlp_beta, slope, stats)
+        more = {"up2": True} if up2 else {}
+        return spherenet.spade_norm_modulate(x, self.param_free_norm, actv, self.mlp_gamma, self.mlp_beta, slope, stats, **more)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -128,20 +131,26 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
-    def forward(self, x, seg, out_slope=1.0):
+    def forward(self, x, seg, out_slope=1.0, up2=False):
         """``out_slope``: a LeakyReLU the caller applies to the block's output (``generator.py:84`` before the last
         convolution), folded -- like the residual sum itself -- into ``conv_1``'s epilogue."""
         stats = None
         n0 = self.norm_0.param_free_norm
         ns = self.norm_s.param_free_norm if self.learned_shortcut else None
+        # ``up2``: the caller's ``x = self.up(x)`` (generator.py:70-82) is left to this block.  With a learned shortcut x only
+        # feeds norm_0 / norm_s, whose HIP kernels read the map before the upsample; otherwise it is upsampled here.
+        fold = bool(up2 and self.learned_shortcut and x.is_cuda and x.shape[1] % 4 == 0 and isinstance(n0, nn.BatchNorm2d)
+                    and isinstance(ns, nn.BatchNorm2d) and getattr(spherenet.spade_norm_modulate, "folds_upsample", False))
+        if up2 and not fold:
+            x = F.interpolate(x, scale_factor=2)
         if (self.learned_shortcut and isinstance(n0, nn.BatchNorm2d) and n0.training and ns.training and ns.eps == n0.eps
                 and x.shape[1] % 4 == 0 and x.is_cuda):
             # training: norm_0 and norm_s normalise the same x with parameter-free BatchNorms -- one reduction serves both,
             # and each norm's running buffers are updated from it with its own momentum.  (In eval every norm uses its OWN
             # running statistics: a checkpoint may hold different buffers for the two.)
-            stats = spherenet.spade_batch_stats(x, n0, also=(ns,))
-        x_s = self.conv_s(self.norm_s(x, seg, stats=stats)) if self.learned_shortcut else x
-        dx = self.conv_0(self.norm_0(x, seg, slope=2e-1, stats=stats))   # leaky_relu(norm(.), 0.2), fused into the modulation
+            stats = spherenet.spade_batch_stats(x, n0, also=(ns,), **({"repeat": 4} if fold else {}))
+        x_s = self.conv_s(self.norm_s(x, seg, stats=stats, up2=fold)) if self.learned_shortcut else x
+        dx = self.conv_0(self.norm_0(x, seg, slope=2e-1, stats=stats, up2=fold))   # leaky_relu(norm(.), 0.2) in the modulation
         return self.conv_1(self.norm_1(dx, seg, slope=2e-1), residual=x_s, act_slope=out_slope)   # act(x_s + dx)
 
 
@@ -212,8 +221,8 @@ class SPADEGenerator(nn.Module):
         x = self.G_middle_0(x, guide)
         x = self.G_middle_1(x, guide)
         for blk in (self.up_0, self.up_1, self.up_2):
-            x = blk(self.up(x), guide)
-        x = self.up_3(self.up(x), guide, out_slope=2e-1)    # = F.leaky_relu(up_3(...), 2e-1) of generator.py:84
+            x = blk(x, guide, up2=True)                     # = blk(self.up(x), guide): the upsample is folded into the block
+        x = self.up_3(x, guide, out_slope=2e-1, up2=True)   # = F.leaky_relu(up_3(self.up(x), ...), 2e-1) of generator.py:84
         x = self.sphere_conv1(x)
         return (torch.tanh(x) + 1) * 25
 

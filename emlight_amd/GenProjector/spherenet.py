@@ -200,11 +200,9 @@ class _SphereConvFn(torch.autograd.Function):
                 raise ValueError("SphereConv2D residual %s does not match the output (%d, %d, %d, %d)"
                                  % (tuple(residual.shape), B, O, geo.ho, geo.wo))
             res = residual.permute(0, 2, 3, 1).contiguous().view(B * po, O)    # a view when it is channels-last
-        # few-channel input layers (SPADE's mlp_shared 3 -> 128, the discriminator's 6 -> 64, VGG's 3 -> 64): bound by the
+        # 3-channel input layers (SPADE's mlp_shared 3 -> 128, VGG's 3 -> 64; not the discriminator's 6 -> 64): bound by the
         # write of their output -- one pass each way with the activation (and its backward, and the bias gradient) folded in
-        # (C = 3 only: the 6 -> 64 first stage of the discriminator always needs its input gradient, and with it the general
-        # backward measured faster than these kernels' -- tools/small_conv_bench.py)
-        ctx.small = bool(B > 0 and res is None and C == 3 and L.eml_sphere_conv_small_supported(C, O))
+        ctx.small = bool(B > 0 and res is None and L.eml_sphere_conv_small_supported(C, O))
         if ctx.small:
             ctx.fused_fwd = ctx.fused_wgrad = False
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
@@ -392,20 +390,23 @@ def _bn_sync():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def _reduce_sums(partials, rows, C):
-    """[grid][C][2] f64 partials -> sums (2C+1,) f64 = per-channel pairs then the row count; all-reduced across ranks."""
+def _reduce_sums(partials, rows, C, repeat=1):
+    """[grid][C][2] f64 partials -> sums (2C+1,) f64 = per-channel pairs then the row count; all-reduced across ranks.
+    ``repeat``: every row counts that many times (statistics of a nearest-upsampled map taken from the map itself)."""
     from .. import _lib
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
     sums = torch.empty(2 * C + 1, dtype=torch.float64, device=partials.device)
     sums[2 * C] = float(rows)
     _lib.check(L.eml_bn_fold_f64(p(partials), partials.shape[0], 2 * C, p(sums), st), "eml_bn_fold_f64")
+    if repeat != 1:
+        sums *= float(repeat)
     if _bn_sync():
         import torch.distributed as dist
         dist.all_reduce(sums)
     return sums
 
 
-def spade_batch_stats(x, bn, also=()):
+def spade_batch_stats(x, bn, also=(), repeat=1):
     """(mean, istd) of SPADE's parameter-free BatchNorm for input ``x`` (normalization.py:101-104): batch statistics in
     training (one read of x, f64 accumulation; running statistics of ``bn`` updated like nn.BatchNorm2d), running
     statistics in eval.  Not differentiable: the statistics' gradient is part of ``spade_norm_modulate``'s backward.
@@ -423,7 +424,7 @@ def spade_batch_stats(x, bn, also=()):
         grid = _stats_grid(rows, C)
         partials = torch.empty(grid, C, 2, dtype=torch.float64, device=x.device)
         _lib.check(L.eml_bn_stats_f32(p(xr), ld, rows, C, p(partials), grid, st), "eml_bn_stats_f32")
-        sums = _reduce_sums(partials, rows, C)
+        sums = _reduce_sums(partials, rows, C, repeat)   # repeat = 4: x stands for its nearest x2 upsample
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         istd = torch.empty(C, dtype=torch.float32, device=x.device)
         mom = bn.momentum if bn.momentum is not None else 0.1
@@ -446,16 +447,27 @@ class _SpadeNormModulateFn(torch.autograd.Function):
     modulation pass itself and finishes dx = istd*(dxn - S1/n - xhat*S2/n) in one more streaming pass."""
 
     @staticmethod
-    def forward(ctx, x, gb, mean, istd, slope, training):
+    def forward(ctx, x, gb, mean, istd, slope, training, up2=False):
+        """``up2``: ``x`` (B, C, H/2, W/2) is the block input BEFORE the generator's nearest x2 upsample; ``gb`` and the result
+        live on the (H, W) grid and the 4x tensor is never written (``eml_spade_norm_modulate_up2_*``)."""
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         _require_gpu_f32(x, "SPADE input")
-        B, C, H, W = x.shape
-        x, ldx = _rows_view(x)
-        gb, ldg = _rows_view(gb)
-        y = torch.empty_like(x, memory_format=torch.channels_last)
-        _lib.check(L.eml_spade_norm_modulate_fwd_f32(p(x), ldx, p(gb), ldg, p(y), C, B * H * W, C, float(slope), p(mean),
-                                                     p(istd), st), "eml_spade_norm_modulate_fwd_f32")
+        B, C = x.shape[:2]
+        H, W = gb.shape[2:]
+        ctx.up2 = bool(up2)
+        if up2:
+            x = x.contiguous(memory_format=torch.channels_last)
+            gb = gb.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            _lib.check(L.eml_spade_norm_modulate_up2_fwd_f32(p(x), p(gb), p(y), B, H, W, C, float(slope), p(mean), p(istd), st),
+                       "eml_spade_norm_modulate_up2_fwd_f32")
+        else:
+            x, ldx = _rows_view(x)
+            gb, ldg = _rows_view(gb)
+            y = torch.empty_like(x, memory_format=torch.channels_last)
+            _lib.check(L.eml_spade_norm_modulate_fwd_f32(p(x), ldx, p(gb), ldg, p(y), C, B * H * W, C, float(slope), p(mean),
+                                                         p(istd), st), "eml_spade_norm_modulate_fwd_f32")
         ctx.save_for_backward(x, gb, mean, istd)
         ctx.slope, ctx.training = float(slope), bool(training)
         return y
@@ -465,23 +477,35 @@ class _SpadeNormModulateFn(torch.autograd.Function):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         x, gb, mean, istd = ctx.saved_tensors
-        B, C, H, W = x.shape
+        B, C = x.shape[:2]
+        H, W = gb.shape[2:]
         rows = B * H * W
-        gy, ldy = _rows_view(gy)
-        dx = torch.empty_like(x, memory_format=torch.channels_last)
         dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         grid = _stats_grid(rows, C)
         partials = torch.empty(grid, C, 2, dtype=torch.float64, device=x.device)
+        if ctx.up2:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            dxn = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            _lib.check(L.eml_spade_norm_modulate_up2_bwd_f32(p(gy), p(x), p(gb), p(dxn), p(dgb), B, H, W, C, ctx.slope, p(mean),
+                                                             p(istd), p(partials), grid, st),
+                       "eml_spade_norm_modulate_up2_bwd_f32")
+            sums = _reduce_sums(partials, rows, C) if ctx.training else None
+            dx = torch.empty_like(x, memory_format=torch.channels_last)     # gradient of the map BEFORE the upsample
+            _lib.check(L.eml_bn_bwd_apply_up2_f32(p(dxn), p(x), B, H, W, C, p(mean), p(istd), p(sums), p(dx), st),
+                       "eml_bn_bwd_apply_up2_f32")
+            return dx, dgb, None, None, None, None, None
+        gy, ldy = _rows_view(gy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
         _lib.check(L.eml_spade_norm_modulate_bwd_f32(p(gy), ldy, p(x), x.stride(3), p(gb), gb.stride(3), p(dx), C, p(dgb),
                                                      2 * C, rows, C, ctx.slope, p(mean), p(istd), p(partials), grid, st),
                    "eml_spade_norm_modulate_bwd_f32")
         sums = _reduce_sums(partials, rows, C) if ctx.training else None
         _lib.check(L.eml_bn_bwd_apply_f32(p(dx), C, p(x), x.stride(3), rows, C, p(mean), p(istd), p(sums), p(dx), C, st),
                    "eml_bn_bwd_apply_f32")
-        return dx, dgb, None, None, None, None
+        return dx, dgb, None, None, None, None, None
 
 
-def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=None):
+def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=None, up2=False):
     """SPADE (normalization.py:101-115) + the LeakyReLU that follows it (architecture.py:56-57; slope 1 = none):
     ``leaky_relu(BN(x) * (1 + gamma(actv)) + beta(actv), slope)``.  gamma | beta come from ONE SphereConv (one gather,
     one GEMM over the concatenated heads); BatchNorm's statistics come from ``spade_batch_stats`` (or ``stats`` when
@@ -491,12 +515,17 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     gb = sphere_conv(actv, w, b, 1)
     C = x.shape[1]
     if C % 4 == 0 and isinstance(bn, nn.BatchNorm2d):
-        mean, istd = stats if stats is not None else spade_batch_stats(x, bn)
-        return _SpadeNormModulateFn.apply(x, gb, mean.detach(), istd.detach(), slope, bn.training)
+        mean, istd = stats if stats is not None else spade_batch_stats(x, bn, repeat=4 if up2 else 1)
+        return _SpadeNormModulateFn.apply(x, gb, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+    if up2:   # ``up2`` = x stands for its nearest x2 upsample (supported by the fused path only; callers check can_fold_up2)
+        x = nn.functional.interpolate(x, scale_factor=2)
     # widths that are not a multiple of 4 (never in EMLight) or an instance norm: library norm + elementwise formula
     gamma, beta = torch.split(gb, C, dim=1)
     out = bn(x) * (1 + gamma) + beta
     return out if slope == 1.0 else nn.functional.leaky_relu(out, slope)
+
+
+spade_norm_modulate.folds_upsample = True   # the oracle's stock-op stand-in does not: callers upsample first
 
 
 class _SpectralW2Fn(torch.autograd.Function):

@@ -170,18 +170,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// UP2 variants: x is the block input BEFORE the generator's nearest-neighbour x2 upsample (generator.py:70-82); the output
+// pixel (b, h, w) of the (H, W) map reads x at (b, h/2, w/2).  The 4x tensor is never materialised: BatchNorm's statistics of
+// an upsampled map are those of the map (every value 4 times), and the backward sums the four children of a source pixel.
+__device__ __forceinline__ unsigned up2_src_row(unsigned row, int H, int W) {
+  const unsigned w = row % (unsigned)W, t = row / (unsigned)W, h = t % (unsigned)H, b = t / (unsigned)H;
+  return (b * (unsigned)(H >> 1) + (h >> 1)) * (unsigned)(W >> 1) + (w >> 1);
+}
+
 // y = leaky_relu(((x - mean) * istd) * (1 + gamma) + beta): the normalised activation is never stored
+template <bool UP2>
 __global__ __launch_bounds__(256) void spade_norm_modulate_fwd_kernel(const float* __restrict__ x, int ld_x,
                                                                       const float* __restrict__ gb, int ld_gb,
                                                                       float* __restrict__ y, int ld_y, int rows, int C,
                                                                       float slope, const float* __restrict__ mean,
-                                                                      const float* __restrict__ istd) {
+                                                                      const float* __restrict__ istd, int H, int W) {
   const int cv = C >> 2;
   const size_t total = (size_t)rows * cv;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const size_t row = e / cv;
     const int c = (int)(e - row * cv) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(x + row * ld_x + c);
+    const size_t xrow = UP2 ? (size_t)up2_src_row((unsigned)row, H, W) : row;
+    const float4 a = *reinterpret_cast<const float4*>(x + xrow * ld_x + c);
     const float4 g = *reinterpret_cast<const float4*>(gb + row * ld_gb + c);
     const float4 b = *reinterpret_cast<const float4*>(gb + row * ld_gb + C + c);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c);
@@ -197,10 +207,11 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_fwd_kernel(const floa
 
 // backward of the above w.r.t. the NORMALISED activation (dxn) and (gamma | beta), + the per-block partial sums
 // (sum dxn, sum dxn*xhat) BatchNorm's backward needs; fixed-column layout so that a thread keeps its channels
+template <bool UP2>
 __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
     const float* __restrict__ gy, int ld_gy, const float* __restrict__ x, int ld_x, const float* __restrict__ gb, int ld_gb,
     float* __restrict__ dxn, int ld_dx, float* __restrict__ dgb, int ld_dgb, int rows, int C, float slope,
-    const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials) {
+    const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials, int H, int W) {
   __shared__ double red[256 * 8];
   const ColMap m(C);
   double* out = partials + (size_t)blockIdx.x * C * 2;
@@ -212,7 +223,8 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
       const float4 is = *reinterpret_cast<const float4*>(istd + c);
       for (int row = blockIdx.x * m.rpp + m.rl; row < rows; row += gridDim.x * m.rpp) {
         const float4 u = *reinterpret_cast<const float4*>(gy + (size_t)row * ld_gy + c);
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ld_x + c);
+        const size_t xrow = UP2 ? (size_t)up2_src_row((unsigned)row, H, W) : (size_t)row;
+        const float4 xv = *reinterpret_cast<const float4*>(x + xrow * ld_x + c);
         const float4 g = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + c);
         const float4 b = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + C + c);
         const float a[4] = {(xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z, (xv.w - mu.w) * is.w};
@@ -260,6 +272,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o[k] = ii[k] * (dd[k] - m1 - (xx[k] - mm[k]) * ii[k] * m2);
     }
     *reinterpret_cast<float4*>(dx + row * ld_o + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// UP2 backward: dx of the SOURCE pixel = istd * (sum of its 4 children's dxn - 4 S1/n - 4 xhat S2/n), n = the upsampled count
+__global__ __launch_bounds__(256) void bn_bwd_apply_up2_kernel(const float* __restrict__ dxn, int ld_d,
+                                                               const float* __restrict__ x, int ld_x, int rows_lo, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ istd,
+                                                               const double* __restrict__ sums, float* __restrict__ dx,
+                                                               int ld_o, int H, int W) {
+  const int cv = C >> 2, Hl = H >> 1, Wl = W >> 1;
+  const size_t total = (size_t)rows_lo * cv;
+  const double n = sums ? sums[2 * C] : 1.0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const unsigned q = (unsigned)(e / cv);
+    const int c = (int)(e - (size_t)q * cv) * 4;
+    const unsigned wl = q % (unsigned)Wl, t = q / (unsigned)Wl, hl = t % (unsigned)Hl, b = t / (unsigned)Hl;
+    const size_t r0 = ((size_t)b * H + 2 * hl) * W + 2 * wl;
+    const float4 d0 = *reinterpret_cast<const float4*>(dxn + r0 * ld_d + c);
+    const float4 d1 = *reinterpret_cast<const float4*>(dxn + (r0 + 1) * ld_d + c);
+    const float4 d2 = *reinterpret_cast<const float4*>(dxn + (r0 + W) * ld_d + c);
+    const float4 d3 = *reinterpret_cast<const float4*>(dxn + (r0 + W + 1) * ld_d + c);
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)q * ld_x + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(istd + c);
+    const float dd[4] = {(d0.x + d1.x) + (d2.x + d3.x), (d0.y + d1.y) + (d2.y + d3.y), (d0.z + d1.z) + (d2.z + d3.z),
+                         (d0.w + d1.w) + (d2.w + d3.w)};
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float m1 = sums ? (float)(4.0 * sums[2 * (c + k)] / n) : 0.f;
+      const float m2 = sums ? (float)(4.0 * sums[2 * (c + k) + 1] / n) : 0.f;
+      o[k] = ii[k] * (dd[k] - m1 - (xx[k] - mm[k]) * ii[k] * m2);
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)q * ld_o + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -325,8 +372,8 @@ extern "C" int eml_spade_norm_modulate_fwd_f32(const float* x, int ld_x, const f
       bad_ld(ld_gb, 2 * C) || bad_ld(ld_y, C))
     return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_fwd_f32: bad arguments");
   if (rows == 0) return EML_OK;
-  hipLaunchKernelGGL(spade_norm_modulate_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0,
-                     (hipStream_t)stream, x, ld_x, gb, ld_gb, y, ld_y, (int)rows, C, slope, mean, istd);
+  hipLaunchKernelGGL(spade_norm_modulate_fwd_kernel<false>, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, ld_x, gb, ld_gb, y, ld_y, (int)rows, C, slope, mean, istd, 0, 0);
   return eml::check_launch("eml_spade_norm_modulate_fwd_f32");
 }
 
@@ -338,8 +385,8 @@ extern "C" int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const
       (C & 3) || bad_ld(ld_gy, C) || bad_ld(ld_x, C) || bad_ld(ld_gb, 2 * C) || bad_ld(ld_dx, C) || bad_ld(ld_dgb, 2 * C) ||
       grid < 1)
     return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_bwd_f32: bad arguments");
-  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, ld_gy, x, ld_x, gb,
-                     ld_gb, dxn, ld_dx, dgb, ld_dgb, (int)rows, C, slope, mean, istd, partials);
+  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, ld_gy, x, ld_x,
+                     gb, ld_gb, dxn, ld_dx, dgb, ld_dgb, (int)rows, C, slope, mean, istd, partials, 0, 0);
   return eml::check_launch("eml_spade_norm_modulate_bwd_f32");
 }
 
@@ -353,4 +400,46 @@ extern "C" int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, 
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, dxn,
                      ld_d, x, ld_x, (int)rows, C, mean, istd, sums, dx, ld_o);
   return eml::check_launch("eml_bn_bwd_apply_f32");
+}
+
+// ------------------------------------------------------------ the same three passes with the x2 nearest upsample folded in
+namespace {
+int up2_args(const char* what, int B, int H, int W, int C) {
+  if (B < 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || (C & 3) || (long)B * H * W > 2147483647L)
+    return eml::fail(EML_EINVAL, "%s: need even H, W >= 2, C %% 4 == 0 (B=%d, H=%d, W=%d, C=%d)", what, B, H, W, C);
+  return EML_OK;
+}
+}  // namespace
+
+extern "C" int eml_spade_norm_modulate_up2_fwd_f32(const float* x_lo, const float* gb, float* y, int B, int H, int W, int C,
+                                                   float slope, const float* mean, const float* istd, eml_stream_t stream) {
+  if (!x_lo || !gb || !y || !mean || !istd) return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_up2_fwd_f32: null pointer");
+  if (int rc = up2_args("eml_spade_norm_modulate_up2_fwd_f32", B, H, W, C)) return rc;
+  const size_t rows = (size_t)B * H * W;
+  if (rows == 0) return EML_OK;
+  hipLaunchKernelGGL(spade_norm_modulate_fwd_kernel<true>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     x_lo, C, gb, 2 * C, y, C, (int)rows, C, slope, mean, istd, H, W);
+  return eml::check_launch("eml_spade_norm_modulate_up2_fwd_f32");
+}
+
+extern "C" int eml_spade_norm_modulate_up2_bwd_f32(const float* gy, const float* x_lo, const float* gb, float* dxn, float* dgb,
+                                                   int B, int H, int W, int C, float slope, const float* mean,
+                                                   const float* istd, double* partials, int grid, eml_stream_t stream) {
+  if (!gy || !x_lo || !gb || !dxn || !dgb || !mean || !istd || !partials || grid < 1 || B < 1)
+    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_up2_bwd_f32: null pointer, empty batch or grid < 1");
+  if (int rc = up2_args("eml_spade_norm_modulate_up2_bwd_f32", B, H, W, C)) return rc;
+  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x_lo, C, gb,
+                     2 * C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, H, W);
+  return eml::check_launch("eml_spade_norm_modulate_up2_bwd_f32");
+}
+
+extern "C" int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int B, int H, int W, int C, const float* mean,
+                                        const float* istd, const double* sums, float* dx_lo, eml_stream_t stream) {
+  if (!dxn || !x_lo || !mean || !istd || !dx_lo) return eml::fail(EML_EINVAL, "eml_bn_bwd_apply_up2_f32: null pointer");
+  if (int rc = up2_args("eml_bn_bwd_apply_up2_f32", B, H, W, C)) return rc;
+  const size_t rows_lo = (size_t)B * (H / 2) * (W / 2);
+  if (rows_lo == 0) return EML_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_up2_kernel, dim3(grid_for(rows_lo * (C / 4))), dim3(256), 0, (hipStream_t)stream, dxn, C,
+                     x_lo, C, (int)rows_lo, C, mean, istd, sums, dx_lo, C, H, W);
+  return eml::check_launch("eml_bn_bwd_apply_up2_f32");
 }

@@ -1,12 +1,13 @@
 // SphereConv2D (and the ordinary 3x3 convolution written as a gather) for the few-channel INPUT layers of the GenProjector:
-// SPADE's mlp_shared 3 -> 128 + ReLU on the guide map (normalization.py:92-96, 28 of them per generator pass), the
-// discriminator's first stage 6 -> 64 + LeakyReLU (discriminator.py:80-82), VGG19's conv1_1 3 -> 64 + ReLU.
+// SPADE's mlp_shared 3 -> 128 + ReLU on the guide map (normalization.py:92-96, 28 of them per generator pass) and VGG19's
+// conv1_1 3 -> 64 + ReLU.  (The discriminator's 6 -> 64 first stage stays on the general path: it always needs its input
+// gradient, and with the masked dY formed for that anyway the general weight gradient measured faster.)
 //
-// These layers are HBM-bound on their OUTPUT: K = 9 * Cin = 27 or 54, so per pixel they write O floats for O * 2K flops.
+// These layers are HBM-bound on their OUTPUT: K = 9 * Cin = 27, so per pixel they write O floats for O * 2K flops.
 // On the general path they were im2col (a 9x operand) + library GEMM + a separate activation pass, and in the backward an
 // activation-backward pass, a bias-gradient reduction and a split-K batched GEMM -- 3 and 5 traversals of the (pixels, O)
 // tensor.  Here: one traversal each way.
-//   forward : wave = 32 pixels x all O channels; the K <= 56 interpolated taps of a pixel are built in registers straight from
+//   forward : wave = 32 pixels x all O channels; the 27 interpolated taps of a pixel are built in registers straight from
 //             the tap table (x is a few MB: L2 resident), W2 lives in registers (56 VGPRs), f32 MFMA 16x16x4 with the channels
 //             on the rows so that a lane's 4 results are 4 consecutive channels of one pixel (16-byte stores);
 //             bias + leaky ReLU in the epilogue.
@@ -234,7 +235,7 @@ void launch_small_wgrad(const float* X, const int* idx, const float* wgt, const 
 }
 
 int small_kp(int C) { return 16 * ((9 * C + 1 + 15) / 16); }
-bool small_supported(int C, int O) { return (C == 3 && (O == 64 || O == 128)) || (C == 6 && O == 64); }
+bool small_supported(int C, int O) { return C == 3 && (O == 64 || O == 128); }
 int small_wgrad_grid(long M) { return (int)std::min<long>(kSmallGrid, std::max<long>(1, (M + 1023) / 1024)); }
 
 }  // namespace
@@ -247,7 +248,7 @@ extern "C" int eml_sphere_conv_small_fwd_f32(const float* X, const int* idx, con
   if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1)
     return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: null pointer or empty shape");
   if (!small_supported(C, O))
-    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128), (6, 64)}", C, O);
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128)}", C, O);
   if (!(act_slope >= 0.f && act_slope <= 1.f))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_small_fwd_f32: act_slope %g outside [0, 1]", (double)act_slope);
   const long M = (long)B * Po;
@@ -258,9 +259,8 @@ extern "C" int eml_sphere_conv_small_fwd_f32(const float* X, const int* idx, con
 #define EML_SMALL_FWD(CV, OV)                                                                                              \
   hipLaunchKernelGGL((sphere_conv_small_fwd_kernel<CV, OV>), dim3(grid), dim3(256), 0, st, X, idx, wgt, W2, bias, Y, (int)M, HW, \
                      Po, act_slope)
-  if (C == 3 && O == 128) EML_SMALL_FWD(3, 128);
-  else if (C == 3) EML_SMALL_FWD(3, 64);
-  else EML_SMALL_FWD(6, 64);
+  if (O == 128) EML_SMALL_FWD(3, 128);
+  else EML_SMALL_FWD(3, 64);
 #undef EML_SMALL_FWD
   return eml::check_launch("eml_sphere_conv_small_fwd_f32");
 }
@@ -276,7 +276,7 @@ extern "C" int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, c
   if (!X || !idx || !wgt || !dY || !partial || !dW2 || B < 0 || HW < 1 || Po < 1)
     return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: null pointer or empty shape");
   if (!small_supported(C, O))
-    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128), (6, 64)}", C, O);
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128)}", C, O);
   if (!(act_slope >= 0.f && act_slope <= 1.f) || (act_slope != 1.f && !Yact))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_small_wgrad_f32: act_slope %g needs Yact and a slope in [0, 1]", (double)act_slope);
   const long M = (long)B * Po;
@@ -289,8 +289,7 @@ extern "C" int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, c
   }
   const int grid = small_wgrad_grid(M);
   const float* ya = act_slope != 1.f ? Yact : nullptr;
-  if (C == 3 && O == 128) launch_small_wgrad<3, 128>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
-  else if (C == 3) launch_small_wgrad<3, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
-  else launch_small_wgrad<6, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
+  if (O == 128) launch_small_wgrad<3, 128>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
+  else launch_small_wgrad<3, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
   return eml::check_launch("eml_sphere_conv_small_wgrad_f32");
 }

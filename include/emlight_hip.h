@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 13
+#define EML_ABI_VERSION 14
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -373,10 +373,10 @@ int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* w
 int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                      const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
                                      const float* residual, float act_slope, eml_stream_t stream);
-/* The few-channel input layers -- SPADE's mlp_shared 3 -> 128 + ReLU (normalization.py:92-96), the discriminator's first
- * stage 6 -> 64 + LeakyReLU (discriminator.py:80-82), VGG19's conv1_1 3 -> 64 + ReLU -- are bound by the write of their
- * output: one pass each way.  (C, O) in {(3, 64), (3, 128), (6, 64)} (eml_sphere_conv_small_supported); idx / wgt = the
- * 4-entry tap table; X (B, HW, C), W2 (O, 9C), Y (B*Po, O) = leaky_relu(conv + bias, act_slope).
+/* The 3-channel input layers -- SPADE's mlp_shared 3 -> 128 + ReLU (normalization.py:92-96) and VGG19's conv1_1
+ * 3 -> 64 + ReLU -- are bound by the write of their output: one pass each way.  (C, O) in {(3, 64), (3, 128)}
+ * (eml_sphere_conv_small_supported); idx / wgt = the 4-entry tap table; X (B, HW, C), W2 (O, 9C),
+ * Y (B*Po, O) = leaky_relu(conv + bias, act_slope).
  * Weight gradient: dW2 (O, 9C) = sum_m g'[m] (x) A[m] and db (O, or NULL) = sum_m g'[m], g' = dY * (Yact > 0 ? 1 : act_slope)
  * (Yact = the forward's output; NULL with act_slope = 1); partial = eml_sphere_conv_small_wgrad_partial_floats floats of
  * scratch (per-workgroup partial sums, reduced in a fixed order: deterministic). */
@@ -437,6 +437,20 @@ int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, 
 int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
                          const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
                          eml_stream_t stream);
+
+/* The same three SPADE passes with the generator's nearest-neighbour x2 upsample of the block input (generator.py:70-82,
+ * `x = self.up(x)` before up_0..up_3) folded in: x_lo (B, H/2, W/2, C) is the map BEFORE the upsample, everything else lives
+ * on the (B, H, W) grid; pixel (b, h, w) reads x_lo at (b, h/2, w/2).  All tensors dense pixel-major (row stride C, 2C for
+ * gb / dgb).  mean / istd are the statistics of x_lo (those of the upsampled map: every value appears four times); the
+ * backward's partials and `sums` count the B*H*W upsampled pixels; eml_bn_bwd_apply_up2_f32 returns the gradient of x_lo:
+ *   dx_lo[q] = istd * (sum over q's 4 children of dxn - 4 S1/n - 4 xhat[q] S2/n). */
+int eml_spade_norm_modulate_up2_fwd_f32(const float* x_lo, const float* gb, float* y, int B, int H, int W, int C, float slope,
+                                        const float* mean, const float* istd, eml_stream_t stream);
+int eml_spade_norm_modulate_up2_bwd_f32(const float* gy, const float* x_lo, const float* gb, float* dxn, float* dgb, int B,
+                                        int H, int W, int C, float slope, const float* mean, const float* istd,
+                                        double* partials, int grid, eml_stream_t stream);
+int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int B, int H, int W, int C, const float* mean,
+                             const float* istd, const double* sums, float* dx_lo, eml_stream_t stream);
 
 /* torch.nn.utils.spectral_norm of a 3x3 convolution weight (normalization.py:24-33, architecture.py:41-45), fused with
  * the (O, tap, c) re-layout of the gather-GEMM kernels.  W (O, C, 3, 3) = weight_orig; u (O), v (9C) = the module's

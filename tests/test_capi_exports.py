@@ -83,12 +83,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 1, 32, 32, 4, 128, f(0.0), None) == -1 and b"(C, O)" in L.eml_last_error()
     assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 0, 32, 32, 3, 128, f(0.0), None) == 0       # empty batch
     assert L.eml_sphere_conv_small_wgrad_partial_floats(32, 32768, 3, 128) == 512 * 128 * 32
-    assert L.eml_sphere_conv_small_wgrad_partial_floats(1, 100, 6, 64) == 64 * 64
+    assert L.eml_sphere_conv_small_wgrad_partial_floats(1, 100, 3, 64) == 64 * 32 and L.eml_sphere_conv_small_supported(6, 64) == 0
     assert L.eml_sphere_conv_small_wgrad_f32(one, one, one, one, None, f(0.0), one, one, None, 1, 32, 32, 3, 128, None) == -1   # ReLU needs Yact
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 6, 1, f(1e-5), f(0.2), None) == -1    # pixel-major: C % 4
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 1, 16, 8, 1, f(1e-5), f(-0.2), None) == -1 and b"slope" in L.eml_last_error()
     assert L.eml_instance_norm_act_fwd_f32(one, one, one, 0, 16, 8, 0, f(1e-5), f(0.2), None) == 0      # empty batch
     assert L.eml_instance_norm_act_bwd_f32(one, one, one, None, 1, 16, 8, 0, f(0.2), None) == -1        # null dx
+    assert L.eml_spade_norm_modulate_up2_fwd_f32(one, one, one, 1, 5, 8, 8, f(0.2), one, one, None) == -1 and b"even H" in L.eml_last_error()
+    assert L.eml_spade_norm_modulate_up2_fwd_f32(one, one, one, 0, 4, 8, 8, f(0.2), one, one, None) == 0      # empty batch
+    assert L.eml_spade_norm_modulate_up2_bwd_f32(one, one, one, one, one, 1, 4, 8, 6, f(0.2), one, one, one, 4, None) == -1   # C % 4
+    assert L.eml_bn_bwd_apply_up2_f32(one, one, 1, 4, 8, 8, one, one, None, None, None) == -1                  # null dx
     assert L.eml_spectral_norm_scratch_floats(1024, 128) == 17 * 9 * 128 + 1024 + 2 * (5 + 1)   # t partials, t, s, 5 norm partials (f64)
     assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(0.0), one, one, one, one, 8, 4, None) == -1 and b"eps" in L.eml_last_error()
     assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(1e-12), one, one, one, one, 8, 8192, None) == -1   # row does not fit LDS

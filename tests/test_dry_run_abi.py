@@ -130,3 +130,12 @@ def test_spade_norm_modulate_calls_match_the_abi(recorder, monkeypatch):
     n = len(recorder.calls)
     spherenet.spade_norm_modulate(x, bn, torch.rand(2, nh, 4, 8), g_, b_, 1.0).sum().backward()
     assert "eml_bn_stats_f32" not in recorder.calls[n:]   # eval: running statistics, no reduction
+    # the nearest x2 upsample of the block input folded into the three passes
+    bn.train()
+    n = len(recorder.calls)
+    xl = torch.rand(2, C, 2, 4, requires_grad=True)
+    spherenet.spade_norm_modulate(xl, bn, torch.rand(2, nh, 4, 8), g_, b_, 0.2, None, up2=True).sum().backward()
+    for name in ("eml_bn_stats_f32", "eml_spade_norm_modulate_up2_fwd_f32", "eml_spade_norm_modulate_up2_bwd_f32",
+                 "eml_bn_bwd_apply_up2_f32"):
+        assert name in recorder.calls[n:], name
+    assert xl.grad.shape == xl.shape

@@ -445,7 +445,7 @@ def test_generator_step_includes_the_vgg_term():
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride,slope,with_res", [
     (2, 64, 64, 16, 32, 1, 0.2, True), (2, 128, 128, 32, 64, 1, 1.0, True), (1, 64, 128, 16, 32, 1, 0.0, False),   # fused kernel
     (2, 6, 8, 8, 16, 1, 0.2, True), (2, 3, 16, 8, 16, 1, 0.0, False),                                               # library GEMM
-    (2, 3, 128, 16, 32, 1, 0.0, False), (3, 6, 64, 16, 32, 2, 0.2, False), (2, 3, 64, 8, 16, 1, 0.0, False),        # few-channel kernels
+    (2, 3, 128, 16, 32, 1, 0.0, False), (3, 6, 64, 16, 32, 2, 0.2, False), (2, 3, 64, 8, 16, 1, 0.0, False),        # 3-channel kernels (6 -> 64: general)
     (1, 3, 128, 5, 6, 1, 1.0, False), (2, 3, 128, 64, 128, 1, 0.0, False)])
 def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, stride, slope, with_res):
     """``leaky_relu(conv(x) + residual, slope)`` in the kernel's epilogue (fused kernel: first three shapes with
@@ -456,7 +456,7 @@ def test_sphere_conv_epilogue_residual_and_activation(B, Cin, Cout, H, W, stride
     from emlight_amd.GenProjector.spherenet import SphereConv2D
     torch.manual_seed(Cin + Cout)
     conv = SphereConv2D(Cin, Cout, stride=stride).cuda()
-    assert bool(_lib.lib().eml_sphere_conv_small_supported(Cin, Cout)) == ((Cin, Cout) in ((3, 64), (3, 128), (6, 64)))
+    assert bool(_lib.lib().eml_sphere_conv_small_supported(Cin, Cout)) == ((Cin, Cout) in ((3, 64), (3, 128)))
     with torch.no_grad():
         conv.bias.uniform_(-0.5, 0.5)
     x = torch.randn(B, Cin, H, W, device="cuda")
@@ -560,3 +560,37 @@ def test_fused_spectral_norm_vs_torch_hook(O, C):
     # the (O, C, 3, 3) weight the hook hands to the convolution is a view of the kernels' (O, tap, c) operand: no re-layout copy
     w2 = hip.weight.permute(0, 2, 3, 1)
     assert w2.is_contiguous()
+
+
+@pytest.mark.parametrize("fin,fout,H,W,train", [(64, 32, 8, 16, True), (128, 64, 16, 32, True), (32, 16, 4, 8, False)])
+def test_spade_block_with_the_upsample_folded_in(fin, fout, H, W, train):
+    """``blk(x, seg, up2=True)`` (the nearest x2 upsample of generator.py:70-82 folded into the SPADE kernels: statistics from the
+    low-resolution map, indexing in the modulation, the 4-children sum in BatchNorm's backward) against ``blk(up(x), seg)`` on
+    the same HIP kernels: output, running statistics, d/dx and every parameter gradient."""
+    import copy
+    from emlight_amd.GenProjector import networks
+    torch.manual_seed(fin)
+    opt = networks.default_options()
+    a = networks.SPADEResnetBlock(fin, fout, opt).cuda()
+    networks.init_weights(a, "xavier", 0.02)
+    b = copy.deepcopy(a)
+    a.train(train)
+    b.train(train)
+    x = torch.randn(3, fin, H, W, device="cuda")
+    seg = torch.rand(3, 3, 128, 256, device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = a(xa, seg, up2=True)
+    yb = b(torch.nn.functional.interpolate(xb, scale_factor=2), seg)
+    assert ya.shape == yb.shape == (3, fout, 2 * H, 2 * W)
+    s = float(yb.detach().abs().max())
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-4, atol=1e-5 * s)
+    gy = torch.randn_like(yb)
+    ya.backward(gy)
+    yb.backward(gy)
+    err = float((xa.grad - xb.grad).norm() / xb.grad.norm())
+    assert err < 1e-4, err
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        e = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-20))
+        assert e < 2e-4, (k, e)
+    for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
+        torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6, msg=k)

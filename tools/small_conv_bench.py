@@ -1,4 +1,4 @@
-"""Few-channel input layers: csrc/sphere_conv_small.hip against the general path (im2col + library GEMM + ATen activation)."""
+"""3-channel input layers (the 6 -> 64 row shows the general path twice: not dispatched to these kernels): csrc/sphere_conv_small.hip against the general path (im2col + library GEMM + ATen activation)."""
 import os
 import sys
 
