@@ -357,7 +357,9 @@ PROJECTOR_FAMILIES = {
     "eml_sphere_im2col_f32": ("sphere_im2col_kernel (gather for the layers that keep the library GEMM)", None),
     "eml_sphere_col2im_f32": ("sphere_col2im_kernel (transpose gather of the unfused input gradient)", None),
     "eml_spade_norm_modulate_fwd_f32": ("spade_norm_modulate_fwd_kernel (BN + modulation + LeakyReLU)", None),
-    "eml_spade_norm_modulate_bwd_f32": ("spade_norm_modulate_bwd_kernel", None),
+    "eml_spade_norm_modulate_up2_fwd_f32": ("spade_norm_modulate_fwd_kernel<up2> (the block's x2 upsample folded in)", None),
+    "eml_bn_bwd_apply_up2_f32": ("bn_bwd_apply_up2_kernel", None),
+    "eml_spade_norm_modulate_bwd_cols_f32": ("spade_norm_modulate_bwd_kernel (+ BatchNorm partials, + the gamma|beta bias gradient)", None),
     "eml_bn_stats_f32": ("bn_stats_kernel (SPADE batch statistics)", None),
     "eml_bn_bwd_apply_f32": ("bn_bwd_apply_kernel", None),
     "eml_sphere_conv_small_fwd_f32": ("sphere_conv_small_fwd_kernel (3 -> 64/128 input layers + ReLU, one pass)", None),

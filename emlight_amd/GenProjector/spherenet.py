@@ -264,7 +264,9 @@ class _SphereConvFn(torch.autograd.Function):
         if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5]:
             gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2] and not small_w:
-            gb = gyr.sum(0)
+            # the SPADE modulation's backward leaves the column sums of the dgb it produced on the tensor (f64-accumulated)
+            pre = getattr(gy, "_eml_colsum", None)
+            gb = pre if (pre is not None and y is None and pre.shape == (O,)) else gyr.sum(0)
         if ctx.needs_input_grad[1] and not small_w:
             if ctx.fused_wgrad and B:
                 bn = 128 if C % 128 == 0 else 64
@@ -480,28 +482,35 @@ class _SpadeNormModulateFn(torch.autograd.Function):
         B, C = x.shape[:2]
         H, W = gb.shape[2:]
         rows = B * H * W
-        dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        cl = torch.channels_last
+        gy, x, gb = gy.contiguous(memory_format=cl), x.contiguous(memory_format=cl), gb.contiguous(memory_format=cl)
+        dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
+        dxn = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
         grid = _stats_grid(rows, C)
-        partials = torch.empty(grid, C, 2, dtype=torch.float64, device=x.device)
+        # one pass: dxn, dgb, BatchNorm's (sum dxn, sum dxn*xhat) and the column sums of dgb (= the bias gradient of the
+        # gamma | beta convolution, handed to its backward on the tensor itself instead of a second read of dgb)
+        partials = torch.empty(grid, 4 * C + 1, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_spade_norm_modulate_bwd_cols_f32(p(gy), p(x), p(gb), p(dxn), p(dgb), B, H, W, C, int(ctx.up2), ctx.slope,
+                                                          p(mean), p(istd), p(partials), grid, st),
+                   "eml_spade_norm_modulate_bwd_cols_f32")
+        folded = torch.empty(4 * C + 1, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_bn_fold_f64(p(partials), grid, 4 * C + 1, p(folded), st), "eml_bn_fold_f64")
+        sums = None
+        if ctx.training:
+            sums = folded[:2 * C + 1]
+            sums[2 * C] = float(rows)
+            if _bn_sync():
+                import torch.distributed as dist
+                dist.all_reduce(sums)
+        dgb._eml_colsum = folded[2 * C + 1:].view(C, 2).t().reshape(2 * C).float()
         if ctx.up2:
-            gy = gy.contiguous(memory_format=torch.channels_last)
-            dxn = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-            _lib.check(L.eml_spade_norm_modulate_up2_bwd_f32(p(gy), p(x), p(gb), p(dxn), p(dgb), B, H, W, C, ctx.slope, p(mean),
-                                                             p(istd), p(partials), grid, st),
-                       "eml_spade_norm_modulate_up2_bwd_f32")
-            sums = _reduce_sums(partials, rows, C) if ctx.training else None
-            dx = torch.empty_like(x, memory_format=torch.channels_last)     # gradient of the map BEFORE the upsample
+            dx = torch.empty_like(x, memory_format=cl)     # gradient of the map BEFORE the upsample
             _lib.check(L.eml_bn_bwd_apply_up2_f32(p(dxn), p(x), B, H, W, C, p(mean), p(istd), p(sums), p(dx), st),
                        "eml_bn_bwd_apply_up2_f32")
-            return dx, dgb, None, None, None, None, None
-        gy, ldy = _rows_view(gy)
-        dx = torch.empty_like(x, memory_format=torch.channels_last)
-        _lib.check(L.eml_spade_norm_modulate_bwd_f32(p(gy), ldy, p(x), x.stride(3), p(gb), gb.stride(3), p(dx), C, p(dgb),
-                                                     2 * C, rows, C, ctx.slope, p(mean), p(istd), p(partials), grid, st),
-                   "eml_spade_norm_modulate_bwd_f32")
-        sums = _reduce_sums(partials, rows, C) if ctx.training else None
-        _lib.check(L.eml_bn_bwd_apply_f32(p(dx), C, p(x), x.stride(3), rows, C, p(mean), p(istd), p(sums), p(dx), C, st),
-                   "eml_bn_bwd_apply_f32")
+        else:
+            dx = dxn
+            _lib.check(L.eml_bn_bwd_apply_f32(p(dx), C, p(x), C, rows, C, p(mean), p(istd), p(sums), p(dx), C, st),
+                       "eml_bn_bwd_apply_f32")
         return dx, dgb, None, None, None, None, None
 
 

@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 14   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 15   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -51,8 +51,8 @@ SIGNATURES = {
                                                _int, _int, _int, _int, _stream]),
     "eml_spade_norm_modulate_up2_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _f32p, _f32p,
                                                    _stream]),
-    "eml_spade_norm_modulate_up2_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float,
-                                                   _f32p, _f32p, _f32p, _int, _stream]),
+    "eml_spade_norm_modulate_bwd_cols_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,
+                                                    ctypes.c_float, _f32p, _f32p, _f32p, _int, _stream]),
     "eml_bn_bwd_apply_up2_f32": (_int, [_f32p, _f32p, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _stream]),
     "eml_spectral_norm_scratch_floats": (ctypes.c_size_t, [_int, _int]),
     "eml_spectral_norm_w2_f32": (_int, [_f32p, _f32p, _f32p, _int, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _int, _int,
@@ -75,8 +75,6 @@ SIGNATURES = {
     "eml_bn_finalize_f32": (_int, [_f32p, _int, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _stream]),
     "eml_spade_norm_modulate_fwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, ctypes.c_long, _int, ctypes.c_float,
                                                _f32p, _f32p, _stream]),
-    "eml_spade_norm_modulate_bwd_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _int,
-                                               ctypes.c_long, _int, ctypes.c_float, _f32p, _f32p, _f32p, _int, _stream]),
     "eml_bn_bwd_apply_f32": (_int, [_f32p, _int, _f32p, _int, ctypes.c_long, _int, _f32p, _f32p, _f32p, _f32p, _int,
                                     _stream]),
     # DenseNet-BC encoder, forward

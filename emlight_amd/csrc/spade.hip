@@ -100,8 +100,10 @@ __device__ __forceinline__ void reduce_rows_and_store(const ColMap& m, int cg, d
     for (int k = 0; k < NV; ++k) {
       double t = red[m.cl * NV + k];
       for (int r = 1; r < m.rpp; ++r) t += red[(r * m.cvp + m.cl) * NV + k];
-      // v = {s1[0..3], s2[0..3]}: channel 4*cg + (k & 3), statistic k >> 2
-      out[(size_t)(4 * cg + (k & 3)) * 2 + (k >> 2)] = t;
+      // v = {s1[0..3], s2[0..3] (, s3[0..3], s4[0..3])}: channel 4*cg + (k & 3), statistic k >> 2; statistics 2, 3 form a
+      // second (C, 2) table behind the first and its count slot
+      const int st = k >> 2;
+      out[(st >> 1) * (size_t)(2 * C + 1) + (size_t)(4 * cg + (k & 3)) * 2 + (st & 1)] = t;
     }
   }
 }
@@ -207,16 +209,21 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_fwd_kernel(const floa
 
 // backward of the above w.r.t. the NORMALISED activation (dxn) and (gamma | beta), + the per-block partial sums
 // (sum dxn, sum dxn*xhat) BatchNorm's backward needs; fixed-column layout so that a thread keeps its channels
+// The per-block partial row is (C, 2) (sum dxn, sum dxn*xhat), one unused slot (the count's place in `sums`), then
+// (C, 2) (sum dgamma, sum dbeta) -- the column sums of dgb, i.e. the BIAS gradient of the gamma | beta convolution that
+// produced gb, which would otherwise re-read dgb (the largest gradient tensor of the step) just to add it up.
 template <bool UP2>
 __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
     const float* __restrict__ gy, int ld_gy, const float* __restrict__ x, int ld_x, const float* __restrict__ gb, int ld_gb,
     float* __restrict__ dxn, int ld_dx, float* __restrict__ dgb, int ld_dgb, int rows, int C, float slope,
     const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials, int H, int W) {
-  __shared__ double red[256 * 8];
+  constexpr int NV = 16;
+  __shared__ double red[256 * NV];
   const ColMap m(C);
-  double* out = partials + (size_t)blockIdx.x * C * 2;
+  double* out = partials + (size_t)blockIdx.x * (4 * C + 1);
+  if (threadIdx.x == 0) out[2 * C] = 0.0;
   for (int cg = m.cl; cg < ((m.cv + m.cvp - 1) / m.cvp) * m.cvp; cg += m.cvp) {
-    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double v[NV] = {};
     if (cg < m.cv) {
       const int c = 4 * cg;
       const float4 mu = *reinterpret_cast<const float4*>(mean + c);
@@ -237,13 +244,15 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
           dg[k] = d[k] * a[k];
           v[k] += (double)dx[k];
           v[4 + k] = fma((double)dx[k], (double)a[k], v[4 + k]);
+          v[8 + k] += (double)dg[k];
+          v[12 + k] += (double)d[k];
         }
         *reinterpret_cast<float4*>(dxn + (size_t)row * ld_dx + c) = make_float4(dx[0], dx[1], dx[2], dx[3]);
         *reinterpret_cast<float4*>(dgb + (size_t)row * ld_dgb + c) = make_float4(dg[0], dg[1], dg[2], dg[3]);
         *reinterpret_cast<float4*>(dgb + (size_t)row * ld_dgb + C + c) = make_float4(d[0], d[1], d[2], d[3]);
       }
     }
-    reduce_rows_and_store<8>(m, cg, v, red, out, C);
+    reduce_rows_and_store<NV>(m, cg, v, red, out, C);
   }
 }
 
@@ -377,19 +386,6 @@ extern "C" int eml_spade_norm_modulate_fwd_f32(const float* x, int ld_x, const f
   return eml::check_launch("eml_spade_norm_modulate_fwd_f32");
 }
 
-extern "C" int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, int ld_x, const float* gb,
-                                               int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
-                                               float slope, const float* mean, const float* istd, double* partials,
-                                               int grid, eml_stream_t stream) {
-  if (!gy || !x || !gb || !dxn || !dgb || !mean || !istd || !partials || rows < 1 || rows > 2147483647L || C < 4 ||
-      (C & 3) || bad_ld(ld_gy, C) || bad_ld(ld_x, C) || bad_ld(ld_gb, 2 * C) || bad_ld(ld_dx, C) || bad_ld(ld_dgb, 2 * C) ||
-      grid < 1)
-    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_bwd_f32: bad arguments");
-  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, ld_gy, x, ld_x,
-                     gb, ld_gb, dxn, ld_dx, dgb, ld_dgb, (int)rows, C, slope, mean, istd, partials, 0, 0);
-  return eml::check_launch("eml_spade_norm_modulate_bwd_f32");
-}
-
 extern "C" int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
                                     const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
                                     eml_stream_t stream) {
@@ -422,17 +418,6 @@ extern "C" int eml_spade_norm_modulate_up2_fwd_f32(const float* x_lo, const floa
   return eml::check_launch("eml_spade_norm_modulate_up2_fwd_f32");
 }
 
-extern "C" int eml_spade_norm_modulate_up2_bwd_f32(const float* gy, const float* x_lo, const float* gb, float* dxn, float* dgb,
-                                                   int B, int H, int W, int C, float slope, const float* mean,
-                                                   const float* istd, double* partials, int grid, eml_stream_t stream) {
-  if (!gy || !x_lo || !gb || !dxn || !dgb || !mean || !istd || !partials || grid < 1 || B < 1)
-    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_up2_bwd_f32: null pointer, empty batch or grid < 1");
-  if (int rc = up2_args("eml_spade_norm_modulate_up2_bwd_f32", B, H, W, C)) return rc;
-  hipLaunchKernelGGL(spade_norm_modulate_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x_lo, C, gb,
-                     2 * C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, H, W);
-  return eml::check_launch("eml_spade_norm_modulate_up2_bwd_f32");
-}
-
 extern "C" int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int B, int H, int W, int C, const float* mean,
                                         const float* istd, const double* sums, float* dx_lo, eml_stream_t stream) {
   if (!dxn || !x_lo || !mean || !istd || !dx_lo) return eml::fail(EML_EINVAL, "eml_bn_bwd_apply_up2_f32: null pointer");
@@ -442,4 +427,26 @@ extern "C" int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int
   hipLaunchKernelGGL(bn_bwd_apply_up2_kernel, dim3(grid_for(rows_lo * (C / 4))), dim3(256), 0, (hipStream_t)stream, dxn, C,
                      x_lo, C, (int)rows_lo, C, mean, istd, sums, dx_lo, C, H, W);
   return eml::check_launch("eml_bn_bwd_apply_up2_f32");
+}
+
+// The backward of the modulation that also leaves the column sums of dgb -- the bias gradient of the gamma | beta convolution --
+// in its partials: row layout (C, 2) (sum dxn, sum dxn*xhat) | 1 unused slot | (C, 2) (sum dgamma, sum dbeta) = 4C + 1 doubles per
+// block, so that eml_bn_fold_f64(partials, grid, 4C + 1, sums) yields `sums` (2C + 1; the caller sets the count at [2C]) followed
+// by the (C, 2) table of the bias gradient.  up2 != 0: x_lo is the map before the x2 upsample (H, W = the upsampled size; as
+// eml_spade_norm_modulate_up2_bwd_f32); up2 == 0: x (B*H*W, C).  All tensors dense (row stride C, 2C for gb / dgb).
+extern "C" int eml_spade_norm_modulate_bwd_cols_f32(const float* gy, const float* x, const float* gb, float* dxn, float* dgb,
+                                                    int B, int H, int W, int C, int up2, float slope, const float* mean,
+                                                    const float* istd, double* partials, int grid, eml_stream_t stream) {
+  if (!gy || !x || !gb || !dxn || !dgb || !mean || !istd || !partials || grid < 1 || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) ||
+      (long)B * H * W > 2147483647L)
+    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_bwd_cols_f32: bad arguments");
+  if (up2) {
+    if (int rc = up2_args("eml_spade_norm_modulate_bwd_cols_f32", B, H, W, C)) return rc;
+    hipLaunchKernelGGL((spade_norm_modulate_bwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x, C, gb,
+                       2 * C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, H, W);
+  } else {
+    hipLaunchKernelGGL((spade_norm_modulate_bwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x, C, gb,
+                       2 * C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, 0, 0);
+  }
+  return eml::check_launch("eml_spade_norm_modulate_bwd_cols_f32");
 }

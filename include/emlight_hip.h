@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 14
+#define EML_ABI_VERSION 15
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -419,8 +419,8 @@ int eml_spade_modulate_bwd_f32(const float* gy, int ld_gy, const float* xn, int 
  *   eml_bn_finalize_f32  mean, istd = rsqrt(var + eps) from sums (count at sums[2C]); running_mean / running_var
  *                        (NULL to skip) updated like nn.BatchNorm2d (momentum, unbiased variance)
  *   eml_spade_norm_modulate_fwd_f32   y = leaky_relu(((x-mean)*istd) * (1 + gamma) + beta, slope)
- *   eml_spade_norm_modulate_bwd_f32   dxn, dgb as eml_spade_modulate_bwd_f32 with xn = (x-mean)*istd rebuilt inline,
- *                        + partials[grid][C][2] = (sum dxn, sum dxn*xhat)
+ *   eml_spade_norm_modulate_bwd_cols_f32 (below)   dxn, dgb as eml_spade_modulate_bwd_f32 with xn = (x-mean)*istd rebuilt
+ *                        inline, + per-block partials of (sum dxn, sum dxn*xhat) and of dgb's column sums
  *   eml_bn_bwd_apply_f32 dx = istd * (dxn - S1/n - xhat*S2/n) with (S1,S2) = sums[c][0..1], n = sums[2C];
  *                        sums == NULL: eval mode, dx = istd * dxn.  dx may alias dxn. */
 int eml_bn_stats_f32(const float* x, int ld, long rows, int C, double* partials, int grid, eml_stream_t stream);
@@ -430,10 +430,6 @@ int eml_bn_finalize_f32(const double* sums, int C, float eps, float momentum, fl
 int eml_spade_norm_modulate_fwd_f32(const float* x, int ld_x, const float* gb, int ld_gb, float* y, int ld_y,
                                     long rows, int C, float slope, const float* mean, const float* istd,
                                     eml_stream_t stream);
-int eml_spade_norm_modulate_bwd_f32(const float* gy, int ld_gy, const float* x, int ld_x, const float* gb,
-                                    int ld_gb, float* dxn, int ld_dx, float* dgb, int ld_dgb, long rows, int C,
-                                    float slope, const float* mean, const float* istd, double* partials,
-                                    int grid, eml_stream_t stream);
 int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, long rows, int C,
                          const float* mean, const float* istd, const double* sums, float* dx, int ld_o,
                          eml_stream_t stream);
@@ -442,15 +438,23 @@ int eml_bn_bwd_apply_f32(const float* dxn, int ld_d, const float* x, int ld_x, l
  * `x = self.up(x)` before up_0..up_3) folded in: x_lo (B, H/2, W/2, C) is the map BEFORE the upsample, everything else lives
  * on the (B, H, W) grid; pixel (b, h, w) reads x_lo at (b, h/2, w/2).  All tensors dense pixel-major (row stride C, 2C for
  * gb / dgb).  mean / istd are the statistics of x_lo (those of the upsampled map: every value appears four times); the
- * backward's partials and `sums` count the B*H*W upsampled pixels; eml_bn_bwd_apply_up2_f32 returns the gradient of x_lo:
+ * backward (eml_spade_norm_modulate_bwd_cols_f32 with up2 = 1) reduces over the B*H*W upsampled pixels, and
+ * eml_bn_bwd_apply_up2_f32 returns the gradient of x_lo:
  *   dx_lo[q] = istd * (sum over q's 4 children of dxn - 4 S1/n - 4 xhat[q] S2/n). */
 int eml_spade_norm_modulate_up2_fwd_f32(const float* x_lo, const float* gb, float* y, int B, int H, int W, int C, float slope,
                                         const float* mean, const float* istd, eml_stream_t stream);
-int eml_spade_norm_modulate_up2_bwd_f32(const float* gy, const float* x_lo, const float* gb, float* dxn, float* dgb, int B,
-                                        int H, int W, int C, float slope, const float* mean, const float* istd,
-                                        double* partials, int grid, eml_stream_t stream);
 int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int B, int H, int W, int C, const float* mean,
                              const float* istd, const double* sums, float* dx_lo, eml_stream_t stream);
+
+/* The modulation's backward (plain or with the folded upsample), which also leaves the COLUMN SUMS of dgb -- the bias gradient of the gamma | beta
+ * SphereConv2D that produced gb (normalization.py:97-98) -- in its partials, so that the largest gradient tensor of the step is
+ * not re-read just to be added up.  Partial row = (C, 2) (sum dxn, sum dxn*xhat) | 1 unused slot | (C, 2) (sum dgamma, sum
+ * dbeta) = 4C + 1 doubles per block: eml_bn_fold_f64(partials, grid, 4C + 1, out) gives `sums` (2C + 1, the caller sets the
+ * count at [2C]) followed by the bias-gradient table.  up2 != 0: x = the map before the x2 upsample, (H, W) the upsampled size.
+ * Dense tensors: row stride C (gy, x, dxn), 2C (gb, dgb). */
+int eml_spade_norm_modulate_bwd_cols_f32(const float* gy, const float* x, const float* gb, float* dxn, float* dgb, int B, int H,
+                                         int W, int C, int up2, float slope, const float* mean, const float* istd,
+                                         double* partials, int grid, eml_stream_t stream);
 
 /* torch.nn.utils.spectral_norm of a 3x3 convolution weight (normalization.py:24-33, architecture.py:41-45), fused with
  * the (O, tap, c) re-layout of the gather-GEMM kernels.  W (O, C, 3, 3) = weight_orig; u (O), v (9C) = the module's

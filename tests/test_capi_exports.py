@@ -91,7 +91,8 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_instance_norm_act_bwd_f32(one, one, one, None, 1, 16, 8, 0, f(0.2), None) == -1        # null dx
     assert L.eml_spade_norm_modulate_up2_fwd_f32(one, one, one, 1, 5, 8, 8, f(0.2), one, one, None) == -1 and b"even H" in L.eml_last_error()
     assert L.eml_spade_norm_modulate_up2_fwd_f32(one, one, one, 0, 4, 8, 8, f(0.2), one, one, None) == 0      # empty batch
-    assert L.eml_spade_norm_modulate_up2_bwd_f32(one, one, one, one, one, 1, 4, 8, 6, f(0.2), one, one, one, 4, None) == -1   # C % 4
+    assert L.eml_spade_norm_modulate_bwd_cols_f32(one, one, one, one, one, 1, 4, 8, 6, 0, f(0.2), one, one, one, 4, None) == -1   # C % 4
+    assert L.eml_spade_norm_modulate_bwd_cols_f32(one, one, one, one, one, 1, 5, 8, 8, 1, f(0.2), one, one, one, 4, None) == -1   # up2: even H
     assert L.eml_bn_bwd_apply_up2_f32(one, one, 1, 4, 8, 8, one, one, None, None, None) == -1                  # null dx
     assert L.eml_spectral_norm_scratch_floats(1024, 128) == 17 * 9 * 128 + 1024 + 2 * (5 + 1)   # t partials, t, s, 5 norm partials (f64)
     assert L.eml_spectral_norm_w2_f32(one, one, one, 1, f(0.0), one, one, one, one, 8, 4, None) == -1 and b"eps" in L.eml_last_error()

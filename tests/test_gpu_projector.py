@@ -594,3 +594,23 @@ def test_spade_block_with_the_upsample_folded_in(fin, fout, H, W, train):
         assert e < 2e-4, (k, e)
     for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
         torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_gamma_beta_bias_gradient_comes_from_the_modulation_backward(monkeypatch):
+    """The bias gradient of SPADE's gamma | beta convolution is the column sum of dgb; the modulation's backward leaves it on
+    the dgb tensor (f64-accumulated) and the convolution's backward must use that instead of reducing dgb again."""
+    from emlight_amd.GenProjector import spherenet
+    torch.manual_seed(3)
+    C, nh = 64, 128
+    bn = torch.nn.BatchNorm2d(C, affine=False).cuda().train()
+    g_, b_ = spherenet.SphereConv2D(nh, C).cuda(), spherenet.SphereConv2D(nh, C).cuda()
+    x = torch.randn(4, C, 16, 32, device="cuda", requires_grad=True)
+    actv = torch.randn(4, nh, 16, 32, device="cuda")
+    loss = (spherenet.spade_norm_modulate(x, bn, actv, g_, b_, 0.2) * torch.randn(4, C, 16, 32, device="cuda")).sum()
+    calls = []
+    real_sum = torch.Tensor.sum
+    monkeypatch.setattr(torch.Tensor, "sum", lambda self, *a, **k: (calls.append(tuple(self.shape)), real_sum(self, *a, **k))[1])
+    loss.backward()
+    monkeypatch.undo()
+    assert calls == [], calls
+    assert g_.bias.grad is not None and float(g_.bias.grad.abs().max()) > 0 and float(b_.bias.grad.abs().max()) > 0
