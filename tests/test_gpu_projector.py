@@ -614,3 +614,55 @@ def test_gamma_beta_bias_gradient_comes_from_the_modulation_backward(monkeypatch
     monkeypatch.undo()
     assert calls == [], calls
     assert g_.bias.grad is not None and float(g_.bias.grad.abs().max()) > 0 and float(b_.bias.grad.abs().max()) > 0
+
+
+def test_three_iterations_follow_the_stock_op_trajectory():
+    """Three full projector iterations (G step + D step each, fresh batch each) on the HIP path against the same trainer on the
+    CPU with every op stock (torch's spectral-norm hook, ATen instance norm, unfused Adam, the oracle's SphereConv / SPADE):
+    what a single step cannot show -- the power-iteration buffers after six forwards, SPADE's running statistics, Adam's
+    moments -- stays on the reference's trajectory.  Bounds from the measured distances (tools/debug_trajectory.py: losses
+    <= 3e-4, buffers <= 1.4e-3, parameter UPDATES <= 0.11 of the update's norm), with a factor ~3-5 of head room.  Adam's first
+    updates are sign-like (|update| = lr whatever |grad|), so an element whose gradient is at round-off level may step the other
+    way: updates are compared in norm; the bias of a convolution whose output only ever reaches the rest of the network through
+    a parameter-free BatchNorm (conv_0 of every SPADE block; conv_1 / conv_s of every block but the last, whose sum is
+    renormalised by the next block) has an exactly-zero gradient in exact arithmetic -- both sides walk on their own rounding
+    noise there -- and is only held to the size of three steps."""
+    from emlight_amd.GenProjector import data, networks
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    torch.manual_seed(5)
+    opt = networks.default_options(ngf=8, ndf=8)
+    cpu = Trainer(opt, device="cpu")
+    cpu.model.netG.load_state_dict(oracle.deterministic_projector_state_dict(cpu.model.netG.state_dict(), seed=11))
+    cpu.model.netD.load_state_dict(oracle.deterministic_projector_state_dict(cpu.model.netD.state_dict(), seed=12))
+    hip = Trainer(opt, device="cuda")
+    hip.model.netG.load_state_dict(cpu.model.netG.state_dict())
+    hip.model.netD.load_state_dict(cpu.model.netD.state_dict())
+    start = {n: {k: v.detach().clone().double() for k, v in net.state_dict().items()}
+             for n, net in (("G", cpu.model.netG), ("D", cpu.model.netD))}
+    for it in range(3):
+        batch = data.projector_batch(2, "cuda", seed=30 + it)
+        hip.step(batch)
+        with oracle.stock_sphere_ops():
+            cpu.step({k: v.cpu() for k, v in batch.items()})
+        lh, lc = hip.get_latest_losses(), cpu.get_latest_losses()
+        for k in lc:
+            a, b = float(lh[k].detach().mean()), float(lc[k].detach().mean())
+            assert abs(a - b) <= 2e-3 * abs(b) + 1e-6, (it, k, a, b)
+    for net_h, net_c, name in ((hip.model.netG, cpu.model.netG, "G"), (hip.model.netD, cpu.model.netD, "D")):
+        sh, sc = net_h.state_dict(), net_c.state_dict()
+        assert set(sh) == set(sc)
+        for k in sc:
+            if not sc[k].dtype.is_floating_point:
+                assert int(sh[k]) == int(sc[k]), k
+                continue
+            a, b, z = sh[k].detach().cpu().double(), sc[k].detach().double(), start[name][k]
+            if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+                assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-7, (name, k)
+            elif k.endswith(("conv_0.bias", "conv_1.bias", "conv_s.bias")) and not k.startswith("up_3.conv_1") \
+                    and not k.startswith("up_3.conv_s"):
+                # |Adam update| <= lr / sqrt(1 - beta2) (beta1 = 0, beta2 = 0.9); worst case: opposite directions on all 3 steps
+                lr = (1e-4 if name == "G" else 4e-4) / np.sqrt(1 - 0.9)
+                assert float((a - b).abs().max()) <= 2 * 3 * lr * 1.01, (name, k)
+            else:
+                upd = float((b - z).norm())
+                assert float(((a - z) - (b - z)).norm()) <= 0.3 * upd + 1e-9, (name, k, upd)
