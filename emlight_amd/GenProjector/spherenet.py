@@ -149,9 +149,13 @@ class _SphereConvFn(torch.autograd.Function):
 
     Large layers (by the size of the would-be im2col operand ``A9``, thresholds in ``forward``; channel counts that
     tile): the FUSED kernels of ``csrc/sphere_conv_fused.hip`` -- taps gathered straight into the LDS operand of an
-    f32-MFMA implicit GEMM, forward and weight gradient, so the 9x blown-up operand never exists in HBM.  Small / odd
-    layers: im2col_sphere (HIP) -> library GEMM.  The input gradient is ``dY W2`` (library GEMM) -> col2im_sphere (HIP,
-    deterministic gather over the CSR transpose of the tap table) in both cases.
+    f32-MFMA implicit GEMM: forward (with the consumer's residual sum / activation in the epilogue), weight gradient, and
+    the input gradient by the forward kernel on the transposed tap table, so the 9x blown-up operand never exists in HBM.
+    The 3-channel input layers (3 -> 64 / 128): the one-pass kernels of ``csrc/sphere_conv_small.hip``.  Everything else
+    (wide low-resolution heads, odd channel counts): im2col_sphere (HIP) -> library GEMM, and for the input gradient
+    ``dY W2`` (library GEMM) -> col2im_sphere (HIP, deterministic gather over the CSR transpose of the tap table).
+    ``weight`` may be any (O, C, 3, 3) tensor; one whose memory is already (O, 3, 3, C) -- the fused spectral norm's
+    result -- is used without a re-layout copy, and the weight gradient is returned in that memory order.
     Activations are pixel-major: inputs in ``torch.channels_last`` are used in place, the output is returned as a
     channels-last (B, O, H', W') tensor, so a chain of SphereConvs never transposes."""
 

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_small_fwd_kernel(const flo
   }
 }
 
-// partial[blockIdx.x][O][KP]  (KP = 4 * ceil((9*CIN + 1) / 16) * 4 columns: k < 9*CIN = dW2, k = 9*CIN = the bias gradient)
+// partial[blockIdx.x][O][KP]  (KP = 9*CIN + 1 rounded up to 16 columns: k < 9*CIN = dW2, k = 9*CIN = the bias gradient)
 template <int CIN, int O>
 __global__ __launch_bounds__(256, 2) void sphere_conv_small_wgrad_kernel(const float* __restrict__ X, const int* __restrict__ idx,
                                                                       const float* __restrict__ wgt,
