@@ -652,13 +652,20 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
   // loads of UQ pixel-quads are issued back to back with no control flow between them.
   auto chunk_loop = [&](auto ngw_c) {
     constexpr int NGW = decltype(ngw_c)::value;
+#ifdef EML_WGRAD_DEEP   // experiment build: half-size batches, four buffers, three batches (24 pixels) in flight
+    constexpr int UQ = POOL ? 1 : 2;
+    constexpr int NBUF = POOL ? 2 : 4;
+#else
     constexpr int UQ = POOL ? 1 : 4;      // pixel quads per batch
+    constexpr int NBUF = 2;
+#endif
     constexpr int NS = POOL ? 4 : 1;      // input pixels per output pixel
-    constexpr int NB = 16 / UQ;           // operand batches per 64-pixel chunk (even)
+    constexpr int NB = 16 / UQ;           // operand batches per 64-pixel chunk (a multiple of NBUF)
+    constexpr int AHEAD = NBUF - 1;       // batches requested ahead of their MFMAs
     // x operand of one batch: UNCONDITIONAL loads from clamped pixels (validity is applied when the value is
-    // used); they are requested ONE BATCH AHEAD of their MFMAs, across chunk boundaries -- issued right before
+    // used); they are requested AHEAD of their MFMAs, across chunk boundaries -- issued right before
     // use they exposed an HBM round trip per batch (ISA: global_load; s_waitcnt vmcnt; v_mfma).
-    float2 xr[2][UQ][NGW > 0 ? NGW : 1][NS];
+    float2 xr[NBUF][UQ][NGW > 0 ? NGW : 1][NS];
     auto load_batch = [&](int chunk, int q0, float2 (&dst)[UQ][NGW > 0 ? NGW : 1][NS]) {
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
@@ -680,7 +687,10 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     };
     stage_load(blockIdx.x);
     stage_write(dz_l[0]);
-    if constexpr (NGW > 0) load_batch(min((int)blockIdx.x, nchunks - 1), 0, xr[0]);
+    if constexpr (NGW > 0) {
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a) load_batch(min((int)blockIdx.x, nchunks - 1), a * UQ, xr[a]);
+    }
     __syncthreads();
     int it = 0;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
@@ -703,10 +713,10 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
           const int q0 = bi * UQ;
-          if (bi + 1 < NB)
-            load_batch(chunk, q0 + UQ, xr[(bi + 1) & 1]);
+          if (bi + AHEAD < NB)
+            load_batch(chunk, q0 + AHEAD * UQ, xr[(bi + AHEAD) % NBUF]);
           else
-            load_batch(min(chunk + (int)gridDim.x, nchunks - 1), 0, xr[0]);
+            load_batch(min(chunk + (int)gridDim.x, nchunks - 1), (bi + AHEAD - NB) * UQ, xr[(bi + AHEAD) % NBUF]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < UQ; ++u) {
@@ -720,8 +730,8 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
               float ax = 0.f, ay = 0.f;
 #pragma unroll
               for (int sub = 0; sub < NS; ++sub) {
-                ax += fmaxf(fmaf(xr[bi & 1][u][i][sub].x, s2[i].x, t2[i].x), 0.f);
-                ay += fmaxf(fmaf(xr[bi & 1][u][i][sub].y, s2[i].y, t2[i].y), 0.f);
+                ax += fmaxf(fmaf(xr[bi % NBUF][u][i][sub].x, s2[i].x, t2[i].x), 0.f);
+                ay += fmaxf(fmaf(xr[bi % NBUF][u][i][sub].y, s2[i].y, t2[i].y), 0.f);
               }
               if constexpr (POOL) {
                 ax *= 0.25f;
