@@ -666,3 +666,33 @@ def test_three_iterations_follow_the_stock_op_trajectory():
             else:
                 upd = float((b - z).norm())
                 assert float(((a - z) - (b - z)).norm()) <= 0.3 * upd + 1e-9, (name, k, upd)
+
+
+def test_inference_in_eval_mode_matches_the_stock_ops():
+    """``mode='inference'`` with the networks in eval(): running statistics in SPADE (each norm its own), no power iteration in
+    the spectral norm (sigma from the stored u, v), the folded upsample and the fused epilogues -- against the all-stock CPU path."""
+    from emlight_amd.GenProjector import data, networks
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    torch.manual_seed(9)
+    opt = networks.default_options(ngf=8, ndf=8)
+    cpu = Pix2PixModel(opt)
+    cpu.netG.load_state_dict(oracle.deterministic_projector_state_dict(cpu.netG.state_dict(), seed=11))
+    with torch.no_grad():   # running statistics that differ between the norms of a block, as after training
+        for k, b in cpu.netG.named_buffers():
+            if k.endswith("running_mean"):
+                b.normal_(0, 0.2)
+            elif k.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    hip = Pix2PixModel(opt)
+    hip.netG.load_state_dict(cpu.netG.state_dict())
+    hip = hip.cuda().eval()
+    cpu = cpu.eval()
+    batch = data.projector_batch(2, "cuda", seed=77)
+    u_before = {k: v.clone() for k, v in hip.netG.state_dict().items() if k.endswith(("weight_u", "running_mean"))}
+    got = hip(batch, "inference").cpu()
+    with oracle.stock_sphere_ops():
+        want = cpu({k: v.cpu() for k, v in batch.items()}, "inference")
+    assert got.shape == want.shape == (2, 3, 128, 256)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+    for k, v in u_before.items():   # eval: no buffer moves
+        assert torch.equal(hip.netG.state_dict()[k], v), k
