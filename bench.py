@@ -464,7 +464,7 @@ def leg_projector(args, rank, world, dev, steps, warmup):
     def run(no_vgg):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")   # "random VGG features": stated in the JSON instead
-            tr = Trainer(default_options(no_vgg_loss=no_vgg), device=dev, world=world)
+            tr = Trainer(default_options(no_vgg_loss=no_vgg, vgg_random=True), device=dev, world=world)
         dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
         # EVERY rank runs the instrumented step (it contains DDP's all-reduces and SPADE's statistics all-reduce); rank 0 reports
         fams = time_projector_families(tr, data, 1) if not no_vgg else None
@@ -521,7 +521,7 @@ def leg_joint(args, rank, world, dev, steps, warmup):
     def run(no_vgg):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            tr = JointTrainer(default_options(no_vgg_loss=no_vgg), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
+            tr = JointTrainer(default_options(no_vgg_loss=no_vgg, vgg_random=True), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
                               device=dev, world=world)
         dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
         # every rank runs the instrumented iteration (collectives inside); rank 0 reports

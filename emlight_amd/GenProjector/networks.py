@@ -27,6 +27,26 @@ def default_options(**kw):
     return opt
 
 
+def add_vgg_arguments(ap):
+    """The perceptual-term switches of the training entry points (``GenProjector/train.py``, ``joint.py``)."""
+    ap.add_argument("--vgg_weights", default=None,
+                    help="torchvision vgg19 state dict (.pth): the reference's perceptual term (pix2pix_model.py:119-120)")
+    ap.add_argument("--vgg_random", action="store_true",
+                    help="run the term on seeded RANDOM features: the reference's work (timing), not its objective")
+    ap.add_argument("--no_vgg_loss", action="store_true", help="drop the term (also the default when no weights are given)")
+
+
+def vgg_options(args, verbose=True):
+    """``default_options`` keywords from those switches.  The reference always adds the VGG term; its ImageNet weights
+    cannot be obtained offline, so: weights given -> the reference's objective; ``--vgg_random`` -> explicit opt-in to
+    random features; neither -> the term is OFF and the entry point says so (never a silent objective)."""
+    on = not args.no_vgg_loss and (args.vgg_weights is not None or args.vgg_random)
+    if verbose and not on and not args.no_vgg_loss:
+        print("VGG perceptual term OFF: pass --vgg_weights <torchvision vgg19 .pth> for the reference's objective "
+              "(or --vgg_random to time the term on random features)")
+    return dict(no_vgg_loss=not on, vgg_weights=args.vgg_weights, vgg_random=bool(args.vgg_random))
+
+
 def init_weights(net, init_type="xavier", gain=0.02):
     """``BaseNetwork.init_weights`` (``base_network.py:32-59``): xavier_normal(gain) on conv/linear weights."""
     def f(m):

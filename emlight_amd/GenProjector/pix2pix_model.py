@@ -29,8 +29,15 @@ class Pix2PixModel(torch.nn.Module):
                 # otherwise a seeded random stack that does the same work (vgg.py)
                 from .vgg import VGG19Features
                 path = getattr(opt, "vgg_weights", None)
+                if not path and not getattr(opt, "vgg_random", False):
+                    # never optimise against random features silently
+                    raise ValueError("the VGG perceptual term needs opt.vgg_weights (a torchvision vgg19 state dict: the "
+                                     "reference's objective) or an explicit opt.vgg_random=True (seeded random features: "
+                                     "the reference's WORK, for timing -- not its loss); or set opt.no_vgg_loss=True")
                 vgg_features = VGG19Features(torch.load(path, map_location="cpu") if path else None)
         self.vgg_features = vgg_features
+        # which perceptual term this model is trained against (saved next to the checkpoints by the entry points)
+        self.vgg_variant = "off" if (not opt.isTrain or opt.no_vgg_loss) else getattr(vgg_features, "variant", "injected")
         # D as it is called in the discriminator step (the trainer swaps in its DistributedDataParallel wrapper); kept out of
         # the module tree so that state_dict keys stay the reference's
         object.__setattr__(self, "netD_train", self.netD)

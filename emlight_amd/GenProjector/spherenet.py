@@ -269,8 +269,14 @@ class _SphereConvFn(torch.autograd.Function):
             gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2] and not small_w:
             # the SPADE modulation's backward leaves the column sums of the dgb it produced on the tensor (f64-accumulated)
+            # -- valid only for the very tensor it was computed from: same storage, not written since (autograd accumulates
+            # IN PLACE into a gradient that has a second consumer; a hook may hand over a different tensor): ADVICE round 3
             pre = getattr(gy, "_eml_colsum", None)
-            gb = pre if (pre is not None and y is None and pre.shape == (O,)) else gyr.sum(0)
+            if pre is not None:
+                sums, ptr, ver = pre
+                ok = y is None and sums.shape == (O,) and ptr == gy.data_ptr() and ver == gy._version
+                pre = sums if ok else None
+            gb = pre if pre is not None else gyr.sum(0)
         if ctx.needs_input_grad[1] and not small_w:
             if ctx.fused_wgrad and B:
                 bn = 128 if C % 128 == 0 else 64
@@ -506,7 +512,7 @@ class _SpadeNormModulateFn(torch.autograd.Function):
             if _bn_sync():
                 import torch.distributed as dist
                 dist.all_reduce(sums)
-        dgb._eml_colsum = folded[2 * C + 1:].view(C, 2).t().reshape(2 * C).float()
+        dgb._eml_colsum = (folded[2 * C + 1:].view(C, 2).t().reshape(2 * C).float(), dgb.data_ptr(), dgb._version)
         if ctx.up2:
             dx = torch.empty_like(x, memory_format=cl)     # gradient of the map BEFORE the upsample
             _lib.check(L.eml_bn_bwd_apply_up2_f32(p(dxn), p(x), B, H, W, C, p(mean), p(istd), p(sums), p(dx), st),

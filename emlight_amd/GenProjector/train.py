@@ -35,19 +35,18 @@ def main(argv=None):
     ap.add_argument("--print_freq", type=int, default=100, help="in samples, like the reference")
     ap.add_argument("--continue_train", action="store_true", help="resume from <which_epoch>_net_{G,D}.pth and iter.txt")
     ap.add_argument("--which_epoch", default="latest")
-    ap.add_argument("--no_vgg_loss", action="store_true",
-                    help="drop the VGG perceptual term (the reference always adds it, pix2pix_model.py:119-120)")
-    ap.add_argument("--vgg_weights", default=None,
-                    help="torchvision vgg19 state dict (.pth); without it the term runs on seeded random features")
+    networks.add_vgg_arguments(ap)
     args = ap.parse_args(argv)
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local
     opt = networks.default_options(ngf=args.ngf, ndf=args.ndf, lr=args.lr, no_TTUR=args.no_TTUR,
-                                   no_vgg_loss=args.no_vgg_loss, vgg_weights=args.vgg_weights)
+                                   **networks.vgg_options(args, verbose=rank == 0))
     tr = Trainer(opt, device=dev, world=world)
     save_dir = os.path.join(args.checkpoints_dir, args.name)
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, "objective.txt"), "w") as fh:   # which objective these checkpoints were trained on
+            fh.write("vgg_term: %s\n" % tr.model.vgg_variant)
     if args.continue_train:
         tr.load(args.which_epoch, save_dir)      # every rank loads the same files: replicas start identical
     global_batch = args.batchSize * world

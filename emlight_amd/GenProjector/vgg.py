@@ -30,11 +30,13 @@ _SLICE_ENDS = (1, 6, 11, 20, 29)   # the ReLU indices that close slice1..slice5 
 class PlanarConv3x3(nn.Module):
     """``nn.Conv2d(cin, cout, 3, padding=1)`` (same parameter names and shapes) on the HIP gather-GEMM kernels."""
 
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, generator=None):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
         self.bias = nn.Parameter(torch.zeros(cout))
-        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # torchvision's VGG initialisation
+        # torchvision's VGG initialisation; drawn from a LOCAL generator so that building the stack leaves the global CPU
+        # and CUDA RNG streams (the user's seed, per-rank seeds) alone
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu", generator=generator)
 
     def forward(self, x, act_slope=1.0):
         return spherenet.planar_conv3x3(x, self.weight, self.bias, 1, act_slope)
@@ -45,15 +47,14 @@ class VGG19Features(nn.Module):
 
     def __init__(self, state_dict=None, seed=0):
         super().__init__()
-        gen_state = torch.random.get_rng_state()
-        torch.manual_seed(seed)
+        gen = torch.Generator(device="cpu").manual_seed(seed)   # not torch.manual_seed: that reseeds every CUDA device too
         self.features = nn.ModuleDict()
         for item in _CFG:
             if item != "M":
                 idx, cin, cout = item
-                self.features[str(idx)] = PlanarConv3x3(cin, cout)
-        torch.random.set_rng_state(gen_state)
+                self.features[str(idx)] = PlanarConv3x3(cin, cout, generator=gen)
         self.pretrained = state_dict is not None
+        self.variant = "pretrained" if self.pretrained else "random(seed=%d)" % seed
         if state_dict is not None:
             own = {k: v for k, v in state_dict.items() if k.startswith("features.") and k in self.state_dict()}
             missing = set(self.state_dict()) - set(own)

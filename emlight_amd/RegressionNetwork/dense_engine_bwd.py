@@ -75,17 +75,12 @@ class _BwdBuffers:
         # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
         self.partW = torch.empty(g * max(kp * 48, 2 * 27 * 256, 4 * 1024), **f32)
         # BN1 / transition-norm dgamma: channels whose weight-gradient identity is ill-conditioned (small |gamma|) are flagged
-        # by the finalize kernel and recomputed directly (eml_dense_bn_dgamma_direct_f32).  The fallback launches are
-        # skipped while the previous backward reported no flagged channel (a 4-byte async copy per step, no host sync).
+        # by the finalize kernel and recomputed directly (eml_dense_bn_dgamma_direct_f32; gated on the device by the
+        # flags of the SAME backward -- no host-side report).
         i32 = dict(dtype=torch.int32, device=dev)
         self.cond = [[torch.zeros(lay["Kp"], **i32) for lay in blk["layers"]] for blk in ws.blocks]
         self.condT = [torch.zeros(blk["trans"]["Kp"], **i32) for blk in ws.blocks]
         self.any_ill = torch.zeros(1, **i32)
-        # reports of the last backwards: (event, pinned host int).  The host runs a step or more ahead of the GPU, so the
-        # report of the PREVIOUS backward is usually not in yet; the newest COMPLETED one decides (the flags depend on the
-        # parameters only and drift with the learning rate: a report a few steps old is as good)
-        self.ill_ring = [None] * 8
-        self.ill_step = 0
         self.dg_grid = 128
         self.dg_scratch = torch.empty(self.dg_grid * kp, dtype=torch.float64, device=dev)
         # side stream of the conv3x3 weight gradients (nothing downstream waits for dW2): own partial buffers per slot
@@ -163,19 +158,13 @@ def _run_backward(enc, ws, x, gpooled):
     cA, cB, cC = coefs[0]
     sB, sC = bw.coef[6], bw.coef[7]
 
-    # ---- ill-conditioned dgamma channels: launch the direct recomputation unless the previous backward saw none
-    mode = os.environ.get("EML_DGAMMA_DIRECT", "auto")
-    if mode == "never":
-        direct = False
-    elif mode == "always":
-        direct = True
-    else:
-        direct = True   # nothing known yet (first backwards of this workspace): run the fallback
-        for back in range(1, len(bw.ill_ring) + 1):
-            rep = bw.ill_ring[(bw.ill_step - back) % len(bw.ill_ring)] if bw.ill_step - back >= 0 else None
-            if rep is not None and rep[0].query():
-                direct = int(rep[1][0]) != 0
-                break
+    # ---- ill-conditioned dgamma channels (|gamma| < 1e-3 |beta|, flagged by THIS backward's finalize kernels on the
+    # device): the direct recomputation is always enqueued and returns at once when its layer flagged nothing.  (Round 3
+    # skipped the launches while the newest COMPLETED report of an earlier backward said "none flagged"; that report lags
+    # the parameters by a step or more, so a channel that had just crossed the threshold kept the noisy quotient -- or 0
+    # for gamma == 0 -- for those steps: ADVICE round 3.  The ~100 empty launches cost 0.3 % of the step.)
+    # EML_DGAMMA_DIRECT=never exists for A/B timing only.
+    direct = os.environ.get("EML_DGAMMA_DIRECT", "always") != "never"
     bw.any_ill.zero_()
 
     def dgamma_direct(blk, X_ld, Pin, Hin, Win, pool, DY, ld_dy, Zr, ld_z, co, Cout, conv, Cin, scale1, shift1, cond, bn):
@@ -344,14 +333,6 @@ def _run_backward(enc, ws, x, gpooled):
     _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
                                                 p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
                "eml_dense_conv0_bwd_weight_f32")
-    if dev.type == "cuda":   # report whether any channel was flagged (no sync: later backwards read it once it has landed)
-        slot = bw.ill_step % len(bw.ill_ring)
-        if bw.ill_ring[slot] is None:
-            bw.ill_ring[slot] = (torch.cuda.Event(), torch.zeros(1, dtype=torch.int32).pin_memory())
-        ev, host = bw.ill_ring[slot]
-        host.copy_(bw.any_ill, non_blocking=True)
-        ev.record()
-    bw.ill_step += 1
     if bw.side is not None:
         main.wait_stream(bw.side)   # every dW2 is complete before the gradients leave
     return [grads[id(q)] for q in params]

@@ -16,15 +16,77 @@ from ... import _lib
 from ..util import sphere_points
 
 
+EML_SINKHORN_NO_SPLIT, EML_SINKHORN_FORCE_SPLIT = 1, 2   # include/emlight_hip.h
+
+
+def split_eligible(N):
+    """Shapes whose small batches may take the split kernel (csrc/sinkhorn.hip; the only path that has a status word)."""
+    return 192 <= N <= 512 and N % 64 == 0
+
+
+class _SplitWatch:
+    """Host side of the split kernel's fail-safe.  The library already made the result right on the device (the tiled
+    kernel recomputes a batch whose split kernel gave up: slices not co-resident -- a CU-masked or shared GPU, another
+    stream's kernel); what is left for the host is to NOTICE, so that the next calls stop paying the 50 ms give-up: the
+    status word of a call is copied to pinned memory without a sync (first three calls, then every 64th) and read when a
+    later call finds the copy complete -- the pattern of the dense engine's dgamma ring.  Once raised, this process passes
+    EML_SINKHORN_NO_SPLIT from then on."""
+
+    def __init__(self):
+        self.disabled = False
+        self.fallbacks = 0
+        self.calls = 0
+        self.pending = None   # (pinned int32 tensor, event)
+
+    def flags(self):
+        self.poll()
+        return EML_SINKHORN_NO_SPLIT if self.disabled else 0
+
+    def poll(self, wait=False):
+        if self.pending is None:
+            return
+        host, ev = self.pending
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self.pending = None
+        if int(host[0]) != 0:
+            self.fallbacks += 1
+            if not self.disabled:
+                import warnings
+                warnings.warn("emlight_amd: the split Sinkhorn kernel's workgroups were not co-resident (CU mask, shared "
+                              "GPU or a concurrent kernel); the tiled kernel recomputed the batch. The split path is "
+                              "disabled for the rest of this process.", RuntimeWarning, stacklevel=3)
+            self.disabled = True
+
+    def after_call(self, work, B, N):
+        self.calls += 1
+        if self.disabled or self.pending is not None or not (self.calls <= 3 or self.calls % 64 == 0):
+            return
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(work[24 * B * N:24 * B * N + 1].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (host, ev)
+
+
+split_watch = _SplitWatch()
+
+
 def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
-    """Device buffers one ``eml_sinkhorn_fwd_f32`` call writes (the caller owns every buffer, include/emlight_hip.h)."""
+    """Device buffers one ``eml_sinkhorn_fwd_ex_f32`` call writes (the caller owns every buffer, include/emlight_hip.h)."""
     f32 = dict(dtype=torch.float32, device=dev)
+    n_work = max(int(_lib.lib().eml_sinkhorn_work_floats(B, N)), 8 * B * N)
+    work = torch.empty(n_work, **f32)
+    if split_eligible(N) and n_work > 24 * B * N:
+        work[24 * B * N:].zero_()   # the status word: only calls that take the split path reset it
     return {"eps_s": torch.empty(64, **f32), "n_eps": torch.empty(1, dtype=torch.int32, device=dev),
             "diameter": torch.empty(1, **f32), "loss": torch.empty(B, **f32),
             "gx": torch.empty(B, N, **f32) if need_gx else None, "gy": torch.empty(B, N, **f32) if need_gy else None,
-            # scratch size from the library (duals, expectation rows, the small-batch kernel's exchange buffer); never less
-            # than the (8,B,N) planes every kernel writes
-            "work": torch.empty(max(int(_lib.lib().eml_sinkhorn_work_floats(B, N)), 8 * B * N), **f32)}
+            # scratch size from the library (duals, expectation rows, the small-batch kernel's exchange buffer and status
+            # word); never less than the (8,B,N) planes every kernel writes
+            "work": work}
 
 
 def global_range(x, y):
@@ -42,20 +104,26 @@ def global_range(x, y):
 
 
 def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=True, need_gy=False, out=None,
-                 range_lo_hi=None):
+                 range_lo_hi=None, flags=None):
     """One call into the HIP library; returns every device-side output (no autograd).  ``out``: buffers from
     ``sinkhorn_outputs`` to write into (a timing loop passes them so that no allocation sits between launches).
-    ``range_lo_hi``: device (2,) tensor from ``global_range`` -- the kernel folds it into its own scan."""
+    ``range_lo_hi``: device (2,) tensor from ``global_range`` -- the kernel folds it into its own scan.
+    ``flags``: EML_SINKHORN_* of the C ABI; default: whatever the split kernel's watch says (``_SplitWatch``)."""
     L = _lib.lib()
     B, N = x.shape
     o = out if out is not None else sinkhorn_outputs(B, N, x.device, need_gx, need_gy)
-    _lib.check(L.eml_sinkhorn_fwd_f32(
+    watched = flags is None and split_eligible(N)
+    if flags is None:
+        flags = split_watch.flags() if watched else 0
+    _lib.check(L.eml_sinkhorn_fwd_ex_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
         float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
         _lib.ptr(range_lo_hi), _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
-        _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, _lib.current_stream()), "eml_sinkhorn_fwd_f32")
+        _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, int(flags), _lib.current_stream()), "eml_sinkhorn_fwd_ex_f32")
+    if watched and o["work"].numel() > 24 * B * N:
+        split_watch.after_call(o["work"], B, N)
     return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
-            "diameter": o["diameter"], "duals": o["work"][:4 * B * N].view(4, B, N)}
+            "diameter": o["diameter"], "duals": o["work"][:4 * B * N].view(4, B, N), "work": o["work"]}
 
 
 class _SinkhornDivergence(torch.autograd.Function):
@@ -164,7 +232,7 @@ class SamplesLoss(Module):
         rng = global_range(x2, y2) if (self.sync_diameter and self.diameter is None) else None
         return _SinkhornDivergence.apply(x2, y2, a2, b2, M, Mt, self.p, self.blur, self.scaling, self.diameter, rng)
 
-    def forward_raw(self, x, y, need_gx=True, need_gy=True, out=None):
+    def forward_raw(self, x, y, need_gx=True, need_gy=True, out=None, flags=None):
         """Every device output of one call (loss, unit grads, schedule, duals) -- for parity tests and timing."""
         B = x.shape[0]
         x2 = _lib.require_gpu_tensor(x.reshape(B, self.N), "x")
@@ -172,4 +240,4 @@ class SamplesLoss(Module):
         M, Mt = self.cost_matrix(x2.device)
         rng = global_range(x2, y2) if (self.sync_diameter and self.diameter is None) else None
         return sinkhorn_raw(x2, y2, None, None, M, Mt, self.p, self.blur, self.scaling, self.diameter,
-                            need_gx, need_gy, out, range_lo_hi=rng)
+                            need_gx, need_gy, out, range_lo_hi=rng, flags=flags)

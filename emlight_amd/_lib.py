@@ -15,7 +15,7 @@ _i32p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 15   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 16   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -31,6 +31,9 @@ SIGNATURES = {
     "eml_sinkhorn_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_double, ctypes.c_double, _int,
                                     ctypes.c_double, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                     _stream]),
+    "eml_sinkhorn_fwd_ex_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_double, ctypes.c_double, _int,
+                                       ctypes.c_double, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
+                                       _int, _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
     # ground-truth parametrisation
     "eml_gt_anchor_index_i32": (_int, [_f32p, _int, _int, _int, _i32p, _stream]),

@@ -460,7 +460,10 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
     const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
     int p_exp,
     double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out, int* __restrict__ n_eps_out, float* __restrict__ diameter_out,
-    float* __restrict__ work, int B, int N) {
+    float* __restrict__ work, int B, int N, const int* __restrict__ only_if) {
+  // `only_if` (device, may be NULL): the RESCUE launch behind the split kernel -- it returns at once unless the split
+  // kernel raised its status word (a slice never saw its partners), in which case it recomputes the whole batch here
+  if (only_if && __hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   constexpr int kGT = 512, kWG = 1024;
   constexpr int NR = 512 / LPR;            // row capacity of a softmin group
   constexpr int TJ = 16 * LPR;             // tile columns; every lane folds 16 of them
@@ -639,12 +642,17 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
 // floats per problem) through global memory as 8-byte {epoch, value} granules (cdna_hip_programming.md G16, form R2: the
 // data is the flag -- relaxed agent-scope 8-byte stores and polls, no fences; double-buffered by sweep parity, so a
 // workgroup that runs ahead never overwrites a granule a slower one still waits for; the launcher zeroes the exchange
-// buffer with a memset node in front of the kernel).  Polls are bounded by wall-clock time: a workgroup that never sees its
-// partners (they cannot all be resident -- the launcher sizes S so that they can) gives up after ~2 s and poisons its rows
-// with NaN instead of hanging the GPU.
+// buffer with a memset node in front of the kernel).  The exchange needs all 2 * B * S workgroups RESIDENT at once.  The
+// launcher sizes S from the CUs the stream may use and the kernel's occupancy, but residency cannot be guaranteed from the
+// host (another stream's kernel, a second process on the device, ...), so it is also enforced on the device: polls are
+// bounded by wall-clock time (50 ms -- a healthy exchange takes ~1 us); a workgroup that never sees its partners raises
+// the call's STATUS word (device int, zeroed by the launcher's memset), every other workgroup notices the word in its own
+// poll loop or at its start and leaves, and the launcher has ALREADY enqueued the tiled kernel behind this one, gated on
+// that word: it recomputes the whole batch (an empty ~2 us launch otherwise).  The caller never sees a NaN; the status
+// word tells it that the slow path ran (eml_sinkhorn_fwd_ex_f32).
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr int kSplitLPR = 8;        // lanes per row
-constexpr long long kSpinTicks = 200000000LL;   // 2 s of the 100 MHz wall clock
+constexpr long long kSpinTicks = 5000000LL;   // 50 ms of the 100 MHz wall clock
 
 template <int CPL /* columns per lane = N / 8 */, int R /* rows per workgroup = N / S */>
 __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
     const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
     int p_exp, double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out, float* __restrict__ work,
-    unsigned long long* __restrict__ exch, int B, int S) {
+    unsigned long long* __restrict__ exch, int B, int S, int* __restrict__ status) {
   constexpr int N = CPL * kSplitLPR, kWG = 16 * R, kGT = 8 * R, LDM = N + 32;   // LDM = 32 mod 64: two rows cover all banks
   static_assert(CPL % 4 == 0 && N % 64 == 0 && kWG <= 1024, "split kernel geometry");
   __shared__ float eps_l[EML_MAX_EPS];
@@ -676,7 +684,8 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
     const int e = tid + k * kWG, row = e / (N / 4), c4 = e % (N / 4);
     mreg[k] = *reinterpret_cast<const float4*>(M + (size_t)(r0 + row) * N + 4 * c4);
   }
-  if (tid == 0) failed_l = 0;
+  // a workgroup that starts after a partner already gave up leaves at once (after the schedule's barrier)
+  if (tid == 0) failed_l = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float unif = 1.0f / (float)N;
   for (int i = tid; i < 2 * N; i += kWG) {
     const int which = i / N, k = i - which * N;
@@ -697,6 +706,7 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
                        (slice == 0) ? diameter_out : nullptr);   // ends with a barrier: LDS staging above is visible
   const float* eps_s = eps_l;
   const int n_eps = n_eps_l;
+  if (failed_l) return;   // workgroup-uniform (read after a barrier): the rescue launch recomputes the batch
 
   const int gl = tid / kGT, g = 2 * role + gl, t = tid - gl * kGT;
   const bool rows_x = (g == 0 || g == 3), cols_x = (g == 0 || g == 2);
@@ -795,9 +805,8 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
       tq += eml::lane_xor2(tq);
       tq += eml::dpp_mov<0x141>(tq);
       if (owner) {
-        const bool bad = failed_l != 0;
-        fin_out[i] = bad ? NAN : sm;
-        e_out[i] = bad ? NAN : tq / sum;
+        fin_out[i] = sm;
+        e_out[i] = tq / sum;
       }
       break;
     }
@@ -821,10 +830,12 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
           hdst[k] = __builtin_bit_cast(float, (unsigned)v);
           break;
         }
-        if ((++spins & 1023u) == 0) {   // bounded by wall-clock time, checked rarely
+        if ((++spins & 1023u) == 0) {   // bounded by wall-clock time, checked rarely; a partner's give-up ends the wait too
           const long long now = wall_clock64();
           if (t0 == 0) t0 = now;
-          else if (now - t0 > kSpinTicks) {
+          const bool timed_out = now - t0 > kSpinTicks;
+          if (timed_out || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            if (timed_out) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             failed_l = 1;
             hdst[k] = 0.f;
             break;
@@ -834,6 +845,13 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
       }
     }
     __syncthreads();
+    if (failed_l) {   // workgroup-uniform after the barrier.  Poison this slice's rows: if the rescue launch behind this
+      if (owner) {    // kernel did not run for any reason, the caller gets NaN, never a plausible wrong number
+        fin_out[i] = NAN;
+        e_out[i] = NAN;
+      }
+      return;
+    }
   }
 }
 
@@ -955,8 +973,8 @@ extern "C" int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n,
 }
 
 // (8,B,N) floats of duals / expectation rows + the split kernel's exchange buffer: [2 parity][B][2 roles][2 problems][N]
-// 8-byte granules = 16*B*N floats
-extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)24 * B * N; }
+// 8-byte granules = 16*B*N floats + 4 status words (word 0: the split kernel gave up and the tiled kernel recomputed)
+extern "C" size_t eml_sinkhorn_work_floats(int B, int N) { return (size_t)24 * B * N + 4; }
 
 namespace {
 int device_cu_count() {
@@ -971,6 +989,97 @@ int device_cu_count() {
   }
   return n;
 }
+
+// CUs a kernel launched on `stream` may occupy: the stream's own CU mask (hipExtStreamCreateWithCUMask) or the process-wide
+// one (ROC_GLOBAL_CU_MASK) -- hipExtStreamGetCUMask reports whichever applies -- never more than the device has.
+int stream_cu_count(hipStream_t stream) {
+  const int dev_cus = device_cu_count();
+  uint32_t mask[16] = {0};   // 512 CUs
+  if (hipExtStreamGetCUMask(stream, 16, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return dev_cus;
+  }
+  int n = 0;
+  for (int w = 0; w < 16; ++w) n += __builtin_popcount(mask[w]);
+  return (n < 1 || n > dev_cus) ? dev_cus : n;
+}
+
+// resident workgroups of the split kernel per CU (registers, LDS, wave slots), cached per (instance, device)
+template <typename K>
+int split_occupancy(K kernel, int block, size_t lds, std::atomic<int>* cache) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& c = cache[dev & (eml::kMaxDevices - 1)];
+  int n = c.load(std::memory_order_relaxed);
+  if (n == 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      occ = 0;
+    }
+    n = occ > 0 ? occ : -1;   // -1: cannot be made resident at all
+    c.store(n, std::memory_order_relaxed);
+  }
+  return n > 0 ? n : 0;
+}
+}  // namespace
+
+namespace {
+size_t split_lds_bytes(int N, int R) { return (size_t)(10 * N + R * (N + 32)) * sizeof(float); }
+
+// LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup.
+// `only_if`: see the kernel (the rescue launch behind the split kernel).
+void launch_tiled(const float* x, const float* y, const float* M, const float* alpha, const float* beta, double blur,
+                  double log_blur, double log_scaling, int p, double diameter, const float* range_lo_hi, float* eps_out,
+                  int* n_eps_out, float* diameter_out, float* work, int B, int N, const int* only_if, hipStream_t stream) {
+  const int NP = round_up4(N) + kJPT;
+  const int lpr = N <= 256 ? 2 : 1;
+  const size_t lds = (size_t)(10 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
+  if (lpr == 2) {
+    EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<2>), lds);
+    hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, stream, x, y, M, alpha, beta, blur,
+                       log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out, work, B, N,
+                       only_if);
+  } else {
+    EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<1>), lds);
+    hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, stream, x, y, M, alpha, beta, blur,
+                       log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out, work, B, N,
+                       only_if);
+  }
+}
+
+// Slices per problem pair for the split kernel, or 0 when the batch does not qualify.  All 2 * B * S workgroups must be
+// resident together: S is sized from the CUs the STREAM may use (its CU mask / ROC_GLOBAL_CU_MASK) -- one workgroup per CU
+// is also what makes the split worth it -- and from the occupancy the runtime reports for the instance.
+// EML_SINKHORN_FORCE_SPLIT (tests): skip the sizing and launch S = 8 (or 4) regardless, to exercise the on-device rescue.
+int split_slices(int B, int N, int flags, hipStream_t stream) {
+  const int dev_cus = device_cu_count();
+  if (flags & EML_SINKHORN_FORCE_SPLIT) return (2 * B * 8 <= dev_cus || N > 256) ? 8 : 4;
+  const int cus = stream_cu_count(stream);
+  int S = 0;
+  if (2 * B * 8 <= cus) S = 8;
+  else if (N <= 256 && 2 * B * 4 <= cus) S = 4;
+  if (S == 0) return 0;
+  const int R = N / S;
+  const size_t lds = split_lds_bytes(N, R);
+  int occ = 0;
+#define EML_SPLIT_OCC(CPLV, RV)                                                                 \
+  do {                                                                                          \
+    static std::atomic<int> cache_[eml::kMaxDevices];                                           \
+    EML_ENSURE_LDS((&sinkhorn_loop_split_kernel<CPLV, RV>), lds);                               \
+    occ = split_occupancy(sinkhorn_loop_split_kernel<CPLV, RV>, 16 * RV, lds, cache_);          \
+  } while (0)
+  if (N == 256 && S == 8) EML_SPLIT_OCC(32, 32);
+  else if (N == 256) EML_SPLIT_OCC(32, 64);
+  else if (N == 192 && S == 8) EML_SPLIT_OCC(24, 24);
+  else if (N == 192) EML_SPLIT_OCC(24, 48);
+  else if (N == 320) EML_SPLIT_OCC(40, 40);
+  else if (N == 384) EML_SPLIT_OCC(48, 48);
+  else if (N == 448) EML_SPLIT_OCC(56, 56);
+  else EML_SPLIT_OCC(64, 64);
+#undef EML_SPLIT_OCC
+  return ((long)2 * B * S <= (long)occ * cus) ? S : 0;
+}
 }  // namespace
 
 extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
@@ -978,7 +1087,18 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
                                     double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
                                     float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
                                     eml_stream_t stream) {
+  return eml_sinkhorn_fwd_ex_f32(x, y, M, Mt, alpha, beta, blur, scaling, p, diameter, range_lo_hi, eps_out, n_eps_out,
+                                 diameter_out, loss, gx, gy, work, B, N, 0, stream);
+}
+
+extern "C" int eml_sinkhorn_fwd_ex_f32(const float* x, const float* y, const float* M, const float* Mt,
+                                       const float* alpha, const float* beta, double blur, double scaling, int p,
+                                       double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
+                                       float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
+                                       int flags, eml_stream_t stream) {
   if (!x || !y || !M || !Mt || !loss || !work) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
+  if (flags & ~(EML_SINKHORN_NO_SPLIT | EML_SINKHORN_FORCE_SPLIT))
+    return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_ex_f32: unknown flags 0x%x", flags);
   if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
   if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
     return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need blur>0, 0<scaling<1, p>=1");
@@ -986,27 +1106,31 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
   const double log_blur = std::log(blur), log_scaling = std::log(scaling);   // f64 like numpy; only log(diameter) is data
   const int NP = round_up4(N) + kJPT;
   size_t lds = (size_t)(kSmemVecs * NP) * sizeof(float);
+  int split_s = 0;
   if (N <= 4 * kCJ) {
     lds += (size_t)(N * (round_up4(N) + 4) + kJPT) * sizeof(float);
     EML_ENSURE_LDS((&sinkhorn_loop_kernel<true>), lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<true>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, Mt,
                        alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
                        work, B, N);
-  } else if (N <= 512 && (N & 63) == 0 && N >= 192 && (2 * B * 8 <= device_cu_count() || (N <= 256 && 2 * B * 4 <= device_cu_count()))) {
+  } else if (N <= 512 && (N & 63) == 0 && N >= 192 && !(flags & EML_SINKHORN_NO_SPLIT) &&
+             (split_s = split_slices(B, N, flags, (hipStream_t)stream)) > 0) {
     // small batch: the rows of every problem pair split over S workgroups (one per CU, all resident), duals exchanged
     // through global memory after every sweep (see the kernel).  S = 8 when 16 * B workgroups fit the CUs, else 4.
-    const int S = (2 * B * 8 <= device_cu_count()) ? 8 : 4;
+    const int S = split_s;
     const int R = N / S;
     unsigned long long* exch = reinterpret_cast<unsigned long long*>(work + (size_t)8 * B * N);
-    hipError_t me = hipMemsetAsync(exch, 0, (size_t)16 * B * N * sizeof(float), (hipStream_t)stream);
+    int* status = reinterpret_cast<int*>(work + (size_t)24 * B * N);
+    // one memset: the exchange granules and the status words behind them
+    hipError_t me = hipMemsetAsync(exch, 0, ((size_t)16 * B * N + 4) * sizeof(float), (hipStream_t)stream);
     if (me != hipSuccess) return eml::fail(EML_ELAUNCH, "eml_sinkhorn_fwd_f32: memset of the exchange buffer: %s", hipGetErrorString(me));
-    lds = (size_t)(10 * N + R * (N + 32)) * sizeof(float);
+    lds = split_lds_bytes(N, R);
 #define EML_LAUNCH_SPLIT(CPLV, RV)                                                                                     \
   do {                                                                                                                 \
     EML_ENSURE_LDS((&sinkhorn_loop_split_kernel<CPLV, RV>), lds);                                                      \
     hipLaunchKernelGGL((sinkhorn_loop_split_kernel<CPLV, RV>), dim3(2 * B * S), dim3(16 * RV), lds, (hipStream_t)stream, \
                        x, y, M, alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, \
-                       diameter_out, work, exch, B, S);                                                                \
+                       diameter_out, work, exch, B, S, status);                                                        \
   } while (0)
     if (N == 256 && S == 8) EML_LAUNCH_SPLIT(32, 32);
     else if (N == 256) EML_LAUNCH_SPLIT(32, 64);
@@ -1017,21 +1141,14 @@ extern "C" int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float*
     else if (N == 448) EML_LAUNCH_SPLIT(56, 56);
     else EML_LAUNCH_SPLIT(64, 64);
 #undef EML_LAUNCH_SPLIT
+    int rcs = eml::check_launch("eml_sinkhorn_fwd_f32(split loop)");
+    if (rcs) return rcs;
+    // the rescue: the tiled kernel, gated on the status word -- returns at once unless a slice gave up
+    launch_tiled(x, y, M, alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out,
+                 diameter_out, work, B, N, status, (hipStream_t)stream);
   } else if (N <= 512 && (N & 3) == 0) {
-    // LDS-tiled kernel: chord-matrix column tiles (8192 floats, double-buffered) shared by both problems of a workgroup
-    const int lpr = N <= 256 ? 2 : 1;
-    lds = (size_t)(10 * NP + 2 * (512 / lpr) * (16 * lpr + 4)) * sizeof(float);
-    if (lpr == 2) {
-      EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<2>), lds);
-      hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<2>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
-                       work, B, N);
-    } else {
-      EML_ENSURE_LDS((&sinkhorn_loop_tiled_kernel<1>), lds);
-      hipLaunchKernelGGL(sinkhorn_loop_tiled_kernel<1>, dim3(2 * B), dim3(1024), lds, (hipStream_t)stream, x, y, M, alpha,
-                         beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, diameter_out,
-                       work, B, N);
-    }
+    launch_tiled(x, y, M, alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out,
+                 diameter_out, work, B, N, nullptr, (hipStream_t)stream);
   } else {
     EML_ENSURE_LDS((&sinkhorn_loop_kernel<false>), lds);
     hipLaunchKernelGGL(sinkhorn_loop_kernel<false>, dim3(2 * B), dim3(512), lds, (hipStream_t)stream, x, y, M, Mt,

@@ -115,13 +115,12 @@ def main(argv=None):
     ap.add_argument("--ngf", type=int, default=64)
     ap.add_argument("--ndf", type=int, default=64)
     ap.add_argument("--max_iters", type=int, default=100)
-    ap.add_argument("--no_vgg_loss", action="store_true", help="drop the VGG perceptual term of the generator losses")
-    ap.add_argument("--vgg_weights", default=None, help="torchvision vgg19 state dict; without it: seeded random features")
+    networks.add_vgg_arguments(ap)
     args = ap.parse_args(argv)
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local
-    tr = JointTrainer(networks.default_options(ngf=args.ngf, ndf=args.ndf, no_vgg_loss=args.no_vgg_loss,
-                                               vgg_weights=args.vgg_weights), anchors=args.anchors,
+    tr = JointTrainer(networks.default_options(ngf=args.ngf, ndf=args.ndf, **networks.vgg_options(args, verbose=rank == 0)),
+                      anchors=args.anchors,
                       crop_hw=tuple(args.crop_hw), blur=args.blur, device=dev, world=world)
     for it in range(args.max_iters):
         batch = joint_batch(args.batch, dev, args.anchors, tuple(args.crop_hw), seed=1234 + rank + 977 * it)

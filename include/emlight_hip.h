@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 15
+#define EML_ABI_VERSION 16
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -104,13 +104,32 @@ int eml_sinkhorn_schedule_f32(const float* x, const float* y, long n, double blu
  *   work        caller-owned scratch of eml_sinkhorn_work_floats(B,N) floats (16-byte aligned); on return its first
  *                      (4,B,N) floats hold the final duals a_x, b_y, a_y, b_x (the next (4,B,N) the expectation rows of
  *                      the gradient; the rest is the inter-workgroup exchange buffer of the small-batch kernel, zeroed
- *                      by the call itself) */
+ *                      by the call itself, and the status word described below) */
 size_t eml_sinkhorn_work_floats(int B, int N);
 int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const float* Mt,
                          const float* alpha, const float* beta, double blur, double scaling, int p,
                          double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
                          float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
                          eml_stream_t stream);
+
+/* The same call with options.  Small batches at N >= 192 (N % 64 == 0, N <= 512) run the SPLIT kernel: a sample's rows
+ * over S = 8 (or 4) workgroups that exchange the dual vectors through global memory after every sweep, which needs all
+ * 2*B*S workgroups resident at once.  The launcher takes that path only when they fit the CUs the STREAM may use (its CU
+ * mask or ROC_GLOBAL_CU_MASK, hipExtStreamGetCUMask) at the occupancy the runtime reports; since residency still cannot be
+ * guaranteed from the host (another stream, another process on the device), a slice that does not see its partners within
+ * 50 ms raises a status word, and the tiled kernel -- enqueued behind the split kernel by the same call, gated on that
+ * word -- recomputes the batch: the outputs are always those of a completed Sinkhorn loop, never NaN.
+ *   flags   EML_SINKHORN_NO_SPLIT    never take the split path (a caller that saw the status word raised)
+ *           EML_SINKHORN_FORCE_SPLIT take it whenever the shape allows, without the residency sizing (tests of the rescue)
+ *   status  = ((int*)work)[24*B*N]: set to 1 by a call whose split kernel gave up (the rescue ran); zeroed at the start
+ *           of every call that takes the split path, untouched by calls that do not. */
+#define EML_SINKHORN_NO_SPLIT 1
+#define EML_SINKHORN_FORCE_SPLIT 2
+int eml_sinkhorn_fwd_ex_f32(const float* x, const float* y, const float* M, const float* Mt,
+                            const float* alpha, const float* beta, double blur, double scaling, int p,
+                            double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,
+                            float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
+                            int flags, eml_stream_t stream);
 
 /* Backward of the loss vector: gout[b,i] = gloss[b] * gunit[b,i]  (gunit = gx or gy above). */
 int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, int B, int N,

@@ -36,7 +36,7 @@ def test_loader_and_abi_version(built_lib):
     L = built_lib.lib()
     header = open(os.path.join(ROOT, "include", "emlight_hip.h")).read()
     assert L.eml_abi_version() == built_lib.ABI_VERSION == int(re.search(r"#define EML_ABI_VERSION (\d+)", header).group(1))
-    assert L.eml_sinkhorn_work_floats(3, 5) == 24 * 3 * 5   # (8,B,N) planes + the 16*B*N-float exchange buffer
+    assert L.eml_sinkhorn_work_floats(3, 5) == 24 * 3 * 5 + 4   # (8,B,N) planes + the 16*B*N-float exchange buffer + status
 
 
 def test_argument_validation_without_gpu(built_lib):
@@ -49,6 +49,9 @@ def test_argument_validation_without_gpu(built_lib):
     assert rc == -1 and b"W==2H" in L.eml_last_error()
     rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, None, one, None, None, one, 2, 0, None)
     assert rc == -1
+    rc = L.eml_sinkhorn_fwd_ex_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, None, one, None, None, one,
+                                   2, 256, 4, None)
+    assert rc == -1 and b"unknown flags" in L.eml_last_error()
     # encoder / projector launchers: nulls, odd pooling sizes, misaligned channel counts
     assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None, None) == -1
     assert L.eml_dense_conv3x3_bwd_data_f32(one, 224, 24, one, one, one, one, one, 1, 8, 8, one, 512, one, 224, 24, None,

@@ -433,7 +433,7 @@ def test_generator_step_includes_the_vgg_term():
     from emlight_amd.GenProjector.model_trainer import Trainer
     torch.manual_seed(0)
     with pytest.warns(UserWarning, match="RANDOM features"):
-        tr = Trainer(networks.default_options(ngf=4, ndf=4, no_vgg_loss=False), device="cuda")
+        tr = Trainer(networks.default_options(ngf=4, ndf=4, no_vgg_loss=False, vgg_random=True), device="cuda")
     tr.step(data.projector_batch(2, "cuda", seed=3))
     losses = tr.get_latest_losses()
     assert set(losses) == {"GAN", "GAN_Feat", "VGG", "COS", "D_Fake", "D_real"}
@@ -614,6 +614,39 @@ def test_gamma_beta_bias_gradient_comes_from_the_modulation_backward(monkeypatch
     monkeypatch.undo()
     assert calls == [], calls
     assert g_.bias.grad is not None and float(g_.bias.grad.abs().max()) > 0 and float(b_.bias.grad.abs().max()) > 0
+
+
+def test_stale_column_sums_are_not_used_for_the_bias_gradient(monkeypatch):
+    """the column sums travel as an attribute of the dgb tensor.  If that tensor is written between the
+    modulation's backward and the convolution's (autograd accumulating a second consumer's gradient in place, a hook), the
+    sums are stale: the convolution's backward must notice (storage pointer + version counter) and reduce dgb itself.  Here a
+    hook doubles dgb IN PLACE (same tensor object, attribute still attached): the bias gradients must double too."""
+    from emlight_amd.GenProjector import spherenet
+    C, nh = 64, 128
+
+    def run(hook):
+        torch.manual_seed(3)
+        bn = torch.nn.BatchNorm2d(C, affine=False).cuda().train()
+        g_, b_ = spherenet.SphereConv2D(nh, C).cuda(), spherenet.SphereConv2D(nh, C).cuda()
+        x = torch.randn(4, C, 16, 32, device="cuda", requires_grad=True)
+        actv = torch.randn(4, nh, 16, 32, device="cuda")
+        wgt = torch.randn(4, C, 16, 32, device="cuda")
+        real = spherenet.sphere_conv
+
+        def hooked(*a, **k):
+            out = real(*a, **k)
+            if hook:
+                out.register_hook(lambda g: g.mul_(2.0))
+            return out
+        monkeypatch.setattr(spherenet, "sphere_conv", hooked)
+        (spherenet.spade_norm_modulate(x, bn, actv, g_, b_, 0.2) * wgt).sum().backward()
+        monkeypatch.undo()
+        return g_.bias.grad.clone(), b_.bias.grad.clone(), g_.weight.grad.clone()
+    g0, b0, w0 = run(False)
+    g1, b1, w1 = run(True)
+    torch.testing.assert_close(w1, 2 * w0, rtol=1e-5, atol=1e-6)   # the hook took effect
+    torch.testing.assert_close(g1, 2 * g0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(b1, 2 * b0, rtol=1e-4, atol=1e-5)
 
 
 def test_three_iterations_follow_the_stock_op_trajectory():

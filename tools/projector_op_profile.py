@@ -15,7 +15,7 @@ from emlight_amd.GenProjector.model_trainer import Trainer
 from emlight_amd.GenProjector.networks import default_options
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-tr = Trainer(default_options(no_vgg_loss=False), device="cuda:0")
+tr = Trainer(default_options(no_vgg_loss=False, vgg_random=True), device="cuda:0")
 data = projector_batch(B, "cuda:0")
 for _ in range(3):
     tr.step(data)
