@@ -13,9 +13,11 @@ from .pix2pix_model import Pix2PixModel
 
 
 class Trainer:
-    def __init__(self, opt, device="cuda", world=1):
+    def __init__(self, opt, device="cuda", world=1, vgg_features=None):
+        """``vgg_features``: a ready VGG19 feature callable for the perceptual term (see ``Pix2PixModel``), instead of
+        building one from ``opt.vgg_weights``."""
         self.opt = opt
-        self.model = Pix2PixModel(opt).to(device)
+        self.model = Pix2PixModel(opt, vgg_features=vgg_features).to(device)
         self.world = world
         if world > 1:
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None

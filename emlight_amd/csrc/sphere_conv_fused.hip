@@ -23,7 +23,9 @@
 //   wgrad:   K = pixels; tiles keep their natural [pixel][channel] layout (row stride 144 puts the four k-rows of a
 //            ds_read_b32 on disjoint bank quarters); split-K over blockIdx.z, partials + a deterministic reduction.
 #include "eml_common.h"
+#include "gather_gemm2.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -461,6 +463,11 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }  // namespace
 
 namespace {
+// EML_GG_V1=1: A/B switch back to the round-2 kernel for every table (read once)
+bool getenv_flag(const char* name) {
+  static const bool on = [name] { const char* v = getenv(name); return v && v[0] == '1'; }();
+  return on;
+}
 int launch_gather_gemm(const char* what, const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
                        float* Y, int B, int HW, int Po, int C, int O, int ke, const unsigned char* rowmax,
                        const float* res, float slope, eml_stream_t stream) {
@@ -468,6 +475,26 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   const long M = (long)B * Po;
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
   const int bn = (O % 128 == 0) ? 128 : 64;
+  // Round 4: the second-generation kernel (gather_gemm2.h: dense operand and tap table by LDS-DMA, half-line gathers, one
+  // 32-bit offset per load, pole rows as a second virtual tap) for the bilinear tables -- +2 ... +15 % per layer shape on
+  // the same box (profiles/r04_gg2_variants.jsonl, variant v2.2).  It needs two chunks per tap (C >= 64) and its 32-bit
+  // offsets to reach two samples / the weight tile; single-entry (planar) tables keep the round-2 kernel, which schedules
+  // their four loads per chunk better (vgg 64 -> 64: 107 against 98 TF/s).
+  if (ke != 1 && C >= 64 && (unsigned long long)HW * C < (1ull << 29) && (unsigned long long)O * 9 * C < (1ull << 30) &&
+      !getenv_flag("EML_GG_V1")) {
+    const long n_mt2 = (M + gg2::kBM - 1) / gg2::kBM, per_xcd2 = (n_mt2 + 7) / 8;
+    const dim3 grid2((unsigned)(8 * per_xcd2 * (O / bn)));
+#define EML_LAUNCH_GG2(BNV)                                                                                          \
+  do {                                                                                                              \
+    auto kern = gg2::gather_gemm2_kernel<BNV, 256, 4, false, false>;                                                \
+    EML_ENSURE_LDS(kern, (gg2::lds_bytes<BNV, 256>()));                                                             \
+    hipLaunchKernelGGL(kern, grid2, dim3(256), (gg2::lds_bytes<BNV, 256>()), (hipStream_t)stream, X, idx, wgt, W2,  \
+                       bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope);                                      \
+  } while (0)
+    if (bn == 128) EML_LAUNCH_GG2(128); else EML_LAUNCH_GG2(64);
+#undef EML_LAUNCH_GG2
+    return eml::check_launch(what);
+  }
   const size_t lds = (size_t)(2 * kBM * kLdF + 2 * bn * kLdF) * sizeof(float);
   const long n_mt = (M + kBM - 1) / kBM, per_xcd = (n_mt + 7) / 8;
   const dim3 grid((unsigned)(8 * per_xcd * (O / bn)));   // 1-D: the kernel maps id -> (XCD band, pixel tile, O-tile)

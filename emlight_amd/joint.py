@@ -41,12 +41,13 @@ def predicted_gaussian_map(pred, ln, pano_hw=(128, 256)):
 
 class JointTrainer:
     def __init__(self, opt=None, anchors=128, crop_hw=(240, 320), blur=.05, diameter=None, device="cuda", world=1,
-                 pano_hw=(128, 256), encoder=None, sam_loss=None, sync_diameter=None):
-        """``encoder`` / ``sam_loss``: see ``RegressionTrainer`` (CPU-only distributed tests inject the oracle's)."""
+                 pano_hw=(128, 256), encoder=None, sam_loss=None, sync_diameter=None, vgg_features=None):
+        """``encoder`` / ``sam_loss``: see ``RegressionTrainer`` (CPU-only distributed tests inject the oracle's);
+        ``vgg_features``: see ``GenProjector.model_trainer.Trainer``."""
         self.ln, self.pano_hw, self.world = anchors, tuple(pano_hw), world
         self.reg = RegressionTrainer(anchors=anchors, crop_hw=crop_hw, blur=blur, diameter=diameter, device=device,
                                      world=world, model=encoder, sam_loss=sam_loss, sync_diameter=sync_diameter)
-        self.proj = Trainer(opt or networks.default_options(), device=device, world=world)
+        self.proj = Trainer(opt or networks.default_options(), device=device, world=world, vgg_features=vgg_features)
         self.losses = {}
 
     def projector_inputs(self, batch, pred):

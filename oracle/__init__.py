@@ -25,7 +25,8 @@ from .sinkhorn import (sphere_points, anchor_cost_matrix, geometric_points, cost
                        samples_loss_grad_analytic)
 from .rasteriser import pano_grid, convert_to_panorama
 from .representation import ExtractMesh
-from .projector import sampling_grid, sphere_conv, spade_modulate, spade_norm_modulate, stock_sphere_ops
+from .projector import (sampling_grid, sphere_conv, spade_modulate, spade_norm_modulate, stock_sphere_ops,
+                        StockVGG19, seeded_vgg19_state_dict)
 from .joint import (predicted_gaussian_map, joint_step, joint_generator_step, joint_discriminator_step,
                     stock_rasteriser)
 from .densenet import (OracleDenseNet, deterministic_state_dict, regression_loss,
@@ -37,6 +38,7 @@ __all__ = [
     "samples_loss", "samples_loss_grad_analytic", "pano_grid",
     "convert_to_panorama", "ExtractMesh", "OracleDenseNet", "deterministic_state_dict",
     "regression_loss", "deterministic_projector_state_dict",
+    "StockVGG19", "seeded_vgg19_state_dict",
     "predicted_gaussian_map", "joint_step", "joint_generator_step", "joint_discriminator_step", "stock_rasteriser",
     "sampling_grid", "sphere_conv", "spade_modulate", "spade_norm_modulate", "stock_sphere_ops",
 ]

@@ -84,6 +84,56 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     return spade_modulate(bn(x), actv, conv_gamma, conv_beta, slope)
 
 
+# torchvision ``vgg19().features`` up to relu5_1: conv index -> (in, out)
+_VGG19_CONVS = {0: (3, 64), 2: (64, 64), 5: (64, 128), 7: (128, 128), 10: (128, 256), 12: (256, 256), 14: (256, 256),
+                16: (256, 256), 19: (256, 512), 21: (512, 512), 23: (512, 512), 25: (512, 512), 28: (512, 512)}
+_VGG19_POOLS = (4, 9, 18, 27)
+_VGG19_SLICE_ENDS = (1, 6, 11, 20, 29)
+
+
+def seeded_vgg19_state_dict(seed=3):
+    """A torchvision-STYLE ``vgg19`` state dict (keys ``features.N.weight|bias`` + a classifier entry that consumers must
+    ignore) with seeded Kaiming weights: the ImageNet ones cannot be obtained offline, so parity tests inject
+    the same seeded dict on both sides."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for idx, (ci, co) in _VGG19_CONVS.items():
+        w = torch.empty(co, ci, 3, 3)
+        torch.nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu", generator=g)
+        sd["features.%d.weight" % idx] = w
+        sd["features.%d.bias" % idx] = torch.empty(co).uniform_(-0.1, 0.1, generator=g)
+    sd["classifier.0.weight"] = torch.zeros(4, 4)
+    return sd
+
+
+class StockVGG19(torch.nn.Module):
+    """``VGG19`` of ``models/networks/architecture.py:92-125`` on stock ops: torchvision's ``features`` indices 0..29
+    (Conv2d 3x3 pad 1 / ReLU / MaxPool2d 2), outputs after relu1_1, relu2_1, relu3_1, relu4_1, relu5_1; weights frozen."""
+
+    def __init__(self, state_dict):
+        super().__init__()
+        seq = []
+        for i in range(30):
+            if i in _VGG19_CONVS:
+                conv = torch.nn.Conv2d(*_VGG19_CONVS[i], 3, padding=1)
+                conv.weight.data.copy_(state_dict["features.%d.weight" % i])
+                conv.bias.data.copy_(state_dict["features.%d.bias" % i])
+                seq.append(conv)
+            else:
+                seq.append(torch.nn.MaxPool2d(2, 2) if i in _VGG19_POOLS else torch.nn.ReLU())
+        self.features = torch.nn.Sequential(*seq)
+        for q in self.parameters():
+            q.requires_grad = False
+
+    def forward(self, x):
+        out = []
+        for i, m in enumerate(self.features):
+            x = m(x)
+            if i in _VGG19_SLICE_ENDS:
+                out.append(x)
+        return out
+
+
 @contextlib.contextmanager
 def stock_sphere_ops():
     """Inside the block the product's SphereConv2D / SPADE norm + modulation run the restatements above."""

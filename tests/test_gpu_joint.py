@@ -25,14 +25,18 @@ def test_joint_step_small_vs_oracle_composition():
     from emlight_amd.GenProjector import networks
     from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
     from emlight_amd.joint import JointTrainer, joint_batch
+    from emlight_amd.GenProjector.vgg import VGG19Features
     ln, crop, B = 128, (64, 96), 2
-    opt = networks.default_options(ngf=8, ndf=8)
-    tr = JointTrainer(opt, anchors=ln, crop_hw=crop, blur=.05, device="cuda:0")
+    # the configuration bench.py and the CLIs time: VGG perceptual term ON, the same seeded
+    # torchvision-style state dict on both sides (HIP gather-GEMM stack vs stock nn.Sequential)
+    vgg_sd = oracle.seeded_vgg19_state_dict(seed=3)
+    opt = networks.default_options(ngf=8, ndf=8, no_vgg_loss=False)
+    tr = JointTrainer(opt, anchors=ln, crop_hw=crop, blur=.05, device="cuda:0", vgg_features=VGG19Features(state_dict=vgg_sd))
     enc_o = oracle.OracleDenseNet(anchors=ln, crop_hw=crop).train()
     sd = oracle.deterministic_state_dict(enc_o.state_dict(), seed=21)
     enc_o.load_state_dict(sd)
     tr.reg.model.load_state_dict(sd)
-    pm_o = Pix2PixModel(opt).train()
+    pm_o = Pix2PixModel(opt, vgg_features=oracle.StockVGG19(vgg_sd)).train()
     sdG = oracle.deterministic_projector_state_dict(pm_o.netG.state_dict(), seed=11)
     sdD = oracle.deterministic_projector_state_dict(pm_o.netD.state_dict(), seed=12)
     for m in (pm_o, tr.proj.model):
@@ -61,7 +65,7 @@ def test_joint_step_small_vs_oracle_composition():
     fk = want["fake"].detach().numpy()
     np.testing.assert_allclose(tr.generated.detach().cpu().numpy(), fk, rtol=1e-3, atol=2e-3)
     ref_losses = {**want["terms"], **want["g_losses"]}
-    assert set(got) == set(ref_losses)
+    assert set(got) == set(ref_losses) and "VGG" in got
     for k, v in ref_losses.items():
         np.testing.assert_allclose(float(got[k].detach().mean()), float(v.detach().mean()), rtol=1e-4, atol=1e-6, err_msg=k)
 
@@ -71,9 +75,11 @@ def test_joint_step_small_vs_oracle_composition():
         floor = 1e-3 * float(np.median([np.sqrt(np.mean(np.square(g))) for g in grads.values()]))
         errs = sorted(((_rel_l2(named_got[k].grad.cpu().numpy(), g, floor), k) for k, g in grads.items()), reverse=True)
         assert all(np.isfinite(e) for e, _ in errs), what
+        print("%s gradients: worst %s, median %.2e" % (what, errs[:3], np.median([e for e, _ in errs])))
         assert errs[0][0] < max_bound, "%s: largest relative L2 grad errors %s" % (what, errs[:6])
         assert np.median([e for e, _ in errs]) < med_bound, "%s: median %g" % (what, np.median([e for e, _ in errs]))
-    check(dict(tr.reg.model.named_parameters()), dict(enc_o.named_parameters()), 5e-2, 5e-3, "encoder")
+    # the stand-alone encoder meets 2e-2 (tests/test_gpu_densenet.py); so does the one driven through the rasteriser
+    check(dict(tr.reg.model.named_parameters()), dict(enc_o.named_parameters()), 2e-2, 5e-3, "encoder")
     check(dict(tr.proj.model.netG.named_parameters()), dict(pm_o.netG.named_parameters()), 2e-2, 2e-3, "generator")
 
     # ---- D half from IDENTICAL generator weights (the oracle's post-Adam G, spectral-norm vectors and BN buffers included)

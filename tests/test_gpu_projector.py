@@ -414,18 +414,120 @@ def test_vgg19_features_and_loss_vs_stock_ops():
     proj = [torch.randn_like(c) for c in want]
     gh, = torch.autograd.grad(sum(w * (a * q).mean() for w, a, q in zip(w5, got, proj)), fake, retain_graph=True)
     gr, = torch.autograd.grad(sum(w * (c * q).mean() for w, c, q in zip(w5, want, proj)), fake_r, retain_graph=True)
-    # measured 5.7e-3 on the MI355X: through 13 ReLU layers and 4 max-pools a fraction ~1e-5 of the units sits within f32
-    # round-off of a kink and takes the other branch in the two evaluations (each layer's own d/dx is held to 1e-4 by
-    # test_planar_conv3x3_vs_conv2d); a wrong kernel or a wrong tap table is O(1)
-    assert float((gh - gr).double().norm() / gr.double().norm()) < 2e-2
+    # Through 13 ReLU layers and 4 max-pools a fraction ~1e-5 of the units sits within f32 round-off of a kink and takes the
+    # other branch in two f32 evaluations; HOW many depends on the rounding of both sides (measured HIP vs MIOpen f32:
+    # 5.7e-3 on one box, 1.6e-2 on another, same seeds -- the library picks its convolution algorithm per device).  So the
+    # bound is set against the TRUTH: the same stack in f64 on the CPU; the HIP stack must be as close to it as the stock f32
+    # stack is (factor 2), and never further than 2e-2.  Each layer's own d/dx is held to 1e-4 by test_planar_conv3x3_vs_conv2d;
+    # a wrong kernel or a wrong tap table is O(1).
+    stock64 = oracle.StockVGG19(sd).double()
+    fake64 = fake.detach().cpu().double().requires_grad_(True)
+    want64 = stock64(fake64)
+    g64, = torch.autograd.grad(sum(w * (c * q.cpu().double()).mean() for w, c, q in zip(w5, want64, proj)), fake64)
+    rel = lambda g: float((g.detach().cpu().double() - g64).norm() / g64.norm())
+    e_hip, e_stock = rel(gh), rel(gr)
+    e_lin = float((gh - gr).double().norm() / gr.double().norm())
+    print("VGG stack data gradient, linear functional: vs f64 HIP %.2e, stock f32 %.2e; HIP vs stock f32 %.2e" % (e_hip, e_stock, e_lin))
+    assert e_hip <= max(2 * e_stock, 5e-3) and e_hip < 2e-2
     # ... then through the L1 loss itself: sign(a - b) flips wherever two f32 evaluations of a feature difference straddle
     # zero (a fraction f of the elements moves the gradient by ~2 sqrt(f) in relative L2), so: relative L2, loose
     l_h.backward()
     l_r.backward()
     d = (fake.grad - fake_r.grad).double()
-    assert float(d.norm() / fake_r.grad.double().norm()) < 2e-2
+    e_l1 = float(d.norm() / fake_r.grad.double().norm())
+    print("VGG stack data gradient, L1 loss: rel L2 %.2e" % e_l1)
+    assert e_l1 < 2e-2
     with pytest.warns(UserWarning, match="RANDOM features"):
         VGG19Features()
+
+
+def test_vgg_stack_construction_leaves_the_global_rng_alone():
+    """building the (random) feature stack must not reseed the CPU or the CUDA generators."""
+    from emlight_amd.GenProjector.vgg import VGG19Features
+    torch.manual_seed(1234)
+    torch.cuda.manual_seed(99)
+    c0, g0 = torch.random.get_rng_state().clone(), torch.cuda.get_rng_state().clone()
+    with pytest.warns(UserWarning, match="RANDOM features"):
+        a = VGG19Features(seed=0)
+    assert torch.equal(torch.random.get_rng_state(), c0) and torch.equal(torch.cuda.get_rng_state(), g0)
+    with pytest.warns(UserWarning, match="RANDOM features"):
+        b = VGG19Features(seed=0)
+    assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))   # still seeded
+
+
+def test_random_vgg_features_need_an_explicit_opt_in():
+    """with the term on, no weights and no ``vgg_random`` the model refuses to be built."""
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    with pytest.raises(ValueError, match="vgg_random"):
+        Pix2PixModel(networks.default_options(ngf=4, ndf=4, no_vgg_loss=False))
+    import argparse
+    ap = argparse.ArgumentParser()
+    networks.add_vgg_arguments(ap)
+    assert networks.vgg_options(ap.parse_args([]), verbose=False)["no_vgg_loss"] is True          # default: OFF, said so
+    assert networks.vgg_options(ap.parse_args(["--vgg_random"]), verbose=False)["no_vgg_loss"] is False
+    assert networks.vgg_options(ap.parse_args(["--vgg_weights", "x.pth"]), verbose=False)["no_vgg_loss"] is False
+
+
+def _rel_l2_report(named_got, named_want):
+    """per-tensor relative L2 gradient errors (floor: 1e-3 of the median tensor RMS), largest first"""
+    grads = {k: q.grad.detach().cpu().double() for k, q in named_want.items() if q.grad is not None}
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    floor = 1e-3 * float(np.median([rms(g) for g in grads.values()]))
+    return sorted(((rms(named_got[k].grad.detach().cpu().double() - g) / max(rms(g), floor), k) for k, g in grads.items()),
+                  reverse=True)
+
+
+def test_generator_and_discriminator_step_with_the_vgg_term_vs_stock_ops():
+    """the configuration that is TIMED (bench.py, the CLIs: VGG perceptual term on) pinned at trainer
+    level.  The same seeded torchvision-style vgg19 state dict is injected into the HIP feature stack (gather-GEMM kernels)
+    and into a stock nn.Sequential on the all-stock CPU side (oracle SphereConv / SPADE, ATen norms); one generator step and
+    one discriminator step (pix2pix_model.py:92-141): every loss term incl. VGG <= 2e-3 rel, generator gradients <= 2e-2
+    relative L2 per tensor (median 2e-3), discriminator gradients likewise."""
+    from emlight_amd.GenProjector import data, networks
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    from emlight_amd.GenProjector.vgg import VGG19Features
+    torch.manual_seed(5)
+    sd = oracle.seeded_vgg19_state_dict(seed=3)
+    opt = networks.default_options(ngf=8, ndf=8, no_vgg_loss=False)
+    cpu = Trainer(opt, device="cpu", vgg_features=oracle.StockVGG19(sd))
+    cpu.model.netG.load_state_dict(oracle.deterministic_projector_state_dict(cpu.model.netG.state_dict(), seed=11))
+    cpu.model.netD.load_state_dict(oracle.deterministic_projector_state_dict(cpu.model.netD.state_dict(), seed=12))
+    hip = Trainer(opt, device="cuda", vgg_features=VGG19Features(state_dict=sd))
+    assert hip.model.vgg_variant == "pretrained"
+    hip.model.netG.load_state_dict(cpu.model.netG.state_dict())
+    hip.model.netD.load_state_dict(cpu.model.netD.state_dict())
+    batch = data.projector_batch(2, "cuda", seed=31)
+    batch_cpu = {k: v.cpu() for k, v in batch.items()}
+    # generator half: losses + gradients BEFORE Adam (model_trainer.py:34-42 without the step)
+    gl_h, fake_h = hip.model(batch, mode="generator")
+    sum(gl_h.values()).mean().backward()
+    with oracle.stock_sphere_ops():
+        gl_c, fake_c = cpu.model(batch_cpu, mode="generator")
+        sum(gl_c.values()).mean().backward()
+    assert set(gl_h) == set(gl_c) == {"GAN", "GAN_Feat", "VGG", "COS"}
+    for k in gl_c:
+        a, b = float(gl_h[k].detach().mean()), float(gl_c[k].detach().mean())
+        print("G loss %-8s hip %.6f  stock %.6f" % (k, a, b))
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-6, (k, a, b)
+    np.testing.assert_allclose(fake_h.detach().cpu().numpy(), fake_c.detach().numpy(), rtol=1e-3, atol=2e-3)
+    errs = _rel_l2_report(dict(hip.model.netG.named_parameters()), dict(cpu.model.netG.named_parameters()))
+    print("generator gradients with the VGG term: worst %s, median %.2e" % (errs[:3], np.median([e for e, _ in errs])))
+    assert errs[0][0] < 2e-2 and np.median([e for e, _ in errs]) < 2e-3, errs[:6]
+    # discriminator half from the same (un-updated) weights
+    for tr in (hip, cpu):
+        tr.optimizer_D.zero_grad()
+    dl_h = hip.model(batch, mode="discriminator")
+    sum(dl_h.values()).mean().backward()
+    with oracle.stock_sphere_ops():
+        dl_c = cpu.model(batch_cpu, mode="discriminator")
+        sum(dl_c.values()).mean().backward()
+    for k in dl_c:
+        a, b = float(dl_h[k].detach().mean()), float(dl_c[k].detach().mean())
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-6, (k, a, b)
+    errs = _rel_l2_report(dict(hip.model.netD.named_parameters()), dict(cpu.model.netD.named_parameters()))
+    print("discriminator gradients: worst %s, median %.2e" % (errs[:3], np.median([e for e, _ in errs])))
+    assert errs[0][0] < 2e-2 and np.median([e for e, _ in errs]) < 2e-3, errs[:6]
 
 
 def test_generator_step_includes_the_vgg_term():
@@ -654,7 +756,8 @@ def test_three_iterations_follow_the_stock_op_trajectory():
     CPU with every op stock (torch's spectral-norm hook, ATen instance norm, unfused Adam, the oracle's SphereConv / SPADE):
     what a single step cannot show -- the power-iteration buffers after six forwards, SPADE's running statistics, Adam's
     moments -- stays on the reference's trajectory.  Bounds from the measured distances (tools/debug_trajectory.py: losses
-    <= 3e-4, buffers <= 1.4e-3, parameter UPDATES <= 0.11 of the update's norm), with a factor ~3-5 of head room.  Adam's first
+    <= 3e-4, buffers <= 1.4e-3, parameter UPDATES <= 0.11 of the update's norm), with a factor <= 2 of head room on the
+    updates.  Adam's first
     updates are sign-like (|update| = lr whatever |grad|), so an element whose gradient is at round-off level may step the other
     way: updates are compared in norm; the bias of a convolution whose output only ever reaches the rest of the network through
     a parameter-free BatchNorm (conv_0 of every SPADE block; conv_1 / conv_s of every block but the last, whose sum is
@@ -698,7 +801,7 @@ def test_three_iterations_follow_the_stock_op_trajectory():
                 assert float((a - b).abs().max()) <= 2 * 3 * lr * 1.01, (name, k)
             else:
                 upd = float((b - z).norm())
-                assert float(((a - z) - (b - z)).norm()) <= 0.3 * upd + 1e-9, (name, k, upd)
+                assert float(((a - z) - (b - z)).norm()) <= 0.2 * upd + 1e-9, (name, k, upd)   # measured 0.11 (<= 2x)
 
 
 def test_inference_in_eval_mode_matches_the_stock_ops():

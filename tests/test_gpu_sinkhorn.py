@@ -241,9 +241,12 @@ def test_split_kernel_is_not_chosen_on_a_stream_with_too_few_cus():
 
 
 def test_split_kernel_gives_up_and_the_tiled_kernel_recomputes():
-    """The on-device half of the fail-safe: the split kernel FORCED onto a 32-CU stream (256 workgroups, at most ~100
-    resident) cannot complete its exchange.  It must give up within its 50 ms bound, raise the status word, and the gated
-    tiled launch behind it must recompute the batch: the caller gets the tiled kernel's numbers, never NaN."""
+    """The on-device half of the fail-safe.  What the exchange needs co-resident is the S = 8 slices of one (sample, role):
+    consecutive workgroup ids, which the dispatcher places together -- on a 32-CU stream the forced split kernel still
+    completes (measured; that is also why it survives a second process on the device).  On a stream with TWO CUs (at most
+    6 resident workgroups) no group of 8 ever is: the slices must give up within the 50 ms bound, raise the status word,
+    every later workgroup leaves at once, and the gated tiled launch behind the kernel recomputes the batch: the caller
+    gets the tiled kernel's numbers, never NaN."""
     from emlight_amd.RegressionNetwork.geomloss.samples_loss import EML_SINKHORN_FORCE_SPLIT, EML_SINKHORN_NO_SPLIT
     B, n = 16, 256
     x, y, crit = _split_case(B, n)
@@ -255,15 +258,15 @@ def test_split_kernel_gives_up_and_the_tiled_kernel_recomputes():
     torch.cuda.synchronize()
     assert _status_word(ok, B, n) == 0
     np.testing.assert_allclose(ok["loss"].cpu().numpy(), ref["loss"].cpu().numpy(), rtol=0, atol=LOSS_ATOL)
-    s = _masked_stream(32)
+    s = _masked_stream(2)
     with torch.cuda.stream(s):
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
         r = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
         t1.record()
         s.synchronize()
-    assert _status_word(r, B, n) == 1, "the split kernel completed on 32 CUs?"
-    assert t0.elapsed_time(t1) < 1000.0          # bounded: 50 ms per give-up generation, not 2 s per poll
+    assert _status_word(r, B, n) == 1, "the split kernel completed on 2 CUs?"
+    assert t0.elapsed_time(t1) < 2000.0          # bounded: 50 ms per give-up generation (+ the tiled kernel on 2 CUs), not 2 s per poll
     assert torch.isfinite(r["loss"]).all() and torch.isfinite(r["gx"]).all() and torch.isfinite(r["duals"]).all()
     assert torch.equal(r["loss"], ref["loss"]) and torch.equal(r["gx"], ref["gx"])   # the tiled kernel's own numbers
 
