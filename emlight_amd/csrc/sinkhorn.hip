@@ -642,8 +642,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_loop_tiled_kernel(
 // floats per problem) through global memory as 8-byte {epoch, value} granules (cdna_hip_programming.md G16, form R2: the
 // data is the flag -- relaxed agent-scope 8-byte stores and polls, no fences; double-buffered by sweep parity, so a
 // workgroup that runs ahead never overwrites a granule a slower one still waits for; the launcher zeroes the exchange
-// buffer with a memset node in front of the kernel).  The exchange needs all 2 * B * S workgroups RESIDENT at once.  The
-// launcher sizes S from the CUs the stream may use and the kernel's occupancy, but residency cannot be guaranteed from the
+// buffer with a memset node in front of the kernel).  The exchange is confined to the S slices of one (sample, role) --
+// S consecutive workgroup ids -- and needs THOSE co-resident (measured: forced onto a stream masked down to 32 CUs the
+// 256-workgroup launch still completes, the dispatcher places consecutive ids together; on 2 CUs, 6 resident workgroups,
+// it cannot).  The launcher only takes this path when every workgroup gets a CU of its own on the CUs the STREAM may use
+// (that is what makes the split pay, and far more than residency needs), but residency cannot be guaranteed from the
 // host (another stream's kernel, a second process on the device, ...), so it is also enforced on the device: polls are
 // bounded by wall-clock time (50 ms -- a healthy exchange takes ~1 us); a workgroup that never sees its partners raises
 // the call's STATUS word (device int, zeroed by the launcher's memset), every other workgroup notices the word in its own
@@ -1048,9 +1051,10 @@ void launch_tiled(const float* x, const float* y, const float* M, const float* a
   }
 }
 
-// Slices per problem pair for the split kernel, or 0 when the batch does not qualify.  All 2 * B * S workgroups must be
-// resident together: S is sized from the CUs the STREAM may use (its CU mask / ROC_GLOBAL_CU_MASK) -- one workgroup per CU
-// is also what makes the split worth it -- and from the occupancy the runtime reports for the instance.
+// Slices per problem pair for the split kernel, or 0 when the batch does not qualify.  S is sized so that every one of the
+// 2 * B * S workgroups has a CU of its own among the CUs the STREAM may use (its CU mask / ROC_GLOBAL_CU_MASK): that is what
+// makes the split worth it, and it implies what the exchange needs (the S slices of a (sample, role) co-resident) with a
+// wide margin; the occupancy the runtime reports for the instance guards the degenerate cases (0: cannot launch).
 // EML_SINKHORN_FORCE_SPLIT (tests): skip the sizing and launch S = 8 (or 4) regardless, to exercise the on-device rescue.
 int split_slices(int B, int N, int flags, hipStream_t stream) {
   const int dev_cus = device_cu_count();

@@ -113,9 +113,9 @@ int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const f
                          eml_stream_t stream);
 
 /* The same call with options.  Small batches at N >= 192 (N % 64 == 0, N <= 512) run the SPLIT kernel: a sample's rows
- * over S = 8 (or 4) workgroups that exchange the dual vectors through global memory after every sweep, which needs all
- * 2*B*S workgroups resident at once.  The launcher takes that path only when they fit the CUs the STREAM may use (its CU
- * mask or ROC_GLOBAL_CU_MASK, hipExtStreamGetCUMask) at the occupancy the runtime reports; since residency still cannot be
+ * over S = 8 (or 4) workgroups that exchange the dual vectors through global memory after every sweep, which needs the S
+ * slices of a (sample, role) resident together.  The launcher takes that path only when every workgroup has a CU of its own
+ * among the CUs the STREAM may use (its CU mask or ROC_GLOBAL_CU_MASK, hipExtStreamGetCUMask); since residency still cannot be
  * guaranteed from the host (another stream, another process on the device), a slice that does not see its partners within
  * 50 ms raises a status word, and the tiled kernel -- enqueued behind the split kernel by the same call, gated on that
  * word -- recomputes the batch: the outputs are always those of a completed Sinkhorn loop, never NaN.
