@@ -16,7 +16,7 @@ from ... import _lib
 from ..util import sphere_points
 
 
-EML_SINKHORN_NO_SPLIT, EML_SINKHORN_FORCE_SPLIT = 1, 2   # include/emlight_hip.h
+EML_SINKHORN_NO_SPLIT, EML_SINKHORN_FORCE_SPLIT, EML_SINKHORN_TEST_STALL = 1, 2, 4   # include/emlight_hip.h
 
 
 def split_eligible(N):

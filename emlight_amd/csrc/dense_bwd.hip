@@ -22,6 +22,8 @@
 // reductions are per-block partials + a finishing kernel: deterministic, no atomics.
 #include "eml_common.h"
 
+#include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -57,7 +59,11 @@ constexpr int kGPass = kHH / kGRows;                        // 5 passes of float
 // G may be the block gradient (ldg = ld, c0 = the layer's channel offset) or the compact (P,12) tensor that
 // conv1x1_bwd_narrow_kernel leaves for the lower layer of a pair (ldg = 12, c0 = 0); cx is the layer's channel
 // offset in X / sB / sC either way.
-template <bool FUSE>
+// WIDE (round 4): the halo tile is staged as 340 pixels x 3 float4 = 1020 items, two per thread, instead of five float2
+// passes over (2 rows x 34 columns x 6 float2) -- 4 (FUSE: with x) 16-byte loads per thread and tile instead of 10 eight-
+// byte ones, and the compact GF leaves as float4.  Needs the channel offsets to be multiples of 4 (blocks 1 and 2 of
+// EMLight's encoder; block 3 starts at channel 150 and keeps the float2 path).
+template <bool FUSE, bool WIDE>
 __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
@@ -65,8 +71,12 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF) {
   __shared__ __attribute__((aligned(16))) float g_l[2][kHH * kHW * kPSG];
   __shared__ double red[8 * 48 * 2];
+  __shared__ __attribute__((aligned(16))) float coef_l[24];   // WIDE + FUSE: sB | sC of the layer's 12 channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
+  if constexpr (FUSE && WIDE) {
+    if (tid < 24) coef_l[tid] = tid < 12 ? sB[cx + tid] : sC[cx + tid - 12];   // visible after the barrier below the prologue
+  }
 
   // A fragments (D^T form): lane (kk, c = 16n + r) holds W2[o = 4s + kk][c][tap]
   float bw[9][3][3];
@@ -85,14 +95,26 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) s1[n][g] = s2[n][g] = 0.0;
 
-  // staging map: 408 threads = 2 halo rows x 34 columns x 6 float2; threads >= 408 duplicate the last item.
+  // staging map (narrow): 408 threads = 2 halo rows x 34 columns x 6 float2; threads >= 408 duplicate the last item.
+  // staging map (WIDE): item t = tid + 512 * it (it < 2; < 1020, the last four duplicate): halo pixel t / 3, float4 t % 3
+  constexpr int kPass = WIDE ? 2 : kGPass;
   const int st = min(tid, kGRows * kHW * 6 - 1);
   const int s_row = st / (kHW * 6), s_rem = st - s_row * (kHW * 6);
   const int s_hx = s_rem / 6, s_q = s_rem - 6 * s_hx;
   const int s_dst = (s_row * kHW + s_hx) * kPSG + 2 * s_q;
-  float2 gt[kGPass], xt[FUSE ? kGPass : 1];
+  float2 gt[WIDE ? 1 : kGPass], xt[(FUSE && !WIDE) ? kGPass : 1];
+  float4 gt4[WIDE ? 2 : 1], xt4[(FUSE && WIDE) ? 2 : 1];
   float2 fb = make_float2(0.f, 0.f), fc = make_float2(0.f, 0.f);
-  if constexpr (FUSE) {
+  int w_hy[2], w_hx[2], w_q[2];
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int t = min(tid + 512 * it, kHH * kHW * 3 - 1), hp = t / 3;
+      w_q[it] = t - 3 * hp;
+      w_hy[it] = hp / kHW;
+      w_hx[it] = hp - w_hy[it] * kHW;
+    }
+  } else if constexpr (FUSE) {
     fb = *reinterpret_cast<const float2*>(sB + cx + 2 * s_q);
     fc = *reinterpret_cast<const float2*>(sC + cx + 2 * s_q);
   }
@@ -101,9 +123,24 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   float* s_gf = GF;
   int s_y0 = 0;
   bool s_col = false, s_own = false;
+  int w_pix[2] = {0, 0};   // clamped source pixel of the item (addresses are formed at the load: registers are scarce here)
+  bool w_ok[2] = {false, false}, w_own[2] = {false, false};
   auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int gy = ty * kTH - 1 + w_hy[it], gx = tx * kTW - 1 + w_hx[it];
+        w_ok[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        w_pix[it] = (b * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1);
+        if constexpr (FUSE) {
+          // a pixel of the tile itself (not halo); the duplicated tail items of pass 1 write the same value twice
+          w_own[it] = w_ok[it] && w_hy[it] >= 1 && w_hy[it] <= kTH && w_hx[it] >= 1 && w_hx[it] <= kTW;
+        }
+      }
+      return;
+    }
     const int gx = tx * kTW - 1 + s_hx;
     s_y0 = ty * kTH - 1 + s_row;
     s_col = gx >= 0 && gx < W;
@@ -116,11 +153,35 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     }
   };
   auto stage_load = [&](int it) {  // unconditional (clamped): exec-masked loads make the compiler stall MFMAs on them
+    if constexpr (WIDE) {
+      gt4[it] = *reinterpret_cast<const float4*>(G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it]);
+      if constexpr (FUSE) xt4[it] = *reinterpret_cast<const float4*>(Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it]);
+      return;
+    }
     const size_t row = (size_t)min(max(s_y0 + kGRows * it, 0), H - 1) * W;
     gt[it] = *reinterpret_cast<const float2*>(s_src + row * ldg);
     if constexpr (FUSE) xt[it] = *reinterpret_cast<const float2*>(s_srcx + row * ldx);
   };
   auto stage_commit = [&](int it, float* dst) {
+    if constexpr (WIDE) {
+      float4 v = gt4[it];
+      if constexpr (FUSE) {
+        const float4 fb4 = *reinterpret_cast<const float4*>(coef_l + 4 * w_q[it]);
+        const float4 fc4 = *reinterpret_cast<const float4*>(coef_l + 12 + 4 * w_q[it]);
+        v.x = fmaf(fb4.x, xt4[it].x, v.x) + fc4.x;
+        v.y = fmaf(fb4.y, xt4[it].y, v.y) + fc4.y;
+        v.z = fmaf(fb4.z, xt4[it].z, v.z) + fc4.z;
+        v.w = fmaf(fb4.w, xt4[it].w, v.w) + fc4.w;
+      }
+      if (!w_ok[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float* d = dst + (w_hy[it] * kHW + w_hx[it]) * kPSG + 4 * w_q[it];   // 56-byte pixel stride: 8-byte aligned
+      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      if constexpr (FUSE) {
+        if (w_own[it]) *reinterpret_cast<float4*>(GF + (size_t)w_pix[it] * 12 + 4 * w_q[it]) = v;
+      }
+      return;
+    }
     const int gy = s_y0 + kGRows * it;
     const bool ok = s_col && gy >= 0 && gy < H;
     float2 v;
@@ -139,12 +200,13 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   };
 
   int tile = blockIdx.x, cur = 0;
+  if constexpr (FUSE && WIDE) __syncthreads();   // coef_l
   if (tile < ntiles) {
     stage_begin(tile);
 #pragma unroll
-    for (int it = 0; it < kGPass; ++it) stage_load(it);
+    for (int it = 0; it < kPass; ++it) stage_load(it);
 #pragma unroll
-    for (int it = 0; it < kGPass; ++it) stage_commit(it, g_l[0]);
+    for (int it = 0; it < kPass; ++it) stage_commit(it, g_l[0]);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): bw[] is complete on every path into the loop (see conv3x3_fwd)
   __syncthreads();
@@ -178,11 +240,11 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int gi = tap * 3 + s;
-        if (gi < kGPass) {
+        if (gi < kPass) {
           stage_load(gi);
           __builtin_amdgcn_sched_barrier(0);  // keep the request here; the scheduler would sink it to its use
-        } else if (gi < kGPass + 6) {
-          const int zi = gi - kGPass;
+        } else if (gi < kPass + 6) {
+          const int zi = gi - kPass;
           zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -194,9 +256,9 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(bw[tap][s][n], a[m], acc[m][n]);  // D[channel][pixel]
-        if (gi >= 27 - kGPass) {
+        if (gi >= 27 - kPass) {
           __builtin_amdgcn_sched_barrier(0);
-          stage_commit(gi - (27 - kGPass), gn);
+          stage_commit(gi - (27 - kPass), gn);
         }
       }
     }
@@ -274,7 +336,15 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
 // place right after its last use.
 constexpr int kPSW = 48;   // 48 dwords: the two pixels of a ds_read_b32 lane group fall on disjoint bank halves
 constexpr int kBW = 512;
+constexpr int kGL = kTH * kTW * 12;   // floats of a tile's own g pixels in LDS ([pixel][12]: two pixels of a ds_read_b32 lane
+                                      // group sit 12 banks apart -- disjoint for the 12 channels)
 
+// GLDS (round 4): the g operand (k = pixel, lane (kk, o) needs g[pixel 4ks + kk][o] for 32 k-steps) comes from an LDS copy
+// of the tile's 256 x 12 own pixels, staged by TWO 16-byte loads per thread, instead of 32 four-byte loads per lane and
+// tile -- 42 vector-memory instructions per wave and tile become 12.  (Round 4's gather-GEMM measurements priced a
+// vector-memory instruction at ~45 matrix-pipe cycles whatever it fetches: it holds the issuing wave ~60 cycles.)
+// GLDS = false keeps the round-1 register path for the A/B (EML_W3_GREG=1).
+template <bool GLDS>
 __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ Z, const float* __restrict__ scale2,
     const float* __restrict__ shift2, int B, int H, int W, float* __restrict__ partial /*[2*grid][27][16][16]*/) {
@@ -303,9 +373,15 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
   int s_y0 = 0;
   bool s_col = false;
   // g operand of the tile being prefetched: lane (kk, o = r) needs g[pixel 128*half + 4*ks + kk][o]
-  float gb[32];
+  float gb[GLDS ? 1 : 32];
   const float* g_src = G;
   int g_y0 = 0, g_x0 = 0;
+  // GLDS staging map: item t = (pixel t / 3 of the 8 x 32 tile, float4 t % 3 of its 12 channels); thread tid owns items
+  // tid and tid + 512 (the second only for tid < 256)
+  float* gl_base = smem + 2 * kHH * kHW * kPSW;   // [2][kGL]
+  float4 gq[2];
+  const float* gq_src[2] = {G, G};
+  bool gq_ok[2] = {false, false};
   auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
@@ -316,6 +392,21 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     g_y0 = ty * kTH + 4 * half;
     g_x0 = tx * kTW + kk;
     g_src = G + (size_t)b * H * W * ldg + c0 + min(r, 11);
+    if constexpr (GLDS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = min(tid + 512 * j, 767), pix = t / 3, piece = t - 3 * pix;
+        const int gy = ty * kTH + (pix >> 5), gx = tx * kTW + (pix & 31);
+        gq_ok[j] = gy < H && gx < W;
+        gq_src[j] = G + ((size_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * ldg + c0 + 4 * piece;
+      }
+    }
+  };
+  auto gq_load = [&](int j) { gq[j] = *reinterpret_cast<const float4*>(gq_src[j]); };   // unconditional, clamped
+  auto gq_commit = [&](int j, float* dst) {   // pixels outside the image contribute zero
+    const int t = min(tid + 512 * j, 767);
+    const float4 v = gq_ok[j] ? gq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j == 0 || tid < 256) *reinterpret_cast<float4*>(dst + 4 * t) = v;
   };
   auto stage_load = [&](int it) {
     zt[it] = *reinterpret_cast<const float4*>(s_src + (size_t)min(max(s_y0 + it, 0), H - 1) * W * 48);
@@ -339,8 +430,15 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     stage_begin(tile);
 #pragma unroll
     for (int it = 0; it < kHH; ++it) stage_load(it);
+    if constexpr (GLDS) {
+      gq_load(0);
+      gq_load(1);
+      gq_commit(0, gl_base);
+      gq_commit(1, gl_base);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) g_load(ks);
+      for (int ks = 0; ks < 32; ++ks) g_load(ks);
+    }
 #pragma unroll
     for (int it = 0; it < kHH; ++it) stage_commit(it, smem);
   }
@@ -352,23 +450,32 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     stage_begin(nxt < ntiles ? nxt : tile);
     const float* tile_l = smem + cur * (kHH * kHW * kPSW);
     float* tile_n = smem + (cur ^ 1) * (kHH * kHW * kPSW);
+    const float* gl_c = gl_base + cur * kGL + (128 * half + kk) * 12 + min(r, 11);
+    float* gl_n = gl_base + (cur ^ 1) * kGL;
     float av[2][7];  // A fragments are read one k-step ahead of their MFMAs (the fences below pin this order)
 #pragma unroll
     for (int i = 0; i < 7; ++i) av[0][i] = tile_l[aoff[i]];
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
       if (ks < kHH) stage_load(ks);
+      if (GLDS && ks >= kHH && ks < kHH + 2) gq_load(ks - kHH);
       if (ks + 1 < 32) {
         const float* base = tile_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
 #pragma unroll
         for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const bool gok = r < 12 && cy0 + (ks >> 3) < H && cx0 + 4 * (ks & 7) < W;
-      const float gv = gok ? gb[ks] : 0.f;
+      float gv;
+      if constexpr (GLDS) {
+        gv = r < 12 ? gl_c[4 * ks * 12] : 0.f;   // lanes 12..15 of a row: the unused MFMA columns
+      } else {
+        const bool gok = r < 12 && cy0 + (ks >> 3) < H && cx0 + 4 * (ks & 7) < W;
+        gv = gok ? gb[ks] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc[i] = mfma16(av[ks & 1][i], gv, acc[i]);
-      g_load(ks);  // next tile's value, in place
+      if constexpr (!GLDS) g_load(ks);  // next tile's value, in place
+      if (GLDS && ks >= 32 - kHH - 2 && ks < 32 - kHH) gq_commit(ks - (32 - kHH - 2), gl_n);
       if (ks >= 32 - kHH) stage_commit(ks - (32 - kHH), tile_n);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1805,11 +1912,26 @@ extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, c
     if (!sB || !sC || !GF || (ldx & 1))
       return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: fused affine needs X, sB, sC, GF");
     if (cx < 0 || (cx & 1)) return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: cx must be even");
-    hipLaunchKernelGGL(conv3x3_bwd_data_kernel<true>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
-                       zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
+  }
+  // 16-byte staging where every slice it touches is 16-byte aligned (EML_D3_NARROW=1: the float2 path, for the A/B)
+  static const bool narrow = [] { const char* v = getenv("EML_D3_NARROW"); return v && v[0] == '1'; }();
+  const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool wide = !narrow && (ldg & 3) == 0 && (c0 & 3) == 0 && al16(G) &&
+                    (!X || ((ldx & 3) == 0 && (cx & 3) == 0 && al16(X) && al16(sB) && al16(sC) && al16(GF)));
+  if (X) {
+    if (wide)
+      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<true, true>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2,
+                         Z, zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
+    else
+      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<true, false>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2,
+                         Z, zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
   } else {
-    hipLaunchKernelGGL(conv3x3_bwd_data_kernel<false>, dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2, Z,
-                       zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    if (wide)
+      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<false, true>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0,
+                         W2, Z, zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    else
+      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<false, false>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0,
+                         W2, Z, zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
   }
   return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
 }
@@ -1819,10 +1941,19 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
                                                 int grid, eml_stream_t stream) {
   if (!G || !Z || !scale2 || !shift2 || !partial || !dW2 || B < 1 || H < 1 || W < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_weight_f32: bad arguments");
-  const size_t lds = (size_t)(2 * kHH * kHW * kPSW) * sizeof(float);
-  EML_ENSURE_LDS((&conv3x3_bwd_weight_kernel), lds);
-  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(grid), dim3(kBW), lds, (hipStream_t)stream, G, ldg, c0, Z, scale2,
-                     shift2, B, H, W, partial);
+  // 16-byte loads of the 12-channel slice need ldg and c0 multiples of 4 (always true for the engine's buffers)
+  static const bool greg = [] { const char* v = getenv("EML_W3_GREG"); return v && v[0] == '1'; }();
+  if (!greg && (ldg & 3) == 0 && (c0 & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
+    const size_t lds = (size_t)(2 * kHH * kHW * kPSW + 2 * kGL) * sizeof(float);
+    EML_ENSURE_LDS((&conv3x3_bwd_weight_kernel<true>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel<true>, dim3(grid), dim3(kBW), lds, (hipStream_t)stream, G, ldg, c0, Z,
+                       scale2, shift2, B, H, W, partial);
+  } else {
+    const size_t lds = (size_t)(2 * kHH * kHW * kPSW) * sizeof(float);
+    EML_ENSURE_LDS((&conv3x3_bwd_weight_kernel<false>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel<false>, dim3(grid), dim3(kBW), lds, (hipStream_t)stream, G, ldg, c0, Z,
+                       scale2, shift2, B, H, W, partial);
+  }
   int rc = eml::check_launch("eml_dense_conv3x3_bwd_weight_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partial, 2 * grid,

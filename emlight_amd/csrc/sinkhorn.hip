@@ -663,7 +663,7 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
     const float* __restrict__ alpha, const float* __restrict__ beta, double blur, double log_blur, double log_scaling,
     int p_exp, double diameter, const float* __restrict__ range_dev, float* __restrict__ eps_out,
     int* __restrict__ n_eps_out, float* __restrict__ diameter_out, float* __restrict__ work,
-    unsigned long long* __restrict__ exch, int B, int S, int* __restrict__ status) {
+    unsigned long long* __restrict__ exch, int B, int S, int* __restrict__ status, int test_stall) {
   constexpr int N = CPL * kSplitLPR, kWG = 16 * R, kGT = 8 * R, LDM = N + 32;   // LDM = 32 mod 64: two rows cover all banks
   static_assert(CPL % 4 == 0 && N % 64 == 0 && kWG <= 1024, "split kernel geometry");
   __shared__ float eps_l[EML_MAX_EPS];
@@ -818,7 +818,9 @@ __global__ __launch_bounds__(16 * R) void sinkhorn_loop_split_kernel(
     // sweep's n = -k_next); every workgroup of the (sample, role) then collects all 2 * N granules of the new parity
     const unsigned epoch = (unsigned)(s + 1);
     gu64* xw = xg + ((s + 1) & 1) * xpar + xbase;
-    if (owner) {
+    // test_stall (EML_SINKHORN_TEST_STALL): slice 3 of every group never publishes -- what its partners would see if it were
+    // not resident -- so that the give-up and the rescue can be exercised on an idle device
+    if (owner && !(test_stall && slice == 3)) {
       const float hv = fmaf(pot, k_next, lw2_rows[i]) - k_next * (0.05f * pi * pi);
       __hip_atomic_store(xw + consumer_l * N + i, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, hv),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1101,7 +1103,7 @@ extern "C" int eml_sinkhorn_fwd_ex_f32(const float* x, const float* y, const flo
                                        float* diameter_out, float* loss, float* gx, float* gy, float* work, int B, int N,
                                        int flags, eml_stream_t stream) {
   if (!x || !y || !M || !Mt || !loss || !work) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: null pointer");
-  if (flags & ~(EML_SINKHORN_NO_SPLIT | EML_SINKHORN_FORCE_SPLIT))
+  if (flags & ~(EML_SINKHORN_NO_SPLIT | EML_SINKHORN_FORCE_SPLIT | EML_SINKHORN_TEST_STALL))
     return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_ex_f32: unknown flags 0x%x", flags);
   if (B < 0 || N < 1 || N > 2048) return eml::fail(EML_EINVAL, "eml_sinkhorn_fwd_f32: need 1<=N<=2048 (got %d)", N);
   if (!(blur > 0.0) || !(scaling > 0.0 && scaling < 1.0) || p < 1)
@@ -1134,7 +1136,7 @@ extern "C" int eml_sinkhorn_fwd_ex_f32(const float* x, const float* y, const flo
     EML_ENSURE_LDS((&sinkhorn_loop_split_kernel<CPLV, RV>), lds);                                                      \
     hipLaunchKernelGGL((sinkhorn_loop_split_kernel<CPLV, RV>), dim3(2 * B * S), dim3(16 * RV), lds, (hipStream_t)stream, \
                        x, y, M, alpha, beta, blur, log_blur, log_scaling, p, diameter, range_lo_hi, eps_out, n_eps_out, \
-                       diameter_out, work, exch, B, S, status);                                                        \
+                       diameter_out, work, exch, B, S, status, (flags & EML_SINKHORN_TEST_STALL) ? 1 : 0);              \
   } while (0)
     if (N == 256 && S == 8) EML_LAUNCH_SPLIT(32, 32);
     else if (N == 256) EML_LAUNCH_SPLIT(32, 64);

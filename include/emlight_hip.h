@@ -120,11 +120,14 @@ int eml_sinkhorn_fwd_f32(const float* x, const float* y, const float* M, const f
  * 50 ms raises a status word, and the tiled kernel -- enqueued behind the split kernel by the same call, gated on that
  * word -- recomputes the batch: the outputs are always those of a completed Sinkhorn loop, never NaN.
  *   flags   EML_SINKHORN_NO_SPLIT    never take the split path (a caller that saw the status word raised)
- *           EML_SINKHORN_FORCE_SPLIT take it whenever the shape allows, without the residency sizing (tests of the rescue)
+ *           EML_SINKHORN_FORCE_SPLIT take it whenever the shape allows, without the sizing (tests)
+ *           EML_SINKHORN_TEST_STALL  (tests) one slice of every group withholds its exchange granules, as if it were not
+ *                                    resident: its partners must give up and the rescue must recompute the batch
  *   status  = ((int*)work)[24*B*N]: set to 1 by a call whose split kernel gave up (the rescue ran); zeroed at the start
  *           of every call that takes the split path, untouched by calls that do not. */
 #define EML_SINKHORN_NO_SPLIT 1
 #define EML_SINKHORN_FORCE_SPLIT 2
+#define EML_SINKHORN_TEST_STALL 4
 int eml_sinkhorn_fwd_ex_f32(const float* x, const float* y, const float* M, const float* Mt,
                             const float* alpha, const float* beta, double blur, double scaling, int p,
                             double diameter, const float* range_lo_hi, float* eps_out, int* n_eps_out,

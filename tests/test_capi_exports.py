@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(built_lib):
     rc = L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, None, one, None, None, one, 2, 0, None)
     assert rc == -1
     rc = L.eml_sinkhorn_fwd_ex_f32(one, one, one, one, None, None, .05, .5, 2, -1.0, None, None, None, None, one, None, None, one,
-                                   2, 256, 4, None)
+                                   2, 256, 8, None)
     assert rc == -1 and b"unknown flags" in L.eml_last_error()
     # encoder / projector launchers: nulls, odd pooling sizes, misaligned channel counts
     assert L.eml_dense_pool_act_f32(one, 224, 2, 7, 8, 224, one, one, one, 224, None, None) == -1

@@ -242,33 +242,43 @@ def test_split_kernel_is_not_chosen_on_a_stream_with_too_few_cus():
 
 def test_split_kernel_gives_up_and_the_tiled_kernel_recomputes():
     """The on-device half of the fail-safe.  What the exchange needs co-resident is the S = 8 slices of one (sample, role):
-    consecutive workgroup ids, which the dispatcher places together -- on a 32-CU stream the forced split kernel still
-    completes (measured; that is also why it survives a second process on the device).  On a stream with TWO CUs (at most
-    6 resident workgroups) no group of 8 ever is: the slices must give up within the 50 ms bound, raise the status word,
-    every later workgroup leaves at once, and the gated tiled launch behind the kernel recomputes the batch: the caller
-    gets the tiled kernel's numbers, never NaN."""
-    from emlight_amd.RegressionNetwork.geomloss.samples_loss import EML_SINKHORN_FORCE_SPLIT, EML_SINKHORN_NO_SPLIT
+    consecutive workgroup ids, which the dispatcher places together -- forced onto streams masked down to 32 and to 2 CUs the
+    256-workgroup launch still completed (measured, round 4): the failure cannot be provoked from outside on an idle device.
+    EML_SINKHORN_TEST_STALL makes one slice of every group withhold its granules, which is exactly what its partners see when
+    it is not resident: they must give up within the 50 ms bound and raise the status word, and the gated tiled launch behind
+    the kernel must recompute the batch -- the caller gets the tiled kernel's numbers, never NaN, never a hang."""
+    from emlight_amd.RegressionNetwork.geomloss.samples_loss import (EML_SINKHORN_FORCE_SPLIT, EML_SINKHORN_NO_SPLIT,
+                                                                     EML_SINKHORN_TEST_STALL)
     B, n = 16, 256
     x, y, crit = _split_case(B, n)
     xc, yc = x.cuda(), y.cuda()
     ref = crit.forward_raw(xc, yc, flags=EML_SINKHORN_NO_SPLIT)
     torch.cuda.synchronize()
-    # control: forced split on the whole device completes on its own (status 0) and agrees with the tiled kernel
+    # control: the split kernel completes on its own (status 0) and agrees with the tiled kernel -- also on a 2-CU stream
     ok = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
     torch.cuda.synchronize()
     assert _status_word(ok, B, n) == 0
     np.testing.assert_allclose(ok["loss"].cpu().numpy(), ref["loss"].cpu().numpy(), rtol=0, atol=LOSS_ATOL)
     s = _masked_stream(2)
     with torch.cuda.stream(s):
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record()
-        r = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
-        t1.record()
+        ok2 = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT)
         s.synchronize()
-    assert _status_word(r, B, n) == 1, "the split kernel completed on 2 CUs?"
-    assert t0.elapsed_time(t1) < 2000.0          # bounded: 50 ms per give-up generation (+ the tiled kernel on 2 CUs), not 2 s per poll
+    assert torch.isfinite(ok2["loss"]).all()
+    np.testing.assert_allclose(ok2["loss"].cpu().numpy(), ref["loss"].cpu().numpy(), rtol=0, atol=LOSS_ATOL)
+    # the give-up
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    r = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT | EML_SINKHORN_TEST_STALL)
+    t1.record()
+    torch.cuda.synchronize()
+    assert _status_word(r, B, n) == 1, "a slice withheld its granules and nobody noticed"
+    assert 40.0 < t0.elapsed_time(t1) < 500.0    # one 50 ms give-up generation, not 2 s per poll and not a hang
     assert torch.isfinite(r["loss"]).all() and torch.isfinite(r["gx"]).all() and torch.isfinite(r["duals"]).all()
     assert torch.equal(r["loss"], ref["loss"]) and torch.equal(r["gx"], ref["gx"])   # the tiled kernel's own numbers
+    # and the next healthy call on the same buffers clears the word
+    again = crit.forward_raw(xc, yc, flags=EML_SINKHORN_FORCE_SPLIT, out={k: v for k, v in r.items() if k != "duals"} | {"work": r["work"]})
+    torch.cuda.synchronize()
+    assert _status_word(again, B, n) == 0
 
 
 def test_split_watch_disables_the_split_path_after_a_give_up():
