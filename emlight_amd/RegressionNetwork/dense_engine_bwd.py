@@ -126,6 +126,8 @@ def _run_backward(enc, ws, x, gpooled):
     B, _, H, W = x.shape
     G = enc._grid(dev)
     G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
+    # ... except the data gradient since round 4: 256-thread workgroups on 4-row tiles, two per CU (csrc/dense_bwd.hip)
+    G3d = enc._tuned("EML_GRID3_DGRAD", G3 if os.environ.get("EML_D3_TALL") == "1" else 2 * G3)
     Gw = enc._tuned("EML_GRID_WGRAD1", G)   # per-family knobs for A/B runs (default: the common 2 x #CU)
     Gd = enc._tuned("EML_GRID_DGRAD", G)
     Gb = min(enc.grid_max, 4 * enc._cu)
@@ -249,7 +251,7 @@ def _run_backward(enc, ws, x, gpooled):
             if bw.side is not None and bw.ev_done[r] is not None:
                 main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
             _lib.check(L.eml_dense_conv3x3_bwd_data_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
-                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3, p(blk["X"]), ld,
+                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3d, p(blk["X"]), ld,
                                                         cin, p(sB), p(sC), p(bw.GF12[r]), st),
                        "eml_dense_conv3x3_bwd_data_f32")
             if bw.side is None:
@@ -268,7 +270,7 @@ def _run_backward(enc, ws, x, gpooled):
                 if bw.ev_done[r] is None:
                     bw.ev_done[r] = torch.cuda.Event()
                 bw.ev_done[r].record(bw.side)
-            finalize(G3, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
+            finalize(G3d, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,

@@ -63,14 +63,23 @@ constexpr int kGPass = kHH / kGRows;                        // 5 passes of float
 // passes over (2 rows x 34 columns x 6 float2) -- 4 (FUSE: with x) 16-byte loads per thread and tile instead of 10 eight-
 // byte ones, and the compact GF leaves as float4.  Needs the channel offsets to be multiples of 4 (blocks 1 and 2 of
 // EMLight's encoder; block 3 starts at channel 150 and keeps the float2 path).
-template <bool FUSE, bool WIDE>
-__global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
+// TH (round 4): output rows per tile = waves per workgroup.  8 (512 threads, one workgroup per CU) is round 1's geometry;
+// 4 (256 threads, TWO independent workgroups per CU) is the default now: with one workgroup per CU the two waves of a SIMD
+// run the same tile in the same phase, so nobody issues MFMAs while both sit in the epilogue (f64 statistics, 6 stores per
+// lane, the barrier) -- the kernel sat at 49 % matrix-pipe time; two workgroups on different tiles fill each other's
+// epilogues.  The halo overhead of the shorter tile (6 x 34 against 10 x 34 rows for 4 / 8 own rows) only touches the
+// 12-channel g operand; z and dzn have no halo.
+template <bool FUSE, bool WIDE, int TH>
+__global__ __launch_bounds__(TH * 64, 2) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
     double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx, int cx,
     const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF) {
-  __shared__ __attribute__((aligned(16))) float g_l[2][kHH * kHW * kPSG];
-  __shared__ double red[8 * 48 * 2];
+  constexpr int HH = TH + 2, NT = TH * 64;
+  constexpr int GR = TH == 8 ? 2 : 1;                       // halo rows staged per pass of the float2 path
+  constexpr int kNarrowPass = HH / GR;
+  __shared__ __attribute__((aligned(16))) float g_l[2][HH * kHW * kPSG];
+  __shared__ double red[TH * 48 * 2];
   __shared__ __attribute__((aligned(16))) float coef_l[24];   // WIDE + FUSE: sB | sC of the layer's 12 channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
 #pragma unroll
       for (int n = 0; n < 3; ++n) bw[tap][s][n] = W2[((size_t)(4 * s + kk) * 48 + 16 * n + r) * 9 + tap];
 
-  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + TH - 1) / TH;
   const int ntiles = B * ty_n * tx_n;
   double s1[3][4], s2[3][4];  // sum dzn, sum dzn*z  (xhat is applied to the f64 totals at the end)
 #pragma unroll
@@ -95,21 +104,23 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) s1[n][g] = s2[n][g] = 0.0;
 
-  // staging map (narrow): 408 threads = 2 halo rows x 34 columns x 6 float2; threads >= 408 duplicate the last item.
-  // staging map (WIDE): item t = tid + 512 * it (it < 2; < 1020, the last four duplicate): halo pixel t / 3, float4 t % 3
-  constexpr int kPass = WIDE ? 2 : kGPass;
-  const int st = min(tid, kGRows * kHW * 6 - 1);
+  // staging map (narrow): GR halo rows x 34 columns x 6 float2 per pass (408 / 204 threads; the rest duplicate the last item)
+  // staging map (WIDE): item t = tid + NT * it (< HH * 34 * 3, the tail duplicates the last): halo pixel t / 3, float4 t % 3
+  constexpr int kWideItems = HH * kHW * 3;
+  constexpr int kPass = WIDE ? (kWideItems + NT - 1) / NT : kNarrowPass;
+  const int st = min(tid, GR * kHW * 6 - 1);
   const int s_row = st / (kHW * 6), s_rem = st - s_row * (kHW * 6);
   const int s_hx = s_rem / 6, s_q = s_rem - 6 * s_hx;
   const int s_dst = (s_row * kHW + s_hx) * kPSG + 2 * s_q;
-  float2 gt[WIDE ? 1 : kGPass], xt[(FUSE && !WIDE) ? kGPass : 1];
-  float4 gt4[WIDE ? 2 : 1], xt4[(FUSE && WIDE) ? 2 : 1];
+  float2 gt[WIDE ? 1 : kPass], xt[(FUSE && !WIDE) ? kPass : 1];
+  float4 gt4[WIDE ? kPass : 1], xt4[(FUSE && WIDE) ? kPass : 1];
   float2 fb = make_float2(0.f, 0.f), fc = make_float2(0.f, 0.f);
-  int w_hy[2], w_hx[2], w_q[2];
+  constexpr int kWP = WIDE ? kPass : 1;
+  int w_hy[kWP], w_hx[kWP], w_q[kWP];
   if constexpr (WIDE) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int t = min(tid + 512 * it, kHH * kHW * 3 - 1), hp = t / 3;
+    for (int it = 0; it < kWP; ++it) {
+      const int t = min(tid + NT * it, kWideItems - 1), hp = t / 3;
       w_q[it] = t - 3 * hp;
       w_hy[it] = hp / kHW;
       w_hx[it] = hp - w_hy[it] * kHW;
@@ -123,33 +134,33 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   float* s_gf = GF;
   int s_y0 = 0;
   bool s_col = false, s_own = false;
-  int w_pix[2] = {0, 0};   // clamped source pixel of the item (addresses are formed at the load: registers are scarce here)
-  bool w_ok[2] = {false, false}, w_own[2] = {false, false};
+  int w_pix[kWP];          // clamped source pixel of the item (addresses are formed at the load: registers are scarce here)
+  bool w_ok[kWP], w_own[kWP];
   auto stage_begin = [&](int tile) {
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
     if constexpr (WIDE) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int gy = ty * kTH - 1 + w_hy[it], gx = tx * kTW - 1 + w_hx[it];
+      for (int it = 0; it < kWP; ++it) {
+        const int gy = ty * TH - 1 + w_hy[it], gx = tx * kTW - 1 + w_hx[it];
         w_ok[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
         w_pix[it] = (b * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1);
         if constexpr (FUSE) {
           // a pixel of the tile itself (not halo); the duplicated tail items of pass 1 write the same value twice
-          w_own[it] = w_ok[it] && w_hy[it] >= 1 && w_hy[it] <= kTH && w_hx[it] >= 1 && w_hx[it] <= kTW;
+          w_own[it] = w_ok[it] && w_hy[it] >= 1 && w_hy[it] <= TH && w_hx[it] >= 1 && w_hx[it] <= kTW;
         }
       }
       return;
     }
     const int gx = tx * kTW - 1 + s_hx;
-    s_y0 = ty * kTH - 1 + s_row;
+    s_y0 = ty * TH - 1 + s_row;
     s_col = gx >= 0 && gx < W;
     const size_t col = (size_t)b * H * W + min(max(gx, 0), W - 1);
     s_src = G + col * ldg + c0 + 2 * s_q;
     if constexpr (FUSE) {
       s_srcx = Xb + col * ldx + cx + 2 * s_q;
       s_gf = GF + col * 12 + 2 * s_q;
-      s_own = s_col && tid < kGRows * kHW * 6 && s_hx >= 1 && s_hx <= kTW;  // a column of the tile itself (not halo)
+      s_own = s_col && tid < GR * kHW * 6 && s_hx >= 1 && s_hx <= kTW;  // a column of the tile itself (not halo)
     }
   };
   auto stage_load = [&](int it) {  // unconditional (clamped): exec-masked loads make the compiler stall MFMAs on them
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
       if constexpr (FUSE) xt4[it] = *reinterpret_cast<const float4*>(Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it]);
       return;
     }
-    const size_t row = (size_t)min(max(s_y0 + kGRows * it, 0), H - 1) * W;
+    const size_t row = (size_t)min(max(s_y0 + GR * it, 0), H - 1) * W;
     gt[it] = *reinterpret_cast<const float2*>(s_src + row * ldg);
     if constexpr (FUSE) xt[it] = *reinterpret_cast<const float2*>(s_srcx + row * ldx);
   };
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
       }
       return;
     }
-    const int gy = s_y0 + kGRows * it;
+    const int gy = s_y0 + GR * it;
     const bool ok = s_col && gy >= 0 && gy < H;
     float2 v;
     if constexpr (FUSE) {
@@ -192,10 +203,10 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
       v.x = ok ? gt[it].x : 0.f;
       v.y = ok ? gt[it].y : 0.f;
     }
-    *reinterpret_cast<float2*>(dst + s_dst + it * kGRows * kHW * kPSG) = v;
+    *reinterpret_cast<float2*>(dst + s_dst + it * GR * kHW * kPSG) = v;
     if constexpr (FUSE) {
-      const int hy = s_row + kGRows * it;  // halo row 0..9; rows 1..8 are the tile's own
-      if (s_own && ok && hy >= 1 && hy <= kTH) *reinterpret_cast<float2*>(s_gf + (size_t)gy * W * 12) = v;
+      const int hy = s_row + GR * it;  // halo row 0..HH-1; rows 1..TH are the tile's own
+      if (s_own && ok && hy >= 1 && hy <= TH) *reinterpret_cast<float2*>(s_gf + (size_t)gy * W * 12) = v;
     }
   };
 
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
     float* gn = g_l[cur ^ 1];
     const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
     const int ty = rem / tx_n, tx = rem - ty * tx_n;
-    const int gy = ty * kTH + wave;
+    const int gy = ty * TH + wave;
     // this lane's two output pixels (row gy, columns 16m + r); clamped copies for the unconditional z loads
     size_t prow[2];
     bool pv[2];
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(kBD) void conv3x3_bwd_data_kernel(
   if (tid < 48) {
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) {
+    for (int w8 = 0; w8 < TH; ++w8) {
       t1 += red[(w8 * 48 + tid) * 2 + 0];
       t2 += red[(w8 * 48 + tid) * 2 + 1];
     }
@@ -1913,26 +1924,24 @@ extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, c
       return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: fused affine needs X, sB, sC, GF");
     if (cx < 0 || (cx & 1)) return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: cx must be even");
   }
-  // 16-byte staging where every slice it touches is 16-byte aligned (EML_D3_NARROW=1: the float2 path, for the A/B)
+  // 16-byte staging where every slice it touches is 16-byte aligned (EML_D3_NARROW=1: the float2 path, for the A/B);
+  // 4-row tiles / 256 threads / two workgroups per CU unless EML_D3_TALL=1 (round 1's 8-row tile, one workgroup per CU)
   static const bool narrow = [] { const char* v = getenv("EML_D3_NARROW"); return v && v[0] == '1'; }();
+  static const bool tall = [] { const char* v = getenv("EML_D3_TALL"); return v && v[0] == '1'; }();
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool wide = !narrow && (ldg & 3) == 0 && (c0 & 3) == 0 && al16(G) &&
                     (!X || ((ldx & 3) == 0 && (cx & 3) == 0 && al16(X) && al16(sB) && al16(sC) && al16(GF)));
+#define EML_LAUNCH_D3(FUSEV, WIDEV, THV)                                                                                \
+  hipLaunchKernelGGL((conv3x3_bwd_data_kernel<FUSEV, WIDEV, THV>), dim3(grid), dim3(THV * 64), 0, (hipStream_t)stream, G, ldg, \
+                     c0, W2, Z, zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF)
   if (X) {
-    if (wide)
-      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<true, true>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2,
-                         Z, zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
-    else
-      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<true, false>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0, W2,
-                         Z, zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF);
+    if (tall) { if (wide) EML_LAUNCH_D3(true, true, 8); else EML_LAUNCH_D3(true, false, 8); }
+    else      { EML_LAUNCH_D3(true, false, 4); }   // (the 16-byte staging spills 18 registers next to the fused affine here)
   } else {
-    if (wide)
-      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<false, true>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0,
-                         W2, Z, zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
-    else
-      hipLaunchKernelGGL((conv3x3_bwd_data_kernel<false, false>), dim3(grid), dim3(kBD), 0, (hipStream_t)stream, G, ldg, c0,
-                         W2, Z, zmean, zistd, DZ, B, H, W, partials, nullptr, 0, 0, nullptr, nullptr, nullptr);
+    if (tall) { if (wide) EML_LAUNCH_D3(false, true, 8); else EML_LAUNCH_D3(false, false, 8); }
+    else      { if (wide) EML_LAUNCH_D3(false, true, 4); else EML_LAUNCH_D3(false, false, 4); }
   }
+#undef EML_LAUNCH_D3
   return eml::check_launch("eml_dense_conv3x3_bwd_data_f32");
 }
 
