@@ -126,8 +126,8 @@ def _run_backward(enc, ws, x, gpooled):
     B, _, H, W = x.shape
     G = enc._grid(dev)
     G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
-    # ... except the data gradient since round 4: 256-thread workgroups on 4-row tiles, two per CU (csrc/dense_bwd.hip)
-    G3d = enc._tuned("EML_GRID3_DGRAD", G3 if os.environ.get("EML_D3_TALL") == "1" else 2 * G3)
+    # (EML_D3_SHORT=1: the data gradient's 256-thread / 4-row-tile A/B geometry wants two workgroups per CU, csrc/dense_bwd.hip)
+    G3d = enc._tuned("EML_GRID3_DGRAD", 2 * G3 if os.environ.get("EML_D3_SHORT") == "1" else G3)
     Gw = enc._tuned("EML_GRID_WGRAD1", G)   # per-family knobs for A/B runs (default: the common 2 x #CU)
     Gd = enc._tuned("EML_GRID_DGRAD", G)
     Gb = min(enc.grid_max, 4 * enc._cu)

@@ -63,12 +63,11 @@ constexpr int kGPass = kHH / kGRows;                        // 5 passes of float
 // passes over (2 rows x 34 columns x 6 float2) -- 4 (FUSE: with x) 16-byte loads per thread and tile instead of 10 eight-
 // byte ones, and the compact GF leaves as float4.  Needs the channel offsets to be multiples of 4 (blocks 1 and 2 of
 // EMLight's encoder; block 3 starts at channel 150 and keeps the float2 path).
-// TH (round 4): output rows per tile = waves per workgroup.  8 (512 threads, one workgroup per CU) is round 1's geometry;
-// 4 (256 threads, TWO independent workgroups per CU) is the default now: with one workgroup per CU the two waves of a SIMD
-// run the same tile in the same phase, so nobody issues MFMAs while both sit in the epilogue (f64 statistics, 6 stores per
-// lane, the barrier) -- the kernel sat at 49 % matrix-pipe time; two workgroups on different tiles fill each other's
-// epilogues.  The halo overhead of the shorter tile (6 x 34 against 10 x 34 rows for 4 / 8 own rows) only touches the
-// 12-channel g operand; z and dzn have no halo.
+// TH (round 4): output rows per tile = waves per workgroup.  8 (512 threads, one workgroup per CU) is round 1's geometry and
+// the one that runs.  4 (256 threads, TWO independent workgroups per CU, EML_D3_SHORT=1) was the experiment "with one
+// workgroup per CU the two waves of a SIMD share a phase, so nobody issues MFMAs while both sit in the epilogue": measured
+// 15.34 against 14.43 ms per step -- SLOWER.  The kernel moves 4.0 TB/s with 43 % of its bytes written (dzn, GF): it sits on
+// what this part delivers for that read / write mix (4.0-4.7 TB/s, profiles/r03_row_access_probe.txt), not on its phases.
 template <bool FUSE, bool WIDE, int TH>
 __global__ __launch_bounds__(TH * 64, 2) void conv3x3_bwd_data_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
@@ -1925,9 +1924,10 @@ extern "C" int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, c
     if (cx < 0 || (cx & 1)) return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_data_f32: cx must be even");
   }
   // 16-byte staging where every slice it touches is 16-byte aligned (EML_D3_NARROW=1: the float2 path, for the A/B);
-  // 4-row tiles / 256 threads / two workgroups per CU unless EML_D3_TALL=1 (round 1's 8-row tile, one workgroup per CU)
+  // 8-row tiles / 512 threads / one workgroup per CU; EML_D3_SHORT=1: the 4-row / 256-thread / two-per-CU geometry of the
+  // round-4 A/B (15.34 against 14.43 ms per step: slower, profiles/r04_ab_conv3x3.txt)
   static const bool narrow = [] { const char* v = getenv("EML_D3_NARROW"); return v && v[0] == '1'; }();
-  static const bool tall = [] { const char* v = getenv("EML_D3_TALL"); return v && v[0] == '1'; }();
+  static const bool tall = [] { const char* v = getenv("EML_D3_SHORT"); return !(v && v[0] == '1'); }();
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool wide = !narrow && (ldg & 3) == 0 && (c0 & 3) == 0 && al16(G) &&
                     (!X || ((ldx & 3) == 0 && (cx & 3) == 0 && al16(X) && al16(sB) && al16(sC) && al16(GF)));
