@@ -636,8 +636,14 @@ struct NarrowArgs {
   double* partials;    // [grid][Kp][2]: S1 of channels k_lo .. k_lo+11 (S2 slot = 0: it comes from the weight gradient)
   int Cin, k_lo, ldg;
 };
-template <bool POOL, bool NARROW = false>
-__global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel(
+// VEC (round 4): floats per lane of the x operand.  2 = round 1's float2 (lane i of a 32-channel group
+// carries channels 2i, 2i+1: a wave instruction reads 4 rows x 128 B); 4 = float4 over 64-channel groups (4 rows x 256 B):
+// half as many vector-memory instructions for the operand that is 80 % of this kernel's bytes.  The access-shape probe
+// (profiles/r04_row_access_probe_wgrad.txt) streams the float2 shape at 4.6-5.0 TB/s and the float4 shape at 5.5-5.9 at
+// k = 208 / 224 (2.7-2.95 against 3.4-3.65 with two workgroups per CU).  The 64-channel groups are dealt to the 4 waves
+// like the 32-channel ones, so the launcher only takes VEC = 4 where that deal is as balanced (Kp in [160, 256]).
+template <bool POOL, bool NARROW = false, int VEC = 2>
+__global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp, const float* __restrict__ scale1,
     const float* __restrict__ shift1, const float* __restrict__ DY, int ld_dy, const float* __restrict__ Zr,
     int ld_z, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n_valid,
@@ -649,7 +655,10 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
   __shared__ __attribute__((aligned(16))) float dz_l[2][64 * 48];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
-  const int ngroups = (Kp + 31) >> 5;
+  static_assert(VEC == 2 || (VEC == 4 && !POOL), "float4 operand: dense layers only");
+  constexpr int GW = 16 * VEC;            // channels per group
+  constexpr int MAXG = VEC == 2 ? 3 : 2;  // groups per wave (Kp <= 384)
+  const int ngroups = (Kp + GW - 1) / GW;
   // narrow pass: A fragments (rows = the 12 channels, k = o), BN1 affine of this lane's 4 channels, f64 statistics
   float nsk[4] = {0.f, 0.f, 0.f, 0.f}, ntk[4] = {0.f, 0.f, 0.f, 0.f};
   double ns1[4] = {0.0, 0.0, 0.0, 0.0};
@@ -662,17 +671,20 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     }
   }
 
-  float2 s2[3], t2[3];
-  int coff[3];
-  bool gv[3];
+  float sv[MAXG][VEC], tv[MAXG][VEC];
+  int coff[MAXG];
+  bool gv[MAXG];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < MAXG; ++i) {
     const int cg = wave + 4 * i;
-    const int ch = 32 * cg + 2 * r;
+    const int ch = GW * cg + VEC * r;
     gv[i] = cg < ngroups && ch < Kp;
     coff[i] = gv[i] ? ch : 0;
-    s2[i] = gv[i] ? *reinterpret_cast<const float2*>(scale1 + ch) : make_float2(0.f, 0.f);
-    t2[i] = gv[i] ? *reinterpret_cast<const float2*>(shift1 + ch) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      sv[i][t] = gv[i] ? scale1[ch + t] : 0.f;
+      tv[i][t] = gv[i] ? shift1[ch + t] : 0.f;
+    }
   }
   // dz staging role: pixel = tid >> 2, columns 4*(q + 4j), j = 0..2.  NARROW: the BN2-backward affine (cA, cB, cC; 0
   // past n_valid) and the narrow pass's weight fragments live in LDS (read once per chunk): the plain kernel sits at the
@@ -681,8 +693,9 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
   const int spix = tid >> 2, sq = tid & 3;
   __shared__ __attribute__((aligned(16))) float co_l[3 * 48];
   __shared__ float wn_l[NARROW ? 12 * 64 : 1];
-  float4 sa_r[NARROW ? 1 : 3], sb_r[NARROW ? 1 : 3], sc_r[NARROW ? 1 : 3];   // plain variant: the affine in registers
-  if constexpr (NARROW) {
+  constexpr bool CO_LDS = NARROW || VEC == 4;   // the float4 variant needs the registers for its accumulators
+  float4 sa_r[CO_LDS ? 1 : 3], sb_r[CO_LDS ? 1 : 3], sc_r[CO_LDS ? 1 : 3];   // plain variant: the affine in registers
+  if constexpr (CO_LDS) {
     if (tid < 48) {
       const bool v = tid < n_valid;
       co_l[tid] = v ? cA[tid] : 0.f;
@@ -713,11 +726,11 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     }
   }
   __syncthreads();
-  f32x4 acc[3][2][3];
+  f32x4 acc[MAXG][VEC][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < MAXG; ++i)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < VEC; ++t)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[i][t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -747,7 +760,7 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     for (int j = 0; j < 3; ++j) {
       const int col = 4 * (sq + 4 * j);
       float4 sa, sb, sc;
-      if constexpr (NARROW) {
+      if constexpr (CO_LDS) {
         sa = *reinterpret_cast<const float4*>(co_l + col);
         sb = *reinterpret_cast<const float4*>(co_l + 48 + col);
         sc = *reinterpret_cast<const float4*>(co_l + 96 + col);
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     constexpr int UQ = POOL ? 1 : 2;
     constexpr int NBUF = POOL ? 2 : 4;
 #else
-    constexpr int UQ = POOL ? 1 : 4;      // pixel quads per batch
+    constexpr int UQ = POOL ? 1 : (VEC == 4 ? 2 : 4);   // pixel quads per batch (the same bytes in flight for both VEC)
     constexpr int NBUF = 2;
 #endif
     constexpr int NS = POOL ? 4 : 1;      // input pixels per output pixel
@@ -782,8 +795,9 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     // x operand of one batch: UNCONDITIONAL loads from clamped pixels (validity is applied when the value is
     // used); they are requested AHEAD of their MFMAs, across chunk boundaries -- issued right before
     // use they exposed an HBM round trip per batch (ISA: global_load; s_waitcnt vmcnt; v_mfma).
-    float2 xr[NBUF][UQ][NGW > 0 ? NGW : 1][NS];
-    auto load_batch = [&](int chunk, int q0, float2 (&dst)[UQ][NGW > 0 ? NGW : 1][NS]) {
+    using xv_t = std::conditional_t<VEC == 2, float2, float4>;
+    xv_t xr[NBUF][UQ][NGW > 0 ? NGW : 1][NS];
+    auto load_batch = [&](int chunk, int q0, xv_t (&dst)[UQ][NGW > 0 ? NGW : 1][NS]) {
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         const int pc = min(chunk * 64 + 4 * (q0 + u) + kk, P - 1);
@@ -799,7 +813,7 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
         for (int i = 0; i < NGW; ++i)
 #pragma unroll
           for (int sub = 0; sub < NS; ++sub)
-            dst[u][i][sub] = *reinterpret_cast<const float2*>(xp + ((sub >> 1) * (size_t)Win + (sub & 1)) * ldx + coff[i]);
+            dst[u][i][sub] = *reinterpret_cast<const xv_t*>(xp + ((sub >> 1) * (size_t)Win + (sub & 1)) * ldx + coff[i]);
       }
     };
     stage_load(blockIdx.x);
@@ -844,22 +858,28 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
             for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
 #pragma unroll
             for (int i = 0; i < NGW; ++i) {
-              float ax = 0.f, ay = 0.f;
+              float av[VEC];
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) av[t] = 0.f;
 #pragma unroll
               for (int sub = 0; sub < NS; ++sub) {
-                ax += fmaxf(fmaf(xr[bi % NBUF][u][i][sub].x, s2[i].x, t2[i].x), 0.f);
-                ay += fmaxf(fmaf(xr[bi % NBUF][u][i][sub].y, s2[i].y, t2[i].y), 0.f);
+                const xv_t xv = xr[bi % NBUF][u][i][sub];
+                av[0] += fmaxf(fmaf(xv.x, sv[i][0], tv[i][0]), 0.f);
+                av[1] += fmaxf(fmaf(xv.y, sv[i][1], tv[i][1]), 0.f);
+                if constexpr (VEC == 4) {
+                  av[2] += fmaxf(fmaf(xv.z, sv[i][2], tv[i][2]), 0.f);
+                  av[3] += fmaxf(fmaf(xv.w, sv[i][3], tv[i][3]), 0.f);
+                }
               }
-              if constexpr (POOL) {
-                ax *= 0.25f;
-                ay *= 0.25f;
-              }
-              if (!pvu) ax = ay = 0.f;
 #pragma unroll
-              for (int n = 0; n < 3; ++n) {
-                acc[i][0][n] = mfma16(ax, bz[n], acc[i][0][n]);
-                acc[i][1][n] = mfma16(ay, bz[n], acc[i][1][n]);
+              for (int t = 0; t < VEC; ++t) {
+                if constexpr (POOL) av[t] *= 0.25f;
+                if (!pvu) av[t] = 0.f;
               }
+#pragma unroll
+              for (int n = 0; n < 3; ++n)
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) acc[i][t][n] = mfma16(av[t], bz[n], acc[i][t][n]);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -890,17 +910,17 @@ __global__ __launch_bounds__(256, NARROW ? 2 : 1) void conv1x1_bwd_weight_kernel
     case 0: chunk_loop(std::integral_constant<int, 0>{}); break;
     case 1: chunk_loop(std::integral_constant<int, 1>{}); break;
     case 2: chunk_loop(std::integral_constant<int, 2>{}); break;
-    default: chunk_loop(std::integral_constant<int, 3>{}); break;
+    default: chunk_loop(std::integral_constant<int, MAXG>{}); break;
   }
   float* out = partial + (size_t)blockIdx.x * Kp * 48;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < MAXG; ++i) {
     const int cg = wave + 4 * i;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < VEC; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ch = 32 * cg + 2 * (4 * kk + g) + t;  // D row 4kk+g of tile t
+        const int ch = GW * cg + VEC * (4 * kk + g) + t;  // D row 4kk+g of tile t
         if (cg < ngroups && ch < Kp) {
 #pragma unroll
           for (int n = 0; n < 3; ++n) out[(size_t)ch * 48 + 16 * n + r] = acc[i][t][n][g];
@@ -2029,7 +2049,20 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
     if (n_load > 48) n_load = 48;
     if (n_load < nv) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: DY/Zr rows narrower than Cout");
     const NarrowArgs na{W1, G, N12, partials_n, Cin, k_lo, ldg};
-    if (pool)
+    // float4 x operand where its 64-channel groups deal to the 4 waves as evenly as the 32-channel ones (EML_W1_VEC=2 / 4
+    // forces one form for the A/B); rows of X are 64-byte aligned (ldx % 16 == 0, checked by the engine's buffers)
+    static const int vec_env = [] { const char* v = getenv("EML_W1_VEC"); return v ? atoi(v) : 0; }();
+    const bool vec4 = !pool && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                      (vec_env == 4 || (vec_env == 0 && Kp >= 160 && Kp <= 256));
+    if (vec4 && N12 && vec_env == 4)   // (the narrow epilogue + float4 operand spills 39 registers: A/B only)
+      hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                         (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
+                         nv, n_load, partial, dz_out, na);
+    else if (vec4 && !N12)
+      hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<false, false, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                         (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
+                         nv, n_load, partial, dz_out, na);
+    else if (pool)
       hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
                          (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
                          nv, n_load, partial, nullptr, na);

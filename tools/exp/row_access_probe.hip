@@ -5,6 +5,9 @@
 //           (exactly the forward / dgrad kernels' pattern, 2 row tiles in flight per wave)
 //   mode 1  "rows":    lane i loads float4 at row p, column 4*i (i < k/4): one whole row per wave instruction (sequential bursts)
 //   mode 2/3: the same two shapes as read-modify-write (G += 1)
+//   mode 4  "wgrad":   conv1x1_bwd_weight's x operand (round 4): lane (r, kk) loads float2 at pixel 4q + kk,
+//           channels 32 * (wave + 4i) + 2r -- a wave instruction = 4 rows x 128 B, 8 bytes per lane; 4 pixel quads in flight
+//   mode 5  "wgrad4":  the same rows as float4: channels 64 * (wave + 4i) + 4r -- 4 rows x 256 B, 16 bytes per lane
 // Persistent grid, 256 threads; prints nothing: timed from the host with HIP events.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/exp/row_access_probe.hip -o build_exp/row_probe.so
 #include <hip/hip_runtime.h>
@@ -40,6 +43,46 @@ extern "C" __global__ __launch_bounds__(256, 2) void probe_kernel(float* __restr
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc += v[q].x + v[q].y + v[q].z + v[q].w;
+        }
+      }
+    }
+  } else if (mode == 4 || mode == 5) {
+    const int r = lane & 15, kk = lane >> 4;
+    const int gw = mode == 4 ? 32 : 64;                 // channels per group
+    const int ngroups = (k + gw - 1) / gw;
+    const long nchunks = (P + 63) / 64;
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+      for (int q0 = 0; q0 < 16; q0 += 4) {
+        if (mode == 4) {
+          float2 v[4][3];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const long pc = min(chunk * 64 + 4 * (q0 + u) + kk, P - 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const int g = wave + 4 * i, c = min(gw * g + 2 * r, k - 2);
+              v[u][i] = g < ngroups ? *reinterpret_cast<const float2*>(X + pc * ld + c) : make_float2(0.f, 0.f);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc += v[u][i].x + v[u][i].y;
+        } else {
+          float4 v[4][2];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const long pc = min(chunk * 64 + 4 * (q0 + u) + kk, P - 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int g = wave + 4 * i, c = min(gw * g + 4 * r, k - 4);
+              v[u][i] = g < ngroups ? *reinterpret_cast<const float4*>(X + pc * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc += v[u][i].x + v[u][i].y + v[u][i].z + v[u][i].w;
         }
       }
     }

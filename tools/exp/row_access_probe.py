@@ -26,14 +26,16 @@ def run(mode, k, grid, reps=5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    nbytes = P * k * 4 * (2 if mode >= 2 else 1)
+    nbytes = P * k * 4 * (2 if mode in (2, 3) else 1)
     return ms, nbytes / ms / 1e6
 
 
 names = {0: "read, operand shape (16 rows x 64 B per wave instruction)", 1: "read, whole rows (one row per wave instruction)",
-         2: "read-modify-write, operand shape", 3: "read-modify-write, whole rows"}
-for k in (64, 128, 208):
-    for mode in (0, 1, 2, 3):
+         2: "read-modify-write, operand shape", 3: "read-modify-write, whole rows",
+         4: "read, 1x1 weight gradient's x operand (4 rows x 128 B, 8 B per lane)",
+         5: "read, the same as float4 (4 rows x 256 B, 16 B per lane)"}
+for k in (64, 128, 208, 224):
+    for mode in ((4, 5) if os.environ.get("PROBE_WGRAD_ONLY") else (0, 1, 2, 3, 4, 5)):
         for grid in (512, 1024):
             ms, gbps = run(mode, k, grid)
             print("k=%3d grid=%4d  %-62s %7.3f ms  %7.1f GB/s" % (k, grid, names[mode], ms, gbps), flush=True)
