@@ -640,8 +640,8 @@ struct NarrowArgs {
 // carries channels 2i, 2i+1: a wave instruction reads 4 rows x 128 B); 4 = float4 over 64-channel groups (4 rows x 256 B):
 // half as many vector-memory instructions for the operand that is 80 % of this kernel's bytes.  The access-shape probe
 // (profiles/r04_row_access_probe_wgrad.txt) streams the float2 shape at 4.6-5.0 TB/s and the float4 shape at 5.5-5.9 at
-// k = 208 / 224 (2.7-2.95 against 3.4-3.65 with two workgroups per CU).  The 64-channel groups are dealt to the 4 waves
-// like the 32-channel ones, so the launcher only takes VEC = 4 where that deal is as balanced (Kp in [160, 256]).
+// k = 208 / 224 (2.7-2.95 against 3.4-3.65 with two workgroups per CU) -- but the kernel itself did not get faster with it
+// (see the launcher): kept as an A/B build (EML_W1_VEC=4), the float2 form runs.
 template <bool POOL, bool NARROW = false, int VEC = 2>
 __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp, const float* __restrict__ scale1,
@@ -2049,11 +2049,13 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
     if (n_load > 48) n_load = 48;
     if (n_load < nv) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: DY/Zr rows narrower than Cout");
     const NarrowArgs na{W1, G, N12, partials_n, Cin, k_lo, ldg};
-    // float4 x operand where its 64-channel groups deal to the 4 waves as evenly as the 32-channel ones (EML_W1_VEC=2 / 4
-    // forces one form for the A/B); rows of X are 64-byte aligned (ldx % 16 == 0, checked by the engine's buffers)
+    // float4 x operand: A/B only (EML_W1_VEC=4).  Measured (profiles/r04_ab_w1_vec.txt): on the layers where its 64-channel
+    // groups deal evenly (Kp in [160, 256], the plain variant) 30.4 against 29.95-30.4 ms per step -- no gain, although the
+    // access-shape probe streams the float4 shape 19-24 % faster: the x stream's shape is not what bounds this kernel.
+    // Everywhere (uneven deals, the narrow variant spilling 39 registers): 34.6 ms.
     static const int vec_env = [] { const char* v = getenv("EML_W1_VEC"); return v ? atoi(v) : 0; }();
     const bool vec4 = !pool && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
-                      (vec_env == 4 || (vec_env == 0 && Kp >= 160 && Kp <= 256));
+                      vec_env == 4;
     if (vec4 && N12 && vec_env == 4)   // (the narrow epilogue + float4 operand spills 39 registers: A/B only)
       hipLaunchKernelGGL((conv1x1_bwd_weight_kernel<false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ldx,
                          (int)P, Hin, Win, Kp, scale1, shift1, DY + n0, ld_dy, Zr + n0, ld_z, cA + n0, cB + n0, cC + n0,
