@@ -442,6 +442,70 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
     return rows
 
 
+def other_breakdown(step_fn, world):
+    """What the `other` row of a per-family table is made of: one step under torch.profiler, every device
+    kernel that is NOT one of this repo's bucketed by its name -- library GEMM (rocBLAS / Tensile `Cijk_*`; with the FLOPs of
+    the aten::mm / addmm / bmm calls that launched them: 2*M*K*N from the recorded shapes), ATen (elementwise, reductions,
+    copies issued by torch), MIOpen, the fused Adam, runtime copies / memsets, RCCL.  Kernel durations are the profiler's (the
+    profiled step's HOST side is slower; its kernels are not).  Returns a list of rows, or None when profiling fails."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step_fn()
+            torch.cuda.synchronize()
+        rows = prof.key_averages(group_by_input_shape=True)
+    except Exception as e:   # noqa: BLE001 -- evidence, not the product: never fail the bench line over it
+        return [{"error": repr(e)[:200]}]
+    dev_us = lambda e: getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0) or 0
+    is_kernel = lambda e: str(getattr(e, "device_type", "")).endswith("CUDA")
+    buckets = {"library GEMM (rocBLAS / Tensile Cijk_*)": 0.0, "ATen (elementwise, reductions, layout copies)": 0.0,
+               "MIOpen (the crop encoder's / discriminator's stock convolutions)": 0.0, "fused Adam": 0.0,
+               "runtime copies / memsets": 0.0, "RCCL": 0.0, "this repo's kernels (for reference)": 0.0, "unclassified": 0.0}
+    counts = {k: 0 for k in buckets}
+    for e in rows:
+        if not is_kernel(e):
+            continue
+        n, us = e.key, dev_us(e)
+        if n.startswith("Cijk_") or "Tensile" in n or "rocblas" in n.lower():
+            k = "library GEMM (rocBLAS / Tensile Cijk_*)"
+        elif "multi_tensor_apply" in n or "FusedAdam" in n or "fused_adam" in n.lower():
+            k = "fused Adam"
+        elif "miopen" in n.lower() or "MIOpen" in n or "naive_conv" in n or "igemm" in n.lower() or "gridwise" in n.lower():
+            k = "MIOpen (the crop encoder's / discriminator's stock convolutions)"
+        elif "at::native" in n or "at_cuda_detail" in n or "cub::" in n or "rocprim" in n or "elementwise" in n or "vectorized" in n:
+            k = "ATen (elementwise, reductions, layout copies)"
+        elif "rocclr" in n or "copyBuffer" in n or "fillBuffer" in n or n.lower().startswith("memcpy") or n.lower().startswith("memset"):
+            k = "runtime copies / memsets"
+        elif "nccl" in n.lower() or "rccl" in n.lower():
+            k = "RCCL"
+        elif "(anonymous namespace)::" in n or "gg2::" in n or "_kernel" in n and "void " in n and "at::" not in n:
+            k = "this repo's kernels (for reference)"
+        else:
+            k = "unclassified"
+        buckets[k] += us / 1e3
+        counts[k] += e.count
+    gemm_flops = 0.0
+    for e in rows:
+        if is_kernel(e) or e.key not in ("aten::mm", "aten::addmm", "aten::bmm", "aten::baddbmm"):
+            continue
+        sh = [s for s in (e.input_shapes or []) if len(s) >= 2]
+        if len(sh) < 2:
+            continue
+        a, b = sh[-2], sh[-1]
+        batch = a[0] if len(a) == 3 else 1
+        gemm_flops += 2.0 * batch * a[-2] * a[-1] * b[-1] * e.count
+    out = []
+    for k, ms in buckets.items():
+        if ms <= 0:
+            continue
+        row = {"bucket": k, "ms_per_step": round(ms, 3), "launches_per_step": counts[k]}
+        if k.startswith("library GEMM") and gemm_flops:
+            row["tflops"] = round(gemm_flops / (ms * 1e-3) / 1e12, 1)
+            row["gflop_per_step"] = round(gemm_flops / 1e9, 1)
+        out.append(row)
+    return out
+
+
 def _free_gpu():
     import gc
     gc.collect()
@@ -468,14 +532,15 @@ def leg_projector(args, rank, world, dev, steps, warmup):
         dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
         # EVERY rank runs the instrumented step (it contains DDP's all-reduces and SPADE's statistics all-reduce); rank 0 reports
         fams = time_projector_families(tr, data, 1) if not no_vgg else None
+        other = other_breakdown(lambda: tr.step(data), world) if not no_vgg else None
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
-        return dt, peak, fams
+        return dt, peak, fams, other
     # headline: the reference's step, VGG perceptual term included (pix2pix_model.py:119-120) -- torchvision's weights are
     # not obtainable offline, so the feature stack holds seeded random weights: same work, not the reference's loss value
-    dt, peak, fams = run(False)
-    dt0, _, _ = run(True)
+    dt, peak, fams, other = run(False)
+    dt0, _, _, _ = run(True)
     value, value0 = B * world * steps / dt, B * world * steps / dt0
     gflop = PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
     tf = gflop * value / world / 1e3
@@ -503,6 +568,7 @@ def leg_projector(args, rank, world, dev, steps, warmup):
                                    "instrumented step); achieved = the algorithmic conv FLOPs of exactly those launches "
                                    "(2*M*K*N from the launcher arguments) / their summed duration"}
         out["kernel_families"] = fams
+        out["other_breakdown"] = other   # what the table's last row is made of (one step under torch.profiler)
     del data
     _free_gpu()
     return out
@@ -528,12 +594,13 @@ def leg_joint(args, rank, world, dev, steps, warmup):
         fams = None if no_vgg else time_projector_families(
             tr, batch, 1, {**ENCODER_FAMILIES, **PROJECTOR_FAMILIES},
             "other (encoder BN / pooling / head passes, Sinkhorn, rasteriser, library GEMMs of the unfused layers, ATen glue, Adam)")
+        other = None if no_vgg else other_breakdown(lambda: tr.step(batch), world)
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
-        return dt, peak, fams
-    dt, peak, fams = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
-    dt0, _, _ = run(True)
+        return dt, peak, fams, other
+    dt, peak, fams, other = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
+    dt0, _, _, _ = run(True)
     value, value0 = B * world * steps / dt, B * world * steps / dt0
     enc_gflop = STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
     gflop = enc_gflop + PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
@@ -556,6 +623,7 @@ def leg_joint(args, rank, world, dev, steps, warmup):
                                 "regression legs" % (enc_gflop, PROJECTOR_STEP_GFLOP, VGG_STEP_GFLOP)}}
     if fams and rank == 0:
         out["kernel_families"] = fams
+        out["other_breakdown"] = other
     del batch
     _free_gpu()
     return out

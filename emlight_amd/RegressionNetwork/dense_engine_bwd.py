@@ -250,11 +250,24 @@ def _run_backward(enc, ws, x, gpooled):
             r = ring[0] = (ring[0] + 1) % bw.ring
             if bw.side is not None and bw.ev_done[r] is not None:
                 main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
-            _lib.check(L.eml_dense_conv3x3_bwd_data_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
-                                                        p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3d, p(blk["X"]), ld,
-                                                        cin, p(sB), p(sC), p(bw.GF12[r]), st),
-                       "eml_dense_conv3x3_bwd_data_f32")
-            if bw.side is None:
+            # round 4: data gradient + weight gradient of the layer in one pass over the tiles where the buffers allow the
+            # 16-byte staging (blocks 1 and 2; block 3 starts at channel 150) -- EML_C3_FOLD=0: the two launches (A/B)
+            fold = (bw.side is None and os.environ.get("EML_C3_FOLD", "1") != "0"
+                    and L.eml_dense_conv3x3_bwd_fused_supported(gsrc[1], gsrc[2], ld, cin) == 1)
+            if fold:
+                _lib.check(L.eml_dense_conv3x3_bwd_fused_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]), p(lay["zistd"]),
+                                                             p(dz), B, Hb, Wb, p(part), G3d, p(blk["X"]), ld, cin, p(sB),
+                                                             p(sC), p(bw.GF12[r]), p(lay["scale2"]), p(lay["shift2"]),
+                                                             p(bw.partW), gr(Lm.conv2.weight), st),
+                           "eml_dense_conv3x3_bwd_fused_f32")
+            else:
+                _lib.check(L.eml_dense_conv3x3_bwd_data_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]),
+                                                            p(lay["zistd"]), p(dz), B, Hb, Wb, p(part), G3d, p(blk["X"]), ld,
+                                                            cin, p(sB), p(sC), p(bw.GF12[r]), st),
+                           "eml_dense_conv3x3_bwd_data_f32")
+            if fold:
+                pass
+            elif bw.side is None:
                 _lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(bw.GF12[r]), 12, 0, p(z), p(lay["scale2"]),
                                                               p(lay["shift2"]), B, Hb, Wb, p(bw.partW),
                                                               gr(Lm.conv2.weight), G3, st),

@@ -12,10 +12,11 @@ LIB_PATH = os.environ.get("EML_LIB_PATH") or os.path.join(_HERE, "libemlight_hip
 
 _f32p = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _i32p = ctypes.c_void_p
+_f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 16   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 17   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -100,6 +101,9 @@ SIGNATURES = {
     # DenseNet-BC encoder, backward
     "eml_dense_conv3x3_bwd_data_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int,
                                               _f32p, _int, _f32p, _int, _int, _f32p, _f32p, _f32p, _stream]),
+    "eml_dense_conv3x3_bwd_fused_supported": (_int, [_int, _int, _int, _int]),
+    "eml_dense_conv3x3_bwd_fused_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _f64p, _int,
+                                               _f32p, _int, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _stream]),
     "eml_dense_conv3x3_bwd_weight_f32": (_int, [_f32p, _int, _int, _f32p, _f32p, _f32p, _int, _int, _int, _f32p,
                                                 _f32p, _int, _stream]),
     "eml_dense_bn_bwd_finalize_f32": (_int, [_f32p, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _int, _int,

@@ -504,6 +504,277 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
 }
 
 
+// =============================================================================== conv3x3 backward: data + weight, one pass
+// Round 4: conv3x3_bwd_data is bound by HBM (4.0 TB/s, 43 % of it written) with the matrix pipe half
+// idle; conv3x3_bwd_weight is bound by the matrix pipe and then re-reads the g and z tiles the data gradient had just
+// staged (24.8 GB per step).  Here one 512-thread workgroup does both for a tile: the g halo tile (double-buffered) feeds
+// the data gradient (K = 9 x 12) and, through its own-pixel rows, the weight gradient's k = pixel operand; the BN2(z)
+// halo tile -- the weight gradient's other operand -- is read ONCE (10 x 34 pixels, +33 % over the tile's own z, which the
+// statistics still take from HBM/L2 as raw z) into a single LDS buffer, refilled for the next tile from registers between
+// two barriers.  The data gradient's 81 weight fragments live in LDS (they were 81 VGPRs); the weight gradient's
+// accumulators persist across tiles exactly as in conv3x3_bwd_weight_kernel (same deal of the 27 (tap, 16-channel) tiles
+// to waves and halves, same tile order per workgroup -> bitwise the same partials for the same grid).
+// Needs the 16-byte staging of the WIDE path (channel offsets multiples of 4) and the fused BN1 affine (X given).
+__global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
+    const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
+    const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
+    double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx, int cx,
+    const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF,
+    const float* __restrict__ scale2, const float* __restrict__ shift2, float* __restrict__ partialW /*[2*grid][27][16][16]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kGT = kHH * kHW * kPSG;                 // floats of a g halo tile
+  float* g_l = smem;                                    // [2][kGT]
+  float* z_l = g_l + 2 * kGT;                           // [kHH * kHW][kPSW]   BN2(z) halo tile, zero outside the image
+  float* w_l = z_l + kHH * kHW * kPSW;                  // [27][3][64]         data-gradient A fragments
+  float* coef_l = w_l + 27 * 3 * 64;                    // [24 (+8)]           sB | sC of the layer's 12 channels
+  double* red = reinterpret_cast<double*>(coef_l + 32); // [8][48][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int half = wave >> 2, w4 = wave & 3;
+
+  // data-gradient fragments (D^T form): entry ((tap*3 + s)*3 + n)*64 + (kk*16 + r) = W2[o = 4s + kk][c = 16n + r][tap]
+  for (int e = tid; e < 27 * 3 * 64; e += 512) {
+    const int l = e & 63, g3 = e >> 6, n = g3 % 3, ts = g3 / 3, s3 = ts % 3, tap = ts / 3;
+    w_l[e] = W2[((size_t)(4 * s3 + (l >> 4)) * 48 + 16 * n + (l & 15)) * 9 + tap];
+  }
+  if (tid < 24) coef_l[tid] = tid < 12 ? sB[cx + tid] : sC[cx + tid - 12];
+
+  // weight-gradient accumulators and operand offsets (conv3x3_bwd_weight_kernel)
+  f32x4 accw[7];
+  int aoff[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    accw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int idx = min(w4 + 4 * i, 26), tap = idx / 3, mc = idx - 3 * tap;
+    aoff[i] = ((tap / 3 + 4 * half) * kHW + (tap % 3) + kk) * kPSW + 16 * mc + r;
+  }
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int ntiles = B * ty_n * tx_n;
+  // BatchNorm statistics: f64 running sums per (wave, channel) in LDS (`red`), updated once per tile by the lane that owns
+  // the channel after a DPP reduction over the 16 pixel lanes -- as 48 VGPRs of doubles they pushed the kernel into spills
+  for (int e = tid; e < 8 * 48 * 2; e += 512) red[e] = 0.0;
+
+  // ---- g halo staging (the WIDE map of conv3x3_bwd_data_kernel): item t = tid + 512*it, halo pixel t / 3, float4 t % 3
+  constexpr int kWideItems = kHH * kHW * 3;
+  int w_hy[2], w_hx[2], w_q[2], w_pix[2];
+  bool w_ok[2], w_own[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = min(tid + 512 * it, kWideItems - 1), hp = t / 3;
+    w_q[it] = t - 3 * hp;
+    w_hy[it] = hp / kHW;
+    w_hx[it] = hp - w_hy[it] * kHW;
+  }
+  float4 gt4[2], xt4[2];
+  // ---- z halo staging (conv3x3_bwd_weight_kernel): thread = (halo column, 16-byte slice), one halo row per pass
+  const int s_hx = min(tid / 12, kHW - 1), s_q = tid % 12;
+  const float4 sc = *reinterpret_cast<const float4*>(scale2 + 4 * s_q);
+  const float4 sh = *reinterpret_cast<const float4*>(shift2 + 4 * s_q);
+  const int s_dst = s_hx * kPSW + 4 * s_q;
+  float4 zt[kHH];
+  const float* s_src = Z;
+  int s_y0 = 0;
+  bool s_col = false;
+  auto stage_begin = [&](int tile) {
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int gy = ty * kTH - 1 + w_hy[it], gx = tx * kTW - 1 + w_hx[it];
+      w_ok[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      w_pix[it] = (b * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1);
+      w_own[it] = w_ok[it] && w_hy[it] >= 1 && w_hy[it] <= kTH && w_hx[it] >= 1 && w_hx[it] <= kTW;
+    }
+    const int gx = tx * kTW - 1 + s_hx;
+    s_y0 = ty * kTH - 1;
+    s_col = gx >= 0 && gx < W;
+    s_src = Z + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * 48 + 4 * s_q;
+  };
+  auto g_load = [&](int it) {   // unconditional, clamped
+    gt4[it] = *reinterpret_cast<const float4*>(G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it]);
+    xt4[it] = *reinterpret_cast<const float4*>(Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it]);
+  };
+  auto g_commit = [&](int it, float* dst) {
+    const float4 fb4 = *reinterpret_cast<const float4*>(coef_l + 4 * w_q[it]);
+    const float4 fc4 = *reinterpret_cast<const float4*>(coef_l + 12 + 4 * w_q[it]);
+    float4 v;
+    v.x = fmaf(fb4.x, xt4[it].x, gt4[it].x) + fc4.x;
+    v.y = fmaf(fb4.y, xt4[it].y, gt4[it].y) + fc4.y;
+    v.z = fmaf(fb4.z, xt4[it].z, gt4[it].z) + fc4.z;
+    v.w = fmaf(fb4.w, xt4[it].w, gt4[it].w) + fc4.w;
+    if (!w_ok[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = dst + (w_hy[it] * kHW + w_hx[it]) * kPSG + 4 * w_q[it];   // 56-byte pixel stride: 8-byte aligned
+    *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    if (w_own[it]) *reinterpret_cast<float4*>(GF + (size_t)w_pix[it] * 12 + 4 * w_q[it]) = v;
+  };
+  auto z_load = [&](int it) {
+    zt[it] = *reinterpret_cast<const float4*>(s_src + (size_t)min(max(s_y0 + it, 0), H - 1) * W * 48);
+  };
+  auto z_commit = [&](int it) {
+    const bool ok = s_col && s_y0 + it >= 0 && s_y0 + it < H;
+    float4 v;
+    v.x = ok ? fmaf(zt[it].x, sc.x, sh.x) : 0.f;
+    v.y = ok ? fmaf(zt[it].y, sc.y, sh.y) : 0.f;
+    v.z = ok ? fmaf(zt[it].z, sc.z, sh.z) : 0.f;
+    v.w = ok ? fmaf(zt[it].w, sc.w, sh.w) : 0.f;
+    *reinterpret_cast<float4*>(z_l + s_dst + it * kHW * kPSW) = v;   // threads >= 408 duplicate column 33
+  };
+
+  int tile = blockIdx.x, cur = 0;
+  __syncthreads();   // coef_l, w_l
+  if (tile < ntiles) {
+    stage_begin(tile);
+    g_load(0);
+    g_load(1);
+#pragma unroll
+    for (int it = 0; it < kHH; ++it) z_load(it);
+    g_commit(0, g_l);
+    g_commit(1, g_l);
+#pragma unroll
+    for (int it = 0; it < kHH; ++it) z_commit(it);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const float* gc = g_l + cur * kGT;
+    float* gn = g_l + (cur ^ 1) * kGT;
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int gy = ty * kTH + wave;
+    size_t prow[2];
+    bool pv[2];
+    float4 zr[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int gx = tx * kTW + 16 * m + r;
+      pv[m] = gy < H && gx < W;
+      prow[m] = ((size_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * 48;
+    }
+    stage_begin(nxt < ntiles ? nxt : tile);   // (the last tile re-stages itself: loads stay unconditional)
+
+    // ------------------------------------------------------------------ phase A: data gradient (162 MFMAs per wave)
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int gi = tap * 3 + s3;
+        if (gi < 2) {
+          g_load(gi);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (gi < 8) {
+          const int zi = gi - 2;
+          zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        float a[2], wv[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) wv[n] = w_l[(gi * 3 + n) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a[m] = gc[((wave + 2 - dy) * kHW + 16 * m + r + 2 - dx) * kPSG + 4 * s3 + kk];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(wv[n], a[m], acc[m][n]);  // D[channel][pixel]
+        if (gi >= 25) {
+          __builtin_amdgcn_sched_barrier(0);
+          g_commit(gi - 25, gn);
+        }
+      }
+    }
+    // statistics, then the dzn stores (see conv3x3_bwd_data_kernel for the ordering notes)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float4 z = zr[m][n];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v = pv[m] ? acc[m][n][g] : 0.f;
+          l1[g] += v;
+          l2[g] = fmaf(v, f4c(z, g), l2[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float t1 = eml::row16_sum(l1[g]), t2 = eml::row16_sum(l2[g]);   // over this tile row's 32 pixels (2 per lane)
+        if (r == 0) {   // wave-private slots: no other lane touches them
+          double* d = red + (wave * 48 + 16 * n + 4 * kk + g) * 2;
+          d[0] += (double)t1;
+          d[1] += (double)t2;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      if (pv[m]) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+          *reinterpret_cast<float4*>(DZ + prow[m] + 16 * n + 4 * kk) =
+              make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ------------------------------------------------------------------ phase B: weight gradient (216 MFMAs per wave)
+    // k = pixel: lane (kk, o = r) takes g of own pixel 128*half + 4*ks + kk from the g halo tile (halo row / column + 1);
+    // the next tile's z halo rows are requested under the first 10 k-steps and committed after the barrier below
+    const float* gl_c = gc + ((4 * half + 1) * kHW + kk + 1) * kPSG + min(r, 11);
+    float av[2][7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) av[0][i] = z_l[aoff[i]];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks < kHH) z_load(ks);
+      if (ks + 1 < 32) {
+        const float* base = z_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float gv = r < 12 ? gl_c[((ks >> 3) * kHW + 4 * (ks & 7)) * kPSG] : 0.f;   // zero outside the image (staged so)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) accw[i] = mfma16(av[ks & 1][i], gv, accw[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    eml::lds_barrier();          // everyone is done with z_l and g_l[cur]; g_l[cur ^ 1] is complete
+#pragma unroll
+    for (int it = 0; it < kHH; ++it) z_commit(it);
+    eml::lds_barrier();          // the next tile's z halo is in place
+    cur ^= 1;
+  }
+  // ---- outputs: weight-gradient partials per (workgroup, half), then the BatchNorm statistics
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int idx = w4 + 4 * i;
+    if (idx < 27) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        partialW[((((size_t)blockIdx.x * 2 + half) * 27 + idx) * 16 + 4 * kk + g) * 16 + r] = accw[i][g];
+    }
+  }
+  __syncthreads();
+  if (tid < 48) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) {
+      t1 += red[(w8 * 48 + tid) * 2 + 0];
+      t2 += red[(w8 * 48 + tid) * 2 + 1];
+    }
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 0] = t1;
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 1] = (double)zistd[tid] * (t2 - (double)zmean[tid] * t1);
+  }
+}
+
+
 // =============================================================================== BN backward: finalize
 // From the partial (S1 = sum dy, S2 = sum dy*xhat) of C channels: dgamma = S2, dbeta = S1 and the
 // per-channel affine of the input gradient  dx = cA*dy + cB*x + cC  where
@@ -1988,6 +2259,34 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partial, 2 * grid,
                      (size_t)27 * 256, 1, 0, 0, 0, dW2);
   return eml::check_launch("eml_dense_conv3x3_bwd_weight_f32(reduce)");
+}
+
+// One launch for the pair above (see conv3x3_bwd_fused_kernel).  Returns EML_EINVAL when the buffers do not allow the
+// 16-byte staging (the caller then issues the two separate launches).
+extern "C" int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx) {
+  return ((ldg & 3) == 0 && (c0 & 3) == 0 && (ldx & 3) == 0 && (cx & 3) == 0) ? 1 : 0;
+}
+extern "C" int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
+                                               const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
+                                               double* partials, int grid, const float* X, int ldx, int cx,
+                                               const float* sB, const float* sC, float* GF, const float* scale2,
+                                               const float* shift2, float* partialW, float* dW2, eml_stream_t stream) {
+  if (!G || !W2 || !Z || !zmean || !zistd || !DZ || !partials || !X || !sB || !sC || !GF || !scale2 || !shift2 || !partialW ||
+      !dW2 || B < 1 || H < 1 || W < 1 || grid < 1 || cx < 0)
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: bad arguments");
+  const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!eml_dense_conv3x3_bwd_fused_supported(ldg, c0, ldx, cx) || !al16(G) || !al16(X) || !al16(sB) || !al16(sC) || !al16(GF) ||
+      !al16(Z) || !al16(scale2) || !al16(shift2))
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: needs ldg, c0, ldx, cx multiples of 4 and 16-byte aligned buffers");
+  const size_t lds = (size_t)(2 * kHH * kHW * kPSG + kHH * kHW * kPSW + 27 * 3 * 64 + 32) * sizeof(float) + 8 * 48 * 2 * sizeof(double);
+  EML_ENSURE_LDS((&conv3x3_bwd_fused_kernel), lds);
+  hipLaunchKernelGGL(conv3x3_bwd_fused_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean, zistd,
+                     DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  int rc = eml::check_launch("eml_dense_conv3x3_bwd_fused_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partialW, 2 * grid,
+                     (size_t)27 * 256, 1, 0, 0, 0, dW2);
+  return eml::check_launch("eml_dense_conv3x3_bwd_fused_f32(reduce)");
 }
 
 extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,

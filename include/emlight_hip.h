@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 16
+#define EML_ABI_VERSION 17
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -231,6 +231,20 @@ int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float*
                                    const float* zmean, const float* zistd, float* DZ, int B, int H,
                                    int W, double* partials, int grid, const float* X, int ldx, int cx,
                                    const float* sB, const float* sC, float* GF, eml_stream_t stream);
+
+/* The two launches around this comment as ONE pass over the tiles (round 4): the data gradient with the fused BN1 affine
+ * (X, sB, sC, GF as in eml_dense_conv3x3_bwd_data_f32 with X != NULL) and the weight gradient of the same layer,
+ * dW2 = sum_p g[p] (x) (scale2*Z + shift2)[p+tap], whose g and z tiles the data gradient has just staged: the BN2(z) halo
+ * tile is read once for both (autograd of DenseNet.py:38-43: conv2's backward w.r.t. its input and its weight).
+ * Needs ldg, c0, ldx, cx multiples of 4 and 16-byte aligned buffers (eml_dense_conv3x3_bwd_fused_supported; otherwise
+ * EML_EINVAL: issue the two launches).  partials / grid as the data gradient's, partialW (2*grid*27*256 floats) / dW2 as
+ * the weight gradient's: for the same grid the weight gradient is bitwise what the separate launch returns. */
+int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx);
+int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
+                                    const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
+                                    double* partials, int grid, const float* X, int ldx, int cx,
+                                    const float* sB, const float* sC, float* GF, const float* scale2,
+                                    const float* shift2, float* partialW, float* dW2, eml_stream_t stream);
 
 /* dW2 (12,48,3,3) = sum_p G[p, c0:c0+12] (x) (scale2*Z + shift2)[p+tap]; partial: 2*grid*27*256 floats (two pixel halves per block). */
 int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0, const float* Z,

@@ -294,6 +294,62 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
     close(dW2, w.grad, what="dW2 (compact g)", rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W,c0,ld,compact", [(2, 20, 44, 24, 64, False), (1, 8, 32, 108, 128, True), (3, 7, 9, 36, 64, True),
+                                                   (4, 24, 64, 60, 224, False), (2, 17, 70, 120, 304, True)])
+def test_conv3x3_bwd_fused_equals_the_two_launches(lib, B, H, W, c0, ld, compact):
+    """Round 4: data gradient (with the fused BN1 affine) + weight gradient of a layer in ONE pass over the tiles
+    (conv3x3_bwd_fused_kernel) against the two separate launches on the same buffers and the same grid: dzn, GF and dW2
+    bitwise (same MFMA order, same tile order per workgroup), the BatchNorm statistics to f32 round-off of a 32-pixel row sum
+    (they are reduced over the tile row before the f64 accumulation instead of after it), and all of it against f64 autograd.
+    Ragged tiles (H, W not multiples of 8 / 32), the block gradient and the compact (P, 12) tensor as the g source."""
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    P = B * H * W
+    Gd, Z, X = rnd(P, ld), rnd(P, 48), rnd(P, ld)
+    N12 = rnd(P, 12)
+    W2 = rnd(12, 48, 3, 3, scale=0.05)
+    s2, t2 = torch.rand(48, device=DEV) + 0.5, rnd(48, scale=0.3)
+    zmean, zistd = rnd(48, scale=0.1), torch.rand(48, device=DEV) + 0.5
+    sB, sC = rnd(ld, scale=0.3), rnd(ld, scale=0.3)
+    gsrc = (N12, 12, 0) if compact else (Gd, ld, c0)
+    assert L.eml_dense_conv3x3_bwd_fused_supported(gsrc[1], gsrc[2], ld, c0) == 1
+    out = {}
+    for mode in ("two", "one"):
+        DZ = torch.full((P, 48), 3.0, device=DEV)
+        GF = torch.full((P, 12), 7.0, device=DEV)
+        part = torch.zeros(G * 96, dtype=torch.float64, device=DEV)
+        partW = torch.zeros(2 * G * 27 * 256, device=DEV)
+        dW2 = torch.empty(12, 48, 3, 3, device=DEV)
+        if mode == "two":
+            lib.check(L.eml_dense_conv3x3_bwd_data_f32(p(gsrc[0]), gsrc[1], gsrc[2], p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H, W,
+                                                       p(part), G, p(X), ld, c0, p(sB), p(sC), p(GF), st), "c3 bwd data")
+            lib.check(L.eml_dense_conv3x3_bwd_weight_f32(p(GF), 12, 0, p(Z), p(s2), p(t2), B, H, W, p(partW), p(dW2), G, st),
+                      "c3 bwd weight")
+        else:
+            lib.check(L.eml_dense_conv3x3_bwd_fused_f32(p(gsrc[0]), gsrc[1], gsrc[2], p(W2), p(Z), p(zmean), p(zistd), p(DZ), B, H,
+                                                        W, p(part), G, p(X), ld, c0, p(sB), p(sC), p(GF), p(s2), p(t2), p(partW),
+                                                        p(dW2), st), "c3 bwd fused")
+        out[mode] = (DZ, GF, dW2, fold_partials(part, G, 48))
+    for name, a, b in zip(("dzn", "GF", "dW2"), out["one"][:3], out["two"][:3]):
+        assert torch.equal(a, b), "%s differs from the separate launches: max %g" % (name, float((a - b).abs().max()))
+    for a, b, name in zip(out["one"][3], out["two"][3], ("S1", "S2")):
+        close(a, b, what=name + " vs the separate launch", rtol=1e-6, atol=1e-5 * float(b.abs().max()))
+    # and against f64 autograd
+    g0 = gsrc[0][:, gsrc[2]:gsrc[2] + 12].double()
+    gfull = g0 + sB[c0:c0 + 12].double() * X[:, c0:c0 + 12].double() + sC[c0:c0 + 12].double()
+    zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W).requires_grad_(True)
+    w = W2.double().requires_grad_(True)
+    (F.conv2d(zn, w, padding=1) * nchw(gfull, B, H, W)).sum().backward()
+    dzn = nhwc(zn.grad)
+    close(out["one"][0], dzn, what="dzn vs f64")
+    close(out["one"][1], gfull, what="GF vs f64", rtol=1e-6, atol=1e-6)
+    close(out["one"][2], w.grad, what="dW2 vs f64", rtol=1e-4)
+    zh = (Z.double() - zmean.double()) * zistd.double()
+    close(out["one"][3][0], dzn.sum(0), what="S1 vs f64", rtol=1e-6, atol=1e-4)
+    close(out["one"][3][1], (dzn * zh).sum(0), what="S2 vs f64", rtol=1e-6, atol=1e-4)
+    # unaligned channel offsets are refused (block 3 of EMLight's encoder starts at channel 150)
+    assert L.eml_dense_conv3x3_bwd_fused_supported(176, 162, 176, 162) == 0
+
+
 def test_bn_bwd_finalize(lib):
     L, p, st = lib.lib(), lib.ptr, lib.current_stream()
     C, Cpad, R, n = 150, 160, 37, 1234.0
