@@ -244,9 +244,11 @@ __global__ __launch_bounds__(TH * 64, 2) void conv3x3_bwd_data_kernel(
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float aq[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aq[0][m] = gc[((wave + 2) * kHW + 16 * m + r + 2) * kPSG + kk];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int gi = tap * 3 + s;
@@ -258,14 +260,17 @@ __global__ __launch_bounds__(TH * 64, 2) void conv3x3_bwd_data_kernel(
           zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
           __builtin_amdgcn_sched_barrier(0);
         }
-        float a[2];
+        if (gi + 1 < 27) {   // the g operand of group gi + 1 is requested before the MFMAs of group gi (round 4)
+          const int tn = (gi + 1) / 3, sn = (gi + 1) - 3 * tn, dyn = tn / 3, dxn = tn - 3 * dyn;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            aq[(gi + 1) & 1][m] = gc[((wave + 2 - dyn) * kHW + 16 * m + r + 2 - dxn) * kPSG + 4 * sn + kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a[m] = gc[((wave + 2 - dy) * kHW + 16 * m + r + 2 - dx) * kPSG + 4 * s + kk];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(bw[tap][s][n], a[m], acc[m][n]);  // D[channel][pixel]
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(bw[tap][s][n], aq[gi & 1][m], acc[m][n]);  // D[channel][pixel]
         if (gi >= 27 - kPass) {
           __builtin_amdgcn_sched_barrier(0);
           stage_commit(gi - (27 - kPass), gn);
@@ -463,8 +468,11 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
     const float* gl_c = gl_base + cur * kGL + (128 * half + kk) * 12 + min(r, 11);
     float* gl_n = gl_base + (cur ^ 1) * kGL;
     float av[2][7];  // A fragments are read one k-step ahead of their MFMAs (the fences below pin this order)
+    float gvl[2] = {0.f, 0.f};   // GLDS: so is the g operand -- read with the CURRENT step it made every MFMA group wait
+                                 // for the prefetch issued in front of it (lgkmcnt(0))
 #pragma unroll
     for (int i = 0; i < 7; ++i) av[0][i] = tile_l[aoff[i]];
+    if constexpr (GLDS) gvl[0] = gl_c[0];
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
       if (ks < kHH) stage_load(ks);
@@ -473,11 +481,12 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
         const float* base = tile_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
 #pragma unroll
         for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
+        if constexpr (GLDS) gvl[(ks + 1) & 1] = gl_c[4 * (ks + 1) * 12];
       }
       __builtin_amdgcn_sched_barrier(0);
       float gv;
       if constexpr (GLDS) {
-        gv = r < 12 ? gl_c[4 * ks * 12] : 0.f;   // lanes 12..15 of a row: the unused MFMA columns
+        gv = r < 12 ? gvl[ks & 1] : 0.f;   // lanes 12..15 of a row: the unused MFMA columns
       } else {
         const bool gok = r < 12 && cy0 + (ks >> 3) < H && cx0 + 4 * (ks & 7) < W;
         gv = gok ? gb[ks] : 0.f;
@@ -659,9 +668,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float aq[2][2], wq[2][3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) wq[0][n] = w_l[n * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aq[0][m] = gc[((wave + 2) * kHW + 16 * m + r + 2) * kPSG + kk];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
         const int gi = tap * 3 + s3;
@@ -673,16 +686,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
           zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
           __builtin_amdgcn_sched_barrier(0);
         }
-        float a[2], wv[3];
+        // operands of group gi + 1 are requested before the MFMAs of group gi (read right in front of their MFMAs every
+        // group of 6 waited out an LDS round trip)
+        if (gi + 1 < 27) {
+          const int tn = (gi + 1) / 3, sn = (gi + 1) - 3 * tn, dyn = tn / 3, dxn = tn - 3 * dyn;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) wv[n] = w_l[(gi * 3 + n) * 64 + lane];
+          for (int n = 0; n < 3; ++n) wq[(gi + 1) & 1][n] = w_l[((gi + 1) * 3 + n) * 64 + lane];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            aq[(gi + 1) & 1][m] = gc[((wave + 2 - dyn) * kHW + 16 * m + r + 2 - dxn) * kPSG + 4 * sn + kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a[m] = gc[((wave + 2 - dy) * kHW + 16 * m + r + 2 - dx) * kPSG + 4 * s3 + kk];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(wv[n], a[m], acc[m][n]);  // D[channel][pixel]
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(wq[gi & 1][n], aq[gi & 1][m], acc[m][n]);  // D[channel][pixel]
         if (gi >= 25) {
           __builtin_amdgcn_sched_barrier(0);
           g_commit(gi - 25, gn);
@@ -728,9 +746,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
     // k = pixel: lane (kk, o = r) takes g of own pixel 128*half + 4*ks + kk from the g halo tile (halo row / column + 1);
     // the next tile's z halo rows are requested under the first 10 k-steps and committed after the barrier below
     const float* gl_c = gc + ((4 * half + 1) * kHW + kk + 1) * kPSG + min(r, 11);
-    float av[2][7];
+    float av[2][7], gvl[2];   // both operands are read one k-step ahead of their MFMAs
 #pragma unroll
     for (int i = 0; i < 7; ++i) av[0][i] = z_l[aoff[i]];
+    gvl[0] = gl_c[0];
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
       if (ks < kHH) z_load(ks);
@@ -738,9 +757,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
         const float* base = z_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
 #pragma unroll
         for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
+        gvl[(ks + 1) & 1] = gl_c[(((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSG];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const float gv = r < 12 ? gl_c[((ks >> 3) * kHW + 4 * (ks & 7)) * kPSG] : 0.f;   // zero outside the image (staged so)
+      const float gv = r < 12 ? gvl[ks & 1] : 0.f;   // (zero outside the image: staged so)
 #pragma unroll
       for (int i = 0; i < 7; ++i) accw[i] = mfma16(av[ks & 1][i], gv, accw[i]);
       __builtin_amdgcn_sched_barrier(0);
