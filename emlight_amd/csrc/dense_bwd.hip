@@ -620,8 +620,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
   auto z_load = [&](int it) {
     zt[it] = *reinterpret_cast<const float4*>(s_src + (size_t)min(max(s_y0 + it, 0), H - 1) * W * 48);
   };
-  auto z_commit = [&](int it) {
-    const bool ok = s_col && s_y0 + it >= 0 && s_y0 + it < H;
+  auto z_commit = [&](int it, int y0, bool col) {
+    const bool ok = col && y0 + it >= 0 && y0 + it < H;
     float4 v;
     v.x = ok ? fmaf(zt[it].x, sc.x, sh.x) : 0.f;
     v.y = ok ? fmaf(zt[it].y, sc.y, sh.y) : 0.f;
@@ -631,19 +631,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
   };
 
   int tile = blockIdx.x, cur = 0;
-  __syncthreads();   // coef_l, w_l
+  __syncthreads();   // coef_l, w_l, red
   if (tile < ntiles) {
     stage_begin(tile);
     g_load(0);
     g_load(1);
 #pragma unroll
-    for (int it = 0; it < kHH; ++it) z_load(it);
+    for (int it = 0; it < kHH; ++it) z_load(it);   // committed by the first phase A, like every later tile's
     g_commit(0, g_l);
     g_commit(1, g_l);
-#pragma unroll
-    for (int it = 0; it < kHH; ++it) z_commit(it);
   }
   __syncthreads();
+  // Per tile: phase A (data gradient) with the z halo's LDS commit riding on it; barrier; phase B (weight gradient) with
+  // the data gradient's epilogue (statistics, dzn stores) and the next tile's z halo loads riding on it; barrier.  Nothing
+  // but MFMA-fed work sits between the barriers: with one workgroup per CU the two waves of a SIMD share every phase, so
+  // any serial section (the epilogue was ~150 VALU + 6 stores per lane, the z commit 10 ds_write_b128) idled the matrix pipe.
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
     const float* gc = g_l + cur * kGT;
@@ -660,6 +662,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
       pv[m] = gy < H && gx < W;
       prow[m] = ((size_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * 48;
     }
+    // validity of THIS tile's z halo rows / column (stage_begin below moves on to the next tile)
+    const int cz_y0 = s_y0;
+    const bool cz_col = s_col;
     stage_begin(nxt < ntiles ? nxt : tile);   // (the last tile re-stages itself: loads stay unconditional)
 
     // ------------------------------------------------------------------ phase A: data gradient (162 MFMAs per wave)
@@ -681,9 +686,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
         if (gi < 2) {
           g_load(gi);
           __builtin_amdgcn_sched_barrier(0);
-        } else if (gi < 8) {
-          const int zi = gi - 2;
-          zr[zi / 3][zi % 3] = *reinterpret_cast<const float4*>(Z + prow[zi / 3] + 16 * (zi % 3) + 4 * kk);
+        } else if (gi < 2 + kHH) {
+          z_commit(gi - 2, cz_y0, cz_col);   // this tile's BN2(z) halo row: nobody reads z_l before the barrier below
           __builtin_amdgcn_sched_barrier(0);
         }
         // operands of group gi + 1 are requested before the MFMAs of group gi (read right in front of their MFMAs every
@@ -707,41 +711,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
         }
       }
     }
-    // statistics, then the dzn stores (see conv3x3_bwd_data_kernel for the ordering notes)
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float4 z = zr[m][n];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v = pv[m] ? acc[m][n][g] : 0.f;
-          l1[g] += v;
-          l2[g] = fmaf(v, f4c(z, g), l2[g]);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float t1 = eml::row16_sum(l1[g]), t2 = eml::row16_sum(l2[g]);   // over this tile row's 32 pixels (2 per lane)
-        if (r == 0) {   // wave-private slots: no other lane touches them
-          double* d = red + (wave * 48 + 16 * n + 4 * kk + g) * 2;
-          d[0] += (double)t1;
-          d[1] += (double)t2;
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-      if (pv[m]) {
-#pragma unroll
-        for (int n = 0; n < 3; ++n)
-          *reinterpret_cast<float4*>(DZ + prow[m] + 16 * n + 4 * kk) =
-              make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-
+    eml::lds_barrier();          // this tile's z halo is in place (and g_l[cur ^ 1] complete)
     // ------------------------------------------------------------------ phase B: weight gradient (216 MFMAs per wave)
     // k = pixel: lane (kk, o = r) takes g of own pixel 128*half + 4*ks + kk from the g halo tile (halo row / column + 1);
     // the next tile's z halo rows are requested under the first 10 k-steps and committed after the barrier below
@@ -752,7 +722,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
     gvl[0] = gl_c[0];
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
-      if (ks < kHH) z_load(ks);
+      // requests riding on this phase: the tile's own raw z rows (statistics, k-steps 0..5), then the NEXT tile's z halo
+      if (ks < 6) zr[ks / 3][ks % 3] = *reinterpret_cast<const float4*>(Z + prow[ks / 3] + 16 * (ks % 3) + 4 * kk);
+      else if (ks < 6 + kHH) z_load(ks - 6);
       if (ks + 1 < 32) {
         const float* base = z_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
 #pragma unroll
@@ -763,12 +735,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
       const float gv = r < 12 ? gvl[ks & 1] : 0.f;   // (zero outside the image: staged so)
 #pragma unroll
       for (int i = 0; i < 7; ++i) accw[i] = mfma16(av[ks & 1][i], gv, accw[i]);
+      // the data gradient's epilogue, piecewise behind these MFMAs: statistics of channel group n at k-step 16 + n (its z
+      // rows were requested ten k-steps ago), then one 16-byte dzn store per k-step
+      if (ks >= 6 + kHH && ks < 9 + kHH) {
+        const int n = ks - (6 + kHH);
+        float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float4 z = zr[m][n];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v = pv[m] ? acc[m][n][g] : 0.f;
+            l1[g] += v;
+            l2[g] = fmaf(v, f4c(z, g), l2[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float t1 = eml::row16_sum(l1[g]), t2 = eml::row16_sum(l2[g]);   // over this tile row's 32 pixels
+          if (r == 0) {   // wave-private slots: no other lane touches them
+            double* d = red + (wave * 48 + 16 * n + 4 * kk + g) * 2;
+            d[0] += (double)t1;
+            d[1] += (double)t2;
+          }
+        }
+      } else if (ks >= 9 + kHH && ks < 15 + kHH) {
+        const int si = ks - (9 + kHH), m = si / 3, n = si - 3 * m;
+        if (pv[m])
+          *reinterpret_cast<float4*>(DZ + prow[m] + 16 * n + 4 * kk) =
+              make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    eml::lds_barrier();          // everyone is done with z_l and g_l[cur]; g_l[cur ^ 1] is complete
-#pragma unroll
-    for (int it = 0; it < kHH; ++it) z_commit(it);
-    eml::lds_barrier();          // the next tile's z halo is in place
+    eml::lds_barrier();          // everyone is done with z_l and g_l[cur]
     cur ^= 1;
   }
   // ---- outputs: weight-gradient partials per (workgroup, half), then the BatchNorm statistics
