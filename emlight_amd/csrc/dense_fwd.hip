@@ -380,9 +380,11 @@ __global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     // wave w owns output row w; pixel tile m = 16 columns at 16*m.  D^T form (weights as the A operand): lane
     // (r, kk) ends up with output channels 4kk..4kk+3 of pixel 16m + r -> one 16-byte store per pixel tile.
+    float4 aq[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aq[0][m] = *reinterpret_cast<const float4*>(tile_l + (wave * kHW + 16 * m + r) * kPS + 4 * kk);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int gi = tap * 3 + j;
@@ -390,14 +392,20 @@ __global__ __launch_bounds__(kC3Threads) void conv3x3_fwd_kernel(
           stage_load(gi);
           __builtin_amdgcn_sched_barrier(0);  // keep the load HERE: the scheduler otherwise sinks it to its use
         }
-        float4 a[2];
+        // the operand of group gi + 1 is requested before the MFMAs of group gi (round 4: read right in front of its
+        // MFMAs, every group of 8 waited out an LDS round trip -- both waves of a SIMD share the phase here)
+        if (gi + 1 < 27) {
+          const int tn = (gi + 1) / 3, jn = (gi + 1) - 3 * tn, dyn = tn / 3, dxn = tn - 3 * dyn;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-          a[m] = *reinterpret_cast<const float4*>(tile_l + ((wave + dy) * kHW + 16 * m + r + dx) * kPS + 16 * j + 4 * kk);
+          for (int m = 0; m < 2; ++m)
+            aq[(gi + 1) & 1][m] =
+                *reinterpret_cast<const float4*>(tile_l + ((wave + dyn) * kHW + 16 * m + r + dxn) * kPS + 16 * jn + 4 * kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[m] = mfma16(f4c(bw[tap][j], t), f4c(a[m], t), acc[m]);
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(f4c(bw[tap][j], t), f4c(aq[gi & 1][m], t), acc[m]);
         if (gi >= 27 - kHH) {
           __builtin_amdgcn_sched_barrier(0);
           stage_commit(gi - (27 - kHH), tile_n);
