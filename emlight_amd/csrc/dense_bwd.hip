@@ -1131,6 +1131,9 @@ __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd
         ng[1] = *reinterpret_cast<const float2*>(gs + 2);
       }
       if constexpr (NGW > 0) {
+        float bzq[2][3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bzq[0][n] = dzb[kk * 48 + 16 * n + r];
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
           const int q0 = bi * UQ;
@@ -1143,9 +1146,15 @@ __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd
           for (int u = 0; u < UQ; ++u) {
             const int pl = 4 * (q0 + u) + kk;
             const bool pvu = chunk * 64 + pl < P;
+            // the dz fragments of the NEXT pixel quad are requested before this quad's MFMAs (round 4; quad 0 of a chunk
+            // is read right after the chunk's barrier, below)
             float bz[3];
 #pragma unroll
-            for (int n = 0; n < 3; ++n) bz[n] = dzb[pl * 48 + 16 * n + r];
+            for (int n = 0; n < 3; ++n) bz[n] = bzq[(q0 + u) & 1][n];
+            if (q0 + u + 1 < 16) {
+#pragma unroll
+              for (int n = 0; n < 3; ++n) bzq[(q0 + u + 1) & 1][n] = dzb[(pl + 4) * 48 + 16 * n + r];
+            }
 #pragma unroll
             for (int i = 0; i < NGW; ++i) {
               float av[VEC];
