@@ -8,6 +8,8 @@ it is built once, vectorised in float64 numpy (the reference loops H*W times in 
 from functools import lru_cache
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 from torch.nn.parameter import Parameter
@@ -665,7 +667,8 @@ class SphereConv2D(nn.Module):
     stock ops (grid_sample + conv2d) are restated in ``oracle/projector.py`` for the tests."""
 
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
-    fused_min_bytes = 64 << 20   # unit of the fused-kernel thresholds on the size of the im2col operand (see forward)
+    # unit of the fused-kernel thresholds on the size of the im2col operand (see forward); EML_FUSED_MIN_MB: A/B knob
+    fused_min_bytes = int(os.environ.get("EML_FUSED_MIN_MB", "64")) << 20
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()
