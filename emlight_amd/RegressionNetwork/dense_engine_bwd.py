@@ -250,8 +250,8 @@ def _run_backward(enc, ws, x, gpooled):
             r = ring[0] = (ring[0] + 1) % bw.ring
             if bw.side is not None and bw.ev_done[r] is not None:
                 main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
-            # round 4: data gradient + weight gradient of the layer in one pass over the tiles where the buffers allow the
-            # 16-byte staging (blocks 1 and 2; block 3 starts at channel 150) -- EML_C3_FOLD=0: the two launches (A/B)
+            # round 4: data gradient + weight gradient of the layer in one pass over the tiles (16-byte staging loads in
+            # blocks 1 and 2, pairs of 8-byte ones in block 3, which starts at channel 150) -- EML_C3_FOLD=0: the two launches (A/B)
             fold = (bw.side is None and os.environ.get("EML_C3_FOLD", "1") != "0"
                     and L.eml_dense_conv3x3_bwd_fused_supported(gsrc[1], gsrc[2], ld, cin) == 1)
             if fold:

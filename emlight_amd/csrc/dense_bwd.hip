@@ -523,7 +523,9 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
 // two barriers.  The data gradient's 81 weight fragments live in LDS (they were 81 VGPRs); the weight gradient's
 // accumulators persist across tiles exactly as in conv3x3_bwd_weight_kernel (same deal of the 27 (tap, 16-channel) tiles
 // to waves and halves, same tile order per workgroup -> bitwise the same partials for the same grid).
-// Needs the 16-byte staging of the WIDE path (channel offsets multiples of 4) and the fused BN1 affine (X given).
+// Needs the fused BN1 affine (X given).  A16: the 12-channel slices of G and X are 16-byte aligned (blocks 1 and 2); otherwise
+// (block 3 of EMLight's encoder starts at channel 150) each staged item is fetched as two 8-byte loads.
+template <bool A16>
 __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
     const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
     const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
@@ -600,8 +602,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
     s_src = Z + ((size_t)b * H * W + min(max(gx, 0), W - 1)) * 48 + 4 * s_q;
   };
   auto g_load = [&](int it) {   // unconditional, clamped
-    gt4[it] = *reinterpret_cast<const float4*>(G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it]);
-    xt4[it] = *reinterpret_cast<const float4*>(Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it]);
+    const float* gp = G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it];
+    const float* xp = Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it];
+    if constexpr (A16) {
+      gt4[it] = *reinterpret_cast<const float4*>(gp);
+      xt4[it] = *reinterpret_cast<const float4*>(xp);
+    } else {
+      const float2 g0 = *reinterpret_cast<const float2*>(gp), g1 = *reinterpret_cast<const float2*>(gp + 2);
+      const float2 x0 = *reinterpret_cast<const float2*>(xp), x1 = *reinterpret_cast<const float2*>(xp + 2);
+      gt4[it] = make_float4(g0.x, g0.y, g1.x, g1.y);
+      xt4[it] = make_float4(x0.x, x0.y, x1.x, x1.y);
+    }
   };
   auto g_commit = [&](int it, float* dst) {
     const float4 fb4 = *reinterpret_cast<const float4*>(coef_l + 4 * w_q[it]);
@@ -2292,7 +2303,7 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
 // One launch for the pair above (see conv3x3_bwd_fused_kernel).  Returns EML_EINVAL when the buffers do not allow the
 // 16-byte staging (the caller then issues the two separate launches).
 extern "C" int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx) {
-  return ((ldg & 3) == 0 && (c0 & 3) == 0 && (ldx & 3) == 0 && (cx & 3) == 0) ? 1 : 0;
+  return ((ldg & 1) == 0 && (c0 & 1) == 0 && (ldx & 1) == 0 && (cx & 1) == 0) ? 1 : 0;
 }
 extern "C" int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                                const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
@@ -2303,13 +2314,20 @@ extern "C" int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, 
       !dW2 || B < 1 || H < 1 || W < 1 || grid < 1 || cx < 0)
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: bad arguments");
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (!eml_dense_conv3x3_bwd_fused_supported(ldg, c0, ldx, cx) || !al16(G) || !al16(X) || !al16(sB) || !al16(sC) || !al16(GF) ||
-      !al16(Z) || !al16(scale2) || !al16(shift2))
-    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: needs ldg, c0, ldx, cx multiples of 4 and 16-byte aligned buffers");
+  if (!eml_dense_conv3x3_bwd_fused_supported(ldg, c0, ldx, cx) || !al16(G) || !al16(X) || !al16(GF) || !al16(Z) || !al16(scale2) ||
+      !al16(shift2))
+    return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: needs even ldg, c0, ldx, cx and 16-byte aligned buffers");
+  const bool a16 = (ldg & 3) == 0 && (c0 & 3) == 0 && (ldx & 3) == 0 && (cx & 3) == 0;
   const size_t lds = (size_t)(2 * kHH * kHW * kPSG + kHH * kHW * kPSW + 27 * 3 * 64 + 32) * sizeof(float) + 8 * 48 * 2 * sizeof(double);
-  EML_ENSURE_LDS((&conv3x3_bwd_fused_kernel), lds);
-  hipLaunchKernelGGL(conv3x3_bwd_fused_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean, zistd,
-                     DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  if (a16) {
+    EML_ENSURE_LDS((&conv3x3_bwd_fused_kernel<true>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_fused_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
+                       zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  } else {
+    EML_ENSURE_LDS((&conv3x3_bwd_fused_kernel<false>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_fused_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z, zmean,
+                       zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  }
   int rc = eml::check_launch("eml_dense_conv3x3_bwd_fused_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partialW, 2 * grid,

@@ -236,8 +236,8 @@ int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float*
  * (X, sB, sC, GF as in eml_dense_conv3x3_bwd_data_f32 with X != NULL) and the weight gradient of the same layer,
  * dW2 = sum_p g[p] (x) (scale2*Z + shift2)[p+tap], whose g and z tiles the data gradient has just staged: the BN2(z) halo
  * tile is read once for both (autograd of DenseNet.py:38-43: conv2's backward w.r.t. its input and its weight).
- * Needs ldg, c0, ldx, cx multiples of 4 and 16-byte aligned buffers (eml_dense_conv3x3_bwd_fused_supported; otherwise
- * EML_EINVAL: issue the two launches).  partials / grid as the data gradient's, partialW (2*grid*27*256 floats) / dW2 as
+ * Needs even ldg, c0, ldx, cx and 16-byte aligned buffers (eml_dense_conv3x3_bwd_fused_supported; otherwise EML_EINVAL:
+ * issue the two launches); offsets that are multiples of 4 get 16-byte staging loads, the others pairs of 8-byte ones.  partials / grid as the data gradient's, partialW (2*grid*27*256 floats) / dW2 as
  * the weight gradient's: for the same grid the weight gradient is bitwise what the separate launch returns. */
 int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx);
 int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,

@@ -295,7 +295,8 @@ def test_conv3x3_bwd_data_and_weight(lib, B, H, W, c0, ld):
 
 
 @pytest.mark.parametrize("B,H,W,c0,ld,compact", [(2, 20, 44, 24, 64, False), (1, 8, 32, 108, 128, True), (3, 7, 9, 36, 64, True),
-                                                   (4, 24, 64, 60, 224, False), (2, 17, 70, 120, 304, True)])
+                                                   (4, 24, 64, 60, 224, False), (2, 17, 70, 120, 304, True),
+                                                   (1, 8, 32, 162, 176, False), (2, 15, 20, 150, 352, True)])
 def test_conv3x3_bwd_fused_equals_the_two_launches(lib, B, H, W, c0, ld, compact):
     """Round 4: data gradient (with the fused BN1 affine) + weight gradient of a layer in ONE pass over the tiles
     (conv3x3_bwd_fused_kernel) against the two separate launches on the same buffers and the same grid: dzn, GF and dW2
@@ -346,8 +347,10 @@ def test_conv3x3_bwd_fused_equals_the_two_launches(lib, B, H, W, c0, ld, compact
     zh = (Z.double() - zmean.double()) * zistd.double()
     close(out["one"][3][0], dzn.sum(0), what="S1 vs f64", rtol=1e-6, atol=1e-4)
     close(out["one"][3][1], (dzn * zh).sum(0), what="S2 vs f64", rtol=1e-6, atol=1e-4)
-    # unaligned channel offsets are refused (block 3 of EMLight's encoder starts at channel 150)
-    assert L.eml_dense_conv3x3_bwd_fused_supported(176, 162, 176, 162) == 0
+    # 8-byte aligned channel offsets (block 3 of EMLight's encoder starts at channel 150) are taken with paired 8-byte loads;
+    # odd ones are refused
+    assert L.eml_dense_conv3x3_bwd_fused_supported(176, 162, 176, 162) == 1
+    assert L.eml_dense_conv3x3_bwd_fused_supported(176, 161, 176, 161) == 0
 
 
 def test_bn_bwd_finalize(lib):
