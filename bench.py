@@ -76,6 +76,8 @@ def family_bytes(B, crop_hw):
             # G, X (deferred affine), Z in; dzn, GF out; the lower layer of a pair also reads the compact N12
             by["eml_dense_conv3x3_bwd_data_f32"] += (12 + 12 + 48 + 48 + 12 + (12 if l % 2 == 0 else 0)) * 4 * P
             by["eml_dense_conv3x3_bwd_weight_f32"] += (12 + 48) * 4 * P  # dY, Z in
+            # the two above in one pass (round 4): every operand once -- Z serves the statistics and the weight gradient
+            by["eml_dense_conv3x3_bwd_fused_f32"] += (12 + 12 + 48 + 48 + 12 + (12 if l % 2 == 0 else 0)) * 4 * P
             if l % 2 == 0:  # layers (l+1, l): narrow pass over l's 12 output channels, fused pass over [0, k)
                 # old G in, new G out, 2 x dz in, the two layers' ReLU bit masks in (round 2, late: X is no longer read)
                 by["eml_dense_conv1x1_bwd_data_multi_f32"] += ((2 * k + 96) * 4 + 2 * kp / 8) * P
@@ -100,6 +102,9 @@ FAMILIES = {
     "eml_dense_conv3x3_fwd_f32": ("conv3x3_fwd_kernel (BN2 fused into the halo-tile staging)", 1),
     "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),
     "eml_dense_conv3x3_bwd_weight_f32": ("conv3x3_bwd_weight_kernel", 1),
+    "eml_dense_conv3x3_bwd_fused_f32": ("conv3x3_bwd_fused_kernel (data gradient + weight gradient of a layer in one pass over "
+                                        "the tiles: replaces the two rows above, whose algorithmic bytes / FLOPs then count "
+                                        "for launches that did not happen)", 4),
 }
 
 
@@ -144,7 +149,7 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
         ct = c + 192
         ftr += 2.0 * ct * (ct // 2) * (h // 2) * (w // 2) * B
         c, h, w = ct // 2, h // 2, w // 2
-    flops = (f1, f3, ftr, 0.0)
+    flops = (f1, f3, ftr, 0.0, 2.0 * f3)
     nbytes = family_bytes(B, crop_hw)
     rows = []
     for k, (label, which) in FAMILIES.items():
@@ -389,6 +394,8 @@ ENCODER_FAMILIES = {
     "eml_dense_conv3x3_fwd_f32": ("encoder conv3x3_fwd_kernel", lambda a: 2.0 * a[7] * a[8] * a[9] * 9 * 48 * 12),
     "eml_dense_conv3x3_bwd_data_f32": ("encoder conv3x3_bwd_data_kernel", lambda a: 2.0 * a[8] * a[9] * a[10] * 9 * 48 * 12),
     "eml_dense_conv3x3_bwd_weight_f32": ("encoder conv3x3_bwd_weight_kernel", lambda a: 2.0 * a[6] * a[7] * a[8] * 9 * 48 * 12),
+    "eml_dense_conv3x3_bwd_fused_f32": ("encoder conv3x3_bwd_fused_kernel (data + weight gradient in one pass)",
+                                        lambda a: 4.0 * a[8] * a[9] * a[10] * 9 * 48 * 12),
 }
 
 

@@ -11,7 +11,7 @@ for tag in base exp base exp; do
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 f={r['kernel'].split(' ')[0]: r['ms_per_step'] for r in j.get('kernel_families', [])}
-keys=['conv1x1_fwd_kernel','conv1x1_bwd_weight_kernel','conv1x1_bwd_data_multi_kernel','conv3x3_fwd_kernel','conv3x3_bwd_data_kernel','conv3x3_bwd_weight_kernel','transition_bwd_data_kernel']
+keys=['conv1x1_fwd_kernel','conv1x1_bwd_weight_kernel','conv1x1_bwd_data_multi_kernel','conv3x3_fwd_kernel','conv3x3_bwd_fused_kernel','conv3x3_bwd_data_kernel','conv3x3_bwd_weight_kernel','transition_bwd_data_kernel']
 print('%-5s [%s] %7.2f img/s %8.3f ms | ' % ('$tag', '$ENVS' if '$tag'=='exp' else '', j['value'], j['ms_per_step']) + ' '.join('%s %.2f' % (k.replace('_kernel','').replace('conv',''), f.get(k, -1)) for k in keys))"
   )
 done >> $OUT
