@@ -473,17 +473,20 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
 #pragma unroll
     for (int i = 0; i < 7; ++i) av[0][i] = tile_l[aoff[i]];
     if constexpr (GLDS) gvl[0] = gl_c[0];
+#ifndef EML_WX   // experiment builds (-DEML_WX=<bits>): 1 = no staging of the next tile (wrong results), 2 = no barrier,
+#define EML_WX 0  // 4 = no scheduling fences in the k-loop, 8 = reads interleaved with the MFMAs by a sched_group_barrier pipeline
+#endif
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
-      if (ks < kHH) stage_load(ks);
-      if (GLDS && ks >= kHH && ks < kHH + 2) gq_load(ks - kHH);
+      if (!(EML_WX & 1) && ks < kHH) stage_load(ks);
+      if (!(EML_WX & 1) && GLDS && ks >= kHH && ks < kHH + 2) gq_load(ks - kHH);
       if (ks + 1 < 32) {
         const float* base = tile_l + (((ks + 1) >> 3) * kHW + 4 * ((ks + 1) & 7)) * kPSW;
 #pragma unroll
         for (int i = 0; i < 7; ++i) av[(ks + 1) & 1][i] = base[aoff[i]];
         if constexpr (GLDS) gvl[(ks + 1) & 1] = gl_c[4 * (ks + 1) * 12];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(EML_WX & 12)) __builtin_amdgcn_sched_barrier(0);
       float gv;
       if constexpr (GLDS) {
         gv = r < 12 ? gvl[ks & 1] : 0.f;   // lanes 12..15 of a row: the unused MFMA columns
@@ -494,12 +497,20 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc[i] = mfma16(av[ks & 1][i], gv, acc[i]);
       if constexpr (!GLDS) g_load(ks);  // next tile's value, in place
-      if (GLDS && ks >= 32 - kHH - 2 && ks < 32 - kHH) gq_commit(ks - (32 - kHH - 2), gl_n);
-      if (ks >= 32 - kHH) stage_commit(ks - (32 - kHH), tile_n);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(EML_WX & 1) && GLDS && ks >= 32 - kHH - 2 && ks < 32 - kHH) gq_commit(ks - (32 - kHH - 2), gl_n);
+      if (!(EML_WX & 1) && ks >= 32 - kHH) stage_commit(ks - (32 - kHH), tile_n);
+      if (EML_WX & 8) {   // experiment: the next step's LDS reads one by one in the shadow of this step's MFMAs (no burst)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (!(EML_WX & 4)) __builtin_amdgcn_sched_barrier(0);
     }
-    eml::lds_barrier();
-    cur ^= 1;
+    if (!(EML_WX & 2)) eml::lds_barrier();
+    if (!(EML_WX & 1)) cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -523,6 +534,18 @@ __global__ __launch_bounds__(kBW) void conv3x3_bwd_weight_kernel(
 // two barriers.  The data gradient's 81 weight fragments live in LDS (they were 81 VGPRs); the weight gradient's
 // accumulators persist across tiles exactly as in conv3x3_bwd_weight_kernel (same deal of the 27 (tap, 16-channel) tiles
 // to waves and halves, same tile order per workgroup -> bitwise the same partials for the same grid).
+#ifdef EML_STAMPS   // experiment build (tools/exp_build.sh stamps -DEML_STAMPS): shader-clock cycles wave 0 of every workgroup spends
+// in each part of a tile, summed over tiles and workgroups: [0] phase A, [1] barrier 2, [2] phase B, [3] barrier 1, [4] tiles
+__device__ unsigned long long eml_c3_stamps[8];
+#define EML_C3_STAMP(slot)                                                   \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter();            \
+    st_acc[slot] += now_ - st_last;                                          \
+    st_last = now_;                                                          \
+  } while (0)
+#else
+#define EML_C3_STAMP(slot) do {} while (0)
+#endif
 // Needs the fused BN1 affine (X given).  A16: the 12-channel slices of G and X are 16-byte aligned (blocks 1 and 2); otherwise
 // (block 3 of EMLight's encoder starts at channel 150) each staged item is fetched as two 8-byte loads.
 template <bool A16>
@@ -657,6 +680,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
   // the data gradient's epilogue (statistics, dzn stores) and the next tile's z halo loads riding on it; barrier.  Nothing
   // but MFMA-fed work sits between the barriers: with one workgroup per CU the two waves of a SIMD share every phase, so
   // any serial section (the epilogue was ~150 VALU + 6 stores per lane, the z commit 10 ds_write_b128) idled the matrix pipe.
+#ifdef EML_STAMPS
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
     const float* gc = g_l + cur * kGT;
@@ -722,7 +748,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
         }
       }
     }
+    EML_C3_STAMP(0);
     eml::lds_barrier();          // this tile's z halo is in place (and g_l[cur ^ 1] complete)
+    EML_C3_STAMP(1);
     // ------------------------------------------------------------------ phase B: weight gradient (216 MFMAs per wave)
     // k = pixel: lane (kk, o = r) takes g of own pixel 128*half + 4*ks + kk from the g halo tile (halo row / column + 1);
     // the next tile's z halo rows are requested under the first 10 k-steps and committed after the barrier below
@@ -778,9 +806,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    EML_C3_STAMP(2);
     eml::lds_barrier();          // everyone is done with z_l and g_l[cur]
+    EML_C3_STAMP(3);
+#ifdef EML_STAMPS
+    st_acc[4] += 1;
+#endif
     cur ^= 1;
   }
+#ifdef EML_STAMPS
+  if (tid == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&eml_c3_stamps[i], st_acc[i]);
+#endif
   // ---- outputs: weight-gradient partials per (workgroup, half), then the BatchNorm statistics
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -2300,6 +2337,16 @@ extern "C" int eml_dense_conv3x3_bwd_weight_f32(const float* G, int ldg, int c0,
   return eml::check_launch("eml_dense_conv3x3_bwd_weight_f32(reduce)");
 }
 
+#ifdef EML_STAMPS
+extern "C" int eml_c3_read_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eml_c3_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(eml_c3_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 // One launch for the pair above (see conv3x3_bwd_fused_kernel).  Returns EML_EINVAL when the buffers do not allow the
 // 16-byte staging (the caller then issues the two separate launches).
 extern "C" int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx) {
