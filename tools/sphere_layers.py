@@ -41,26 +41,32 @@ def events(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for name, C, O, H, W, stride in LAYERS:
-    bb = B * 2 if name.startswith("D ") else B
-    m = SphereConv2D(C, O, stride=stride).cuda()
-    x = torch.randn(bb, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
-    po = (H // stride) * (W // stride)
-    gflop = 2.0 * bb * po * 9 * C * O / 1e9
-    row = {"layer": name, "B": bb, "gflop": round(gflop, 1), "A9_GB": round(bb * po * 9 * C * 4 / 1e9, 2)}
-    default = SphereConv2D.fused_min_bytes
-    for mode, thr in (("fused", 0), ("unfused", 1 << 62), ("auto", 64 << 20)):
-        SphereConv2D.fused_min_bytes = thr
-        with torch.no_grad():
-            t_f = events(lambda: m(x))
-        xg = x.clone().requires_grad_(True)
-        y = m(xg)
-        gy = torch.randn_like(y)
-        t_w = events(lambda: torch.autograd.grad(y, m.weight, gy, retain_graph=True))   # weight gradient only
-        t_d = events(lambda: torch.autograd.grad(y, xg, gy, retain_graph=True))         # input gradient only
-        row[mode] = {"fwd_ms": round(t_f, 3), "fwd_tflops": round(gflop / t_f, 1), "wgrad_ms": round(t_w, 3),
-                     "wgrad_tflops": round(gflop / t_w, 1), "dgrad_ms": round(t_d, 3), "dgrad_tflops": round(gflop / t_d, 1)}
-        del y, gy
-    print(json.dumps(row), flush=True)
-    del m, x
-    torch.cuda.empty_cache()
+
+def main():
+    for name, C, O, H, W, stride in LAYERS:
+        bb = B * 2 if name.startswith("D ") else B
+        m = SphereConv2D(C, O, stride=stride).cuda()
+        x = torch.randn(bb, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        po = (H // stride) * (W // stride)
+        gflop = 2.0 * bb * po * 9 * C * O / 1e9
+        row = {"layer": name, "B": bb, "gflop": round(gflop, 1), "A9_GB": round(bb * po * 9 * C * 4 / 1e9, 2)}
+        default = SphereConv2D.fused_min_bytes
+        for mode, thr in (("fused", 0), ("unfused", 1 << 62), ("auto", 64 << 20)):
+            SphereConv2D.fused_min_bytes = thr
+            with torch.no_grad():
+                t_f = events(lambda: m(x))
+            xg = x.clone().requires_grad_(True)
+            y = m(xg)
+            gy = torch.randn_like(y)
+            t_w = events(lambda: torch.autograd.grad(y, m.weight, gy, retain_graph=True))   # weight gradient only
+            t_d = events(lambda: torch.autograd.grad(y, xg, gy, retain_graph=True))         # input gradient only
+            row[mode] = {"fwd_ms": round(t_f, 3), "fwd_tflops": round(gflop / t_f, 1), "wgrad_ms": round(t_w, 3),
+                         "wgrad_tflops": round(gflop / t_w, 1), "dgrad_ms": round(t_d, 3), "dgrad_tflops": round(gflop / t_d, 1)}
+            del y, gy
+        print(json.dumps(row), flush=True)
+        del m, x
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
