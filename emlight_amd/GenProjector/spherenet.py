@@ -191,13 +191,7 @@ class _SphereConvFn(torch.autograd.Function):
         lim = SphereConv2D.fused_min_bytes
         ctx.fused_fwd = (B > 0 and C % 32 == 0 and O % 64 == 0 and
                          (a9_bytes >= 32 * lim or (O <= 256 and a9_bytes >= lim)))
-        # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C).  Measured: it beats
-        # dY W2 (library) + col2im where the pixel count is large and O <= 256; wide heads (K = 9*O >= 4608) stay unfused
-        ctx.fused_dgrad = (B > 0 and O % 32 == 0 and C % 64 == 0 and stride == 1 and
-                           (lim == 0 or (O <= 256 and B * po >= 131072)))
-        # weight gradient: K = pixels; below ~32k pixels the split-K tiles are short and the library's long-K GEMM wins
-        ctx.fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
-                           (B * po >= 32768 or lim == 0))
+        ctx.fused_dgrad, ctx.fused_wgrad = _backward_dispatch(B, po, C, O, stride)
         a9 = None
         slope = float(slope)
         res = None
@@ -239,96 +233,117 @@ class _SphereConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        from .. import _lib
-        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-        xr, weight = ctx.saved_tensors[:2]
-        geo = ctx.geo
-        B, C, H, W, O = ctx.shape
-        po = geo.ho * geo.wo
-        gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
-        y = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
-        gx = gw = gb = gres = None
-        # (when the input gradient is wanted too -- the discriminator's first stage -- the masked dY has to be formed for it
-        # anyway and the general weight-gradient path on it measured faster: tools/small_conv_bench.py)
-        small_w = ctx.small and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-        if small_w:
-            # dW2, the bias gradient and the activation's backward in one pass over (dY, Y)
-            part = torch.empty(L.eml_sphere_conv_small_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
+        return _sphere_conv_backward(ctx, gy, ctx.saved_tensors, ctx.needs_input_grad)
+
+
+def _backward_dispatch(B, po, C, O, stride):
+    """(fused input gradient?, fused weight gradient?) of a SphereConv layer, measured per shape (tools/sphere_layers.py)."""
+    lim = SphereConv2D.fused_min_bytes
+    a9_bytes = B * po * 9 * C * 4
+    # input gradient: the forward kernel on the transposed tap table (K = 9*O, N = C).  Measured: it beats
+    # dY W2 (library) + col2im where the pixel count is large and O <= 256; wide heads (K = 9*O >= 4608) stay unfused
+    fused_dgrad = (B > 0 and O % 32 == 0 and C % 64 == 0 and stride == 1 and
+                   (lim == 0 or (O <= 256 and B * po >= 131072)))
+    # weight gradient: K = pixels; below ~32k pixels the split-K tiles are short and the library's long-K GEMM wins
+    fused_wgrad = (B > 0 and C % 64 == 0 and O >= 64 and O % 16 == 0 and a9_bytes >= 4 * lim and
+                   (B * po >= 32768 or lim == 0))
+    return fused_dgrad, fused_wgrad
+
+
+def _sphere_conv_backward(ctx, gy, saved, needs):
+    """Backward of ``_SphereConvFn`` given its recorded state ``ctx`` (geo, shape, slope, dispatch flags), the saved tensors and
+    the needs-gradient flags in ``forward``'s argument order; shared with the fused SPADE forward, whose backward feeds it the
+    (dgamma | dbeta) tensor."""
+    from .. import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    xr, weight = saved[:2]
+    geo = ctx.geo
+    B, C, H, W, O = ctx.shape
+    po = geo.ho * geo.wo
+    gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
+    y = saved[2] if ctx.slope != 1.0 else None
+    gx = gw = gb = gres = None
+    # (when the input gradient is wanted too -- the discriminator's first stage -- the masked dY has to be formed for it
+    # anyway and the general weight-gradient path on it measured faster: tools/small_conv_bench.py)
+    small_w = ctx.small and needs[1] and not needs[0]
+    if small_w:
+        # dW2, the bias gradient and the activation's backward in one pass over (dY, Y)
+        part = torch.empty(L.eml_sphere_conv_small_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
+        gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
+        gb_ = torch.empty(O, dtype=torch.float32, device=gy.device) if ctx.has_bias else None
+        _lib.check(L.eml_sphere_conv_small_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(y) if y is not None else None,
+                                                     ctx.slope, p(part), p(gw2), p(gb_) if gb_ is not None else None, B,
+                                                     H * W, po, C, O, st), "eml_sphere_conv_small_wgrad_f32")
+        gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
+        gb = gb_ if (ctx.has_bias and needs[2]) else None
+        del part
+    need_masked = (needs[0] or (len(needs) > 5 and needs[5])
+                   or (not small_w and (needs[1] or (ctx.has_bias and needs[2]))))
+    if y is not None and need_masked:
+        gyr = (torch.ops.aten.threshold_backward(gyr, y, 0.0) if ctx.slope == 0.0
+               else torch.ops.aten.leaky_relu_backward(gyr, y, ctx.slope, True))
+    if len(needs) > 5 and needs[5]:
+        gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
+    if ctx.has_bias and needs[2] and not small_w:
+        # the SPADE modulation's backward leaves the column sums of the dgb it produced on the tensor (f64-accumulated)
+        # -- valid only for the very tensor it was computed from: same storage, not written since (autograd accumulates
+        # IN PLACE into a gradient that has a second consumer; a hook may hand over a different tensor): ADVICE round 3
+        pre = getattr(gy, "_eml_colsum", None)
+        if pre is not None:
+            sums, ptr, ver = pre
+            ok = y is None and sums.shape == (O,) and ptr == gy.data_ptr() and ver == gy._version
+            pre = sums if ok else None
+        gb = pre if pre is not None else gyr.sum(0)
+    if needs[1] and not small_w:
+        if ctx.fused_wgrad and B:
+            bn = 128 if C % 128 == 0 else 64
+            bmo = 128 if (O % 128 == 0 or O > 192) else 64
+            tiles = 9 * (C // bn) * ((O + bmo - 1) // bmo)
+            nchunks = (B * po + 31) // 32
+            split = max(1, min(nchunks, 2048 // tiles, (512 << 20) // (O * 9 * C * 4)))
+            part = torch.empty(L.eml_sphere_conv_wgrad_partial_floats(C, O, split), dtype=torch.float32, device=gy.device)
             gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
-            gb_ = torch.empty(O, dtype=torch.float32, device=gy.device) if ctx.has_bias else None
-            _lib.check(L.eml_sphere_conv_small_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(y) if y is not None else None,
-                                                         ctx.slope, p(part), p(gw2), p(gb_) if gb_ is not None else None, B,
-                                                         H * W, po, C, O, st), "eml_sphere_conv_small_wgrad_f32")
+            _lib.check(L.eml_sphere_conv_wgrad_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B,
+                                                         H * W, po, C, O, split, st), "eml_sphere_conv_wgrad_fused_f32")
             gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
-            gb = gb_ if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             del part
-        need_masked = (ctx.needs_input_grad[0] or (len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5])
-                       or (not small_w and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]))))
-        if y is not None and need_masked:
-            gyr = (torch.ops.aten.threshold_backward(gyr, y, 0.0) if ctx.slope == 0.0
-                   else torch.ops.aten.leaky_relu_backward(gyr, y, ctx.slope, True))
-        if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5]:
-            gres = gyr.view(B, geo.ho, geo.wo, O).permute(0, 3, 1, 2)
-        if ctx.has_bias and ctx.needs_input_grad[2] and not small_w:
-            # the SPADE modulation's backward leaves the column sums of the dgb it produced on the tensor (f64-accumulated)
-            # -- valid only for the very tensor it was computed from: same storage, not written since (autograd accumulates
-            # IN PLACE into a gradient that has a second consumer; a hook may hand over a different tensor): ADVICE round 3
-            pre = getattr(gy, "_eml_colsum", None)
-            if pre is not None:
-                sums, ptr, ver = pre
-                ok = y is None and sums.shape == (O,) and ptr == gy.data_ptr() and ver == gy._version
-                pre = sums if ok else None
-            gb = pre if pre is not None else gyr.sum(0)
-        if ctx.needs_input_grad[1] and not small_w:
-            if ctx.fused_wgrad and B:
-                bn = 128 if C % 128 == 0 else 64
-                bmo = 128 if (O % 128 == 0 or O > 192) else 64
-                tiles = 9 * (C // bn) * ((O + bmo - 1) // bmo)
-                nchunks = (B * po + 31) // 32
-                split = max(1, min(nchunks, 2048 // tiles, (512 << 20) // (O * 9 * C * 4)))
-                part = torch.empty(L.eml_sphere_conv_wgrad_partial_floats(C, O, split), dtype=torch.float32, device=gy.device)
-                gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
-                _lib.check(L.eml_sphere_conv_wgrad_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B,
-                                                             H * W, po, C, O, split, st), "eml_sphere_conv_wgrad_fused_f32")
-                gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
-                del part
+        else:
+            a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
+            m_rows, split = B * po, 1
+            if (9 * C <= 64 or O <= 16) and m_rows >= 65536:
+                # skinny product (the 3- / 6-channel input layers: 27 or 54 columns against ~1 M rows; the 3-channel
+                # output layers: 1.9 TF/s as one GEMM): as ONE GEMM
+                # the library runs it on a handful of workgroups (1.6 ms for 7 GFLOP); as a batched split-K it is
+                # the HBM-bound read of dY it should be, followed by a fixed-order sum of the partials
+                split = 512
+                while m_rows % split:
+                    split //= 2
+            if split > 1:
+                gw2 = torch.bmm(a9.view(split, m_rows // split, 9 * C).transpose(1, 2),
+                                gyr.view(split, m_rows // split, O)).sum(0)
             else:
-                a9 = xr if ctx.keep else _SphereConvFn._im2col(xr, geo, B, C)
-                m_rows, split = B * po, 1
-                if (9 * C <= 64 or O <= 16) and m_rows >= 65536:
-                    # skinny product (the 3- / 6-channel input layers: 27 or 54 columns against ~1 M rows; the 3-channel
-                    # output layers: 1.9 TF/s as one GEMM): as ONE GEMM
-                    # the library runs it on a handful of workgroups (1.6 ms for 7 GFLOP); as a batched split-K it is
-                    # the HBM-bound read of dY it should be, followed by a fixed-order sum of the partials
-                    split = 512
-                    while m_rows % split:
-                        split //= 2
-                if split > 1:
-                    gw2 = torch.bmm(a9.view(split, m_rows // split, 9 * C).transpose(1, 2),
-                                    gyr.view(split, m_rows // split, O)).sum(0)
-                else:
-                    # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
-                    gw2 = a9.t() @ gyr
-                # (O, tap, c) in memory like the fused kernels' result: the one copy this gradient needs either way
-                gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
-                del a9
-        if ctx.needs_input_grad[0]:
-            gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
-            tt = geo.transposed_table() if (ctx.fused_dgrad and B) else None
-            if tt is not None:
-                # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
-                tidx, twgt, rowmax, ke = tt
-                w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
-                _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gyr), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gxr), B,
-                                                             H * W, po, C, O, st), "eml_sphere_conv_dgrad_fused_f32")
-            else:
-                w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
-                da9 = gyr @ w2                                           # (B*Po, 9C)
-                if B:
-                    _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
-                                                       H * W, po, C, st), "eml_sphere_col2im_f32")
-            gx = gxr.permute(0, 3, 1, 2)
-        return gx, gw, gb, None, None, gres, None
+                # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
+                gw2 = a9.t() @ gyr
+            # (O, tap, c) in memory like the fused kernels' result: the one copy this gradient needs either way
+            gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
+            del a9
+    if needs[0]:
+        gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
+        tt = geo.transposed_table() if (ctx.fused_dgrad and B) else None
+        if tt is not None:
+            # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
+            tidx, twgt, rowmax, ke = tt
+            w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
+            _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gyr), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gxr), B,
+                                                         H * W, po, C, O, st), "eml_sphere_conv_dgrad_fused_f32")
+        else:
+            w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
+            da9 = gyr @ w2                                           # (B*Po, 9C)
+            if B:
+                _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
+                                                   H * W, po, C, st), "eml_sphere_col2im_f32")
+        gx = gxr.permute(0, 3, 1, 2)
+    return gx, gw, gb, None, None, gres, None
 
 
 def sphere_conv(x, weight, bias, stride=1, residual=None, act_slope=1.0):
@@ -526,6 +541,123 @@ class _SpadeNormModulateFn(torch.autograd.Function):
         return dx, dgb, None, None, None, None, None
 
 
+_SPADE_ROWS = {}
+
+
+def spade_row_order(Cn, device):
+    """Row order of the (gamma | beta) weights for ``eml_sphere_conv_spade_fwd_f32`` (include/emlight_hip.h): position p holds
+    row ``c + half * Cn`` of cat(gamma head, beta head)."""
+    key = (int(Cn), str(device))
+    if key not in _SPADE_ROWS:
+        pos = torch.arange(2 * Cn)
+        c = 64 * (pos // 128) + 32 * ((pos % 128) // 64) + pos % 32
+        _SPADE_ROWS[key] = (c + ((pos % 64) // 32) * Cn).to(device)
+    return _SPADE_ROWS[key]
+
+
+class _SpadeConvModulateFn(torch.autograd.Function):
+    """SPADE in one launch: ``leaky_relu(BN(x) * (1 + gamma) + beta, slope)`` with (gamma | beta) = SphereConv(actv; weight,
+    bias) formed in the accumulators of the gather-GEMM and consumed by its epilogue -- the (B, 2C, H, W) tensor is neither
+    written nor re-read (normalization.py:101-115).  For the backward the forward keeps gamma (C per pixel, half of what the
+    two-launch path keeps) and its own output, whose sign is the activation's mask; the (dgamma | dbeta) tensor the modulation's
+    backward forms is handed to the SphereConv backward unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, actv, weight, bias, mean, istd, slope, training, up2):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        _require_gpu_f32(x, "SPADE input")
+        _require_gpu_f32(actv, "SPADE activation")
+        B, Cin, H, W = actv.shape
+        Cn = x.shape[1]
+        cl = torch.channels_last
+        geo = sphere_geometry(H, W, 1, actv.device)
+        ar = actv.permute(0, 2, 3, 1).contiguous()                 # (B, H, W, Cin); a view when channels-last
+        x = x.contiguous(memory_format=cl)
+        order = spade_row_order(Cn, actv.device)
+        w2r = weight.permute(0, 2, 3, 1)[order].reshape(2 * Cn, 9 * Cin)   # the one (gathering) copy the re-layout needs anyway
+        br = bias[order] if bias is not None else None
+        y = torch.empty(B * H * W, Cn, dtype=torch.float32, device=x.device)
+        keep = any(ctx.needs_input_grad[:4])
+        gamma = torch.empty_like(y) if keep else None
+        _lib.check(L.eml_sphere_conv_spade_fwd_f32(p(ar), p(geo.idx), p(geo.wgt), p(w2r), p(br) if br is not None else None,
+                                                   p(x), p(mean), p(istd), p(y), p(gamma) if keep else None, B, H, W, Cin, Cn,
+                                                   int(bool(up2)), float(slope), st), "eml_sphere_conv_spade_fwd_f32")
+        ctx.geo, ctx.shape, ctx.has_bias = geo, (B, Cin, H, W, 2 * Cn), bias is not None
+        ctx.up2, ctx.act_slope, ctx.training = bool(up2), float(slope), bool(training)
+        # the state _sphere_conv_backward reads: a plain (no epilogue, no kept operand) SphereConv 128 -> 2 Cn
+        ctx.slope, ctx.small, ctx.keep = 1.0, False, False
+        ctx.fused_dgrad, ctx.fused_wgrad = _backward_dispatch(B, H * W, Cin, 2 * Cn, 1)
+        if keep:
+            ctx.save_for_backward(ar, weight, x, gamma, y, mean, istd)
+        return y.view(B, H, W, Cn).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+        ar, weight, x, gamma, y, mean, istd = ctx.saved_tensors
+        B, Cin, H, W, O = ctx.shape
+        C = O // 2
+        rows = B * H * W
+        cl = torch.channels_last
+        gy = gy.contiguous(memory_format=cl)
+        dgb = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
+        dxn = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
+        grid = _stats_grid(rows, C)
+        partials = torch.empty(grid, 4 * C + 1, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_spade_norm_modulate_bwd_y_f32(p(gy), p(x), p(gamma), p(y), p(dxn), p(dgb), B, H, W, C, int(ctx.up2),
+                                                       ctx.act_slope, p(mean), p(istd), p(partials), grid, st),
+                   "eml_spade_norm_modulate_bwd_y_f32")
+        folded = torch.empty(4 * C + 1, dtype=torch.float64, device=x.device)
+        _lib.check(L.eml_bn_fold_f64(p(partials), grid, 4 * C + 1, p(folded), st), "eml_bn_fold_f64")
+        sums = None
+        if ctx.training:
+            sums = folded[:2 * C + 1]
+            sums[2 * C] = float(rows)
+            if _bn_sync():
+                import torch.distributed as dist
+                dist.all_reduce(sums)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.up2:
+                dx = torch.empty_like(x, memory_format=cl)     # gradient of the map BEFORE the upsample
+                _lib.check(L.eml_bn_bwd_apply_up2_f32(p(dxn), p(x), B, H, W, C, p(mean), p(istd), p(sums), p(dx), st),
+                           "eml_bn_bwd_apply_up2_f32")
+            else:
+                dx = dxn
+                _lib.check(L.eml_bn_bwd_apply_f32(p(dx), C, p(x), C, rows, C, p(mean), p(istd), p(sums), p(dx), C, st),
+                           "eml_bn_bwd_apply_f32")
+        # the column sums of dgb = the bias gradient of the gamma | beta convolution (see _SpadeNormModulateFn.backward)
+        dgb._eml_colsum = (folded[2 * C + 1:].view(C, 2).t().reshape(2 * C).float(), dgb.data_ptr(), dgb._version)
+        needs = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3], False, False, False, False)
+        gactv, gw, gbias = _sphere_conv_backward(ctx, dgb, (ar, weight), needs)[:3]
+        return dx, gactv, gw, gbias, None, None, None, None, None
+
+
+def spade_conv_modulate(x, actv, weight, bias, mean, istd, slope, training, up2):
+    """``leaky_relu(((x - mean) * istd) * (1 + gamma) + beta, slope)`` with (gamma | beta) = SphereConv(actv; weight, bias) in
+    one launch (a module attribute like ``sphere_conv``, so that tests can observe the layer shapes that take it)."""
+    return _SpadeConvModulateFn.apply(x, actv, weight, bias, mean, istd, slope, training, up2)
+
+
+def _spade_conv_fusable(x, actv, C, up2):
+    """Does this SPADE take the one-launch path?  Where the gamma | beta SphereConv runs on the gather-GEMM kernel anyway, and
+    for O = 2C <= 512 also where the library GEMM alone would be a few percent faster: the modulation pass it saves costs more
+    (tools/sphere_layers.py: 128 -> 512 at 64 x 128, 2.74 against 2.67 + 0.3 ms)."""
+    from .. import _lib
+    if not (SphereConv2D.fuse_spade and x.is_cuda and actv.dim() == 4 and actv.shape[0] > 0):
+        return False
+    B, Cin, H, W = actv.shape
+    if up2 and ((H | W) & 1):
+        return False
+    if not _lib.lib().eml_sphere_conv_spade_supported(Cin, C, H * W):
+        return False
+    lim = SphereConv2D.fused_min_bytes
+    a9_bytes = B * H * W * 9 * Cin * 4
+    return a9_bytes >= 32 * lim or (2 * C <= 256 and a9_bytes >= lim) or (2 * C <= 512 and a9_bytes >= 8 * lim)
+
+
 def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=None, up2=False):
     """SPADE (normalization.py:101-115) + the LeakyReLU that follows it (architecture.py:56-57; slope 1 = none):
     ``leaky_relu(BN(x) * (1 + gamma(actv)) + beta(actv), slope)``.  gamma | beta come from ONE SphereConv (one gather,
@@ -533,11 +665,14 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     the caller already has them for this x) and its normalisation / backward are folded into the modulation kernels."""
     w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
     b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
-    gb = sphere_conv(actv, w, b, 1)
     C = x.shape[1]
     if C % 4 == 0 and isinstance(bn, nn.BatchNorm2d):
         mean, istd = stats if stats is not None else spade_batch_stats(x, bn, repeat=4 if up2 else 1)
+        if _spade_conv_fusable(x, actv, C, up2):
+            return spade_conv_modulate(x, actv, w, b, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+        gb = sphere_conv(actv, w, b, 1)
         return _SpadeNormModulateFn.apply(x, gb, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+    gb = sphere_conv(actv, w, b, 1)
     if up2:   # ``up2`` = x stands for its nearest x2 upsample (supported by the fused path only; callers check can_fold_up2)
         x = nn.functional.interpolate(x, scale_factor=2)
     # widths that are not a multiple of 4 (never in EMLight) or an instance norm: library norm + elementwise formula
@@ -669,6 +804,8 @@ class SphereConv2D(nn.Module):
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
     # unit of the fused-kernel thresholds on the size of the im2col operand (see forward); EML_FUSED_MIN_MB: A/B knob
     fused_min_bytes = int(os.environ.get("EML_FUSED_MIN_MB", "64")) << 20
+    # SPADE's gamma | beta convolution with the modulation as its epilogue (_SpadeConvModulateFn); EML_FUSE_SPADE=0: A/B knob
+    fuse_spade = os.environ.get("EML_FUSE_SPADE", "1") != "0"
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

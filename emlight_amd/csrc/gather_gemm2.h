@@ -54,12 +54,25 @@ __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v
 // LPP: lanes per gathered line (8 = full 128-byte line per instruction; 4 = 64-byte halves, for the A/B record)
 // PK:  bilinear combine on register pairs (v_pk_*) or scalar fmas
 // ONE: single-entry tables (ke == 1: an ordinary 3x3 convolution as a gather, the VGG19 stack)
-template <int BN, int NT, int LPP, bool PK, bool ONE>
+// MOD: SPADE's modulation as the epilogue (normalization.py:101-115).  The O = 2 Cn rows of W2 are the gamma and beta heads,
+//      reordered by the host so that each wave's 64 rows are 32 gamma rows followed by the 32 beta rows of the SAME channels
+//      (spade_row_order below): a lane then holds gamma and beta of four channels of its pixel in two accumulator tiles and
+//      writes  Y[m][c] = leaky_relu(((x - mean) * istd) * (1 + gamma) + beta)  (M, Cn) -- the (M, 2 Cn) gamma | beta tensor is
+//      never stored.  `mod.gamma` (M, Cn), when given, receives gamma for the backward pass.
+struct SpadeEpilogue {
+  const float* x;       // the normalised map's input, pixel-major (rows, Cn); at half resolution when up2
+  const float* mean;    // (Cn)
+  const float* istd;    // (Cn)
+  float* gamma;         // (M, Cn) or NULL
+  int up2, H, W;        // destination grid (Po = H * W); up2: x lives on (H/2, W/2), nearest x2 upsample folded in
+};
+template <int BN, int NT, int LPP, bool PK, bool ONE, bool MOD = false>
 __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_gemm2_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
     int HW /* source pixels per sample */, int Po /* destination pixels per sample */, int C, int O, int ke,
-    const unsigned char* __restrict__ rowmax, const float* __restrict__ res, float slope) {
+    const unsigned char* __restrict__ rowmax, const float* __restrict__ res, float slope, SpadeEpilogue mod) {
+  static_assert(!MOD || (BN == 128 && NT == 256), "the SPADE epilogue pairs tiles ni / ni + 2 of a 64-row wave tile");
   static_assert((BN == 64 || BN == 128 || BN == 256) && (NT == 256 || NT == 512) && (LPP == 8 || LPP == 4), "config");
   static_assert(NT == 512 || BN != 256, "BN = 256 needs 512 threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -349,6 +362,50 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
 #ifndef GG2_NOBAR
     eml::lds_barrier();
 #endif
+  }
+  if constexpr (MOD) {
+    // ---- SPADE epilogue: tiles ni = 0, 1 hold gamma, ni + 2 beta of channels cb + 16 ni + 4kk .. +3; the arithmetic is
+    // spade_norm_modulate_fwd_kernel's (csrc/spade.hip), expression for expression
+    const int Cn = O >> 1;
+    const int cb = (o0 >> 1) + 32 * wn;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int c = cb + 16 * ni + 4 * kk;
+      const int og = o0 + 64 * wn + 16 * ni + 4 * kk;      // row of the (reordered) bias: gamma, + 32: beta
+      float4 bg = make_float4(0.f, 0.f, 0.f, 0.f), bb = bg;
+      if (bias) {
+        bg = *reinterpret_cast<const float4*>(bias + og);
+        bb = *reinterpret_cast<const float4*>(bias + og + 32);
+      }
+      const float4 mu = *reinterpret_cast<const float4*>(mod.mean + c);
+      const float4 is = *reinterpret_cast<const float4*>(mod.istd + c);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + 64 * wm + 16 * mi + r;
+        if (m < M) {
+          size_t xrow = (size_t)m;
+          if (mod.up2) {
+            const unsigned b = (unsigned)m / (unsigned)Po, p = (unsigned)m - b * (unsigned)Po;
+            const unsigned h = p / (unsigned)mod.W, w = p - h * (unsigned)mod.W;
+            xrow = ((size_t)b * (unsigned)(mod.H >> 1) + (h >> 1)) * (unsigned)(mod.W >> 1) + (w >> 1);
+          }
+          const float4 a = *reinterpret_cast<const float4*>(mod.x + xrow * Cn + c);
+          const float4 g = make_float4(acc[ni][mi][0] + bg.x, acc[ni][mi][1] + bg.y, acc[ni][mi][2] + bg.z, acc[ni][mi][3] + bg.w);
+          const float4 be = make_float4(acc[ni + 2][mi][0] + bb.x, acc[ni + 2][mi][1] + bb.y, acc[ni + 2][mi][2] + bb.z,
+                                        acc[ni + 2][mi][3] + bb.w);
+          float4 v;
+          v.x = fmaf((a.x - mu.x) * is.x, 1.f + g.x, be.x);
+          v.y = fmaf((a.y - mu.y) * is.y, 1.f + g.y, be.y);
+          v.z = fmaf((a.z - mu.z) * is.z, 1.f + g.z, be.z);
+          v.w = fmaf((a.w - mu.w) * is.w, 1.f + g.w, be.w);
+          v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+          v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
+          *reinterpret_cast<float4*>(Y + (size_t)m * Cn + c) = v;
+          if (mod.gamma) *reinterpret_cast<float4*>(mod.gamma + (size_t)m * Cn + c) = g;
+        }
+      }
+    }
+    return;
   }
   // ---- epilogue: lane (r, kk) owns output channels 4kk..4kk+3 of tile ni for pixel r of tile mi
 #pragma unroll

@@ -212,11 +212,15 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_fwd_kernel(const floa
 // The per-block partial row is (C, 2) (sum dxn, sum dxn*xhat), one unused slot (the count's place in `sums`), then
 // (C, 2) (sum dgamma, sum dbeta) -- the column sums of dgb, i.e. the BIAS gradient of the gamma | beta convolution that
 // produced gb, which would otherwise re-read dgb (the largest gradient tensor of the step) just to add it up.
-template <bool UP2>
+// FROMY: the activation's mask is taken from the stored OUTPUT y (rows, C) (its sign is the pre-activation's for slope >= 0)
+// and gb holds gamma only (ld_gb = C): the form the fused SphereConv epilogue (eml_sphere_conv_spade_fwd_f32) leaves behind,
+// which never stores beta.
+template <bool UP2, bool FROMY = false>
 __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
     const float* __restrict__ gy, int ld_gy, const float* __restrict__ x, int ld_x, const float* __restrict__ gb, int ld_gb,
     float* __restrict__ dxn, int ld_dx, float* __restrict__ dgb, int ld_dgb, int rows, int C, float slope,
-    const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials, int H, int W) {
+    const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ partials, int H, int W,
+    const float* __restrict__ yout = nullptr) {
   constexpr int NV = 16;
   __shared__ double red[256 * NV];
   const ColMap m(C);
@@ -233,13 +237,15 @@ __global__ __launch_bounds__(256) void spade_norm_modulate_bwd_kernel(
         const size_t xrow = UP2 ? (size_t)up2_src_row((unsigned)row, H, W) : (size_t)row;
         const float4 xv = *reinterpret_cast<const float4*>(x + xrow * ld_x + c);
         const float4 g = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + c);
-        const float4 b = *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + C + c);
+        // FROMY: `b` is the stored output y of the pixel instead of beta
+        const float4 b = FROMY ? *reinterpret_cast<const float4*>(yout + (size_t)row * C + c)
+                               : *reinterpret_cast<const float4*>(gb + (size_t)row * ld_gb + C + c);
         const float a[4] = {(xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z, (xv.w - mu.w) * is.w};
         const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w}, uu[4] = {u.x, u.y, u.z, u.w};
         float d[4], dx[4], dg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          d[k] = fmaf(a[k], 1.f + gg[k], bb[k]) > 0.f ? uu[k] : slope * uu[k];
+          d[k] = (FROMY ? bb[k] : fmaf(a[k], 1.f + gg[k], bb[k])) > 0.f ? uu[k] : slope * uu[k];
           dx[k] = d[k] * (1.f + gg[k]);
           dg[k] = d[k] * a[k];
           v[k] += (double)dx[k];
@@ -449,4 +455,24 @@ extern "C" int eml_spade_norm_modulate_bwd_cols_f32(const float* gy, const float
                        2 * C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, 0, 0);
   }
   return eml::check_launch("eml_spade_norm_modulate_bwd_cols_f32");
+}
+
+// The same pass for the fused SPADE forward (eml_sphere_conv_spade_fwd_f32): `gamma` (B*H*W, C) and the forward's OUTPUT `y`
+// (B*H*W, C) instead of the (gamma | beta) tensor -- the activation's mask is y's sign (slope in [0, 1]; slope == 1: y is not
+// read for its value, any mask gives dy).  dgb (B*H*W, 2C) = (dgamma | dbeta) as before.
+extern "C" int eml_spade_norm_modulate_bwd_y_f32(const float* gy, const float* x, const float* gamma, const float* y, float* dxn,
+                                                 float* dgb, int B, int H, int W, int C, int up2, float slope, const float* mean,
+                                                 const float* istd, double* partials, int grid, eml_stream_t stream) {
+  if (!gy || !x || !gamma || !y || !dxn || !dgb || !mean || !istd || !partials || grid < 1 || B < 1 || H < 1 || W < 1 || C < 4 ||
+      (C & 3) || (long)B * H * W > 2147483647L || !(slope >= 0.f && slope <= 1.f))
+    return eml::fail(EML_EINVAL, "eml_spade_norm_modulate_bwd_y_f32: bad arguments");
+  if (up2) {
+    if (int rc = up2_args("eml_spade_norm_modulate_bwd_y_f32", B, H, W, C)) return rc;
+    hipLaunchKernelGGL((spade_norm_modulate_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x, C,
+                       gamma, C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, H, W, y);
+  } else {
+    hipLaunchKernelGGL((spade_norm_modulate_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, C, x, C,
+                       gamma, C, dxn, C, dgb, 2 * C, B * H * W, C, slope, mean, istd, partials, 0, 0, y);
+  }
+  return eml::check_launch("eml_spade_norm_modulate_bwd_y_f32");
 }

@@ -489,7 +489,7 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
     auto kern = gg2::gather_gemm2_kernel<BNV, 256, 4, false, false>;                                                \
     EML_ENSURE_LDS(kern, (gg2::lds_bytes<BNV, 256>()));                                                             \
     hipLaunchKernelGGL(kern, grid2, dim3(256), (gg2::lds_bytes<BNV, 256>()), (hipStream_t)stream, X, idx, wgt, W2,  \
-                       bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope);                                      \
+                       bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope, gg2::SpadeEpilogue{});                \
   } while (0)
     if (bn == 128) EML_LAUNCH_GG2(128); else EML_LAUNCH_GG2(64);
 #undef EML_LAUNCH_GG2
@@ -536,6 +536,40 @@ extern "C" int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, 
     return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: act_slope %g outside [0, 1]", (double)act_slope);
   return launch_gather_gemm("eml_sphere_conv_fwd_fused_ex_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr,
                             residual, act_slope, stream);
+}
+
+// SPADE (normalization.py:101-115) in one launch: the gamma | beta SphereConv (128 -> 2 Cn over `actv`) with the modulation of
+// the parameter-free-normalised map x as its epilogue,  Y = leaky_relu(((x - mean) * istd) * (1 + gamma) + beta, slope).
+// W2r (2 Cn, 9 Cin) / bias_r (2 Cn): the rows of cat(gamma head, beta head) in the kernel's order -- position p holds
+// source row  c + half * Cn  with  c = 64 (p / 128) + 32 ((p % 128) / 64) + p % 32,  half = (p % 64) / 32.
+extern "C" int eml_sphere_conv_spade_supported(int Cin, int Cn, long HW) {
+  return Cin >= 64 && Cin % 32 == 0 && Cn >= 64 && Cn % 64 == 0 && HW >= 1 &&
+         (unsigned long long)HW * Cin < (1ull << 29) && (unsigned long long)2 * Cn * 9 * Cin < (1ull << 30);
+}
+
+extern "C" int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, const float* wgt, const float* W2r,
+                                             const float* bias_r, const float* x, const float* mean, const float* istd,
+                                             float* Y, float* gamma_out, int B, int H, int W, int Cin, int Cn, int up2,
+                                             float act_slope, eml_stream_t stream) {
+  if (!actv || !idx || !wgt || !W2r || !x || !mean || !istd || !Y || B < 0 || H < 1 || W < 1)
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: null pointer / empty grid");
+  if (!eml_sphere_conv_spade_supported(Cin, Cn, (long)H * W))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: unsupported widths (Cin=%d, Cn=%d, HW=%ld)", Cin, Cn, (long)H * W);
+  if (up2 && ((H | W) & 1)) return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: up2 needs an even grid (%d x %d)", H, W);
+  if (!(act_slope >= 0.f && act_slope <= 1.f))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: act_slope %g outside [0, 1]", (double)act_slope);
+  if (B == 0) return EML_OK;
+  const int HW = H * W, O = 2 * Cn;
+  const long M = (long)B * HW;
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: too many pixels");
+  const long n_mt = (M + gg2::kBM - 1) / gg2::kBM, per_xcd = (n_mt + 7) / 8;
+  const dim3 grid((unsigned)(8 * per_xcd * (O / 128)));
+  auto kern = gg2::gather_gemm2_kernel<128, 256, 4, false, false, true>;
+  EML_ENSURE_LDS(kern, (gg2::lds_bytes<128, 256>()));
+  const gg2::SpadeEpilogue mod{x, mean, istd, gamma_out, up2 ? 1 : 0, H, W};
+  hipLaunchKernelGGL(kern, grid, dim3(256), (gg2::lds_bytes<128, 256>()), (hipStream_t)stream, actv, idx, wgt, W2r, bias_r, Y,
+                     (int)M, HW, HW, Cin, O, 4, nullptr, nullptr, act_slope, mod);
+  return eml::check_launch("eml_sphere_conv_spade_fwd_f32");
 }
 
 // dX (B*HW, C) = gather-GEMM over the transposed tap table: tidx / twgt (HW*9*ke) = for input pixel q and tap t the

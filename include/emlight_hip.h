@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 17
+#define EML_ABI_VERSION 18
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -491,6 +491,28 @@ int eml_bn_bwd_apply_up2_f32(const float* dxn, const float* x_lo, int B, int H, 
 int eml_spade_norm_modulate_bwd_cols_f32(const float* gy, const float* x, const float* gb, float* dxn, float* dgb, int B, int H,
                                          int W, int C, int up2, float slope, const float* mean, const float* istd,
                                          double* partials, int grid, eml_stream_t stream);
+
+/* SPADE in ONE launch (normalization.py:101-115: `normalized * (1 + gamma) + beta` with gamma = mlp_gamma(actv), beta =
+ * mlp_beta(actv), both SphereConv2D 128 -> norm_nc; architecture.py:56-57 for the LeakyReLU that follows): the gather-GEMM of
+ * the concatenated heads over `actv` (B, H, W, Cin) with the modulation of x as its epilogue,
+ *     Y[m][c] = leaky_relu(((x[m'][c] - mean[c]) * istd[c]) * (1 + gamma[m][c]) + beta[m][c], act_slope)       (B*H*W, Cn)
+ * so the (B*H*W, 2 Cn) gamma | beta tensor is never written or re-read.  idx / wgt: the stride-1 bilinear tap table of the
+ * (H, W) grid (ke = 4).  W2r (2 Cn, 9 Cin) / bias_r (2 Cn, or NULL): the rows of cat(gamma head, beta head), columns (tap, c),
+ * REORDERED so that a wave of the kernel holds gamma and beta of the same channels: position p holds source row
+ * c + half * Cn with c = 64 (p / 128) + 32 ((p % 128) / 64) + p % 32 and half = (p % 64) / 32.  up2 != 0: x (B, H/2, W/2, Cn)
+ * is the map before the generator's nearest x2 upsample (m' = the parent pixel), else x (B*H*W, Cn).  gamma_out (B*H*W, Cn) or
+ * NULL: gamma, which the backward needs (eml_spade_norm_modulate_bwd_y_f32 takes it together with Y; beta is not needed: the
+ * activation's mask is Y's sign).  eml_sphere_conv_spade_supported: Cin % 32 == 0, Cin >= 64, Cn % 64 == 0 and the 32-bit
+ * offsets of the kernel reach (H*W*Cin < 2^29, 2 Cn * 9 Cin < 2^30). */
+int eml_sphere_conv_spade_supported(int Cin, int Cn, long HW);
+int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, const float* wgt, const float* W2r, const float* bias_r,
+                                  const float* x, const float* mean, const float* istd, float* Y, float* gamma_out, int B, int H,
+                                  int W, int Cin, int Cn, int up2, float act_slope, eml_stream_t stream);
+/* eml_spade_norm_modulate_bwd_cols_f32 for that forward: gamma (B*H*W, C) and the forward's output y (B*H*W, C) in place of
+ * the (gamma | beta) tensor; dgb (B*H*W, 2C) = (dgamma | dbeta), partials as above.  slope in [0, 1]. */
+int eml_spade_norm_modulate_bwd_y_f32(const float* gy, const float* x, const float* gamma, const float* y, float* dxn, float* dgb,
+                                      int B, int H, int W, int C, int up2, float slope, const float* mean, const float* istd,
+                                      double* partials, int grid, eml_stream_t stream);
 
 /* torch.nn.utils.spectral_norm of a 3x3 convolution weight (normalization.py:24-33, architecture.py:41-45), fused with
  * the (O, tap, c) re-layout of the gather-GEMM kernels.  W (O, C, 3, 3) = weight_orig; u (O), v (9C) = the module's

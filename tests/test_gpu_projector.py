@@ -172,6 +172,12 @@ def test_ngf64_shape_list_is_what_the_networks_run(monkeypatch):
         seen.add((x.shape[0], x.shape[1], weight.shape[0], x.shape[2], x.shape[3], stride))
         return real(x, weight, bias, stride, *more)
     monkeypatch.setattr(spherenet, "sphere_conv", spy)
+    real_spade = spherenet.spade_conv_modulate
+
+    def spy_spade(x, actv, weight, *more):   # the gamma | beta SphereConvs that run with SPADE's modulation as their epilogue
+        seen.add((actv.shape[0], actv.shape[1], weight.shape[0], actv.shape[2], actv.shape[3], 1))
+        return real_spade(x, actv, weight, *more)
+    monkeypatch.setattr(spherenet, "spade_conv_modulate", spy_spade)
     torch.manual_seed(0)
     pm = Pix2PixModel(networks.default_options()).cuda()
     with torch.no_grad():
@@ -320,6 +326,124 @@ def test_spade_norm_modulate_hip_vs_stock_ops(slope, B, C, H, W, mode):
     np.testing.assert_allclose(bn_hip.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(bn_hip.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+def _spy_on_lib(monkeypatch):
+    """Route every C-ABI call through a recorder; returns the list of entry-point names in call order."""
+    from emlight_amd import _lib
+    real, seen = _lib.lib(), []
+
+    class Spy:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+
+            def call(*a):
+                seen.append(name)
+                return fn(*a)
+            return call
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    return seen
+
+
+@pytest.mark.parametrize("mode", [True, False])
+@pytest.mark.parametrize("slope,B,C,nh,H,W,up2", [(0.2, 2, 64, 128, 16, 32, False), (1.0, 1, 128, 128, 8, 16, False),
+                                                   (0.2, 2, 128, 64, 12, 24, True), (0.0, 3, 256, 128, 6, 12, True),
+                                                   (0.2, 1, 64, 96, 10, 20, False)])
+def test_spade_in_one_launch_vs_two_launches_and_stock_ops(slope, B, C, nh, H, W, up2, mode, monkeypatch):
+    """The gamma | beta SphereConv with SPADE's modulation as its epilogue (eml_sphere_conv_spade_fwd_f32: the (B, 2C, H, W)
+    tensor never exists; backward from gamma and the output's sign) against (a) the two-launch HIP path -- same conv kernel,
+    same arithmetic: 1e-6 -- and (b) normalization.py:101-115 / architecture.py:56-57 on stock ops, incl. the folded nearest
+    x2 upsample (generator.py:70-82), partial pixel tiles (B*H*W not a multiple of 128) and eval-mode statistics."""
+    from emlight_amd.GenProjector import spherenet
+    from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_norm_modulate
+    torch.manual_seed(5)
+    monkeypatch.setattr(SphereConv2D, "fused_min_bytes", 0)       # every layer on the fused kernels, whatever its size
+    seen = _spy_on_lib(monkeypatch)
+    bns = [torch.nn.BatchNorm2d(C, affine=False).cuda().train(mode) for _ in range(3)]
+    with torch.no_grad():
+        for bn in bns:
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.3, C))
+            bn.running_var.copy_(torch.linspace(0.5, 2.0, C))
+    heads = [(SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()) for _ in range(3)]
+    with torch.no_grad():
+        for m in heads[0]:
+            m.bias.uniform_(-0.3, 0.3)
+    for g_, b_ in heads[1:]:
+        g_.load_state_dict(heads[0][0].state_dict())
+        b_.load_state_dict(heads[0][1].state_dict())
+    hx, wx = (H // 2, W // 2) if up2 else (H, W)
+    xn0 = (torch.randn(B, C, hx, wx, device="cuda") * 1.7 + 0.4).contiguous(memory_format=torch.channels_last)
+    a0 = torch.randn(B, nh, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    wy = torch.linspace(-1, 1, B * C * H * W, device="cuda").view(B, C, H, W)
+
+    def stock(xn, bn, actv, g_, b_, slope):
+        return oracle.spade_norm_modulate(torch.nn.functional.interpolate(xn, scale_factor=2) if up2 else xn, bn, actv, g_, b_, slope)
+
+    def hip(xn, bn, actv, g_, b_, slope):
+        return spade_norm_modulate(xn, bn, actv, g_, b_, slope, None, up2)
+
+    outs = []
+    for k, (fn, fuse) in enumerate(((stock, True), (hip, False), (hip, True))):
+        monkeypatch.setattr(SphereConv2D, "fuse_spade", fuse)
+        n0 = len(seen)
+        xn, actv = xn0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        g_, b_ = heads[k]
+        y = fn(xn, bns[k], actv, g_, b_, slope)
+        (y * wy).sum().backward()
+        outs.append([y.detach(), xn.grad, actv.grad, g_.weight.grad, g_.bias.grad, b_.weight.grad, b_.bias.grad])
+        if k:
+            assert ("eml_sphere_conv_spade_fwd_f32" in seen[n0:]) == fuse and ("eml_spade_norm_modulate_bwd_y_f32" in seen[n0:]) == fuse
+    names = ["y", "d_x", "d_actv", "dWg", "dbg", "dWb", "dbb"]
+    for name, r, two, one in zip(names, *outs):
+        s_ = float(r.abs().max())
+        np.testing.assert_allclose(one.cpu().numpy(), two.cpu().numpy(), rtol=1e-6, atol=1e-6 * s_, err_msg="one vs two launches: " + name)
+        np.testing.assert_allclose(one.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=3e-5 * s_, err_msg="vs stock ops: " + name)
+    np.testing.assert_allclose(bns[2].running_mean.cpu().numpy(), bns[0].running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bns[2].running_var.cpu().numpy(), bns[0].running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # inference (the discriminator step's generator pass): gamma is not stored either
+    monkeypatch.setattr(SphereConv2D, "fuse_spade", True)
+    with torch.no_grad():
+        y_ng = hip(xn0, bns[2].eval(), a0, *heads[2], slope)
+        y_two = (monkeypatch.setattr(SphereConv2D, "fuse_spade", False), hip(xn0, bns[1].eval(), a0, *heads[1], slope))[1]
+    np.testing.assert_allclose(y_ng.cpu().numpy(), y_two.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(y_two.abs().max()))
+
+
+@pytest.mark.parametrize("C,H,W,up2", [(64, 128, 256, False), (128, 128, 256, True), (256, 64, 128, True), (128, 64, 128, False)])
+def test_spade_in_one_launch_at_cfg3_size_natural_dispatch(C, H, W, up2, monkeypatch):
+    """BASELINE configs[2] geometry (B = 32, ngf = 64: the SPADEs of up_2 / up_3), dispatch left alone: these layers take the
+    one-launch path, and it agrees with the two-launch HIP path (which the per-layer and trainer-level tests pin to the
+    reference's ops) to rounding -- output, d/dx through the batch statistics, d/dactv, the four head gradients."""
+    from emlight_amd.GenProjector.spherenet import SphereConv2D, spade_norm_modulate
+    torch.manual_seed(C + H)
+    B, nh = 32, 128
+    seen = _spy_on_lib(monkeypatch)
+    g_, b_ = SphereConv2D(nh, C).cuda(), SphereConv2D(nh, C).cuda()
+    hx, wx = (H // 2, W // 2) if up2 else (H, W)
+    xn0 = (torch.randn(B, C, hx, wx, device="cuda") * 1.3 - 0.2).contiguous(memory_format=torch.channels_last)
+    a0 = torch.randn(B, nh, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    wy = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(SphereConv2D, "fuse_spade", fuse)
+        bn = torch.nn.BatchNorm2d(C, affine=False).cuda().train()
+        n0 = len(seen)
+        xn, actv = xn0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        for m in (g_, b_):
+            m.zero_grad(set_to_none=True)
+        y = spade_norm_modulate(xn, bn, actv, g_, b_, 0.2, None, up2)
+        (y * wy).sum().backward()
+        outs.append([y.detach(), xn.grad, actv.grad, g_.weight.grad.clone(), g_.bias.grad.clone(), b_.weight.grad.clone(),
+                     b_.bias.grad.clone()])
+        assert ("eml_sphere_conv_spade_fwd_f32" in seen[n0:]) == fuse, "natural dispatch must take the one-launch path here"
+        assert ("eml_spade_norm_modulate_fwd_f32" in seen[n0:] or "eml_spade_norm_modulate_up2_fwd_f32" in seen[n0:]) != fuse
+        del y, xn, actv
+    # (256 @ 64x128: the two-launch path forms gamma | beta with the library GEMM, the one-launch path in the gather-GEMM --
+    # rounding-level differences in the pre-activation flip the LeakyReLU's mask at a handful of near-zero pixels, so the
+    # gradients are compared in the L2 norm; the output is continuous in gamma, beta and is compared entry by entry)
+    for name, two, one in zip(["y", "d_x", "d_actv", "dWg", "dbg", "dWb", "dbb"], *outs):
+        if name == "y":
+            assert float((one - two).abs().max()) <= 2e-6 * float(two.abs().max()), name
+        assert float((one - two).norm()) <= 1e-3 * float(two.norm()), name   # measured 1.3e-4 (three flipped pixels of 67 M)
 
 
 def test_sphere_conv_properties_at_full_size():

@@ -14,7 +14,8 @@ int launch(const float* X, const int* idx, const float* wgt, const float* W2, co
   const dim3 grid((unsigned)(8 * per_xcd * (O / BN)));
   auto kern = gg2::gather_gemm2_kernel<BN, NT, LPP, PK, ONE>;
   EML_ENSURE_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, X, idx, wgt, W2, bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, X, idx, wgt, W2, bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope,
+                     gg2::SpadeEpilogue{});
   return eml::check_launch("gg2_exp");
 }
 template <int BN, int LPP, bool ONE>
