@@ -203,7 +203,16 @@ class _SphereConvFn(torch.autograd.Function):
         # 3-channel input layers (SPADE's mlp_shared 3 -> 128, VGG's 3 -> 64; not the discriminator's 6 -> 64): bound by the
         # write of their output -- one pass each way with the activation (and its backward, and the bias gradient) folded in
         ctx.small = bool(B > 0 and res is None and L.eml_sphere_conv_small_supported(C, O))
-        if ctx.small:
+        # few-channel OUTPUT layers (conv_img 64 -> 3, the discriminators' final convolutions): one-pass kernels, no 9x operand
+        ctx.narrow = bool(SphereConv2D.narrow_kernels and B > 0 and res is None and slope == 1.0 and geo.idx1 is None
+                          and not ctx.small and L.eml_sphere_conv_narrow_supported(C, O))
+        if ctx.narrow:
+            ctx.fused_fwd = ctx.fused_wgrad = ctx.fused_dgrad = False
+            y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
+            _lib.check(L.eml_sphere_conv_narrow_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+                                                        p(bias.contiguous()) if bias is not None else None, p(y), B, H * W, po,
+                                                        C, O, st), "eml_sphere_conv_narrow_fwd_f32")
+        elif ctx.small:
             ctx.fused_fwd = ctx.fused_wgrad = False
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
             _lib.check(L.eml_sphere_conv_small_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
@@ -294,8 +303,16 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             ok = y is None and sums.shape == (O,) and ptr == gy.data_ptr() and ver == gy._version
             pre = sums if ok else None
         gb = pre if pre is not None else gyr.sum(0)
+    narrow = getattr(ctx, "narrow", False)
     if needs[1] and not small_w:
-        if ctx.fused_wgrad and B:
+        if narrow:
+            part = torch.empty(L.eml_sphere_conv_narrow_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
+            gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
+            _lib.check(L.eml_sphere_conv_narrow_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B, H * W, po, C,
+                                                          O, st), "eml_sphere_conv_narrow_wgrad_f32")
+            gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
+            del part
+        elif ctx.fused_wgrad and B:
             bn = 128 if C % 128 == 0 else 64
             bmo = 128 if (O % 128 == 0 or O > 192) else 64
             tiles = 9 * (C // bn) * ((O + bmo - 1) // bmo)
@@ -329,8 +346,13 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             del a9
     if needs[0]:
         gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
-        tt = geo.transposed_table() if (ctx.fused_dgrad and B) else None
-        if tt is not None:
+        tt = geo.transposed_table() if ((ctx.fused_dgrad or narrow) and B) else None
+        if tt is not None and narrow:
+            tidx, twgt, rowmax, ke = tt
+            w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+            _lib.check(L.eml_sphere_conv_narrow_dgrad_f32(p(gyr), p(tidx), p(twgt), ke, p(w2), p(gxr), B, H * W, po, C, O, st),
+                       "eml_sphere_conv_narrow_dgrad_f32")
+        elif tt is not None:
             # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
             tidx, twgt, rowmax, ke = tt
             w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
@@ -806,6 +828,8 @@ class SphereConv2D(nn.Module):
     fused_min_bytes = int(os.environ.get("EML_FUSED_MIN_MB", "64")) << 20
     # SPADE's gamma | beta convolution with the modulation as its epilogue (_SpadeConvModulateFn); EML_FUSE_SPADE=0: A/B knob
     fuse_spade = os.environ.get("EML_FUSE_SPADE", "1") != "0"
+    # O <= 4 layers on the one-pass kernels of csrc/sphere_conv_narrow.hip; EML_NARROW=0: A/B knob (im2col + library GEMM)
+    narrow_kernels = os.environ.get("EML_NARROW", "1") != "0"
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

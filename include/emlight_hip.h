@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 18
+#define EML_ABI_VERSION 19
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -423,6 +423,21 @@ size_t eml_sphere_conv_small_wgrad_partial_floats(int B, int Po, int C, int O);
 int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY, const float* Yact,
                                     float act_slope, float* partial, float* dW2, float* db, int B, int HW, int Po, int C,
                                     int O, eml_stream_t stream);
+/* The few-channel OUTPUT layers (generator.py:60, 84-86: conv_img 64 -> 3 at full resolution; discriminator.py:70-74: the
+ * final 512 -> 1 convolutions): sphere_cnn.py:111-124 with O <= 4 as three one-pass kernels -- no 9x im2col operand, no N = 3
+ * library GEMM, no dA9 + col2im in the backward.  C % 64 == 0, C <= 512, 1 <= O <= 4 (eml_sphere_conv_narrow_supported).
+ * X (B, HW, C) pixel-major, idx / wgt (Po*9*4) the bilinear tap table, W2 (O, 9C) columns (tap, c), Y / dY (B*Po, O).
+ *   fwd   Y = A9(X) W2^T + bias (bias may be NULL)
+ *   dgrad dX (B*HW, C) through the TRANSPOSED tap table tidx / twgt (HW*9*ke, ke in 1..8; -1 / 0 = empty slot): a gather
+ *   wgrad dW2 (O, 9C); partial = eml_sphere_conv_narrow_wgrad_partial_floats(B, Po, C, O) floats of scratch; fixed-order sums */
+int eml_sphere_conv_narrow_supported(int C, int O);
+int eml_sphere_conv_narrow_fwd_f32(const float* X, const int* idx, const float* wgt, const float* W2, const float* bias, float* Y,
+                                   int B, int HW, int Po, int C, int O, eml_stream_t stream);
+int eml_sphere_conv_narrow_dgrad_f32(const float* dY, const int* tidx, const float* twgt, int ke, const float* W2, float* dX, int B,
+                                     int HW, int Po, int C, int O, eml_stream_t stream);
+size_t eml_sphere_conv_narrow_wgrad_partial_floats(int B, int Po, int C, int O);
+int eml_sphere_conv_narrow_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY, float* partial, float* dW2,
+                                     int B, int HW, int Po, int C, int O, eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the

@@ -328,6 +328,41 @@ def test_spade_norm_modulate_hip_vs_stock_ops(slope, B, C, H, W, mode):
     assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", [(2, 64, 3, 16, 32, 1), (3, 128, 1, 10, 20, 1), (2, 512, 3, 8, 16, 1),
+                                                    (1, 64, 4, 6, 12, 1), (2, 192, 2, 12, 24, 2), (1, 64, 3, 2, 4, 1)])
+def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, stride, monkeypatch):
+    """conv_img 64 -> 3 and the discriminators' final convolutions (csrc/sphere_conv_narrow.hip: forward, input gradient by the
+    transposed tap table, weight gradient) against grid_sample + conv2d(stride 3) (sphere_cnn.py:111-124): pixel counts that do
+    not fill a workgroup, several 64-channel groups, stride 2, and a geometry so small that a (pixel, tap) has more than 8
+    sources (the input gradient then falls back to dA9 + col2im)."""
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    torch.manual_seed(Cin + Cout)
+    hip = SphereConv2D(Cin, Cout, stride=stride, bias=True).cuda()
+    with torch.no_grad():
+        hip.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(B, Cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    xr, xh = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    wr, br = hip.weight.detach().clone().requires_grad_(True), hip.bias.detach().clone().requires_grad_(True)
+    seen = _spy_on_lib(monkeypatch)
+    yh = hip(xh)
+    yr = oracle.sphere_conv(xr, wr, br, stride)
+    gy = torch.randn_like(yr)
+    yh.backward(gy)
+    yr.backward(gy)
+    assert "eml_sphere_conv_narrow_fwd_f32" in seen and "eml_sphere_conv_narrow_wgrad_f32" in seen
+    assert "eml_sphere_im2col_f32" not in seen
+    assert ("eml_sphere_conv_narrow_dgrad_f32" in seen) != ("eml_sphere_col2im_f32" in seen)
+    for name, h, r in (("y", yh, yr), ("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad), ("db", hip.bias.grad, br.grad)):
+        np.testing.assert_allclose(h.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=1e-4,
+                                   atol=1e-4 * float(r.detach().abs().max()), err_msg=name)
+    # run-to-run exact (fixed-order sums, no atomics)
+    hip.zero_grad(set_to_none=True)
+    x2 = x.clone().requires_grad_(True)
+    y2 = hip(x2)
+    y2.backward(gy)
+    assert torch.equal(y2, yh) and torch.equal(x2.grad, xh.grad)
+
+
 def _spy_on_lib(monkeypatch):
     """Route every C-ABI call through a recorder; returns the list of entry-point names in call order."""
     from emlight_amd import _lib
