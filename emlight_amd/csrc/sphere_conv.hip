@@ -67,16 +67,19 @@ __global__ __launch_bounds__(256) void sphere_im2col_kernel(const float* __restr
     for (int c = cl; c < cv; c += TPR) {
       if constexpr (VEC == 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // same accumulation order as grid_sampler_2d: nw, ne, sw, se; a corner off the map adds +0 (its load is issued anyway,
+        // at a clamped address: under `if (id >= 0)` each corner was its own basic block -- load, wait, add -- four serial
+        // round trips per element)
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(xb + (size_t)max(ids[k], 0) * C + 4 * c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          // same accumulation order as grid_sampler_2d: nw, ne, sw, se (skipped when out of bounds)
-          if (ids[k] >= 0) {
-            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ids[k] * C + 4 * c);
-            acc.x += v.x * ws[k];
-            acc.y += v.y * ws[k];
-            acc.z += v.z * ws[k];
-            acc.w += v.w * ws[k];
-          }
+          const float wk = ids[k] >= 0 ? ws[k] : 0.f;
+          acc.x += v[k].x * wk;
+          acc.y += v[k].y * wk;
+          acc.z += v[k].z * wk;
+          acc.w += v[k].w * wk;
         }
         // streaming store: A9 is 9x the input and is next read by the GEMM long after it has left L2
         float* dst = ab + (size_t)row * C + 4 * c;
@@ -109,7 +112,23 @@ __global__ __launch_bounds__(256) void sphere_col2im_kernel(const float* __restr
     for (int c = cl; c < cv; c += TPR) {
       if constexpr (VEC == 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = k0; k < k1; ++k) {
+        // four entries per step: their (source row, weight) loads first, then the four row reads, then the FMAs in CSR
+        // order (the sum's order is unchanged).  One entry per iteration was two dependent memory latencies x ~36 entries
+        // per input pixel: the kernel ran at 1.1 TB/s on a tensor it reads exactly once.
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+          const int s0 = src[k], s1 = src[k + 1], s2 = src[k + 2], s3 = src[k + 3];
+          const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+          const float4 v0 = *reinterpret_cast<const float4*>(ab + (size_t)s0 * C + 4 * c);
+          const float4 v1 = *reinterpret_cast<const float4*>(ab + (size_t)s1 * C + 4 * c);
+          const float4 v2 = *reinterpret_cast<const float4*>(ab + (size_t)s2 * C + 4 * c);
+          const float4 v3 = *reinterpret_cast<const float4*>(ab + (size_t)s3 * C + 4 * c);
+          acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+          acc.x = fmaf(w1, v1.x, acc.x); acc.y = fmaf(w1, v1.y, acc.y); acc.z = fmaf(w1, v1.z, acc.z); acc.w = fmaf(w1, v1.w, acc.w);
+          acc.x = fmaf(w2, v2.x, acc.x); acc.y = fmaf(w2, v2.y, acc.y); acc.z = fmaf(w2, v2.z, acc.z); acc.w = fmaf(w2, v2.w, acc.w);
+          acc.x = fmaf(w3, v3.x, acc.x); acc.y = fmaf(w3, v3.y, acc.y); acc.z = fmaf(w3, v3.z, acc.z); acc.w = fmaf(w3, v3.w, acc.w);
+        }
+        for (; k < k1; ++k) {
           const float wk = w[k];
           const float4 v = *reinterpret_cast<const float4*>(ab + (size_t)src[k] * C + 4 * c);
           acc.x = fmaf(wk, v.x, acc.x);

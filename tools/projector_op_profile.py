@@ -37,6 +37,9 @@ tot = sum(dev_us(e) for e in rows)
 print("total device time %.1f ms per iteration" % (tot / n / 1e3))
 for e in rows[:70]:
     print("%8.2f ms %5d  %-44s %s" % (dev_us(e) / n / 1e3, e.count // n, e.key[:44], str(e.input_shapes)[:110]))
+print("\n== glue ops by input shape ==")
+for e in [e for e in rows if e.key.startswith("aten::") and e.key not in ("aten::mm", "aten::addmm", "aten::bmm")][:40]:
+    print("%8.2f ms %5d  %-32s %s" % (dev_us(e) / n / 1e3, e.count // n, e.key, str(e.input_shapes)[:120]))
 print("\n== glue ops by call site ==")
 glue = ("aten::copy_", "aten::sum", "aten::mul", "aten::add", "aten::add_", "aten::clamp_min", "aten::relu", "aten::cat",
         "aten::threshold_backward", "aten::div", "aten::sub", "aten::neg", "aten::fill_", "aten::zero_", "aten::mean",
