@@ -246,12 +246,22 @@ def time_rasteriser(B, anchors, pano_hw, dev, reps=50):
     out = convert_to_panorama(dirs, sizes, colors, pano_hw=pano_hw)
     gout = torch.rand_like(out)
     ms_b = _events(lambda: torch.autograd.grad(out, colors, gout, retain_graph=True), reps)
+    # the colour gradient's two launches (per-patch light lists + the tile sum) back to back, and the round-1 kernel beside it
+    work = torch.empty(max(1, L_.eml_sg_rasterise_bwd_work_floats(B, anchors, H, W)), device=dev)
+    gcol, gq = torch.empty(B, 3 * anchors, device=dev), gout.contiguous()
+    ms_bl = _events(lambda: _lib.check(L_.eml_sg_rasterise_bwd_colors_ex_f32(p_(dirs), p_(sizes), p_(gq), p_(gcol), p_(work), B,
+                                                                             anchors, H, W, 0, _lib.current_stream()),
+                                       "eml_sg_rasterise_bwd_colors_ex_f32"), reps)
+    ms_b1 = _events(lambda: _lib.check(L_.eml_sg_rasterise_bwd_colors_f32(p_(dirs), p_(sizes), p_(gq), p_(gcol), B, anchors, H, W,
+                                                                          _lib.current_stream()),
+                                       "eml_sg_rasterise_bwd_colors_f32"), reps)
     nbytes = B * 3 * H * W * 4 + B * 7 * anchors * 4
     nexp = float(B) * anchors * H * W
     from emlight_amd.RegressionNetwork.util import rasterise_raw
     _, executed = rasterise_raw(dirs, sizes, colors.detach(), pano_hw=pano_hw, count=True)
     return {"batch": B, "anchors": anchors, "pano_hw": [H, W], "ms_fwd": round(ms_f, 4), "ms_fwd_python_entry": round(ms_api, 4),
-            "ms_bwd_colors": round(ms_b, 4),
+            "ms_bwd_colors": round(ms_b, 4), "ms_bwd_colors_launches": round(ms_bl, 4),
+            "ms_bwd_colors_round1_kernel": round(ms_b1, 4),
             "algorithmic_MB": round(nbytes / 1e6, 2), "GBps_on_algorithmic_bytes": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
             "reference_exponentials": int(nexp), "executed_exponentials": executed,
             "executed_fraction": round(executed / nexp, 4),

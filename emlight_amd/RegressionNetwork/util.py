@@ -41,11 +41,27 @@ class _Rasterise(torch.autograd.Function):
                                       "path (anchors and lobe widths are constants)")
         H, W = ctx.hw
         B, N = sizes.shape
-        gcol = torch.empty(B, 3 * N, dtype=torch.float32, device=gout.device)
-        _lib.check(_lib.lib().eml_sg_rasterise_bwd_colors_f32(
-            _lib.ptr(dirs), _lib.ptr(sizes), _lib.ptr(gout.contiguous()), _lib.ptr(gcol), B, N, H, W,
-            _lib.current_stream()), "eml_sg_rasterise_bwd_colors_f32")
-        return None, None, gcol, None, None
+        return None, None, rasterise_bwd_colors_raw(dirs, sizes, gout, (H, W)), None, None
+
+
+def rasterise_bwd_colors_raw(dirs, sizes, gout, pano_hw, exhaustive=False, legacy=False):
+    """d loss / d colors (B, 3N) through ``eml_sg_rasterise_bwd_colors_ex_f32``: the forward's per-patch light lists, per-tile
+    partial sums added in tile order.  ``exhaustive``: every light for every tile (what the culled launch equals bit for bit);
+    ``legacy``: the round-1 kernel (one workgroup per 8 lights sweeping the whole panorama) -- the independent check."""
+    H, W = pano_hw
+    B, N = sizes.shape
+    L = _lib.lib()
+    gout = gout.contiguous()
+    gcol = torch.empty(B, 3 * N, dtype=torch.float32, device=gout.device)
+    if legacy:
+        _lib.check(L.eml_sg_rasterise_bwd_colors_f32(_lib.ptr(dirs), _lib.ptr(sizes), _lib.ptr(gout), _lib.ptr(gcol), B, N, int(H),
+                                                     int(W), _lib.current_stream()), "eml_sg_rasterise_bwd_colors_f32")
+        return gcol
+    work = torch.empty(max(1, L.eml_sg_rasterise_bwd_work_floats(B, N, int(H), int(W))), dtype=torch.float32, device=gout.device)
+    _lib.check(L.eml_sg_rasterise_bwd_colors_ex_f32(_lib.ptr(dirs), _lib.ptr(sizes), _lib.ptr(gout), _lib.ptr(gcol), _lib.ptr(work),
+                                                    B, N, int(H), int(W), 1 if exhaustive else 0, _lib.current_stream()),
+               "eml_sg_rasterise_bwd_colors_ex_f32")
+    return gcol
 
 
 def rasterise_raw(dirs, sizes, colors, pano_hw=(128, 256), exhaustive=False, count=False):

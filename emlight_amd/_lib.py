@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 19   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 20   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -57,6 +57,8 @@ SIGNATURES = {
                                                    _stream]),
     "eml_spade_norm_modulate_bwd_cols_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,
                                                     ctypes.c_float, _f32p, _f32p, _f32p, _int, _stream]),
+    "eml_sg_rasterise_bwd_work_floats": (ctypes.c_size_t, [_int, _int, _int, _int]),
+    "eml_sg_rasterise_bwd_colors_ex_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream]),
     "eml_sphere_conv_narrow_supported": (_int, [_int, _int]),
     "eml_sphere_conv_narrow_fwd_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream]),
     "eml_sphere_conv_narrow_dgrad_f32": (_int, [_f32p, _i32p, _f32p, _int, _f32p, _f32p, _int, _int, _int, _int, _int, _stream]),

@@ -91,6 +91,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// sum over the whole wave without LDS traffic (wave-uniform result): DPP inside the rows, the four row totals by v_readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
 // min / max over the whole wave without LDS traffic: DPP inside the 16-lane rows, then the four row results through
 // v_readlane (wave-uniform result).  The __shfl_xor forms above cost 6 ds_bpermute round trips each.
 __device__ __forceinline__ float wave_min_dpp(float v) {

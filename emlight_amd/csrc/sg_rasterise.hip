@@ -226,6 +226,123 @@ __global__ __launch_bounds__(256) void sg_rasterise_bwd_colors_kernel(
   }
 }
 
+// d/d(colors) with the forward's hierarchical cull (round 4): same tiles, same bounding cap, same survivor lists.  A wave
+// evaluates exp2 only for the lights that reach its 16 x 8 patch, reduces  sum_pixels gout * exp2(.)  over its lanes (three DPP
+// wave sums per survivor) and parks the result in a wave-private LDS row indexed by the light (a light is on a wave's list at
+// most once per chunk: a store, not an accumulation); the four waves are added per workgroup, and the per-tile partials
+// [B][tiles][N][3] by a second kernel in tile order -- no atomics, run-to-run exact.  A culled light contributes exp2(t) == 0
+// to every pixel of the patch, i.e. exactly 0: the result equals the exhaustive evaluation of the same sums.
+__global__ __launch_bounds__(256) void sg_rasterise_bwd_colors_tiled_kernel(
+    const float* __restrict__ dirs, const float* __restrict__ sizes, const float* __restrict__ gout,
+    float* __restrict__ partial, int N, int H, int W, float step, int exhaustive) {
+  __shared__ float4 lobes[kChunk];            // direction, log2(e)/size
+  __shared__ float4 kept[4][kChunk];
+  __shared__ int keptidx[4][kChunk];
+  __shared__ float accw[4][kChunk][3];
+  __shared__ float sin_t[kTileH], cos_t[kTileH], sin_p[kTileW], cos_p[kTileW];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  float4 pre = make_float4(0.f, 0.f, 0.f, 1.f);
+  auto preload = [&](int base) {
+    const size_t li = (size_t)b * N + min(base + tid, N - 1);
+    pre = make_float4(dirs[3 * li + 0], dirs[3 * li + 1], dirs[3 * li + 2], sizes[li]);
+  };
+  if (tid < kChunk) preload(0);
+  if (tid < kTileH) sincosf(((float)(blockIdx.y * kTileH + tid) + 0.5f) * step, &sin_t[tid], &cos_t[tid]);
+  else if (tid < kTileH + kTileW)
+    sincosf(((float)(blockIdx.x * kTileW + tid - kTileH) + 0.5f) * step, &sin_p[tid - kTileH], &cos_p[tid - kTileH]);
+  __syncthreads();
+  const int cw = (wave & 1) * 16 + (lane & 15), r0 = (wave >> 1) * 8 + (lane >> 4), r1 = r0 + 4;
+  const int w = blockIdx.x * kTileW + cw;
+  const int h0 = blockIdx.y * kTileH + r0, h1 = h0 + 4;
+  const float p0x = sin_t[r0] * cos_p[cw], p0y = sin_t[r0] * sin_p[cw], p0z = cos_t[r0];
+  const float p1x = sin_t[r1] * cos_p[cw], p1y = sin_t[r1] * sin_p[cw], p1z = cos_t[r1];
+  float cx, cy, cz, rr;   // bounding cap of the wave's patch: exactly the forward's
+  {
+    auto lane_of = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    cx = lane_of(p0x, 56) + lane_of(p1x, 7);
+    cy = lane_of(p0y, 56) + lane_of(p1y, 7);
+    cz = lane_of(p0z, 56) + lane_of(p1z, 7);
+    const float inv = rsqrtf(fmaf(cz, cz, fmaf(cy, cy, cx * cx)));
+    cx *= inv, cy *= inv, cz *= inv;
+    const float a0 = p0x - cx, a1 = p0y - cy, a2 = p0z - cz, b0 = p1x - cx, b1 = p1y - cy, b2 = p1z - cz;
+    const float d2 = fmaxf(fmaf(a2, a2, fmaf(a1, a1, a0 * a0)), fmaf(b2, b2, fmaf(b1, b1, b0 * b0)));
+    rr = sqrtf(eml::wave_max_dpp(d2)) * 1.0001f + 1e-6f;
+  }
+  // the lane's two pixels of the output gradient (0 off the map)
+  const size_t plane = (size_t)H * W;
+  const float* g = gout + (size_t)b * 3 * plane;
+  float g0[3] = {0.f, 0.f, 0.f}, g1[3] = {0.f, 0.f, 0.f};
+  if (w < W && h0 < H) {
+    const size_t o = (size_t)h0 * W + w;
+    g0[0] = g[o]; g0[1] = g[plane + o]; g0[2] = g[2 * plane + o];
+  }
+  if (w < W && h1 < H) {
+    const size_t o = (size_t)h1 * W + w;
+    g1[0] = g[o]; g1[1] = g[plane + o]; g1[2] = g[2 * plane + o];
+  }
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+  float* out = partial + ((size_t)b * ntiles + tile) * N * 3;
+  for (int base = 0; base < N; base += kChunk) {
+    const int cnt = min(kChunk, N - base);
+    if (base > 0) __syncthreads();   // the previous chunk's lobes / lists / sums are no longer read
+    if (tid < cnt) lobes[tid] = make_float4(pre.x, pre.y, pre.z, kLog2e / pre.w);
+    for (int i = lane; i < kChunk * 3; i += 64) (&accw[wave][0][0])[i] = 0.f;
+    __syncthreads();
+    if (base + kChunk < N && tid < kChunk) preload(base + kChunk);
+    int n = 0;
+    for (int j = 0; j < cnt; j += 64) {
+      const int li = j + lane;
+      const float4 L = lobes[min(li, cnt - 1)];
+      const float len = sqrtf(fmaf(L.z, L.z, fmaf(L.y, L.y, L.x * L.x)));
+      const float s_ = fmaf(L.z, cz, fmaf(L.y, cy, L.x * cx)) + fmaf(len, rr, 1e-5f * (1.0f + len));
+      const bool odd = !(L.w > 0.f) || L.w > 3.0e38f || !(len < 3.0e38f);   // as in the forward: never cull these
+      const bool keep = li < cnt && (exhaustive || odd || !((s_ - 1.0f) * L.w <= kCull));
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      if (keep) {
+        kept[wave][pos] = L;
+        keptidx[wave][pos] = li;
+      }
+      n += __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = 0; i < n; ++i) {
+      const float4 L = kept[wave][i];   // broadcast reads
+      const int li = keptidx[wave][i];
+      const float e0 = __builtin_amdgcn_exp2f((fmaf(L.z, p0z, fmaf(L.y, p0y, L.x * p0x)) - 1.0f) * L.w);
+      const float e1 = __builtin_amdgcn_exp2f((fmaf(L.z, p1z, fmaf(L.y, p1y, L.x * p1x)) - 1.0f) * L.w);
+      const float sr = eml::wave_sum_dpp(fmaf(g1[0], e1, g0[0] * e0));
+      const float sg = eml::wave_sum_dpp(fmaf(g1[1], e1, g0[1] * e0));
+      const float sb = eml::wave_sum_dpp(fmaf(g1[2], e1, g0[2] * e0));
+      if (lane == 0) {
+        accw[wave][li][0] = sr;
+        accw[wave][li][1] = sg;
+        accw[wave][li][2] = sb;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt * 3; i += 256) {
+      const float* a0 = &accw[0][0][0];
+      out[(size_t)base * 3 + i] = (a0[i] + a0[kChunk * 3 + i]) + (a0[2 * kChunk * 3 + i] + a0[3 * kChunk * 3 + i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sg_reduce_tiles_kernel(const float* __restrict__ partial, int ntiles, int n3,
+                                                              float* __restrict__ gcolors, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;   // (b, light, channel)
+  if (e >= total) return;
+  const int b = e / n3, i = e - b * n3;
+  const float* p = partial + (size_t)b * ntiles * n3 + i;
+  float s = 0.f;
+  for (int t = 0; t < ntiles; ++t) s += p[(size_t)t * n3];
+  gcolors[e] = s;
+}
+
 }  // namespace
 
 extern "C" int eml_sg_rasterise_ex_f32(const float* dirs, const float* sizes, const float* colors, float* out, int B,
@@ -273,4 +390,34 @@ extern "C" int eml_sg_rasterise_bwd_colors_f32(const float* dirs, const float* s
   hipLaunchKernelGGL(sg_rasterise_bwd_colors_kernel, grid, dim3(256), lds, (hipStream_t)stream, dirs,
                      sizes, gout, gcolors, N, H, W, step);
   return eml::check_launch("eml_sg_rasterise_bwd_colors_f32");
+}
+
+// The culled form (see sg_rasterise_bwd_colors_tiled_kernel).  work: eml_sg_rasterise_bwd_work_floats(B, N, H, W) floats.
+// flags: EML_SG_EXHAUSTIVE = every light for every tile (the reference sums; what the culled launch must equal bit for bit).
+extern "C" size_t eml_sg_rasterise_bwd_work_floats(int B, int N, int H, int W) {
+  if (B < 1 || N < 1 || H < 1 || W < 1) return 0;
+  return (size_t)B * ((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH) * N * 3;
+}
+
+extern "C" int eml_sg_rasterise_bwd_colors_ex_f32(const float* dirs, const float* sizes, const float* gout, float* gcolors,
+                                                  float* work, int B, int N, int H, int W, int flags, eml_stream_t stream) {
+  if (!dirs || !sizes || !gout || !gcolors || !work)
+    return eml::fail(EML_EINVAL, "eml_sg_rasterise_bwd_colors_ex_f32: null pointer");
+  if (B < 0 || N < 1 || H < 1 || W != 2 * H)
+    return eml::fail(EML_EINVAL, "eml_sg_rasterise_bwd_colors_ex_f32: need N>=1, H>=1, W==2H");
+  if (flags & ~EML_SG_EXHAUSTIVE) return eml::fail(EML_EINVAL, "eml_sg_rasterise_bwd_colors_ex_f32: unknown flags 0x%x", flags);
+  if (B == 0) return EML_OK;
+  if (B > 65535) return eml::fail(EML_EINVAL, "eml_sg_rasterise_bwd_colors_ex_f32: B=%d exceeds grid.z", B);
+  if ((long)B * N * 3 > 2147483647L) return eml::fail(EML_EINVAL, "eml_sg_rasterise_bwd_colors_ex_f32: too many lights");
+  const float step = (float)(3.14159265358979323846 / (double)H);
+  const dim3 grid((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH, B);
+  const hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sg_rasterise_bwd_colors_tiled_kernel, grid, dim3(256), 0, st, dirs, sizes, gout, work, N, H, W, step,
+                     (flags & EML_SG_EXHAUSTIVE) ? 1 : 0);
+  int rc = eml::check_launch("eml_sg_rasterise_bwd_colors_ex_f32");
+  if (rc) return rc;
+  const int total = B * N * 3;
+  hipLaunchKernelGGL(sg_reduce_tiles_kernel, dim3((total + 255) / 256), dim3(256), 0, st, work, (int)(grid.x * grid.y), N * 3,
+                     gcolors, total);
+  return eml::check_launch("eml_sg_rasterise_bwd_colors_ex_f32(reduce)");
 }

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 19
+#define EML_ABI_VERSION 20
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -63,6 +63,13 @@ int eml_sg_rasterise_ex_f32(const float* dirs, const float* sizes, const float* 
 int eml_sg_rasterise_bwd_colors_f32(const float* dirs, const float* sizes, const float* gout,
                                     float* gcolors, int B, int N, int H, int W,
                                     eml_stream_t stream);
+/* The same gradient with the forward's hierarchical cull (same tiles, bounding caps and survivor lists): exponentials are
+ * evaluated only for the lights that reach a wave's 16 x 8 patch; per-tile partial sums in `work`
+ * (eml_sg_rasterise_bwd_work_floats(B, N, H, W) floats) are added in tile order -- no atomics, run-to-run exact.  flags:
+ * EML_SG_EXHAUSTIVE = every light for every tile (a culled light contributes exactly 0, so both give the same bits; tests). */
+size_t eml_sg_rasterise_bwd_work_floats(int B, int N, int H, int W);
+int eml_sg_rasterise_bwd_colors_ex_f32(const float* dirs, const float* sizes, const float* gout, float* gcolors, float* work,
+                                       int B, int N, int H, int W, int flags, eml_stream_t stream);
 
 /* ---------------------------------------------------------------- Sinkhorn (spherical mover's loss)
  * Chord-length ground cost M_ij = ||a_i - a_j||_2 over N anchors (N x 3, f32).

@@ -107,7 +107,7 @@ def test_sinkhorn_and_rasteriser_calls_match_the_abi(recorder):
     c = torch.rand(2, 48, requires_grad=True)
     convert_to_panorama(torch.rand(2, 48), torch.rand(2, 16), c, pano_hw=(8, 16)).sum().backward()
     for name in ("eml_emd_anchor_cost_f32", "eml_sinkhorn_fwd_ex_f32", "eml_sinkhorn_bwd_f32", "eml_sg_rasterise_f32",
-                 "eml_sg_rasterise_bwd_colors_f32"):
+                 "eml_sg_rasterise_bwd_colors_ex_f32"):
         assert name in recorder.calls, name
 
 

@@ -106,3 +106,34 @@ def test_hierarchical_cull_is_bit_identical_to_the_exhaustive_loop(B, n, H, kind
     if kind == "anchors":
         assert n_fast < 0.3 * n_full, (n_fast, n_full)
     print("executed exponentials: %d of %d (%.1f %%)" % (n_fast, n_full, 100.0 * n_fast / n_full))
+
+
+@pytest.mark.parametrize("B,n,H,kind", [(32, 128, 128, "anchors"), (16, 256, 256, "anchors"), (3, 130, 128, "random"),
+                                        (2, 600, 64, "random"), (2, 128, 128, "odd"), (2, 96, 72, "anchors")])
+def test_colour_gradient_with_the_light_lists(B, n, H, kind):
+    """d/d(colors) through the forward's per-patch light lists (sg_rasterise_bwd_colors_tiled_kernel): BIT-identical to the
+    same tile sums with every light evaluated (a culled light's exp2 underflows to exactly 0 on the whole patch), run-to-run
+    exact (no atomics), and equal to the round-1 kernel (one workgroup per 8 lights sweeping the panorama: an independent
+    summation order) to f32 round-off of a sum over H*W pixels."""
+    from emlight_amd.RegressionNetwork.util import rasterise_bwd_colors_raw
+    g = np.random.default_rng([6, B, n])
+    if kind == "anchors":
+        dirs = np.tile(oracle.sphere_points(n).reshape(1, 3 * n), (B, 1)).astype(np.float32)
+        sizes = np.full((B, n), 0.0025, np.float32)
+    else:
+        d = g.standard_normal((B, n, 3))
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        sizes = g.uniform(0.0005, 0.3, (B, n)).astype(np.float32)
+        if kind == "odd":
+            d *= g.uniform(0.2, 1.02, (B, n, 1))          # non-unit directions: exp((|L| cos - 1)/s) exceeds 1 (up to e^40 here)
+            sizes[:, 2::7] = 1e30                          # never culled; exp -> 1 everywhere
+        dirs = d.reshape(B, 3 * n).astype(np.float32)
+    gout = torch.from_numpy(g.standard_normal((B, 3, H, 2 * H)).astype(np.float32)).cuda()
+    dv, sv = torch.from_numpy(dirs).cuda(), torch.from_numpy(sizes).cuda()
+    fast = rasterise_bwd_colors_raw(dv, sv, gout, (H, 2 * H))
+    full = rasterise_bwd_colors_raw(dv, sv, gout, (H, 2 * H), exhaustive=True)
+    assert torch.equal(fast.view(torch.int32), full.view(torch.int32))
+    assert torch.equal(fast.view(torch.int32), rasterise_bwd_colors_raw(dv, sv, gout, (H, 2 * H)).view(torch.int32))
+    old = rasterise_bwd_colors_raw(dv, sv, gout, (H, 2 * H), legacy=True)
+    scale = float(old.abs().max())
+    np.testing.assert_allclose(fast.cpu().numpy(), old.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
