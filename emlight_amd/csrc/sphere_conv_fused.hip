@@ -296,7 +296,11 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
 // ------------------------------------------------------------------------------------------------ weight gradient
 // grid = (column tiles of the (tap, c) axis, row tiles of O, split-K); partial[z][O][9C].  BMO = output channels per
 // tile: 128, or 64 for the 64-channel layers (a 128-row tile would spend half of its MFMAs on padding).
-template <int BN, int BMO>
+// VR (round 4): MFMA row / column r of tile j stands for channel MI*r + j (resp. NI*r + j) of the wave's span instead of
+// 16*j + r -- which channel a row index means is free as long as the epilogue agrees -- so a lane's MI (NI) operand values of a
+// k-step are CONSECUTIVE floats of one LDS row: one ds_read_b128 (b64) instead of four (two) ds_read_b32, 16 LDS read
+// instructions per chunk and wave instead of 64, and the result leaves as 16-byte stores.  Layout and commits are unchanged.
+template <int BN, int BMO, bool VR>
 __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ dY /*[M][O]*/, float* __restrict__ partial, int M, int HW, int Po, int C, int O) {
@@ -404,15 +408,26 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     const size_t xn = x1;
     begin_chunk(nxt, tn);
     __builtin_amdgcn_sched_barrier(0);
-    const float* db = Ds + (size_t)buf * kBK * kLdW + (BMO / 2) * wm + r;
-    const float* gb = Gs + (size_t)buf * kBK * kLdW + (BN / 2) * wn + r;
+    const float* db = Ds + (size_t)buf * kBK * kLdW + (BMO / 2) * wm + (VR ? MI * r : r);
+    const float* gb = Gs + (size_t)buf * kBK * kLdW + (BN / 2) * wn + (VR ? NI * r : r);
 #pragma unroll
     for (int ks = 0; ks < kSteps; ++ks) {
       float a[MI], b[NI];
+      if constexpr (VR) {
+        typedef float vmi __attribute__((ext_vector_type(MI)));
+        typedef float vni __attribute__((ext_vector_type(NI)));
+        const vmi av = *reinterpret_cast<const vmi*>(db + (4 * ks + kk) * kLdW);
+        const vni bv = *reinterpret_cast<const vni*>(gb + (4 * ks + kk) * kLdW);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
+        for (int mi = 0; mi < MI; ++mi) a[mi] = av[mi];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = gb[(4 * ks + kk) * kLdW + 16 * ni];
+        for (int ni = 0; ni < NI; ++ni) b[ni] = bv[ni];
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = db[(4 * ks + kk) * kLdW + 16 * mi];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = gb[(4 * ks + kk) * kLdW + 16 * ni];
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -438,6 +453,23 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   }
   // partial[z][o][tap*C + c]: lane (r, kk) holds rows o = 4kk + g, column c = r of each 16x16 tile
   float* out = partial + (size_t)blockIdx.z * O * 9 * C;
+  if constexpr (VR) {
+    // tile (mi, ni): row index i = 4kk + g is output channel MI*i + mi, column index r is input channel NI*r + ni
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int o = o0 + (BMO / 2) * wm + MI * (4 * kk + g) + mi;
+        if (o < O) {
+          typedef float vni __attribute__((ext_vector_type(NI)));
+          vni v;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) v[ni] = acc[mi][ni][g];
+          *reinterpret_cast<vni*>(out + (size_t)o * 9 * C + tap * C + c0 + (BN / 2) * wn + NI * r) = v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -602,11 +634,18 @@ extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, c
   const int bmo = (O % 128 == 0 || O > 192) ? 128 : 64;   // 64-wide row tiles when a 128-row tile would be mostly padding
   const size_t lds = (size_t)(4 * kBK * kLdW) * sizeof(float);
   const dim3 grid(9 * (C / bn), (O + bmo - 1) / bmo, split_k);
+  static const bool scalar_reads = [] { const char* v = getenv("EML_WG_V1"); return v && v[0] == '1'; }();   // A/B switch
 #define EML_LAUNCH_WGRAD(BNV, BMV)                                                                                   \
   do {                                                                                                              \
-    EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV>), lds);                                 \
-    hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
-                       wgt, dY, partial, (int)M, HW, Po, C, O);                                                      \
+    if (scalar_reads) {                                                                                             \
+      EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV, false>), lds);                                      \
+      hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV, false>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
+                         wgt, dY, partial, (int)M, HW, Po, C, O);                                                    \
+    } else {                                                                                                        \
+      EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV, true>), lds);                                       \
+      hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV, true>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
+                         wgt, dY, partial, (int)M, HW, Po, C, O);                                                    \
+    }                                                                                                               \
   } while (0)
   if (bn == 128) {
     if (bmo == 128) EML_LAUNCH_WGRAD(128, 128); else EML_LAUNCH_WGRAD(128, 64);
