@@ -369,12 +369,17 @@ PROJECTOR_STEP_GFLOP = 3 * G_FWD_GFLOP + 2 * D_PAIR_GFLOP + G_FWD_GFLOP + 3 * D_
 VGG_STEP_GFLOP = 3 * VGG_FWD_GFLOP
 
 
-# projector launchers -> (label, FLOP count of one call from its arguments, or None for the streaming kernels)
+# projector launchers -> (label, FLOP count of one call from its arguments, or None for the streaming kernels); launchers
+# with the same label share a row
+_FWD_LABEL = ("gather-GEMM forward (gather_gemm2_kernel / sphere_conv_fwd_fused_kernel: taps gathered into the LDS operand of an "
+              "f32-MFMA implicit GEMM: SphereConv2D forward with the residual sum / ReLU or SPADE's modulation in the epilogue; "
+              "VGG19's 3x3 convolutions use it with a planar tap table)")
+_SPADE_BWD_LABEL = "spade_norm_modulate_bwd_kernel (+ BatchNorm partials, + the gamma|beta bias gradient)"
+_NARROW_LABEL = "sphere_conv_narrow_{fwd,dgrad,wgrad}_kernel (conv_img 64 -> 3, the discriminators' heads: one pass each way)"
 PROJECTOR_FAMILIES = {
-    "eml_sphere_conv_fwd_fused_ex_f32": ("sphere_conv_fwd_fused_kernel (taps gathered into the LDS operand of an f32-MFMA implicit "
-                                         "GEMM: SphereConv2D forward, residual sum / ReLU in the epilogue; VGG19's 3x3 "
-                                         "convolutions use it with a planar tap table)",
-                                         lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),     # B * Po * 9C * O
+    "eml_sphere_conv_fwd_fused_ex_f32": (_FWD_LABEL, lambda a: 2.0 * a[6] * a[8] * 9 * a[9] * a[10]),     # B * Po * 9C * O
+    # the same kernel with SPADE's modulation as its epilogue (the gamma | beta heads: O = 2 * Cn): same family row
+    "eml_sphere_conv_spade_fwd_f32": (_FWD_LABEL, lambda a: 2.0 * a[10] * a[11] * a[12] * 9 * a[13] * 2 * a[14]),
     "eml_sphere_conv_dgrad_fused_f32": ("sphere_conv_fwd_fused_kernel on the transposed tap table (input gradient)",
                                         lambda a: 2.0 * a[7] * a[8] * 9 * a[10] * a[11]),  # B * HW * 9C * O
     "eml_sphere_conv_wgrad_fused_f32": ("sphere_conv_wgrad_fused_kernel (weight gradient, split-K over pixels)",
@@ -384,7 +389,11 @@ PROJECTOR_FAMILIES = {
     "eml_spade_norm_modulate_fwd_f32": ("spade_norm_modulate_fwd_kernel (BN + modulation + LeakyReLU)", None),
     "eml_spade_norm_modulate_up2_fwd_f32": ("spade_norm_modulate_fwd_kernel<up2> (the block's x2 upsample folded in)", None),
     "eml_bn_bwd_apply_up2_f32": ("bn_bwd_apply_up2_kernel", None),
-    "eml_spade_norm_modulate_bwd_cols_f32": ("spade_norm_modulate_bwd_kernel (+ BatchNorm partials, + the gamma|beta bias gradient)", None),
+    "eml_spade_norm_modulate_bwd_cols_f32": (_SPADE_BWD_LABEL, None),
+    "eml_spade_norm_modulate_bwd_y_f32": (_SPADE_BWD_LABEL, None),
+    "eml_sphere_conv_narrow_fwd_f32": (_NARROW_LABEL, None),
+    "eml_sphere_conv_narrow_dgrad_f32": (_NARROW_LABEL, None),
+    "eml_sphere_conv_narrow_wgrad_f32": (_NARROW_LABEL, None),
     "eml_bn_stats_f32": ("bn_stats_kernel (SPADE batch statistics)", None),
     "eml_bn_bwd_apply_f32": ("bn_bwd_apply_kernel", None),
     "eml_sphere_conv_small_fwd_f32": ("sphere_conv_small_fwd_kernel (3 -> 64/128 input layers + ReLU, one pass)", None),
@@ -447,12 +456,18 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
         for k in FAM:
             setattr(L, k, orig[k])
     total = t0.elapsed_time(t1) / steps
-    rows, acc = [], 0.0
+    rows, acc, by_label = [], 0.0, {}
     for k, (label, fl) in FAM.items():
         ms = sum(a.elapsed_time(b) for a, b in events[k]) / steps
         acc += ms
-        rows.append({"kernel": label, "launches_per_step": len(events[k]) // steps, "ms_per_step": round(ms, 3),
-                     "tflops": round(flops[k] / steps / (ms * 1e-3) / 1e12, 2) if (fl is not None and ms > 0) else None})
+        t = by_label.setdefault(label, [0, 0.0, 0.0, False])
+        t[0] += len(events[k])
+        t[1] += ms
+        t[2] += flops[k]
+        t[3] = t[3] or fl is not None
+    for label, (n, ms, fl_sum, has_fl) in by_label.items():
+        rows.append({"kernel": label, "launches_per_step": n // steps, "ms_per_step": round(ms, 3),
+                     "tflops": round(fl_sum / steps / (ms * 1e-3) / 1e12, 2) if (has_fl and ms > 0) else None})
     rows.sort(key=lambda r: -r["ms_per_step"])
     rows.append({"kernel": other_label or "other (library GEMMs of the unfused layers, ATen elementwise / pooling / norms, Adam)",
                  "launches_per_step": None, "ms_per_step": round(total - acc, 3), "tflops": None})

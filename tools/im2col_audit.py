@@ -17,6 +17,7 @@ from emlight_amd.GenProjector.model_trainer import Trainer  # noqa: E402
 from emlight_amd.GenProjector.networks import default_options  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+NARROW = os.environ.get("AUDIT_NARROW", "1") == "1"   # also time the one-pass kernels of the O <= 4 layers
 tr = Trainer(default_options(no_vgg_loss=False, vgg_random=True), device="cuda:0")
 data = projector_batch(B, "cuda:0")
 for _ in range(3):
@@ -29,7 +30,7 @@ pending = []
 class Spy:
     def __getattr__(self, name):
         fn = getattr(real, name)
-        if name not in ("eml_sphere_im2col_f32", "eml_sphere_col2im_f32"):
+        if name not in ("eml_sphere_im2col_f32", "eml_sphere_col2im_f32") and not (NARROW and "narrow" in name and name.endswith("_f32")):
             return fn
 
         def call(*a):
@@ -37,7 +38,8 @@ class Spy:
             e0.record()
             rc = fn(*a)
             e1.record()
-            ints = tuple(int(v) for v in a if isinstance(v, int))[:4]   # B, HW, Po, C
+            ints = tuple(int(v) for v in a if isinstance(v, int))
+            ints = ints[-5:-1] if "narrow" in name else ints[:4]          # B, HW, Po, C (the narrow entry points end ..., C, O)
             pending.append((name.replace("eml_sphere_", "").replace("_f32", ""), ints, e0, e1))
             return rc
         return call
