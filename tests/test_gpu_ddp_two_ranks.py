@@ -103,6 +103,9 @@ def _spade_case(seed=7, B=4, C=16, H=16, W=32):
 
 
 def _spade_run(mod, x, seg, wy):
+    if x.shape[1] % 64 == 0:   # wide enough for the one-launch path (gamma|beta SphereConv + modulation epilogue): force it
+        from emlight_amd.GenProjector.spherenet import SphereConv2D
+        SphereConv2D.fused_min_bytes = 0
     mod = mod.cuda().train()
     x = x.cuda().requires_grad_(True)
     y = mod(x, seg.cuda(), slope=0.2)
@@ -113,7 +116,7 @@ def _spade_run(mod, x, seg, wy):
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
-def _spade_worker(rank, world, port, out_dir):
+def _spade_worker(rank, world, port, out_dir, C=16):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
@@ -121,7 +124,7 @@ def _spade_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from emlight_amd.RegressionNetwork.engine import init_distributed
     init_distributed()
-    mod, x, seg, wy = _spade_case()
+    mod, x, seg, wy = _spade_case(C=C)
     h = x.shape[0] // world
     sl = slice(rank * h, (rank + 1) * h)
     np.savez(os.path.join(out_dir, "spade%d.npz" % rank), **_spade_run(mod, x[sl], seg[sl], wy[sl]))
@@ -129,17 +132,21 @@ def _spade_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_sync_bn_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("C", [16, 64])
+def test_sync_bn_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, C, monkeypatch):
     """What sync_batchnorm/batchnorm.py:105-145 guarantees: 2 ranks x B/2 samples normalise with the statistics of the
     WHOLE batch.  SPADE's modulation (the HIP kernels + the (2C+1)-float all-reduce of its sums, forward and backward)
     on two ranks against ONE process holding both halves: outputs, input gradients, the summed parameter gradients and the
-    running statistics agree to f32 round-off (the sums are f64; a per-rank norm would be off by O(1) here)."""
+    running statistics agree to f32 round-off (the sums are f64; a per-rank norm would be off by O(1) here).  C = 64: through
+    the one-launch SPADE (the gamma|beta SphereConv with the modulation as its epilogue), whose backward all-reduces the same sums."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_spade_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    want = _spade_run(*_spade_case())
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    monkeypatch.setattr(SphereConv2D, "fused_min_bytes", SphereConv2D.fused_min_bytes)   # _spade_run may force the fused kernels
+    mp.spawn(_spade_worker, args=(2, port, str(tmp_path), C), nprocs=2, join=True)
+    want = _spade_run(*_spade_case(C=C))
     r = [np.load(tmp_path / ("spade%d.npz" % k)) for k in range(2)]
     for k in ("y", "dx"):
         got = np.concatenate([r[0][k], r[1][k]], 0)
@@ -151,7 +158,7 @@ def test_sync_bn_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
         got = r[0][k] + r[1][k]      # DDP would average; the sum of the per-rank gradients is the whole batch's
         np.testing.assert_allclose(got, want[k], rtol=1e-4, atol=2e-5 * np.abs(want[k]).max(), err_msg=k)
     # and the statistics really are the whole batch's, not a rank's own
-    mod, x, seg, wy = _spade_case()
+    mod, x, seg, wy = _spade_case(C=C)
     half = _spade_run(mod, x[:2], seg[:2], wy[:2])
     assert np.abs(half["y"] - want["y"][:2]).max() > 1e-2
 
