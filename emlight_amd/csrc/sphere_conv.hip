@@ -139,7 +139,14 @@ __global__ __launch_bounds__(256) void sphere_col2im_kernel(const float* __restr
         *reinterpret_cast<float4*>(xb + (size_t)q * C + 4 * c) = acc;
       } else {
         float acc = 0.f;
-        for (int k = k0; k < k1; ++k) acc = fmaf(w[k], ab[(size_t)src[k] * C + c], acc);
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {   // as above: the four entries' loads first, the FMAs in CSR order
+          const int s0 = src[k], s1 = src[k + 1], s2 = src[k + 2], s3 = src[k + 3];
+          const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+          const float v0 = ab[(size_t)s0 * C + c], v1 = ab[(size_t)s1 * C + c], v2 = ab[(size_t)s2 * C + c], v3 = ab[(size_t)s3 * C + c];
+          acc = fmaf(w3, v3, fmaf(w2, v2, fmaf(w1, v1, fmaf(w0, v0, acc))));
+        }
+        for (; k < k1; ++k) acc = fmaf(w[k], ab[(size_t)src[k] * C + c], acc);
         xb[(size_t)q * C + c] = acc;
       }
     }
