@@ -592,6 +592,9 @@ class _SpadeConvModulateFn(torch.autograd.Function):
         _require_gpu_f32(actv, "SPADE activation")
         B, Cin, H, W = actv.shape
         Cn = x.shape[1]
+        want = (B, Cn, H // 2, W // 2) if up2 else (B, Cn, H, W)
+        if tuple(x.shape) != want:   # the kernel indexes x from (H, W) alone
+            raise ValueError("SPADE: normalised map %s does not match the guide map's grid (expected %s)" % (tuple(x.shape), want))
         cl = torch.channels_last
         geo = sphere_geometry(H, W, 1, actv.device)
         ar = actv.permute(0, 2, 3, 1).contiguous()                 # (B, H, W, Cin); a view when channels-last
