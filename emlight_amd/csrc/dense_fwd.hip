@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
         __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these requests below the MFMAs
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = bn_relu4(xc[m], s4, t4);
+#ifndef EML_FWD_NOMASK   // experiment build (tools/exp_build.sh nomask -DEML_FWD_NOMASK): what the ballots + 16 selects + the store cost
         if constexpr (MASK) {
           // ReLU mask of this K-step as wave ballots: word (pixel group, K-step, t), bit r + 16*kk <-> pixel 16*pg + r,
           // channel 16*j + 4*kk + t -- the lane layout of the data-gradient kernel, which then needs neither X nor
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
             }
           if (lane < 16) mask_l[((wave * 4 + (lane >> 2)) * nj + j) * 4 + (lane & 3)] = mine;
         }
+#endif
       }
       float4 bw[3];
 #pragma unroll
