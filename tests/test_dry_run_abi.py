@@ -14,6 +14,7 @@ import torch
 class _Recorder:
     def __init__(self, signatures):
         self.signatures, self.calls, self.args = signatures, [], []
+        self.returns = {}   # entry point -> value the stub returns (default 0 = EML_OK / "not supported" / 0 floats)
 
     def __getattr__(self, name):
         if name not in self.signatures:
@@ -29,7 +30,7 @@ class _Recorder:
                     raise AssertionError("%s: argument %d (%r) does not convert to %s" % (name, k, a, t.__name__)) from e
             self.calls.append(name)
             self.args.append((name, args))
-            return 0
+            return self.returns.get(name, 0)
         return call
 
 
@@ -139,3 +140,57 @@ def test_spade_norm_modulate_calls_match_the_abi(recorder, monkeypatch):
                  "eml_bn_bwd_apply_up2_f32"):
         assert name in recorder.calls[n:], name
     assert xl.grad.shape == xl.shape
+
+
+class _FakeGeometry:
+    """Tap tables of the right shapes (the real ones come from a HIP kernel): enough for the call sites' pointer arguments."""
+
+    def __init__(self, h, w, stride):
+        self.h, self.w, self.ho, self.wo = h, w, h // stride, w // stride
+        n = self.ho * self.wo * 9
+        self.idx, self.wgt = torch.zeros(n, 4, dtype=torch.int32), torch.zeros(n, 4)
+        self.idx1 = self.wgt1 = None
+        self.csr_ptr = torch.zeros(h * w + 1, dtype=torch.int32)
+        self.csr_src, self.csr_w = torch.zeros(1, dtype=torch.int32), torch.zeros(1)
+
+    def transposed_table(self):
+        hw = self.h * self.w
+        return torch.zeros(hw * 9, 4, dtype=torch.int32), torch.zeros(hw * 9, 4), torch.zeros(hw, dtype=torch.uint8), 4
+
+
+def test_one_launch_spade_and_few_output_channel_calls_match_the_abi(recorder, monkeypatch):
+    """Round 4's entry points: the gamma|beta SphereConv with SPADE's modulation as its epilogue (+ its backward from gamma and
+    the output), and the one-pass kernels of the layers with at most 4 output channels -- forward, weight gradient and the
+    input gradient through the transposed tap table."""
+    from emlight_amd.GenProjector import spherenet
+    monkeypatch.setattr(spherenet, "_require_gpu_f32", lambda t, name: None)
+    monkeypatch.setattr(spherenet, "sphere_geometry", lambda h, w, stride, device, kind="sphere": _FakeGeometry(h, w, stride))
+    monkeypatch.setattr(spherenet, "_spade_conv_fusable", lambda x, actv, C, up2: True)
+    C, nh = 64, 64
+    bn = torch.nn.BatchNorm2d(C, affine=False).train()
+    g_, b_ = spherenet.SphereConv2D(nh, C), spherenet.SphereConv2D(nh, C)
+    for up2, hw in ((True, (2, 4)), (False, (4, 8))):
+        n = len(recorder.calls)
+        x, actv = torch.rand(2, C, *hw, requires_grad=True), torch.rand(2, nh, 4, 8, requires_grad=True)
+        spherenet.spade_norm_modulate(x, bn, actv, g_, b_, 0.2, None, up2=up2).sum().backward()
+        for name in ("eml_sphere_conv_spade_fwd_f32", "eml_spade_norm_modulate_bwd_y_f32",
+                     "eml_bn_bwd_apply_up2_f32" if up2 else "eml_bn_bwd_apply_f32"):
+            assert name in recorder.calls[n:], name
+        assert "eml_spade_norm_modulate_bwd_cols_f32" not in recorder.calls[n:]
+        assert x.grad.shape == x.shape and actv.grad is not None and g_.weight.grad is not None and b_.bias.grad is not None
+    with pytest.raises(ValueError, match="guide map"):
+        spherenet.spade_norm_modulate(torch.rand(2, C, 3, 8), bn, torch.rand(2, nh, 4, 8), g_, b_, 0.2, None, up2=False)
+    with torch.no_grad():   # the discriminator step's generator pass: gamma is not kept (NULL)
+        spherenet.spade_norm_modulate(torch.rand(2, C, 4, 8), bn, torch.rand(2, nh, 4, 8), g_, b_, 0.2, None)
+    assert [a for nme, a in recorder.args if nme == "eml_sphere_conv_spade_fwd_f32"][-1][9] is None
+    # conv_img 64 -> 3
+    recorder.returns["eml_sphere_conv_narrow_supported"] = 1
+    conv = spherenet.SphereConv2D(64, 3)
+    n = len(recorder.calls)
+    xi = torch.rand(2, 64, 4, 8, requires_grad=True)
+    conv(xi).sum().backward()
+    for name in ("eml_sphere_conv_narrow_fwd_f32", "eml_sphere_conv_narrow_wgrad_partial_floats", "eml_sphere_conv_narrow_wgrad_f32",
+                 "eml_sphere_conv_narrow_dgrad_f32"):
+        assert name in recorder.calls[n:], name
+    assert "eml_sphere_im2col_f32" not in recorder.calls[n:] and "eml_sphere_col2im_f32" not in recorder.calls[n:]
+    assert xi.grad.shape == xi.shape and conv.weight.grad.shape == conv.weight.shape
