@@ -65,8 +65,9 @@ class Pix2PixModel(torch.nn.Module):
     def generate_fake(self, inp, crop):
         return self.netG(inp, crop)
 
-    def discriminate(self, inp, fake, real, for_generator=False):
-        """``for_generator``: the generator step uses D as a fixed critic.  The reference's backward also fills D's ``.grad``
+    def discriminate_raw(self, inp, fake, real, for_generator=False):
+        """D on cat(fake pair, real pair) along the batch: list (per discriminator) of lists (per stage) of (2B, ...) maps.
+        ``for_generator``: the generator step uses D as a fixed critic.  The reference's backward also fills D's ``.grad``
         there, but nothing ever reads it (``optimizer_D.zero_grad()`` opens the D step, model_trainer.py:44-46): D's parameters
         are held out of that graph -- no weight gradients, no spectral-norm backward, and under DDP no all-reduce of them."""
         both = torch.cat([torch.cat([inp, fake], dim=1), torch.cat([inp, real], dim=1)], dim=0)
@@ -75,12 +76,14 @@ class Pix2PixModel(torch.nn.Module):
             for q in held:
                 q.requires_grad_(False)
             try:
-                out = self.netD(both)
+                return self.netD(both)
             finally:
                 for q in held:
                     q.requires_grad_(True)
-        else:
-            out = self.netD_train(both)
+        return self.netD_train(both)
+
+    def discriminate(self, inp, fake, real, for_generator=False):
+        out = self.discriminate_raw(inp, fake, real, for_generator)
         fake_p = [[t[:t.size(0) // 2] for t in p] for p in out]
         real_p = [[t[t.size(0) // 2:] for t in p] for p in out]
         return fake_p, real_p
@@ -88,21 +91,29 @@ class Pix2PixModel(torch.nn.Module):
     def compute_generator_loss(self, inp, crop, real, mask):
         losses = {}
         fake = self.generate_fake(inp, crop)
-        pred_fake, pred_real = self.discriminate(inp, fake, real, for_generator=True)
+        out = self.discriminate_raw(inp, fake, real, for_generator=True)
+        pred_fake = [[t[:t.size(0) // 2] for t in p] for p in out]
         losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False)
         if not self.opt.no_ganFeat_loss:
-            num_D = len(pred_fake)
-            feat = fake.new_zeros(1)
+            num_D = len(out)
+            feats, masks = [], []
             for i in range(num_D):
-                for j in range(len(pred_fake[i]) - 1):
-                    h, w = pred_fake[i][j].shape[2:]
-                    mask = F.interpolate(mask, size=(h, w))  # the reference re-interpolates the running mask
-                    # reference: L1(f*m + f*(1-m)*50, r*m + r*(1-m)*50) -- both sides carry the same per-pixel weight
-                    # m + 50(1-m) = 50 - 49m, so the term is mean(|(f - r) * (50 - 49m)|): 3 passes over the feature pair
-                    # instead of 11 (and as many fewer in the backward); differs from the literal form by f32 rounding only
-                    wgt = 50.0 - 49.0 * mask
-                    feat = feat + ((pred_fake[i][j] - pred_real[i][j].detach()) * wgt).abs().mean() / num_D
-            losses["GAN_Feat"] = feat
+                for j in range(len(out[i]) - 1):
+                    mask = F.interpolate(mask, size=out[i][j].shape[2:])   # the reference re-interpolates the running mask
+                    feats.append(out[i][j])
+                    masks.append(mask)
+            # reference: L1(f*m + f*(1-m)*50, r*m + r*(1-m)*50) -- both sides carry the same per-pixel weight
+            # m + 50(1-m) = 50 - 49m, so a term is mean(|(f - r) * (50 - 49m)|); differs from the literal form by f32 rounding only
+            from . import l1_terms
+            if fake.is_cuda and l1_terms.ENABLED:
+                # all (discriminator, stage) terms in one launch each way, straight on the maps of cat(fake, real)
+                losses["GAN_Feat"] = l1_terms.feature_matching(feats, masks, num_D).reshape(1)
+            else:
+                feat = fake.new_zeros(1)
+                for t, m in zip(feats, masks):
+                    half = t.size(0) // 2
+                    feat = feat + ((t[:half] - t[half:].detach()) * (50.0 - 49.0 * m)).abs().mean() / num_D
+                losses["GAN_Feat"] = feat
         if not self.opt.no_vgg_loss:
             from .vgg import vgg_loss
             losses["VGG"] = vgg_loss(self.vgg_features, fake, real) * 5

@@ -8,11 +8,12 @@ it is built once, vectorised in float64 numpy (the reference loops H*W times in 
 from functools import lru_cache
 
 import numpy as np
-import os
 
 import torch
 from torch import nn
 from torch.nn.parameter import Parameter
+
+from .._knobs import knob_flag, knob_int
 
 
 @lru_cache(None)
@@ -272,11 +273,14 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
     gyr = gy.permute(0, 2, 3, 1).reshape(B * po, O).contiguous()
     y = saved[2] if ctx.slope != 1.0 else None
     gx = gw = gb = gres = None
-    # (when the input gradient is wanted too -- the discriminator's first stage -- the masked dY has to be formed for it
-    # anyway and the general weight-gradient path on it measured faster: tools/small_conv_bench.py)
-    small_w = ctx.small and needs[1] and not needs[0]
+    # the 3-channel input layers: dW2, the bias gradient and the activation's backward in one pass over (dY, Y); where the
+    # input itself carries a gradient (the guide map of the joint step, VGG's conv1_1 on the generated panorama) the masked
+    # dY times W2 in one more pass (eml_sphere_conv_small_da9_f32) -- no activation-backward pass, no N = 27 library GEMM
+    small_w = ctx.small and needs[1]
+    small_x = ctx.small and needs[0] and B > 0 and SphereConv2D.small_input_grad
+    if ctx.small and needs[0] and not small_x:
+        small_w = False   # EML_SMALL_DA9=0 (A/B): round 4's dispatch -- the general path forms the masked dY once for both
     if small_w:
-        # dW2, the bias gradient and the activation's backward in one pass over (dY, Y)
         part = torch.empty(L.eml_sphere_conv_small_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
         gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
         gb_ = torch.empty(O, dtype=torch.float32, device=gy.device) if ctx.has_bias else None
@@ -286,7 +290,16 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
         gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
         gb = gb_ if (ctx.has_bias and needs[2]) else None
         del part
-    need_masked = (needs[0] or (len(needs) > 5 and needs[5])
+    if small_x:
+        w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+        da9 = torch.empty(B * po, 9 * C, dtype=torch.float32, device=gy.device)
+        _lib.check(L.eml_sphere_conv_small_da9_f32(p(gyr), p(y) if y is not None else None, ctx.slope, p(w2), p(da9), B * po, C, O,
+                                                   st), "eml_sphere_conv_small_da9_f32")
+        gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
+        _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B, H * W, po, C, st),
+                   "eml_sphere_col2im_f32")
+        gx = gxr.permute(0, 3, 1, 2)
+    need_masked = ((needs[0] and not small_x) or (len(needs) > 5 and needs[5])
                    or (not small_w and (needs[1] or (ctx.has_bias and needs[2]))))
     if y is not None and need_masked:
         gyr = (torch.ops.aten.threshold_backward(gyr, y, 0.0) if ctx.slope == 0.0
@@ -344,7 +357,7 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             # (O, tap, c) in memory like the fused kernels' result: the one copy this gradient needs either way
             gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
             del a9
-    if needs[0]:
+    if needs[0] and not small_x:
         gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
         tt = geo.transposed_table() if ((ctx.fused_dgrad or narrow) and B) else None
         if tt is not None and narrow:
@@ -828,11 +841,13 @@ class SphereConv2D(nn.Module):
 
     keep_operand = True   # unfused layers: keep the im2col operand of a training forward for the weight gradient
     # unit of the fused-kernel thresholds on the size of the im2col operand (see forward); EML_FUSED_MIN_MB: A/B knob
-    fused_min_bytes = int(os.environ.get("EML_FUSED_MIN_MB", "64")) << 20
+    fused_min_bytes = knob_int("EML_FUSED_MIN_MB", 64, lo=0) << 20
     # SPADE's gamma | beta convolution with the modulation as its epilogue (_SpadeConvModulateFn); EML_FUSE_SPADE=0: A/B knob
-    fuse_spade = os.environ.get("EML_FUSE_SPADE", "1") != "0"
+    fuse_spade = knob_flag("EML_FUSE_SPADE", True)
     # O <= 4 layers on the one-pass kernels of csrc/sphere_conv_narrow.hip; EML_NARROW=0: A/B knob (im2col + library GEMM)
-    narrow_kernels = os.environ.get("EML_NARROW", "1") != "0"
+    narrow_kernels = knob_flag("EML_NARROW", True)
+    # input gradient of the 3-channel input layers through eml_sphere_conv_small_da9_f32; EML_SMALL_DA9=0: A/B knob (general path)
+    small_input_grad = knob_flag("EML_SMALL_DA9", True)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

@@ -87,4 +87,7 @@ def vgg_loss(vgg, fake, real, weights=(1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0
     xf = vgg(fake)
     with torch.no_grad():
         yf = vgg(real)
+    from . import l1_terms
+    if fake.is_cuda and l1_terms.ENABLED:   # the five terms in one launch each way (csrc/losses.hip)
+        return l1_terms.l1_sum(zip(weights, xf, yf))
     return sum(w * F.l1_loss(a, b) for w, a, b in zip(weights, xf, yf))

@@ -11,6 +11,7 @@ import os
 import torch
 
 from .. import _lib
+from .._knobs import knob_choice, knob_flag
 
 
 def _r16(v):
@@ -127,7 +128,7 @@ def _run_backward(enc, ws, x, gpooled):
     G = enc._grid(dev)
     G3 = enc._grid3(dev)   # conv3x3 kernels: one 512-thread workgroup per CU (see HipDenseEncoder._grid3)
     # (EML_D3_SHORT=1: the data gradient's 256-thread / 4-row-tile A/B geometry wants two workgroups per CU, csrc/dense_bwd.hip)
-    G3d = enc._tuned("EML_GRID3_DGRAD", 2 * G3 if os.environ.get("EML_D3_SHORT") == "1" else G3)
+    G3d = enc._tuned("EML_GRID3_DGRAD", 2 * G3 if knob_flag("EML_D3_SHORT", False) else G3)
     Gw = enc._tuned("EML_GRID_WGRAD1", G)   # per-family knobs for A/B runs (default: the common 2 x #CU)
     Gd = enc._tuned("EML_GRID_DGRAD", G)
     Gb = min(enc.grid_max, 4 * enc._cu)
@@ -166,7 +167,8 @@ def _run_backward(enc, ws, x, gpooled):
     # the parameters by a step or more, so a channel that had just crossed the threshold kept the noisy quotient -- or 0
     # for gamma == 0 -- for those steps: ADVICE round 3.  The ~100 empty launches cost 0.3 % of the step.)
     # EML_DGAMMA_DIRECT=never exists for A/B timing only.
-    direct = os.environ.get("EML_DGAMMA_DIRECT", "always") != "never"
+    direct = knob_choice("EML_DGAMMA_DIRECT", "always", ("always", "never")) != "never"
+    c3_fold = knob_flag("EML_C3_FOLD", True)   # read once, not per layer
     bw.any_ill.zero_()
 
     def dgamma_direct(blk, X_ld, Pin, Hin, Win, pool, DY, ld_dy, Zr, ld_z, co, Cout, conv, Cin, scale1, shift1, cond, bn):
@@ -252,7 +254,7 @@ def _run_backward(enc, ws, x, gpooled):
                 main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
             # round 4: data gradient + weight gradient of the layer in one pass over the tiles (16-byte staging loads in
             # blocks 1 and 2, pairs of 8-byte ones in block 3, which starts at channel 150) -- EML_C3_FOLD=0: the two launches (A/B)
-            fold = (bw.side is None and os.environ.get("EML_C3_FOLD", "1") != "0"
+            fold = (bw.side is None and c3_fold
                     and L.eml_dense_conv3x3_bwd_fused_supported(gsrc[1], gsrc[2], ld, cin) == 1)
             if fold:
                 _lib.check(L.eml_dense_conv3x3_bwd_fused_f32(*gsrc, p(Lm.conv2.weight), p(z), p(lay["zmean"]), p(lay["zistd"]),

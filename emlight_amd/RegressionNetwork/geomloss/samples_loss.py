@@ -65,13 +65,24 @@ class _SplitWatch:
         if self.disabled or self.pending is not None or not (self.calls <= 3 or self.calls % 64 == 0):
             return
         host = torch.empty(1, dtype=torch.int32).pin_memory()
-        host.copy_(work[24 * B * N:24 * B * N + 1].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        with torch.cuda.device(work.device):   # copy and event on the device (and its current stream) that ran the call
+            host.copy_(work[24 * B * N:24 * B * N + 1].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         self.pending = (host, ev)
 
 
-split_watch = _SplitWatch()
+_split_watches = {}
+
+
+def split_watch(device):
+    """The watch of one device: whether the slices of the split kernel are co-resident is a property of the device (and of
+    what shares it), so a give-up on one GPU must not disable the path on the others of a process."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _split_watches:
+        _split_watches[idx] = _SplitWatch()
+    return _split_watches[idx]
 
 
 def sinkhorn_outputs(B, N, dev, need_gx=True, need_gy=False):
@@ -114,14 +125,14 @@ def sinkhorn_raw(x, y, alpha, beta, M, Mt, p, blur, scaling, diameter, need_gx=T
     o = out if out is not None else sinkhorn_outputs(B, N, x.device, need_gx, need_gy)
     watched = flags is None and split_eligible(N)
     if flags is None:
-        flags = split_watch.flags() if watched else 0
+        flags = split_watch(x.device).flags() if watched else 0
     _lib.check(L.eml_sinkhorn_fwd_ex_f32(
         _lib.ptr(x), _lib.ptr(y), _lib.ptr(M), _lib.ptr(Mt), _lib.ptr(alpha), _lib.ptr(beta),
         float(blur), float(scaling), int(p), float(diameter) if diameter is not None else -1.0,
         _lib.ptr(range_lo_hi), _lib.ptr(o["eps_s"]), _lib.ptr(o["n_eps"]), _lib.ptr(o["diameter"]), _lib.ptr(o["loss"]), _lib.ptr(o["gx"]),
         _lib.ptr(o["gy"]), _lib.ptr(o["work"]), B, N, int(flags), _lib.current_stream()), "eml_sinkhorn_fwd_ex_f32")
     if watched and o["work"].numel() > 24 * B * N:
-        split_watch.after_call(o["work"], B, N)
+        split_watch(x.device).after_call(o["work"], B, N)
     return {"loss": o["loss"], "gx": o["gx"], "gy": o["gy"], "eps_s": o["eps_s"], "n_eps": o["n_eps"],
             "diameter": o["diameter"], "duals": o["work"][:4 * B * N].view(4, B, N), "work": o["work"]}
 

@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 20   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 21   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -36,6 +36,12 @@ SIGNATURES = {
                                        ctypes.c_double, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                        _int, _stream]),
     "eml_sinkhorn_bwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _stream]),
+    # the generator's L1-type loss terms (host pointer arrays: ctypes arrays of c_void_p / c_long / c_int / c_float)
+    "eml_l1_pairs_partial_doubles": (ctypes.c_size_t, [_int]),
+    "eml_l1_pairs_fwd_f32": (_int, [_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, _f64p, _f32p, _stream]),
+    "eml_l1_pairs_bwd_f32": (_int, [_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, _f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _stream]),
     # ground-truth parametrisation
     "eml_gt_anchor_index_i32": (_int, [_f32p, _int, _int, _int, _i32p, _stream]),
     "eml_gt_parametrise_f64": (_int, [_f32p, _i32p, _i32p, _int, _int, _int, _int, _f32p, _f32p, _f32p, _stream]),
@@ -53,6 +59,7 @@ SIGNATURES = {
     "eml_sphere_conv_small_wgrad_partial_floats": (ctypes.c_size_t, [_int, _int, _int, _int]),
     "eml_sphere_conv_small_wgrad_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p, _int,
                                                _int, _int, _int, _int, _stream]),
+    "eml_sphere_conv_small_da9_f32": (_int, [_f32p, _f32p, ctypes.c_float, _f32p, _f32p, ctypes.c_long, _int, _int, _stream]),
     "eml_spade_norm_modulate_up2_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _f32p, _f32p,
                                                    _stream]),
     "eml_spade_norm_modulate_bwd_cols_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,

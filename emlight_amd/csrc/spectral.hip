@@ -6,7 +6,7 @@
 // the weight by sigma, clones of u and v -- and the SphereConv then copies the result into its (O, tap, c) operand layout:
 // a dozen launches of 4-10 us for 29 convolutions, twice per iteration, and as many again in the backward.  Here:
 //   forward   t = W^T u (partials over row slices) -> v = t / max(|t|, eps) -> s = W v -> u = s / max(|s|, eps),
-//             sigma = u . s, W2[o][tap*C + c] = W[o][c*9 + tap] / sigma                              (4 launches)
+//             sigma = u . s, W2[o][tap*C + c] = W[o][c*9 + tap] / sigma                              (5 launches)
 //   backward  dW[o][c*9 + tap] = (dW2[o][tap*C + c] - <dW2, W2> u[o] v[c*9 + tap]) / sigma          (2 launches)
 // W (O, K = 9C) is the parameter in its natural (o, c, kh, kw) order; u (O), v (K) are the module's buffers, updated in place
 // when `iterate` (training mode, one power iteration as the reference's default), read-only otherwise.  u, v are constants
@@ -87,17 +87,13 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W
   if (lane == 0) s[o] = a;
 }
 
-// one workgroup per output row: sigma (every workgroup recomputes it from the O-vector s), u (workgroup 0), and the row of
-// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma through LDS (coalesced on both sides; stride 9 is odd: no bank conflicts)
-__global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ W, const float* __restrict__ s,
-                                                        float* __restrict__ u, float* __restrict__ v,
-                                                        const float* __restrict__ t, const double* __restrict__ tnorm_part,
-                                                        int np, int iterate, float eps,
-                                                        float* __restrict__ W2, float* __restrict__ sigma_out,
-                                                        float* __restrict__ u_used, int O, int C) {
-  extern __shared__ __attribute__((aligned(16))) float row[];   // [9C]
+// sigma, u and v of this forward, by ONE workgroup (the O-vector s is at most a few KB): sigma = u . (W v), u = s / max(|s|, eps)
+// when `iterate`, the stored u otherwise; the (u | v) actually used are kept for the backward.
+__global__ __launch_bounds__(256) void sn_sigma_kernel(const float* __restrict__ s, float* __restrict__ u, float* __restrict__ v,
+                                                       const float* __restrict__ t, const double* __restrict__ tnorm_part,
+                                                       int np, int iterate, float eps, float* __restrict__ sigma_out,
+                                                       float* __restrict__ u_used, int O, int K) {
   __shared__ double red[16];
-  const int K = 9 * C, o = blockIdx.x;
   double q = 0.;
   for (int i = threadIdx.x; i < O; i += 256) q += iterate ? (double)s[i] * s[i] : (double)s[i] * u[i];
   const double tot = block_sum(q, red);
@@ -108,26 +104,58 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict_
   } else {
     sigma = (float)tot;
   }
-  if (o == 0) {
-    for (int i = threadIdx.x; i < O; i += 256) {
-      const float ui = iterate ? s[i] * unorm : u[i];
-      if (iterate) u[i] = ui;
-      u_used[i] = ui;
-    }
-    const float vscale = iterate ? inv_norm(tnorm_part, np, eps) : 1.f;
-    for (int i = threadIdx.x; i < K; i += 256) {   // the backward's constants: (u | v) as used here
-      const float vi = iterate ? t[i] * vscale : v[i];
-      if (iterate) v[i] = vi;
-      u_used[O + i] = vi;
-    }
-    if (threadIdx.x == 0) *sigma_out = sigma;
+  for (int i = threadIdx.x; i < O; i += 256) {
+    const float ui = iterate ? s[i] * unorm : u[i];
+    if (iterate) u[i] = ui;
+    u_used[i] = ui;
   }
-  const float inv = 1.f / sigma;
-  for (int i = threadIdx.x; i < K; i += 256) row[i] = W[(size_t)o * K + i];
-  __syncthreads();
-  for (int j = threadIdx.x; j < K; j += 256) {
-    const int tap = j / C, c = j - tap * C;
-    W2[(size_t)o * K + j] = row[c * 9 + tap] * inv;
+  const float vscale = iterate ? inv_norm(tnorm_part, np, eps) : 1.f;
+  for (int i = threadIdx.x; i < K; i += 256) {   // the backward's constants: (u | v) as used here
+    const float vi = iterate ? t[i] * vscale : v[i];
+    if (iterate) v[i] = vi;
+    u_used[O + i] = vi;
+  }
+  if (threadIdx.x == 0) *sigma_out = sigma;
+}
+
+// The re-layout itself is a pure stream (read W once, write W2 once: 2 x 289 MB per generator pass at ngf = 64): one
+// workgroup per (row o, chunk of kCC channels), 16-byte accesses on both sides, the (c, tap) -> (tap, c) transpose of the
+// chunk through LDS.  LDS index of element (c, tap) = 9c + tap + (c >> 2): a lane's four channels of one tap sit 9 apart, the
+// lanes of a wave 37 apart -- odd, so neither side conflicts.  (Round 4's kernel gave a whole row of up to 9216 floats to
+// one workgroup, 4-byte accesses, one row in flight per workgroup: 0.18 TB/s, 6 ms of a joint step.)
+constexpr int kCC = 256;
+constexpr int kTile = kCC * 9 + kCC / 4;
+
+// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma
+__global__ __launch_bounds__(256) void sn_relayout_kernel(const float* __restrict__ W, const float* __restrict__ sigma,
+                                                          float* __restrict__ W2, int C) {
+  __shared__ float tile[kTile];
+  const int K = 9 * C, o = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0), tid = threadIdx.x;
+  const float inv = 1.f / *sigma;
+  const float* src = W + (size_t)o * K + (size_t)c0 * 9;
+  float* dst = W2 + (size_t)o * K + c0;
+  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int j = tid; j < (cc * 9) / 4; j += 256) {       // elements 4j .. 4j+3 of the chunk: 36 | 4j' boundaries only
+      const float4 w = src4[j];
+      const int b = 4 * j + j / 9;
+      tile[b] = w.x; tile[b + 1] = w.y; tile[b + 2] = w.z; tile[b + 3] = w.w;
+    }
+    __syncthreads();
+    const int c4 = tid & 63, q = cc >> 2;
+    if (c4 < q) {
+      for (int tap = tid >> 6; tap < 9; tap += 4) {
+        const float* r = tile + 37 * c4 + tap;
+        *reinterpret_cast<float4*>(dst + (size_t)tap * C + 4 * c4) = make_float4(r[0] * inv, r[9] * inv, r[18] * inv, r[27] * inv);
+      }
+    }
+  } else {
+    for (int i = tid; i < cc * 9; i += 256) tile[i + i / 36] = src[i];
+    __syncthreads();
+    for (int j = tid; j < cc * 9; j += 256) {
+      const int tap = j / cc, c = j - tap * cc;
+      dst[(size_t)tap * C + c] = tile[9 * c + tap + (c >> 2)] * inv;
+    }
   }
 }
 
@@ -136,26 +164,55 @@ __global__ __launch_bounds__(256) void sn_inner_kernel(const float* __restrict__
                                                        double* __restrict__ partial) {
   __shared__ double red[16];
   double q = 0.;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q += (double)dW2[i] * W2[i];
+  const size_t n4 = (((reinterpret_cast<uintptr_t>(dW2) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0) ? n >> 2 : 0;
+  const float4* a4 = reinterpret_cast<const float4*>(dW2);
+  const float4* b4 = reinterpret_cast<const float4*>(W2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 a = a4[i], b = b4[i];
+    q += ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w);
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q += (double)dW2[i] * W2[i];
   const double tot = block_sum(q, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// dW[o][c*9 + tap] = (dW2[o][tap*C + c] - <dW2, W2> u[o] v[c*9 + tap]) / sigma: the transposed twin of sn_relayout_kernel
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dW2, const double* __restrict__ partial,
                                                            int P, const float* __restrict__ u, const float* __restrict__ v,
-                                                           const float* __restrict__ sigma, float* __restrict__ dW, int O,
-                                                           int C) {
-  extern __shared__ __attribute__((aligned(16))) float row[];   // [9C]: dW2's row, (tap, c) order
-  const int K = 9 * C, o = blockIdx.x;
+                                                           const float* __restrict__ sigma, float* __restrict__ dW, int C) {
+  __shared__ float tile[kTile];
+  const int K = 9 * C, o = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0), tid = threadIdx.x;
   double inner = 0.;
   for (int i = 0; i < P; ++i) inner += partial[i];   // fixed order, same in every workgroup
   const float inv = 1.f / *sigma;
   const float coef = (float)inner * u[o];
-  for (int j = threadIdx.x; j < K; j += 256) row[j] = dW2[(size_t)o * K + j];
-  __syncthreads();
-  for (int i = threadIdx.x; i < K; i += 256) {
-    const int c = i / 9, tap = i - 9 * c;
-    dW[(size_t)o * K + i] = (row[tap * C + c] - coef * v[i]) * inv;
+  const float* src = dW2 + (size_t)o * K + c0;
+  float* dst = dW + (size_t)o * K + (size_t)c0 * 9;
+  const float* vv = v + (size_t)c0 * 9;
+  if ((C & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(dW2) | reinterpret_cast<uintptr_t>(dW) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+    const int c4 = tid & 63, q = cc >> 2;
+    if (c4 < q) {
+      for (int tap = tid >> 6; tap < 9; tap += 4) {
+        const float4 g = *reinterpret_cast<const float4*>(src + (size_t)tap * C + 4 * c4);
+        float* r = tile + 37 * c4 + tap;
+        r[0] = g.x; r[9] = g.y; r[18] = g.z; r[27] = g.w;
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < (cc * 9) / 4; j += 256) {
+      const int b = 4 * j + j / 9;
+      const float4 x = *reinterpret_cast<const float4*>(vv + 4 * j);
+      *reinterpret_cast<float4*>(dst + 4 * j) = make_float4((tile[b] - coef * x.x) * inv, (tile[b + 1] - coef * x.y) * inv,
+                                                           (tile[b + 2] - coef * x.z) * inv, (tile[b + 3] - coef * x.w) * inv);
+    }
+  } else {
+    for (int j = tid; j < cc * 9; j += 256) {
+      const int tap = j / cc, c = j - tap * cc;
+      tile[9 * c + tap + (c >> 2)] = src[(size_t)tap * C + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < cc * 9; i += 256) dst[i] = (tile[i + i / 36] - coef * vv[i]) * inv;
   }
 }
 
@@ -191,10 +248,9 @@ extern "C" int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int 
   } else {
     hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, v, nullptr, 0, eps, s, O, K);
   }
-  const size_t lds = (size_t)K * sizeof(float);
-  EML_ENSURE_LDS((&sn_finish_kernel), lds);
-  hipLaunchKernelGGL(sn_finish_kernel, dim3(O), dim3(256), lds, st, W, s, u, v, t, tnorm_part, np, iterate ? 1 : 0, eps, W2, sigma,
-                     uv_used, O, C);
+  hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, s, u, v, t, tnorm_part, np, iterate ? 1 : 0, eps, sigma, uv_used,
+                     O, K);
+  hipLaunchKernelGGL(sn_relayout_kernel, dim3(O, (C + kCC - 1) / kCC), dim3(256), 0, st, W, sigma, W2, C);
   return eml::check_launch("eml_spectral_norm_w2_f32");
 }
 
@@ -209,8 +265,7 @@ extern "C" int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, c
   const size_t n = (size_t)O * K;
   const int grid = (int)std::min<size_t>(kInnerGrid, (n + 4095) / 4096);
   hipLaunchKernelGGL(sn_inner_kernel, dim3(grid), dim3(256), 0, st, dW2, W2, n, partial);
-  const size_t lds = (size_t)K * sizeof(float);
-  EML_ENSURE_LDS((&sn_bwd_apply_kernel), lds);
-  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(O), dim3(256), lds, st, dW2, partial, grid, u_used, v, sigma, dW, O, C);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(O, (C + kCC - 1) / kCC), dim3(256), 0, st, dW2, partial, grid, u_used, v, sigma, dW,
+                     C);
   return eml::check_launch("eml_spectral_norm_w2_bwd_f32");
 }

@@ -75,11 +75,14 @@ __global__ __launch_bounds__(256) void sphere_im2col_kernel(const float* __restr
         for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(xb + (size_t)max(ids[k], 0) * C + 4 * c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float wk = ids[k] >= 0 ? ws[k] : 0.f;
-          acc.x += v[k].x * wk;
-          acc.y += v[k].y * wk;
-          acc.z += v[k].z * wk;
-          acc.w += v[k].w * wk;
+          // a corner off the map contributes exactly +0 whatever the clamped address holds (0 * Inf would be NaN where
+          // grid_sample's zero padding is finite: ADVICE round 4) -- the kernel is bound by its stores, the selects are free
+          const bool in = ids[k] >= 0;
+          const float wk = in ? ws[k] : 0.f;
+          acc.x += (in ? v[k].x : 0.f) * wk;
+          acc.y += (in ? v[k].y : 0.f) * wk;
+          acc.z += (in ? v[k].z : 0.f) * wk;
+          acc.w += (in ? v[k].w : 0.f) * wk;
         }
         // streaming store: A9 is 9x the input and is next read by the GEMM long after it has left L2
         float* dst = ab + (size_t)row * C + 4 * c;

@@ -496,9 +496,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 namespace {
 // EML_GG_V1=1: A/B switch back to the round-2 kernel for every table (read once)
-bool getenv_flag(const char* name) {
-  static const bool on = [name] { const char* v = getenv(name); return v && v[0] == '1'; }();
+bool gg_v1_enabled() {
+  static const bool on = [] { const char* v = getenv("EML_GG_V1"); return v && v[0] == '1'; }();
   return on;
+}
+// gather_gemm2's per-pixel 32-bit BYTE offsets are relative to the tile's first sample: a 128-pixel tile spans at most
+// (127 / Po + 2) samples of HW * C floats each (the HW * C bound alone does not cover Po < 128)
+bool gg2_offsets_fit(long HW, int C, int Po) {
+  return (unsigned long long)HW * C < (1ull << 29) &&
+         (unsigned long long)((gg2::kBM - 1) / Po + 2) * (unsigned long long)HW * C * 4ull < (1ull << 32);
 }
 int launch_gather_gemm(const char* what, const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
                        float* Y, int B, int HW, int Po, int C, int O, int ke, const unsigned char* rowmax,
@@ -512,8 +518,7 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   // the same box (profiles/r04_gg2_variants.jsonl, variant v2.2).  It needs two chunks per tap (C >= 64) and its 32-bit
   // offsets to reach two samples / the weight tile; single-entry (planar) tables keep the round-2 kernel, which schedules
   // their four loads per chunk better (vgg 64 -> 64: 107 against 98 TF/s).
-  if (ke != 1 && C >= 64 && (unsigned long long)HW * C < (1ull << 29) && (unsigned long long)O * 9 * C < (1ull << 30) &&
-      !getenv_flag("EML_GG_V1")) {
+  if (ke != 1 && C >= 64 && gg2_offsets_fit(HW, C, Po) && (unsigned long long)O * 9 * C < (1ull << 30) && !gg_v1_enabled()) {
     const long n_mt2 = (M + gg2::kBM - 1) / gg2::kBM, per_xcd2 = (n_mt2 + 7) / 8;
     const dim3 grid2((unsigned)(8 * per_xcd2 * (O / bn)));
 #define EML_LAUNCH_GG2(BNV)                                                                                          \
@@ -575,8 +580,8 @@ extern "C" int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, 
 // W2r (2 Cn, 9 Cin) / bias_r (2 Cn): the rows of cat(gamma head, beta head) in the kernel's order -- position p holds
 // source row  c + half * Cn  with  c = 64 (p / 128) + 32 ((p % 128) / 64) + p % 32,  half = (p % 64) / 32.
 extern "C" int eml_sphere_conv_spade_supported(int Cin, int Cn, long HW) {
-  return Cin >= 64 && Cin % 32 == 0 && Cn >= 64 && Cn % 64 == 0 && HW >= 1 &&
-         (unsigned long long)HW * Cin < (1ull << 29) && (unsigned long long)2 * Cn * 9 * Cin < (1ull << 30);
+  return Cin >= 64 && Cin % 32 == 0 && Cn >= 64 && Cn % 64 == 0 && HW >= 1 && HW <= 2147483647L &&
+         gg2_offsets_fit(HW, Cin, (int)HW) && (unsigned long long)2 * Cn * 9 * Cin < (1ull << 30);
 }
 
 extern "C" int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, const float* wgt, const float* W2r,

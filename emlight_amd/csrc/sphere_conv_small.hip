@@ -110,6 +110,73 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_small_fwd_kernel(const flo
   }
 }
 
+
+// Input gradient, first half: dA9[m][k] = sum_o g'[m][o] * W2[o][k]  (k = tap * CIN + c < 9 * CIN; g' = dY * act'(Y) formed in
+// registers) -- the (M, 9 CIN) tensor eml_sphere_col2im_f32 then gathers into dX.  Needed where the 3-channel INPUT itself
+// carries a gradient: the guide map of the joint step (18 mlp_shared convolutions per generator pass; emlight_amd/joint.py)
+// and VGG19's conv1_1 on the generated panorama.  On the general path this was an activation-backward pass (read dY, Y; write
+// g'), a library GEMM with N = 27 (read g' again) and, for the weights, a bias reduction, an im2col and a batched GEMM: here
+// one read of (dY, Y).  MFMA: rows = k (two 16-row tiles), columns = 16 pixels, K = the output channels; a lane loads
+// 4 consecutive channels of its pixel (16 bytes) and feeds them to four k-steps (MFMA's k index is only a summation label),
+// W2 sits in registers as the A operand of those steps.
+template <int CIN, int O>
+__global__ __launch_bounds__(256, 2) void sphere_conv_small_da9_kernel(const float* __restrict__ dY, const float* __restrict__ Yact,
+                                                                    const float* __restrict__ W2 /*[O][9*CIN]*/,
+                                                                    float* __restrict__ dA9 /*[M][9*CIN]*/, int M, float slope) {
+  constexpr int K = 9 * CIN, NTK = (K + 15) / 16, NS = O / 16;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float wreg[NTK][NS][4];
+#pragma unroll
+  for (int nt = 0; nt < NTK; ++nt)
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * nt + r;
+        wreg[nt][s][i] = k < K ? W2[(size_t)(16 * s + 4 * g + i) * K + k] : 0.f;
+      }
+  const int ntiles = (M + 15) / 16;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const int m = t * 16 + r;
+    const bool ok = m < M;
+    const size_t row = (size_t)(ok ? m : 0) * O + 4 * g;
+    float4 q[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) q[s] = *reinterpret_cast<const float4*>(dY + row + 16 * s);
+    if (Yact) {   // wave-uniform
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float4 yq = *reinterpret_cast<const float4*>(Yact + row + 16 * s);
+        q[s].x = yq.x > 0.f ? q[s].x : q[s].x * slope; q[s].y = yq.y > 0.f ? q[s].y : q[s].y * slope;
+        q[s].z = yq.z > 0.f ? q[s].z : q[s].z * slope; q[s].w = yq.w > 0.f ? q[s].w : q[s].w * slope;
+      }
+    }
+    f32x4 acc[NTK];
+#pragma unroll
+    for (int nt = 0; nt < NTK; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NTK; ++nt) {
+        acc[nt] = mfma16(wreg[nt][s][0], q[s].x, acc[nt]);
+        acc[nt] = mfma16(wreg[nt][s][1], q[s].y, acc[nt]);
+        acc[nt] = mfma16(wreg[nt][s][2], q[s].z, acc[nt]);
+        acc[nt] = mfma16(wreg[nt][s][3], q[s].w, acc[nt]);
+      }
+    if (ok) {   // D element i of tile nt: row 4g + i <-> k = 16 nt + 4g + i, column r <-> this lane's pixel
+      float* dst = dA9 + (size_t)m * K;
+#pragma unroll
+      for (int nt = 0; nt < NTK; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = 16 * nt + 4 * g + i;
+          if (k < K) dst[k] = acc[nt][i];
+        }
+    }
+  }
+}
+
 // partial[blockIdx.x][O][KP]  (KP = 9*CIN + 1 rounded up to 16 columns: k < 9*CIN = dW2, k = 9*CIN = the bias gradient)
 template <int CIN, int O>
 __global__ __launch_bounds__(256, 2) void sphere_conv_small_wgrad_kernel(const float* __restrict__ X, const int* __restrict__ idx,
@@ -292,4 +359,23 @@ extern "C" int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, c
   if (O == 128) launch_small_wgrad<3, 128>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
   else launch_small_wgrad<3, 64>(X, idx, wgt, dY, ya, partial, dW2, db, (int)M, HW, Po, act_slope, grid, st);
   return eml::check_launch("eml_sphere_conv_small_wgrad_f32");
+}
+
+extern "C" int eml_sphere_conv_small_da9_f32(const float* dY, const float* Yact, float act_slope, const float* W2, float* dA9,
+                                             long M, int C, int O, eml_stream_t stream) {
+  if (!dY || !W2 || !dA9 || M < 0) return eml::fail(EML_EINVAL, "eml_sphere_conv_small_da9_f32: null pointer or negative row count");
+  if (!small_supported(C, O))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_da9_f32: (C, O) = (%d, %d) not in {(3, 64), (3, 128)}", C, O);
+  if (!(act_slope >= 0.f && act_slope <= 1.f) || (act_slope != 1.f && !Yact))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_small_da9_f32: act_slope %g needs Yact and a slope in [0, 1]", (double)act_slope);
+  if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_small_da9_f32: too many pixels");
+  if (M == 0) return EML_OK;
+  const int grid = (int)std::min<long>(2048, (M + 63) / 64);   // persistent: W2 is loaded into registers once per wave
+  const float* ya = act_slope != 1.f ? Yact : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (O == 128)
+    hipLaunchKernelGGL((sphere_conv_small_da9_kernel<3, 128>), dim3(grid), dim3(256), 0, st, dY, ya, W2, dA9, (int)M, act_slope);
+  else
+    hipLaunchKernelGGL((sphere_conv_small_da9_kernel<3, 64>), dim3(grid), dim3(256), 0, st, dY, ya, W2, dA9, (int)M, act_slope);
+  return eml::check_launch("eml_sphere_conv_small_da9_f32");
 }

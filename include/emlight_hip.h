@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 20
+#define EML_ABI_VERSION 21
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -402,7 +402,10 @@ int eml_sphere_col2im_f32(const float* dA9, const int* ptr, const int* src, cons
  * idx / wgt = eml_sphere_tap_table_f32's table, W2 (O, 9C) with columns ordered (tap, c) (= weight.permute(0,2,3,1)),
  * bias (O) or NULL, Y (B*Po, O).  Forward: C % 32 == 0, O % 64 == 0.
  * Weight gradient dW2 (O, 9C) = sum_m dY[m] (x) Ag[m]: C % 64 == 0, O >= 64, O % 16 == 0; split_k workgroups share the
- * pixel axis, partial = eml_sphere_conv_wgrad_partial_floats(C, O, split_k) floats of scratch (deterministic sum). */
+ * pixel axis, partial = eml_sphere_conv_wgrad_partial_floats(C, O, split_k) floats of scratch (deterministic sum).
+ * PRECONDITION of the fused / narrow / small gather kernels (not of eml_sphere_im2col_f32, which selects the value): X is
+ * finite.  A corner that falls off the map (idx = -1) is loaded from a clamped address and multiplied by weight 0, so an
+ * Inf / NaN at pixel 0 of a sample would surface where grid_sample's zero padding gives a finite value. */
 /* ke = table entries per (pixel, tap): 4 = the bilinear corners of the tap table; 1 = a single (index, weight) pair
  * (idx / wgt then hold Po*9 entries) -- an ordinary zero-padded 3x3 convolution written as a gather, used by the VGG19
  * feature stack of the perceptual loss (architecture.py:92-125): a quarter of the operand loads, no bilinear combine. */
@@ -430,6 +433,11 @@ size_t eml_sphere_conv_small_wgrad_partial_floats(int B, int Po, int C, int O);
 int eml_sphere_conv_small_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY, const float* Yact,
                                     float act_slope, float* partial, float* dW2, float* db, int B, int HW, int Po, int C,
                                     int O, eml_stream_t stream);
+/* Input gradient of those layers, first half (where the 3-channel input carries a gradient: the guide map of the joint step,
+ * VGG19's conv1_1 on the generated panorama): dA9 (M, 9C) = g' W2, g' as above, M = B*Po pixel rows -- one read of (dY, Yact);
+ * eml_sphere_col2im_f32 then gathers dA9 into dX.  Replaces an activation-backward pass + an N = 27 library GEMM. */
+int eml_sphere_conv_small_da9_f32(const float* dY, const float* Yact, float act_slope, const float* W2, float* dA9, long M,
+                                  int C, int O, eml_stream_t stream);
 /* The few-channel OUTPUT layers (generator.py:60, 84-86: conv_img 64 -> 3 at full resolution; discriminator.py:70-74: the
  * final 512 -> 1 convolutions): sphere_cnn.py:111-124 with O <= 4 as three one-pass kernels -- no 9x im2col operand, no N = 3
  * library GEMM, no dA9 + col2im in the backward.  C % 64 == 0, C <= 512, 1 <= O <= 4 (eml_sphere_conv_narrow_supported).
@@ -561,6 +569,23 @@ int eml_instance_norm_act_fwd_f32(const float* x, float* y, float* stats, int B,
                                   float eps, float slope, eml_stream_t stream);
 int eml_instance_norm_act_bwd_f32(const float* gy, const float* x, const float* stats, float* dx, int B, int HW, int C,
                                   int channels_last, float slope, eml_stream_t stream);
+
+/* ---------------------------------------------------------------- the generator's L1-type loss terms, one launch each way
+ * models/pix2pix_model.py:99-117 (mask-weighted feature matching over the discriminators' feature maps, x50 off the lights)
+ * and models/networks/loss.py:102-114 (VGGLoss: sum_i w_i L1(vgg_i(fake), vgg_i(real))).  A term is a pair (f, r) of
+ * channels-last maps -- rows[i] pixel rows of C[i] floats each -- with an optional per-row weight w[i] (rows[i] floats, or NULL;
+ * |w| is used) and a scale[i] (coefficient / numel):
+ *   fwd  out[0] = sum_i scale[i] * sum_e |f_i[e] - r_i[e]| * |w_i[row(e)]|     partial: eml_l1_pairs_partial_doubles(npairs) f64
+ *   bwd  g_i[e] = gout[0] * scale[i] * sign(f_i[e] - r_i[e]) * |w_i[row(e)]|;  gzero[i] (or NULL): a region of nzero[i] floats
+ *        zero-filled by the same launch (the real half of a feature map whose gradient tensor spans fake | real).
+ * The host arrays (npairs <= 16 entries each) are read during the call and travel in the kernel arguments: no device table, no
+ * host sync.  Deterministic (per-workgroup f64 partials, fixed-order fold). */
+size_t eml_l1_pairs_partial_doubles(int npairs);
+int eml_l1_pairs_fwd_f32(int npairs, const float* const* f, const float* const* r, const float* const* w, const long* rows,
+                         const int* C, const float* scale, double* partial, float* out, eml_stream_t stream);
+int eml_l1_pairs_bwd_f32(int npairs, const float* const* f, const float* const* r, const float* const* w, const long* rows,
+                         const int* C, const float* scale, const float* gout, float* const* g, float* const* gzero,
+                         const long* nzero, eml_stream_t stream);
 
 /* ---------------------------------------------------------------- ground-truth parametrisation (data preparation)
  * representation/distribution_representation.py:65-120 (`extract_mesh`), the inverse of the rasteriser.

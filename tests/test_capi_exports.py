@@ -110,6 +110,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, 1.5, 2, -1.0, None, None, None, None, one, None, None,
                                   one, 2, 96, None) == -1                                                       # 0 < scaling < 1
     assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 1, one, one, 0, 32, 32, 64, 64, None) == 0     # ke = 1, empty batch
+    # round-5 entry points: the fused L1 terms take HOST arrays of device pointers
+    assert L.eml_l1_pairs_partial_doubles(3) == 3 * 1024 and L.eml_l1_pairs_partial_doubles(0) == 0
+    ptrs, rows, cs, sc = (ctypes.c_void_p * 17)(*([8] * 17)), (ctypes.c_long * 17)(*([4] * 17)), (ctypes.c_int * 17)(*([4] * 17)), (ctypes.c_float * 17)()
+    assert L.eml_l1_pairs_fwd_f32(0, ptrs, ptrs, ptrs, rows, cs, sc, one, one, None) == -1 and b"pairs" in L.eml_last_error()
+    assert L.eml_l1_pairs_fwd_f32(17, ptrs, ptrs, ptrs, rows, cs, sc, one, one, None) == -1
+    assert L.eml_l1_pairs_fwd_f32(2, ptrs, ptrs, None, rows, cs, sc, None, one, None) == -1                     # null partial
+    nulls = (ctypes.c_void_p * 2)()
+    assert L.eml_l1_pairs_fwd_f32(2, nulls, ptrs, None, rows, cs, sc, one, one, None) == -1 and b"pair 0" in L.eml_last_error()
+    assert L.eml_l1_pairs_bwd_f32(2, ptrs, ptrs, None, rows, cs, sc, one, nulls, None, None, None) == -1       # null gradient pointer
+    assert L.eml_l1_pairs_bwd_f32(2, ptrs, ptrs, None, rows, cs, sc, None, ptrs, None, None, None) == -1       # null gout
 
 
 def test_product_path_has_no_cpu_fallback():

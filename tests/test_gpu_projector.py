@@ -994,3 +994,44 @@ def test_inference_in_eval_mode_matches_the_stock_ops():
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=1e-3 * float(want.abs().max()))
     for k, v in u_before.items():   # eval: no buffer moves
         assert torch.equal(hip.netG.state_dict()[k], v), k
+
+
+def test_fused_l1_terms_vs_stock_formulas():
+    """``csrc/losses.hip`` (feature matching over the maps of cat(fake, real) with the x50 off-light weight, and the VGG-style
+    weighted L1 sum) against the literal reference formulas (pix2pix_model.py:101-117, loss.py:108-114) in f64: value,
+    gradient (the real half of a feature map gets exactly 0), odd channel counts (scalar path), run-to-run bit equality."""
+    from emlight_amd.GenProjector import l1_terms
+    torch.manual_seed(11)
+    B, num_D = 3, 2
+    shapes = [(64, 16, 32), (128, 8, 16), (6, 8, 16), (512, 4, 8)]
+    feats = [torch.randn(2 * B, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_()
+             for c, h, w in shapes]
+    with torch.no_grad():
+        feats[1][:B, :, 0, 0] = feats[1][B:, :, 0, 0]   # exact ties: sign(0) = 0 like torch's abs backward
+    masks = [(torch.rand(B, 1, h, w, device="cuda") > 0.7).float() for _, h, w in shapes]
+    got = l1_terms.feature_matching(feats, masks, num_D)
+    got.backward()
+    again = l1_terms.feature_matching([t.detach() for t in feats], masks, num_D)
+    assert torch.equal(got.detach(), again)
+    refs = [t.detach().double().requires_grad_() for t in feats]
+    want = 0
+    for t, m in zip(refs, masks):
+        f, r, m = t[:B], t[B:].detach(), m.double()
+        want = want + torch.nn.functional.l1_loss(f * m + f * (1 - m) * 50, r * m + r * (1 - m) * 50) / num_D
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    for t, rt in zip(feats, refs):
+        assert float(t.grad[B:].abs().max()) == 0.0
+        np.testing.assert_allclose(t.grad.cpu().numpy(), rt.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
+    # VGG-style: sum_i w_i L1(a_i, b_i), gradient to a_i only; one NCHW-contiguous input (a stock feature stack)
+    ws = (1 / 32, 1 / 16, 1.0)
+    a = [torch.randn(B, c, h, w, device="cuda", requires_grad=True) for c, h, w in shapes[:3]]
+    b = [torch.randn(B, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last) for c, h, w in shapes[:3]]
+    got = l1_terms.l1_sum(zip(ws, a, b))
+    got.backward()
+    ar = [t.detach().double().requires_grad_() for t in a]
+    want = sum(w * torch.nn.functional.l1_loss(x, y.double()) for w, x, y in zip(ws, ar, b))
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    for t, rt in zip(a, ar):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), rt.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
