@@ -104,6 +104,10 @@ class SphereGeometry:
         self.csr_ptr = torch.zeros(h * w + 1, dtype=torch.int32, device=device)
         self.csr_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=h * w), 0).to(torch.int32)
         self._transposed = None
+        # EML_TAP_ROWSHARE (include/emlight_hip.h): on a stride-1 sphere grid a tap samples source column c + const(row, tap)
+        # of two adjacent rows, so a pixel's east corners ARE its right neighbour's west corners -- verified on the table
+        # itself (once per geometry), never assumed
+        self.rowshare = int(kind == "sphere" and _table_rowshare(self.idx, self.ho * self.wo))
 
     def transposed_table(self):
         """The tap table seen from the INPUT pixels, for the fused input-gradient kernel: for input pixel q and tap t the
@@ -133,8 +137,20 @@ class SphereGeometry:
                 rowmax = counts.view(hw, 9).max(1).values.to(torch.uint8).contiguous()
                 if kmax <= 1 and self.idx1 is not None:   # an ordinary convolution: one source per (pixel, tap)
                     tidx, twgt, ke = tidx[:, :1], twgt[:, :1], 1
-                self._transposed = (tidx.contiguous(), twgt.contiguous(), rowmax, ke)
+                tidx = tidx.contiguous()
+                self.t_rowshare = int(ke == 4 and self.idx1 is None and _table_rowshare(tidx, hw))
+                self._transposed = (tidx, twgt.contiguous(), rowmax, ke)
         return self._transposed if self._transposed[0] is not None else None
+
+
+def _table_rowshare(idx, n_dst):
+    """Does a (n_dst * 9, 4) tap table have the property EML_TAP_ROWSHARE promises?  For every destination pixel p with
+    p % 4 != 3 and every tap: entry 1 of p == entry 0 of p + 1 and entry 3 of p == entry 2 of p + 1; n_dst % 4 == 0."""
+    if n_dst % 4 or idx.dim() != 2 or idx.shape[1] != 4 or idx.shape[0] != n_dst * 9:
+        return False
+    t = idx.view(n_dst // 4, 4, 9, 4)
+    ok = (t[:, :3, :, 1] == t[:, 1:, :, 0]).all() & (t[:, :3, :, 3] == t[:, 1:, :, 2]).all()
+    return bool(ok)
 
 
 _GEOMETRY = {}
@@ -225,7 +241,8 @@ class _SphereConvFn(torch.autograd.Function):
             _lib.check(L.eml_sphere_conv_fwd_fused_ex_f32(p(xr), p(tab[0]), p(tab[1]), p(w2.contiguous()),
                                                           p(bias.contiguous()) if bias is not None else None, p(y), B,
                                                           H * W, po, C, O, tab[2], p(res) if res is not None else None,
-                                                          slope, st), "eml_sphere_conv_fwd_fused_ex_f32")
+                                                          slope, geo.rowshare if tab[2] == 4 else 0, st),
+                       "eml_sphere_conv_fwd_fused_ex_f32")
         else:
             a9 = _SphereConvFn._im2col(xr, geo, B, C) if B else xr.new_empty(0, 9 * C)
             y = torch.addmm(bias, a9, w2.t()) if bias is not None else a9 @ w2.t()
@@ -370,7 +387,8 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             tidx, twgt, rowmax, ke = tt
             w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
             _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gyr), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gxr), B,
-                                                         H * W, po, C, O, st), "eml_sphere_conv_dgrad_fused_f32")
+                                                         H * W, po, C, O, getattr(geo, "t_rowshare", 0), st),
+                       "eml_sphere_conv_dgrad_fused_f32")
         else:
             w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C)
             da9 = gyr @ w2                                           # (B*Po, 9C)
@@ -620,7 +638,7 @@ class _SpadeConvModulateFn(torch.autograd.Function):
         gamma = torch.empty_like(y) if keep else None
         _lib.check(L.eml_sphere_conv_spade_fwd_f32(p(ar), p(geo.idx), p(geo.wgt), p(w2r), p(br) if br is not None else None,
                                                    p(x), p(mean), p(istd), p(y), p(gamma) if keep else None, B, H, W, Cin, Cn,
-                                                   int(bool(up2)), float(slope), st), "eml_sphere_conv_spade_fwd_f32")
+                                                   int(bool(up2)), float(slope), geo.rowshare, st), "eml_sphere_conv_spade_fwd_f32")
         ctx.geo, ctx.shape, ctx.has_bias = geo, (B, Cin, H, W, 2 * Cn), bias is not None
         ctx.up2, ctx.act_slope, ctx.training = bool(up2), float(slope), bool(training)
         # the state _sphere_conv_backward reads: a plain (no epilogue, no kept operand) SphereConv 128 -> 2 Cn

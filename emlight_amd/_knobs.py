@@ -1,4 +1,4 @@
-"""A/B knobs of the HIP engine (``EML_*`` environment variables), parsed ONCE and validated.
+"""A/B knobs of the HIP engine (``EML_*`` environment variables), parsed once per distinct value and validated.
 
 They exist for same-box timing experiments (tools/, profiles/); a production run leaves them unset.  A malformed value does
 not break ``import emlight_amd`` -- it is reported and the default is used -- and every non-default setting is announced once
@@ -6,7 +6,7 @@ on stderr, so that a knob left over from an experiment cannot silently change th
 import os
 import sys
 
-_seen = {}
+_seen = {}   # (name, raw value) -> parsed value: a test or an A/B driver that changes the variable in-process is honoured
 
 
 def _note(name, value, default):
@@ -15,8 +15,9 @@ def _note(name, value, default):
 
 
 def knob_int(name, default, lo=None, hi=None):
-    if name not in _seen:
-        raw, val = os.environ.get(name), default
+    raw = os.environ.get(name)
+    if ("int", name, raw) not in _seen:
+        val = default
         if raw is not None:
             try:
                 val = int(raw)
@@ -27,27 +28,29 @@ def knob_int(name, default, lo=None, hi=None):
                       % (name, raw, "" if lo is None else " >= %d" % lo, default), file=sys.stderr)
                 val = default
         _note(name, val, default)
-        _seen[name] = val
-    return _seen[name]
+        _seen[("int", name, raw)] = val
+    return _seen[("int", name, raw)]
 
 
 def knob_flag(name, default):
     """'0' / '1' switches; anything else is reported and ignored."""
-    if name not in _seen:
-        raw, val = os.environ.get(name), bool(default)
+    raw = os.environ.get(name)
+    if ("flag", name, raw) not in _seen:
+        val = bool(default)
         if raw is not None:
             if raw in ("0", "1"):
                 val = raw == "1"
             else:
                 print("emlight_amd: ignoring %s=%r (want 0 or 1); using %d" % (name, raw, int(default)), file=sys.stderr)
         _note(name, val, bool(default))
-        _seen[name] = val
-    return _seen[name]
+        _seen[("flag", name, raw)] = val
+    return _seen[("flag", name, raw)]
 
 
 def knob_choice(name, default, choices):
-    if name not in _seen:
-        raw, val = os.environ.get(name), default
+    raw = os.environ.get(name)
+    if ("choice", name, raw) not in _seen:
+        val = default
         if raw is not None:
             if raw in choices:
                 val = raw
@@ -55,5 +58,5 @@ def knob_choice(name, default, choices):
                 print("emlight_amd: ignoring %s=%r (want one of %s); using %r" % (name, raw, "/".join(choices), default),
                       file=sys.stderr)
         _note(name, val, default)
-        _seen[name] = val
-    return _seen[name]
+        _seen[("choice", name, raw)] = val
+    return _seen[("choice", name, raw)]

@@ -52,7 +52,7 @@ SIGNATURES = {
     "eml_sphere_conv_fwd_fused_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                                              _stream]),
     "eml_sphere_conv_fwd_fused_ex_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
-                                                _f32p, ctypes.c_float, _stream]),
+                                                _f32p, ctypes.c_float, _int, _stream]),
     "eml_sphere_conv_small_supported": (_int, [_int, _int]),
     "eml_sphere_conv_small_fwd_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,
                                              ctypes.c_float, _stream]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "eml_sphere_conv_narrow_wgrad_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream]),
     "eml_sphere_conv_spade_supported": (_int, [_int, _int, ctypes.c_long]),
     "eml_sphere_conv_spade_fwd_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int,
-                                             _int, _int, _int, _int, ctypes.c_float, _stream]),
+                                             _int, _int, _int, _int, ctypes.c_float, _int, _stream]),
     "eml_spade_norm_modulate_bwd_y_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int,
                                                  ctypes.c_float, _f32p, _f32p, _f32p, _int, _stream]),
     "eml_bn_bwd_apply_up2_f32": (_int, [_f32p, _f32p, _int, _int, _int, _int, _f32p, _f32p, _f32p, _f32p, _stream]),
@@ -85,7 +85,7 @@ SIGNATURES = {
                                              _stream]),
     "eml_instance_norm_act_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _stream]),
     "eml_sphere_conv_dgrad_fused_f32": (_int, [_f32p, _i32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int, _int, _int, _int,
-                                               _stream]),
+                                               _int, _stream]),
     "eml_sphere_conv_wgrad_partial_floats": (ctypes.c_size_t, [_int, _int, _int]),
     "eml_sphere_conv_wgrad_fused_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                                                _stream]),

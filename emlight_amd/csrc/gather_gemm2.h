@@ -19,6 +19,15 @@
 //     ahead and read back (broadcast ds_read_b128) right where they are used.
 //  Pole rows of the transposed table (ke = 8, < 3 % of the tiles) run as TWO virtual taps of 4 entries over the same W2
 //  chunk instead of a second, latency-exposed gather inside the commit.
+//  4. (round 5) ROW-SHARED CORNERS (SH).  On a stride-1 sphere table the tap of pixel (r, c) samples source column
+//     c + const(r, tap) of rows y0(r, tap), y0 + 1 (sphere_cnn.py:31-58: new_theta = theta + f(phi, tap)), so the north-east
+//     corner of a pixel IS the north-west corner of its right neighbour, likewise south-east / south-west -- modulo W
+//     included.  A thread that owns 4 CONSECUTIVE pixels of a row therefore needs 2 x (4 + 1) lines instead of 4 x 4: 10
+//     gathered loads per chunk instead of 16 (every vector-memory instruction costs ~45 matrix-pipe cycles here).
+//     Same values, same combine order: bit-identical results.  The caller vouches for the property
+//     (EML_TAP_ROWSHARE: idx[p][t][1] == idx[p+1][t][0] and idx[p][t][3] == idx[p+1][t][2] for every p % 4 != 3, Po % 4 == 0;
+//     checked once per geometry on the host side).  Tile row rho = 32 (px % 4) + px / 4 holds pixel px, so that the LDS
+//     commit of one load slot still walks consecutive rows (stride 36 floats: conflict-free as before).
 //  Addresses: one wave-uniform 64-bit base (sample of the tile's first pixel + the chunk's channel offset) in SGPRs and a
 //  32-bit per-lane offset -- one v_mad per load instead of 64-bit pointer arithmetic.
 #pragma once
@@ -66,7 +75,7 @@ struct SpadeEpilogue {
   float* gamma;         // (M, Cn) or NULL
   int up2, H, W;        // destination grid (Po = H * W); up2: x lives on (H/2, W/2), nearest x2 upsample folded in
 };
-template <int BN, int NT, int LPP, bool PK, bool ONE, bool MOD = false>
+template <int BN, int NT, int LPP, bool PK, bool ONE, bool MOD = false, bool SH = false>
 __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_gemm2_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
     const float* __restrict__ W2 /*[O][9C]*/, const float* __restrict__ bias, float* __restrict__ Y /*[M][O]*/, int M,
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
   static_assert(!MOD || (BN == 128 && NT == 256), "the SPADE epilogue pairs tiles ni / ni + 2 of a 64-row wave tile");
   static_assert((BN == 64 || BN == 128 || BN == 256) && (NT == 256 || NT == 512) && (LPP == 8 || LPP == 4), "config");
   static_assert(NT == 512 || BN != 256, "BN = 256 needs 512 threads");
+  static_assert(!SH || (LPP == 8 && NT == 256 && !ONE), "row-shared corners: 4 consecutive pixels per thread, full-line loads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                   // [2][kBM][kLdA]
   float* Bs = As + 2 * kBM * kLdA;                    // [2][BN][kLdB]
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
   constexpr int PPT = kBM * LPP / NT;                 // pixels per thread (4 / 2 / 2 / 1)
   constexpr int PCS = 8 / LPP;                        // float4 pieces per (pixel, corner) and thread
   constexpr int NE = ONE ? 1 : 4;                     // table entries per virtual tap
-  constexpr int NA = PPT * PCS * NE;                  // gathered float4 per thread and chunk
+  constexpr int NA = SH ? 2 * (PPT + 1) : PPT * PCS * NE;   // gathered float4 per thread and chunk
   constexpr int NBD = BN * kBK * 4 / 1024 / (NT / 64);   // B DMA instructions per wave and chunk
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: SGPR, usable as an asm "s" operand
@@ -103,12 +113,16 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
 
   // ---- gather roles: lane gl of LPP loads float4 piece(s) gl (+ 4) of the line; pixel gp + (NT / LPP) * u
   const int gl = tid % LPP, gp = tid / LPP;
+  // tile-local pixel of load slot u, and the tile row it is committed to / the pixel a tile row stands for
+  auto pix_of = [&](int u) { return SH ? PPT * gp + u : gp + (NT / LPP) * u; };
+  auto row_of = [&](int px) { return SH ? 32 * (px & 3) + (px >> 2) : px; };
+  auto pix_of_row = [&](int rho) { return SH ? 4 * (rho & 31) + (rho >> 5) : rho; };
   const int sb0 = m0 / Po;                             // sample of the tile's first pixel (workgroup-uniform)
   unsigned poff[PPT];                                  // per pixel, BYTES: (sample - sb0) * HW * C * 4 + the lane's piece
   const unsigned c4 = 4u * (unsigned)C;
 #pragma unroll
   for (int u = 0; u < PPT; ++u) {
-    const int m = min(m0 + gp + (NT / LPP) * u, M - 1);
+    const int m = min(m0 + pix_of(u), M - 1);
     const int sb = m / Po;
     poff[u] = (unsigned)(sb - sb0) * (unsigned)HW * c4 + 16u * gl;
   }
@@ -173,17 +187,26 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
   float4 wv[PPT];
   auto read_ids = [&](int u, int par) {
     const float* tb = Tab + par * kTab;
-    const int px = gp + (NT / LPP) * u;
+    const int px = pix_of(u);
     if constexpr (ONE) ids[u] = make_int4(__builtin_bit_cast(int, tb[px]), 0, 0, 0);
     else ids[u] = *reinterpret_cast<const int4*>(tb + 4 * px);
   };
   auto read_wgt = [&](int u, int par) {
     const float* tb = Tab + par * kTab + kBM * 4;
-    const int px = gp + (NT / LPP) * u;
+    const int px = pix_of(u);
     if constexpr (ONE) wv[u] = make_float4(tb[px], 0.f, 0.f, 0.f);
     else wv[u] = *reinterpret_cast<const float4*>(tb + 4 * px);
   };
   auto load_piece = [&](int piece, const char* cbase) {   // piece = (u * NE + e) * PCS + s
+    if constexpr (SH) {
+      // piece = 2 j + row: column j of the thread's PPT + 1 source columns (j < PPT: the west corners of pixel j;
+      // j == PPT: the east corners of the last pixel), row 0 = north, 1 = south
+      const int j = piece >> 1, row = piece & 1, u = j < PPT ? j : PPT - 1;
+      const int id = j < PPT ? (row ? ids[u].z : ids[u].x) : (row ? ids[u].w : ids[u].y);
+      const unsigned off = __umul24((unsigned)max(id, 0), c4) + poff[u];
+      av[piece] = *reinterpret_cast<const float4*>(cbase + off);
+      return;
+    }
     const int u = piece / (NE * PCS), e = (piece / PCS) % NE, s = piece % PCS;
     const int id = e == 0 ? ids[u].x : e == 1 ? ids[u].y : e == 2 ? ids[u].z : ids[u].w;
     // out-of-bounds corners (-1) carry weight 0: any valid address will do.  24-bit multiply: id < 2^24, 4C < 2^24
@@ -191,9 +214,9 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
     av[piece] = *reinterpret_cast<const float4*>(cbase + off + 64 * s);
   };
   auto commit_pixel = [&](int u, int buf) {
-    const int px = gp + (NT / LPP) * u;
+    const int px = pix_of(u);
     const float4 w = wv[u];
-    float* ad = As + (size_t)buf * kBM * kLdA + px * kLdA + 4 * gl;
+    float* ad = As + (size_t)buf * kBM * kLdA + row_of(px) * kLdA + 4 * gl;
 #pragma unroll
     for (int s = 0; s < PCS; ++s) {
       float4 o;
@@ -201,8 +224,9 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
         const float4 v = av[(u * NE) * PCS + s];
         o = make_float4(v.x * w.x, v.y * w.x, v.z * w.x, v.w * w.x);
       } else {
-        const float4 v0 = av[(u * NE + 0) * PCS + s], v1 = av[(u * NE + 1) * PCS + s];
-        const float4 v2 = av[(u * NE + 2) * PCS + s], v3 = av[(u * NE + 3) * PCS + s];
+        // SH: nw, ne, sw, se = columns u, u + 1 of the north / south source rows (same values as the four explicit loads)
+        const float4 v0 = SH ? av[2 * u] : av[(u * NE + 0) * PCS + s], v1 = SH ? av[2 * u + 2] : av[(u * NE + 1) * PCS + s];
+        const float4 v2 = SH ? av[2 * u + 1] : av[(u * NE + 2) * PCS + s], v3 = SH ? av[2 * u + 3] : av[(u * NE + 3) * PCS + s];
         if constexpr (PK) {
           typedef float v2f __attribute__((ext_vector_type(2)));
           v2f lo = v2f{v0.x, v0.y} * v2f{w.x, w.x}, hi = v2f{v0.z, v0.w} * v2f{w.x, w.x};
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
       const float4 is = *reinterpret_cast<const float4*>(mod.istd + c);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + 64 * wm + 16 * mi + r;
+        const int m = m0 + pix_of_row(64 * wm + 16 * mi + r);
         if (m < M) {
           size_t xrow = (size_t)m;
           if (mod.up2) {
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
     if (bias) bq = *reinterpret_cast<const float4*>(bias + o);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      const int m = m0 + 64 * wm + 16 * mi + r;
+      const int m = m0 + pix_of_row(64 * wm + 16 * mi + r);
       if (m < M) {
         float4 v = make_float4(acc[ni][mi][0] + bq.x, acc[ni][mi][1] + bq.y, acc[ni][mi][2] + bq.z, acc[ni][mi][3] + bq.w);
         if (res) {

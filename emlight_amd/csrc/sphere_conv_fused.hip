@@ -506,9 +506,14 @@ bool gg2_offsets_fit(long HW, int C, int Po) {
   return (unsigned long long)HW * C < (1ull << 29) &&
          (unsigned long long)((gg2::kBM - 1) / Po + 2) * (unsigned long long)HW * C * 4ull < (1ull << 32);
 }
+// EML_GG_NOSHARE=1: A/B switch -- ignore EML_TAP_ROWSHARE (the 16-load gather for every table)
+bool gg_noshare() {
+  static const bool on = [] { const char* v = getenv("EML_GG_NOSHARE"); return v && v[0] == '1'; }();
+  return on;
+}
 int launch_gather_gemm(const char* what, const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
                        float* Y, int B, int HW, int Po, int C, int O, int ke, const unsigned char* rowmax,
-                       const float* res, float slope, eml_stream_t stream) {
+                       const float* res, float slope, eml_stream_t stream, int table_flags = 0) {
   if (B == 0) return EML_OK;
   const long M = (long)B * Po;
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
@@ -521,14 +526,20 @@ int launch_gather_gemm(const char* what, const float* X, const int* idx, const f
   if (ke != 1 && C >= 64 && gg2_offsets_fit(HW, C, Po) && (unsigned long long)O * 9 * C < (1ull << 30) && !gg_v1_enabled()) {
     const long n_mt2 = (M + gg2::kBM - 1) / gg2::kBM, per_xcd2 = (n_mt2 + 7) / 8;
     const dim3 grid2((unsigned)(8 * per_xcd2 * (O / bn)));
-#define EML_LAUNCH_GG2(BNV)                                                                                          \
+#define EML_LAUNCH_GG2(BNV, LPPV, SHV)                                                                               \
   do {                                                                                                              \
-    auto kern = gg2::gather_gemm2_kernel<BNV, 256, 4, false, false>;                                                \
+    auto kern = gg2::gather_gemm2_kernel<BNV, 256, LPPV, false, false, false, SHV>;                                 \
     EML_ENSURE_LDS(kern, (gg2::lds_bytes<BNV, 256>()));                                                             \
     hipLaunchKernelGGL(kern, grid2, dim3(256), (gg2::lds_bytes<BNV, 256>()), (hipStream_t)stream, X, idx, wgt, W2,  \
                        bias, Y, (int)M, HW, Po, C, O, ke, rowmax, res, slope, gg2::SpadeEpilogue{});                \
   } while (0)
-    if (bn == 128) EML_LAUNCH_GG2(128); else EML_LAUNCH_GG2(64);
+    // round 5: row-shared corners (10 gathered loads per chunk instead of 16) where the caller vouches for the table
+    const bool share = (table_flags & EML_TAP_ROWSHARE) && ke == 4 && Po % 4 == 0 && !gg_noshare();
+    if (share) {
+      if (bn == 128) EML_LAUNCH_GG2(128, 8, true); else EML_LAUNCH_GG2(64, 8, true);
+    } else {
+      if (bn == 128) EML_LAUNCH_GG2(128, 4, false); else EML_LAUNCH_GG2(64, 4, false);
+    }
 #undef EML_LAUNCH_GG2
     return eml::check_launch(what);
   }
@@ -565,14 +576,16 @@ extern "C" int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, con
 // `act_slope` (1 = none, 0 = ReLU; in [0, 1]).  `residual` (B*Po, O) or NULL; Y may alias it.
 extern "C" int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                                 const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
-                                                const float* residual, float act_slope, eml_stream_t stream) {
+                                                const float* residual, float act_slope, int table_flags,
+                                                eml_stream_t stream) {
   if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1 || Po < 1 || C < 32 || (C % 32) || O < 64 || (O % 64))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: need C %% 32 == 0, O %% 64 == 0 (C=%d, O=%d)", C, O);
   if (ke != 4 && ke != 1) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: ke must be 4 (bilinear taps) or 1");
   if (!(act_slope >= 0.f && act_slope <= 1.f))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: act_slope %g outside [0, 1]", (double)act_slope);
+  if (table_flags & ~EML_TAP_ROWSHARE) return eml::fail(EML_EINVAL, "eml_sphere_conv_fwd_fused_ex_f32: unknown table_flags %d", table_flags);
   return launch_gather_gemm("eml_sphere_conv_fwd_fused_ex_f32", X, idx, wgt, W2, bias, Y, B, HW, Po, C, O, ke, nullptr,
-                            residual, act_slope, stream);
+                            residual, act_slope, stream, table_flags);
 }
 
 // SPADE (normalization.py:101-115) in one launch: the gamma | beta SphereConv (128 -> 2 Cn over `actv`) with the modulation of
@@ -587,7 +600,7 @@ extern "C" int eml_sphere_conv_spade_supported(int Cin, int Cn, long HW) {
 extern "C" int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, const float* wgt, const float* W2r,
                                              const float* bias_r, const float* x, const float* mean, const float* istd,
                                              float* Y, float* gamma_out, int B, int H, int W, int Cin, int Cn, int up2,
-                                             float act_slope, eml_stream_t stream) {
+                                             float act_slope, int table_flags, eml_stream_t stream) {
   if (!actv || !idx || !wgt || !W2r || !x || !mean || !istd || !Y || B < 0 || H < 1 || W < 1)
     return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: null pointer / empty grid");
   if (!eml_sphere_conv_spade_supported(Cin, Cn, (long)H * W))
@@ -601,11 +614,19 @@ extern "C" int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, 
   if (M > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: too many pixels");
   const long n_mt = (M + gg2::kBM - 1) / gg2::kBM, per_xcd = (n_mt + 7) / 8;
   const dim3 grid((unsigned)(8 * per_xcd * (O / 128)));
-  auto kern = gg2::gather_gemm2_kernel<128, 256, 4, false, false, true>;
-  EML_ENSURE_LDS(kern, (gg2::lds_bytes<128, 256>()));
+  if (table_flags & ~EML_TAP_ROWSHARE) return eml::fail(EML_EINVAL, "eml_sphere_conv_spade_fwd_f32: unknown table_flags %d", table_flags);
   const gg2::SpadeEpilogue mod{x, mean, istd, gamma_out, up2 ? 1 : 0, H, W};
-  hipLaunchKernelGGL(kern, grid, dim3(256), (gg2::lds_bytes<128, 256>()), (hipStream_t)stream, actv, idx, wgt, W2r, bias_r, Y,
-                     (int)M, HW, HW, Cin, O, 4, nullptr, nullptr, act_slope, mod);
+  if ((table_flags & EML_TAP_ROWSHARE) && HW % 4 == 0 && !gg_noshare()) {
+    auto kern = gg2::gather_gemm2_kernel<128, 256, 8, false, false, true, true>;
+    EML_ENSURE_LDS(kern, (gg2::lds_bytes<128, 256>()));
+    hipLaunchKernelGGL(kern, grid, dim3(256), (gg2::lds_bytes<128, 256>()), (hipStream_t)stream, actv, idx, wgt, W2r, bias_r, Y,
+                       (int)M, HW, HW, Cin, O, 4, nullptr, nullptr, act_slope, mod);
+  } else {
+    auto kern = gg2::gather_gemm2_kernel<128, 256, 4, false, false, true>;
+    EML_ENSURE_LDS(kern, (gg2::lds_bytes<128, 256>()));
+    hipLaunchKernelGGL(kern, grid, dim3(256), (gg2::lds_bytes<128, 256>()), (hipStream_t)stream, actv, idx, wgt, W2r, bias_r, Y,
+                       (int)M, HW, HW, Cin, O, 4, nullptr, nullptr, act_slope, mod);
+  }
   return eml::check_launch("eml_sphere_conv_spade_fwd_f32");
 }
 
@@ -613,14 +634,15 @@ extern "C" int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, 
 // output pixels whose tap t samples q (-1 = empty slot, weight 0) and their bilinear weights; W2t (C, 9*O), columns (tap, o)
 extern "C" int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const float* twgt,
                                                const unsigned char* rowmax, int ke, const float* W2t, float* dX, int B,
-                                               int HW, int Po, int C, int O, eml_stream_t stream) {
+                                               int HW, int Po, int C, int O, int table_flags, eml_stream_t stream) {
   if (!dY || !tidx || !twgt || !W2t || !dX || B < 0 || HW < 1 || Po < 1 || O < 32 || (O % 32) || C < 64 || (C % 64) ||
       (ke != 4 && ke != 8 && ke != 1) || (ke == 8 && !rowmax))
     return eml::fail(EML_EINVAL, "eml_sphere_conv_dgrad_fused_f32: need O %% 32 == 0, C %% 64 == 0, ke in {1, 4, 8} (C=%d, O=%d)",
                      C, O);
   // roles swap: the rows gathered are dY's (Po per sample, O wide), the destination pixels are the HW input pixels
+  if (table_flags & ~EML_TAP_ROWSHARE) return eml::fail(EML_EINVAL, "eml_sphere_conv_dgrad_fused_f32: unknown table_flags %d", table_flags);
   return launch_gather_gemm("eml_sphere_conv_dgrad_fused_f32", dY, tidx, twgt, W2t, nullptr, dX, B, Po, HW, O, C, ke, rowmax,
-                            nullptr, 1.f, stream);
+                            nullptr, 1.f, stream, table_flags);
 }
 
 extern "C" size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k) {

@@ -416,9 +416,15 @@ int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* w
  * (B*Po, O) or NULL -- the `x_s + dx` of SPADEResnetBlock (architecture.py:60); Y may alias it.  act_slope in [0, 1]: 1 = none,
  * 0 = ReLU (VGG19's nn.ReLU after every convolution, architecture.py:92-125), 0.2 = the LeakyReLU before the generator's last
  * convolution (generator.py:84).  eml_sphere_conv_fwd_fused_f32 is this entry with (NULL, 1). */
+/* table_flags: EML_TAP_ROWSHARE -- the caller vouches that the table has the row structure of a stride-1 sphere grid
+ * (sphere_cnn.py:31-58: a tap samples source column c + const(row, tap) of two adjacent source rows): for every destination
+ * pixel p with p % 4 != 3 and every tap, idx[p][tap][1] == idx[p+1][tap][0] and idx[p][tap][3] == idx[p+1][tap][2]
+ * (north-east of p = north-west of its right neighbour, likewise south), and Po % 4 == 0.  The kernel then fetches 2 x 5 lines
+ * per 4 pixels instead of 4 x 4 (same values, same summation order: bit-identical results).  Honoured for ke == 4 only. */
+#define EML_TAP_ROWSHARE 1
 int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                      const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
-                                     const float* residual, float act_slope, eml_stream_t stream);
+                                     const float* residual, float act_slope, int table_flags, eml_stream_t stream);
 /* The 3-channel input layers -- SPADE's mlp_shared 3 -> 128 + ReLU (normalization.py:92-96) and VGG19's conv1_1
  * 3 -> 64 + ReLU -- are bound by the write of their output: one pass each way.  (C, O) in {(3, 64), (3, 128)}
  * (eml_sphere_conv_small_supported); idx / wgt = the 4-entry tap table; X (B, HW, C), W2 (O, 9C),
@@ -461,7 +467,7 @@ int eml_sphere_conv_narrow_wgrad_f32(const float* X, const int* idx, const float
  * O % 32 == 0, C % 64 == 0.  Deterministic (a gather, no atomics); neither dA9 nor its col2im pass exist. */
 int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const float* twgt, const unsigned char* rowmax,
                                     int ke, const float* W2t, float* dX, int B, int HW, int Po, int C, int O,
-                                    eml_stream_t stream);
+                                    int table_flags, eml_stream_t stream);
 size_t eml_sphere_conv_wgrad_partial_floats(int C, int O, int split_k);
 int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, const float* wgt, const float* dY,
                                     float* partial, float* dW2, int B, int HW, int Po, int C, int O,
@@ -537,7 +543,7 @@ int eml_spade_norm_modulate_bwd_cols_f32(const float* gy, const float* x, const 
 int eml_sphere_conv_spade_supported(int Cin, int Cn, long HW);
 int eml_sphere_conv_spade_fwd_f32(const float* actv, const int* idx, const float* wgt, const float* W2r, const float* bias_r,
                                   const float* x, const float* mean, const float* istd, float* Y, float* gamma_out, int B, int H,
-                                  int W, int Cin, int Cn, int up2, float act_slope, eml_stream_t stream);
+                                  int W, int Cin, int Cn, int up2, float act_slope, int table_flags, eml_stream_t stream);
 /* eml_spade_norm_modulate_bwd_cols_f32 for that forward: gamma (B*H*W, C) and the forward's output y (B*H*W, C) in place of
  * the (gamma | beta) tensor; dgb (B*H*W, 2C) = (dgamma | dbeta), partials as above.  slope in [0, 1]. */
 int eml_spade_norm_modulate_bwd_y_f32(const float* gy, const float* x, const float* gamma, const float* y, float* dxn, float* dgb,

@@ -70,8 +70,8 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.eml_sphere_conv_fwd_fused_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 2, None) == -1     # ke in {1, 4}
     assert L.eml_sphere_conv_wgrad_fused_f32(one, one, one, one, one, one, 1, 32, 32, 32, 64, 4, None) == -1  # C % 64
     assert L.eml_sphere_conv_wgrad_partial_floats(128, 256, 7) == 7 * 256 * 9 * 128
-    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 8, one, one, 1, 32, 32, 64, 64, None) == -1   # ke = 8 needs rowmax
-    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 5, one, one, 1, 32, 32, 64, 64, None) == -1   # ke in {4, 8}
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 8, one, one, 1, 32, 32, 64, 64, 0, None) == -1   # ke = 8 needs rowmax
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 5, one, one, 1, 32, 32, 64, 64, 0, None) == -1   # ke in {4, 8}
     assert L.eml_bn_stats_f32(one, 6, 10, 6, one, 4, None) == -1                                               # C % 4
     assert L.eml_bn_finalize_f32(one, 8, ctypes.c_float(0.0), ctypes.c_float(0.1), one, one, None, None, None) == -1   # eps > 0
     assert L.eml_bn_bwd_apply_f32(one, 8, one, 8, 0, 8, one, one, None, one, 8, None) == 0                       # no rows
@@ -79,9 +79,9 @@ def test_argument_validation_without_gpu(built_lib):
                                               None) == -1                                                       # odd channel offset
     # round-3 entry points
     f = ctypes.c_float
-    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 4, None, f(1.5), None) == -1
+    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 4, None, f(1.5), 0, None) == -1
     assert b"act_slope" in L.eml_last_error()
-    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, 1, one, f(0.0), None) == 0   # empty
+    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 0, 32, 32, 64, 64, 1, one, f(0.0), 0, None) == 0   # empty
     assert L.eml_sphere_conv_small_supported(3, 128) == 1 and L.eml_sphere_conv_small_supported(6, 128) == 0
     assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 1, 32, 32, 4, 128, f(0.0), None) == -1 and b"(C, O)" in L.eml_last_error()
     assert L.eml_sphere_conv_small_fwd_f32(one, one, one, one, None, one, 0, 32, 32, 3, 128, f(0.0), None) == 0       # empty batch
@@ -109,7 +109,10 @@ def test_argument_validation_without_gpu(built_lib):
                                             one, one, one, one, one, one, one, 64, None) == -1                  # pooled: even maps
     assert L.eml_sinkhorn_fwd_f32(one, one, one, one, None, None, .05, 1.5, 2, -1.0, None, None, None, None, one, None, None,
                                   one, 2, 96, None) == -1                                                       # 0 < scaling < 1
-    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 1, one, one, 0, 32, 32, 64, 64, None) == 0     # ke = 1, empty batch
+    assert L.eml_sphere_conv_dgrad_fused_f32(one, one, one, None, 1, one, one, 0, 32, 32, 64, 64, 0, None) == 0     # ke = 1, empty batch
+    assert L.eml_sphere_conv_fwd_fused_ex_f32(one, one, one, one, None, one, 1, 32, 32, 64, 64, 4, None, f(1.0), 2, None) == -1 and b"table_flags" in L.eml_last_error()
+    assert L.eml_sphere_conv_small_da9_f32(one, None, f(0.0), one, one, 10, 3, 128, None) == -1                   # ReLU needs Yact
+    assert L.eml_sphere_conv_small_da9_f32(one, one, f(0.0), one, one, 0, 3, 64, None) == 0                       # no rows
     # round-5 entry points: the fused L1 terms take HOST arrays of device pointers
     assert L.eml_l1_pairs_partial_doubles(3) == 3 * 1024 and L.eml_l1_pairs_partial_doubles(0) == 0
     ptrs, rows, cs, sc = (ctypes.c_void_p * 17)(*([8] * 17)), (ctypes.c_long * 17)(*([4] * 17)), (ctypes.c_int * 17)(*([4] * 17)), (ctypes.c_float * 17)()

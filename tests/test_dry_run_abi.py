@@ -152,6 +152,7 @@ class _FakeGeometry:
         self.idx1 = self.wgt1 = None
         self.csr_ptr = torch.zeros(h * w + 1, dtype=torch.int32)
         self.csr_src, self.csr_w = torch.zeros(1, dtype=torch.int32), torch.zeros(1)
+        self.rowshare, self.t_rowshare = 1, 0   # EML_TAP_ROWSHARE as the real geometry reports it for a stride-1 sphere table
 
     def transposed_table(self):
         hw = self.h * self.w

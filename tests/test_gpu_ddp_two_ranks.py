@@ -237,3 +237,83 @@ def test_bench_two_ranks_runs_every_leg_without_deadlock():
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 8
     assert j["value"] > 0 and j["projector"]["value"] > 0 and j["joint"]["value"] > 0
     assert j["projector"]["config"]["global_batch"] == 4 and "kernel_families" in j["projector"] and "roofline" in j
+
+
+def _count_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world), EML_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.data import projector_batch
+    from emlight_amd.GenProjector.model_trainer import Trainer
+    r, local, w = init_distributed()
+    torch.manual_seed(0)
+    tr = Trainer(networks.default_options(ngf=4, ndf=4), device="cuda:0", world=w)
+    data = projector_batch(1, "cuda:0", seed=50 + rank)
+    log = []          # (phase, dtype, numel) of every Python-level all-reduce = SPADE's sync-BN sums
+    buckets = {"G": 0, "D": 0}
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        log.append((phase[0], str(t.dtype), t.numel()))
+        return real(t, *a, **k)
+
+    def hook(name):
+        def h(state, bucket):
+            buckets[name] += 1
+            return default_hooks.allreduce_hook(state, bucket)
+        return h
+    tr._ddpG.register_comm_hook(None, hook("G"))
+    tr._ddpD.register_comm_hook(None, hook("D"))
+    phase = ["warm"]
+    tr.step(data)                      # builds DDP's buckets (the first iteration may rebuild them)
+    dist.all_reduce = counting
+    try:
+        buckets.update(G=0, D=0)
+        phase[0] = "g_step"
+        tr.run_generator_one_step(data)
+        g_buckets = dict(buckets)
+        buckets.update(G=0, D=0)
+        phase[0] = "d_step"
+        tr.run_discriminator_one_step(data)
+        d_buckets = dict(buckets)
+    finally:
+        dist.all_reduce = real
+    # SPADE's sums: f64 vectors of 2C+1 entries; anything else that reaches the Python-level all_reduce (DDP's own
+    # bookkeeping) is reported, not counted
+    spade = [(p, n) for p, dt, n in log if dt == "torch.float64" and n % 2 == 1 and n >= 9]
+    other = len(log) - len(spade)
+    n_g = sum(1 for p, n in spade if p == "g_step")
+    n_d = sum(1 for p, n in spade if p == "d_step")
+    np.save(os.path.join(out_dir, "c%d.npy" % rank),
+            np.array([n_g, n_d, g_buckets["G"], g_buckets["D"], d_buckets["G"], d_buckets["D"], other, max(n for p, n in spade)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_collective_counts_of_a_projector_iteration(tmp_path):
+    """what one projector iteration puts on the wire besides DDP's gradient buckets.  SPADE's parameter-free
+    BatchNorm is SYNCHRONISED (sync_batchnorm/batchnorm.py:105-126): per generator pass the forward all-reduces one
+    (2C+1)-f64 vector per distinct normalised input -- norm_0 / norm_s of a block share theirs: 2 per block, 14 in all --
+    and the backward one per norm (18: every normalised input carries a gradient, the head block's through the crop
+    encoder).  The generator step holds D out of the graph (no D buckets); the discriminator step runs G without grad
+    (forward statistics only, no G buckets).  Counted on the wire here, not assumed."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_count_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "c0.npy"), np.load(tmp_path / "c1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    n_g, n_d, gG, gD, dG, dD, other, widest = c0
+    blocks, shortcuts = 7, 4                       # SPADEGenerator: head_0, G_middle_0/1, up_0..3; up_* have a learned shortcut
+    fwd = 2 * blocks                               # norm_0 (+ norm_s on the same sums) and norm_1
+    assert n_d == fwd, "discriminator step: the no-grad generator pass all-reduces its %d forward statistics only (got %d)" % (fwd, n_d)
+    assert n_g == fwd + 2 * blocks + shortcuts, "generator step: %d forward + %d backward sync-BN all-reduces expected, got %d" % (
+        fwd, 2 * blocks + shortcuts, n_g)
+    assert widest == 2 * 64 + 1 and other <= 4       # (2C+1) f64 sums, C <= 16 * ngf = 64 here; DDP's own small reductions
+    assert gG >= 1 and gD == 0 and dG == 0 and dD >= 1

@@ -1035,3 +1035,63 @@ def test_fused_l1_terms_vs_stock_formulas():
     assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
     for t, rt in zip(a, ar):
         np.testing.assert_allclose(t.grad.cpu().numpy(), rt.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("B,C,O,H,W", [(2, 64, 64, 16, 32), (3, 128, 128, 32, 64), (1, 128, 256, 8, 16), (2, 64, 128, 12, 20)])
+def test_row_shared_corners_gather_is_bit_identical(B, C, O, H, W):
+    """EML_TAP_ROWSHARE (include/emlight_hip.h): on a stride-1 sphere table a pixel's east corners are its right neighbour's
+    west corners (sphere_cnn.py:31-58 shifts a whole row by the same amount), so the gather-GEMM fetches 10 lines per 4 pixels
+    instead of 16.  The property is VERIFIED on the table (not assumed) -- here once more, independently -- and the kernel
+    that uses it must reproduce the 16-load kernel bit for bit: forward (+ residual / activation epilogue), the SPADE epilogue,
+    and the input gradient on the transposed table where that table has the property too."""
+    from emlight_amd import _lib
+    from emlight_amd.GenProjector import spherenet
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    torch.manual_seed(C + O + H)
+    geo = spherenet.sphere_geometry(H, W, 1, torch.device("cuda"))
+    po = H * W
+    idx = geo.idx.view(po, 9, 4)
+    same_row = (torch.arange(po, device="cuda") % 4 != 3)[:-1]
+    want = bool(((idx[:-1, :, 1] == idx[1:, :, 0]) & (idx[:-1, :, 3] == idx[1:, :, 2]))[same_row].all())
+    assert want and geo.rowshare == 1          # W % 4 == 0: four consecutive pixels never straddle two rows
+    assert spherenet.sphere_geometry(H, W, 2, torch.device("cuda")).rowshare == 0   # stride 2: neighbours sample 2 columns apart
+    x = torch.randn(B * po, C, device="cuda")
+    w2 = torch.randn(O, 9 * C, device="cuda") * 0.05
+    bias = torch.randn(O, device="cuda")
+    res = torch.randn(B * po, O, device="cuda")
+    ys = []
+    for flags in (0, 1):
+        y = torch.full((B * po, O), float("nan"), device="cuda")
+        _lib.check(L.eml_sphere_conv_fwd_fused_ex_f32(p(x), p(geo.idx), p(geo.wgt), p(w2), p(bias), p(y), B, po, po, C, O, 4, p(res),
+                                                      0.2, flags, st), "fwd")
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    ref = oracle.sphere_conv(x.view(B, H, W, C).permute(0, 3, 1, 2), w2.view(O, 3, 3, C).permute(0, 3, 1, 2), bias, 1,
+                             res.view(B, H, W, O).permute(0, 3, 1, 2), 0.2).permute(0, 2, 3, 1).reshape(B * po, O)
+    np.testing.assert_allclose(ys[1].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=3e-5 * float(ref.abs().max()))
+    # the SPADE epilogue on the same gather (Cin = C -> 2 Cn = O rows of gamma | beta)
+    if L.eml_sphere_conv_spade_supported(C, O // 2, po):
+        Cn = O // 2
+        xn = torch.randn(B * po, Cn, device="cuda")
+        mean, istd = torch.randn(Cn, device="cuda"), torch.rand(Cn, device="cuda") + 0.5
+        outs = []
+        for flags in (0, 1):
+            y = torch.full((B * po, Cn), float("nan"), device="cuda")
+            g = torch.full((B * po, Cn), float("nan"), device="cuda")
+            _lib.check(L.eml_sphere_conv_spade_fwd_f32(p(x), p(geo.idx), p(geo.wgt), p(w2), p(bias), p(xn), p(mean), p(istd), p(y),
+                                                       p(g), B, H, W, C, Cn, 0, 0.2, flags, st), "spade")
+            outs.append((y, g))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # input gradient: the forward kernel on the transposed table (roles of C and O swap)
+    tt = geo.transposed_table()
+    if tt is not None and tt[3] == 4:
+        tidx, twgt, rowmax, ke = tt
+        w2t = torch.randn(C, 9 * O, device="cuda") * 0.05
+        gy = torch.randn(B * po, O, device="cuda")
+        gs = []
+        for flags in (0, geo.t_rowshare):
+            gx = torch.full((B * po, C), float("nan"), device="cuda")
+            _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gy), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gx), B, po, po, C, O,
+                                                         flags, st), "dgrad")
+            gs.append(gx)
+        assert torch.equal(gs[0], gs[1])
