@@ -96,6 +96,23 @@ def nonspade_norm(norm_type):
     return wrap
 
 
+def resized_guide(segmap, size):
+    """``F.interpolate(segmap, size=size, mode="nearest")`` (normalization.py:106), computed once per guide map and size: the
+    generator's 18 SPADE norms see 6 resolutions of the SAME map (30 launches fewer per pass, and in the joint step, where
+    the map carries a gradient, 6 upsample backwards and gradient accumulations instead of 18).  The cache lives on the tensor
+    object, so it dies with it; the full-resolution "resize" is the map itself (nearest to the same size copies)."""
+    size = (int(size[0]), int(size[1]))
+    if tuple(segmap.shape[2:]) == size:
+        return segmap
+    cache = getattr(segmap, "_eml_resized", None)
+    if cache is None or cache[0] != segmap._version:
+        cache = (segmap._version, {})
+        segmap._eml_resized = cache
+    if size not in cache[1]:
+        cache[1][size] = F.interpolate(segmap, size=size, mode="nearest")
+    return cache[1][size]
+
+
 class SPADE(nn.Module):
     """``out = norm(x) * (1 + gamma(seg)) + beta(seg)`` (``normalization.py:68-115``).  The param-free norm is a
     BatchNorm2d(affine=False) module only as the holder of the running statistics (reference state_dict keys); its
@@ -122,7 +139,7 @@ class SPADE(nn.Module):
         ``stats``: (mean, istd) of this x when a sibling norm already reduced it (norm_0 / norm_s share their input);
         ``up2``: ``x`` stands for its nearest x2 upsample (the generator's ``self.up``), which is never materialised."""
         size = (2 * x.size(2), 2 * x.size(3)) if up2 else x.size()[2:]
-        segmap = F.interpolate(segmap, size=size, mode="nearest")
+        segmap = resized_guide(segmap, size)
         conv, act = self.mlp_shared[0], self.mlp_shared[1]
         actv = conv(segmap, act_slope=0.0) if isinstance(act, nn.ReLU) else act(conv(segmap))   # ReLU in the conv's epilogue
         more = {"up2": True} if up2 else {}

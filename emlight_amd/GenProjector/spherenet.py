@@ -107,7 +107,7 @@ class SphereGeometry:
         # EML_TAP_ROWSHARE (include/emlight_hip.h): on a stride-1 sphere grid a tap samples source column c + const(row, tap)
         # of two adjacent rows, so a pixel's east corners ARE its right neighbour's west corners -- verified on the table
         # itself (once per geometry), never assumed
-        self.rowshare = int(kind == "sphere" and _table_rowshare(self.idx, self.ho * self.wo))
+        self.rowshare = int(kind == "sphere" and _table_rowshare(self.idx, self.wgt, self.ho * self.wo))
 
     def transposed_table(self):
         """The tap table seen from the INPUT pixels, for the fused input-gradient kernel: for input pixel q and tap t the
@@ -137,19 +137,23 @@ class SphereGeometry:
                 rowmax = counts.view(hw, 9).max(1).values.to(torch.uint8).contiguous()
                 if kmax <= 1 and self.idx1 is not None:   # an ordinary convolution: one source per (pixel, tap)
                     tidx, twgt, ke = tidx[:, :1], twgt[:, :1], 1
-                tidx = tidx.contiguous()
-                self.t_rowshare = int(ke == 4 and self.idx1 is None and _table_rowshare(tidx, hw))
-                self._transposed = (tidx, twgt.contiguous(), rowmax, ke)
+                tidx, twgt = tidx.contiguous(), twgt.contiguous()
+                self.t_rowshare = int(ke == 4 and self.idx1 is None and _table_rowshare(tidx, twgt, hw))
+                self._transposed = (tidx, twgt, rowmax, ke)
         return self._transposed if self._transposed[0] is not None else None
 
 
-def _table_rowshare(idx, n_dst):
-    """Does a (n_dst * 9, 4) tap table have the property EML_TAP_ROWSHARE promises?  For every destination pixel p with
-    p % 4 != 3 and every tap: entry 1 of p == entry 0 of p + 1 and entry 3 of p == entry 2 of p + 1; n_dst % 4 == 0."""
+def _table_rowshare(idx, wgt, n_dst):
+    """Does a (n_dst * 9, 4) tap table have the property EML_TAP_ROWSHARE promises (include/emlight_hip.h)?  For every
+    destination pixel p with p % 4 != 3 and every tap: entry 1 of p and entry 0 of p + 1 are the same source pixel unless one
+    of them is -1 (grid_sample zero-pads the column that wraps around), likewise entries 3 / 2; -1 entries weigh 0."""
     if n_dst % 4 or idx.dim() != 2 or idx.shape[1] != 4 or idx.shape[0] != n_dst * 9:
         return False
     t = idx.view(n_dst // 4, 4, 9, 4)
-    ok = (t[:, :3, :, 1] == t[:, 1:, :, 0]).all() & (t[:, :3, :, 3] == t[:, 1:, :, 2]).all()
+
+    def same(a, b):
+        return ((a == b) | (a < 0) | (b < 0)).all()
+    ok = same(t[:, :3, :, 1], t[:, 1:, :, 0]) & same(t[:, :3, :, 3], t[:, 1:, :, 2]) & (wgt[idx < 0] == 0).all()
     return bool(ok)
 
 
@@ -332,7 +336,14 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             sums, ptr, ver = pre
             ok = y is None and sums.shape == (O,) and ptr == gy.data_ptr() and ver == gy._version
             pre = sums if ok else None
-        gb = pre if pre is not None else gyr.sum(0)
+        if pre is not None:
+            gb = pre
+        elif O <= 8 and gyr.is_cuda and B > 0:   # tall and skinny: ATen's sum(0) runs it on a few workgroups
+            part = torch.empty(L.eml_colsum_partial_doubles(O), dtype=torch.float64, device=gy.device)
+            gb = torch.empty(O, dtype=torch.float32, device=gy.device)
+            _lib.check(L.eml_colsum_f32(p(gyr), B * po, O, p(part), p(gb), st), "eml_colsum_f32")
+        else:
+            gb = gyr.sum(0)
     narrow = getattr(ctx, "narrow", False)
     if needs[1] and not small_w:
         if narrow:
@@ -608,6 +619,48 @@ def spade_row_order(Cn, device):
     return _SPADE_ROWS[key]
 
 
+def spade_heads_w2(wg, wb, bg, bb, reorder):
+    """(W2 (2 Cn, 9 Cin), b2 (2 Cn) or None): SPADE's gamma and beta heads as one operand in the kernels' (tap, c) column order,
+    rows in cat order or (``reorder``) in the one-launch SPADE's order -- ONE launch (``eml_spade_heads_w2_f32``) instead of
+    cat(weights), cat(biases) and a re-layout copy.  No autograd: callers route the gradients themselves."""
+    from .. import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    Cn, Cin = wg.shape[0], wg.shape[1]
+    wg, wb = wg.detach().contiguous(), wb.detach().contiguous()
+    has_b = bg is not None and bb is not None
+    w2 = torch.empty(2 * Cn, 9 * Cin, dtype=torch.float32, device=wg.device)
+    b2 = torch.empty(2 * Cn, dtype=torch.float32, device=wg.device) if has_b else None
+    _lib.check(L.eml_spade_heads_w2_f32(p(wg), p(wb), p(bg.detach().contiguous()) if has_b else None,
+                                        p(bb.detach().contiguous()) if has_b else None, p(w2), p(b2), Cn, Cin, int(bool(reorder)),
+                                        st), "eml_spade_heads_w2_f32")
+    return w2, b2
+
+
+class _SpadeHeadsFn(torch.autograd.Function):
+    """cat(gamma head, beta head) of a SPADE as ONE weight (2 Cn, Cin, 3, 3) -- a VIEW of the (O, tap, c) operand the
+    SphereConv kernels take without a copy -- and one bias (2 Cn); the gradients are the two halves."""
+
+    @staticmethod
+    def forward(ctx, wg, wb, bg, bb):
+        Cn, Cin = wg.shape[0], wg.shape[1]
+        w2, b2 = spade_heads_w2(wg, wb, bg, bb, False)
+        ctx.Cn, ctx.has_b = Cn, b2 is not None
+        w = w2.view(2 * Cn, 3, 3, Cin).permute(0, 3, 1, 2)
+        if b2 is None:
+            b2 = w2.new_zeros(0)
+            ctx.mark_non_differentiable(b2)
+        return w, b2
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        Cn = ctx.Cn
+        gwg = gw[:Cn] if gw is not None else None
+        gwb = gw[Cn:] if gw is not None else None
+        if ctx.has_b and gb is not None:
+            return gwg, gwb, gb[:Cn], gb[Cn:]
+        return gwg, gwb, None, None
+
+
 class _SpadeConvModulateFn(torch.autograd.Function):
     """SPADE in one launch: ``leaky_relu(BN(x) * (1 + gamma) + beta, slope)`` with (gamma | beta) = SphereConv(actv; weight,
     bias) formed in the accumulators of the gather-GEMM and consumed by its epilogue -- the (B, 2C, H, W) tensor is neither
@@ -616,7 +669,7 @@ class _SpadeConvModulateFn(torch.autograd.Function):
     backward forms is handed to the SphereConv backward unchanged."""
 
     @staticmethod
-    def forward(ctx, x, actv, weight, bias, mean, istd, slope, training, up2):
+    def forward(ctx, x, actv, wg, wb, bg, bb, mean, istd, slope, training, up2):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         _require_gpu_f32(x, "SPADE input")
@@ -630,29 +683,27 @@ class _SpadeConvModulateFn(torch.autograd.Function):
         geo = sphere_geometry(H, W, 1, actv.device)
         ar = actv.permute(0, 2, 3, 1).contiguous()                 # (B, H, W, Cin); a view when channels-last
         x = x.contiguous(memory_format=cl)
-        order = spade_row_order(Cn, actv.device)
-        w2r = weight.permute(0, 2, 3, 1)[order].reshape(2 * Cn, 9 * Cin)   # the one (gathering) copy the re-layout needs anyway
-        br = bias[order] if bias is not None else None
+        w2r, br = spade_heads_w2(wg, wb, bg, bb, True)             # rows in the kernel's order: one launch
         y = torch.empty(B * H * W, Cn, dtype=torch.float32, device=x.device)
-        keep = any(ctx.needs_input_grad[:4])
+        keep = any(ctx.needs_input_grad[:6])
         gamma = torch.empty_like(y) if keep else None
         _lib.check(L.eml_sphere_conv_spade_fwd_f32(p(ar), p(geo.idx), p(geo.wgt), p(w2r), p(br) if br is not None else None,
                                                    p(x), p(mean), p(istd), p(y), p(gamma) if keep else None, B, H, W, Cin, Cn,
                                                    int(bool(up2)), float(slope), geo.rowshare, st), "eml_sphere_conv_spade_fwd_f32")
-        ctx.geo, ctx.shape, ctx.has_bias = geo, (B, Cin, H, W, 2 * Cn), bias is not None
+        ctx.geo, ctx.shape, ctx.has_bias = geo, (B, Cin, H, W, 2 * Cn), br is not None
         ctx.up2, ctx.act_slope, ctx.training = bool(up2), float(slope), bool(training)
         # the state _sphere_conv_backward reads: a plain (no epilogue, no kept operand) SphereConv 128 -> 2 Cn
         ctx.slope, ctx.small, ctx.keep = 1.0, False, False
         ctx.fused_dgrad, ctx.fused_wgrad = _backward_dispatch(B, H * W, Cin, 2 * Cn, 1)
         if keep:
-            ctx.save_for_backward(ar, weight, x, gamma, y, mean, istd)
+            ctx.save_for_backward(ar, wg, wb, x, gamma, y, mean, istd)
         return y.view(B, H, W, Cn).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-        ar, weight, x, gamma, y, mean, istd = ctx.saved_tensors
+        ar, wg, wb, x, gamma, y, mean, istd = ctx.saved_tensors
         B, Cin, H, W, O = ctx.shape
         C = O // 2
         rows = B * H * W
@@ -686,15 +737,28 @@ class _SpadeConvModulateFn(torch.autograd.Function):
                            "eml_bn_bwd_apply_f32")
         # the column sums of dgb = the bias gradient of the gamma | beta convolution (see _SpadeNormModulateFn.backward)
         dgb._eml_colsum = (folded[2 * C + 1:].view(C, 2).t().reshape(2 * C).float(), dgb.data_ptr(), dgb._version)
-        needs = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3], False, False, False, False)
-        gactv, gw, gbias = _sphere_conv_backward(ctx, dgb, (ar, weight), needs)[:3]
-        return dx, gactv, gw, gbias, None, None, None, None, None
+        nig = ctx.needs_input_grad
+        need_w, need_b = nig[2] or nig[3], ctx.has_bias and (nig[4] or nig[5])
+        needs = (nig[1], need_w, need_b, False, False, False, False)
+        # the input gradient wants the heads in cat order: the same one-launch re-layout, without the row reorder
+        wnat = None
+        if nig[1]:
+            wnat = spade_heads_w2(wg, wb, None, None, False)[0].view(O, 3, 3, Cin).permute(0, 3, 1, 2)
+        gactv, gw, gbias = _sphere_conv_backward(ctx, dgb, (ar, wnat), needs)[:3]
+        gwg = gw[:C] if (gw is not None and nig[2]) else None
+        gwb = gw[C:] if (gw is not None and nig[3]) else None
+        gbg = gbias[:C] if (gbias is not None and nig[4]) else None
+        gbb = gbias[C:] if (gbias is not None and nig[5]) else None
+        return dx, gactv, gwg, gwb, gbg, gbb, None, None, None, None, None
 
 
-def spade_conv_modulate(x, actv, weight, bias, mean, istd, slope, training, up2):
-    """``leaky_relu(((x - mean) * istd) * (1 + gamma) + beta, slope)`` with (gamma | beta) = SphereConv(actv; weight, bias) in
-    one launch (a module attribute like ``sphere_conv``, so that tests can observe the layer shapes that take it)."""
-    return _SpadeConvModulateFn.apply(x, actv, weight, bias, mean, istd, slope, training, up2)
+def spade_conv_modulate(x, actv, wg, wb, bg, bb, mean, istd, slope, training, up2):
+    """``leaky_relu(((x - mean) * istd) * (1 + gamma) + beta, slope)`` with gamma = SphereConv(actv; wg, bg) and
+    beta = SphereConv(actv; wb, bb) as ONE gather-GEMM whose epilogue is the modulation (a module attribute like
+    ``sphere_conv``, so that tests can observe the layer shapes that take it)."""
+    if not torch.is_grad_enabled():   # a no-grad pass (the discriminator step's generator): nothing is kept for a backward
+        wg, wb, bg, bb = wg.detach(), wb.detach(), bg.detach(), bb.detach()
+    return _SpadeConvModulateFn.apply(x, actv, wg, wb, bg, bb, mean, istd, slope, training, up2)
 
 
 def _spade_conv_fusable(x, actv, C, up2):
@@ -719,15 +783,21 @@ def spade_norm_modulate(x, bn, actv, conv_gamma, conv_beta, slope=1.0, stats=Non
     ``leaky_relu(BN(x) * (1 + gamma(actv)) + beta(actv), slope)``.  gamma | beta come from ONE SphereConv (one gather,
     one GEMM over the concatenated heads); BatchNorm's statistics come from ``spade_batch_stats`` (or ``stats`` when
     the caller already has them for this x) and its normalisation / backward are folded into the modulation kernels."""
-    w = torch.cat([conv_gamma.weight, conv_beta.weight], 0)
-    b = torch.cat([conv_gamma.bias, conv_beta.bias], 0)
     C = x.shape[1]
+    wg, wb, bg, bb = conv_gamma.weight, conv_beta.weight, conv_gamma.bias, conv_beta.bias
+
+    def heads():   # cat(gamma head, beta head): one launch on the GPU (the (O, tap, c) operand itself), torch.cat elsewhere
+        if wg.is_cuda and wg.dtype == torch.float32 and bg is not None and bb is not None and tuple(wg.shape[2:]) == (3, 3):
+            return _SpadeHeadsFn.apply(wg, wb, bg, bb)
+        return torch.cat([wg, wb], 0), torch.cat([bg, bb], 0)
     if C % 4 == 0 and isinstance(bn, nn.BatchNorm2d):
         mean, istd = stats if stats is not None else spade_batch_stats(x, bn, repeat=4 if up2 else 1)
-        if _spade_conv_fusable(x, actv, C, up2):
-            return spade_conv_modulate(x, actv, w, b, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+        if _spade_conv_fusable(x, actv, C, up2) and bg is not None and bb is not None:
+            return spade_conv_modulate(x, actv, wg, wb, bg, bb, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+        w, b = heads()
         gb = sphere_conv(actv, w, b, 1)
         return _SpadeNormModulateFn.apply(x, gb, mean.detach(), istd.detach(), slope, bn.training, bool(up2))
+    w, b = heads()
     gb = sphere_conv(actv, w, b, 1)
     if up2:   # ``up2`` = x stands for its nearest x2 upsample (supported by the fused path only; callers check can_fold_up2)
         x = nn.functional.interpolate(x, scale_factor=2)

@@ -42,6 +42,8 @@ SIGNATURES = {
                                     ctypes.c_void_p, _f64p, _f32p, _stream]),
     "eml_l1_pairs_bwd_f32": (_int, [_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, _f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _stream]),
+    "eml_colsum_partial_doubles": (ctypes.c_size_t, [_int]),
+    "eml_colsum_f32": (_int, [_f32p, ctypes.c_long, _int, _f64p, _f32p, _stream]),
     # ground-truth parametrisation
     "eml_gt_anchor_index_i32": (_int, [_f32p, _int, _int, _int, _i32p, _stream]),
     "eml_gt_parametrise_f64": (_int, [_f32p, _i32p, _i32p, _int, _int, _int, _int, _f32p, _f32p, _f32p, _stream]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "eml_spectral_norm_w2_f32": (_int, [_f32p, _f32p, _f32p, _int, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                         _stream]),
     "eml_spectral_norm_w2_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _stream]),
+    "eml_spade_heads_w2_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream]),
     "eml_instance_norm_act_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, ctypes.c_float,
                                              _stream]),
     "eml_instance_norm_act_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _stream]),

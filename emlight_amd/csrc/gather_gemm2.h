@@ -25,8 +25,9 @@
 //     included.  A thread that owns 4 CONSECUTIVE pixels of a row therefore needs 2 x (4 + 1) lines instead of 4 x 4: 10
 //     gathered loads per chunk instead of 16 (every vector-memory instruction costs ~45 matrix-pipe cycles here).
 //     Same values, same combine order: bit-identical results.  The caller vouches for the property
-//     (EML_TAP_ROWSHARE: idx[p][t][1] == idx[p+1][t][0] and idx[p][t][3] == idx[p+1][t][2] for every p % 4 != 3, Po % 4 == 0;
-//     checked once per geometry on the host side).  Tile row rho = 32 (px % 4) + px / 4 holds pixel px, so that the LDS
+//     (EML_TAP_ROWSHARE: for every p % 4 != 3, idx[p][t][1] and idx[p+1][t][0] name the same source pixel unless one of them
+//     is -1 -- the zero-padded wrap-around column, weight 0 --, likewise entries 3 / 2; Po % 4 == 0; checked once per
+//     geometry on the host side).  Tile row rho = 32 (px % 4) + px / 4 holds pixel px, so that the LDS
 //     commit of one load slot still walks consecutive rows (stride 36 floats: conflict-free as before).
 //  Addresses: one wave-uniform 64-bit base (sample of the tile's first pixel + the chunk's channel offset) in SGPRs and a
 //  32-bit per-lane offset -- one v_mad per load instead of 64-bit pointer arithmetic.
@@ -201,8 +202,12 @@ __global__ __launch_bounds__(NT, (NT == 512 && BN <= 128) ? 4 : 2) void gather_g
     if constexpr (SH) {
       // piece = 2 j + row: column j of the thread's PPT + 1 source columns (j < PPT: the west corners of pixel j;
       // j == PPT: the east corners of the last pixel), row 0 = north, 1 = south
+      // A column shared by two pixels takes whichever of the two entries is on the map: grid_sample ZERO-PADS the column
+      // that wraps around (index -1, weight 0 on that side; sphere_cnn.py:55,122), so at one seam per row and tap only one
+      // of "east of j - 1" / "west of j" is a real pixel -- max() picks it, the padded side multiplies it by weight 0.
       const int j = piece >> 1, row = piece & 1, u = j < PPT ? j : PPT - 1;
-      const int id = j < PPT ? (row ? ids[u].z : ids[u].x) : (row ? ids[u].w : ids[u].y);
+      int id = j < PPT ? (row ? ids[u].z : ids[u].x) : (row ? ids[u].w : ids[u].y);
+      if (j > 0 && j < PPT) id = max(id, row ? ids[j - 1].w : ids[j - 1].y);
       const unsigned off = __umul24((unsigned)max(id, 0), c4) + poff[u];
       av[piece] = *reinterpret_cast<const float4*>(cbase + off);
       return;

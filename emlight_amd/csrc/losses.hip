@@ -125,6 +125,37 @@ __global__ __launch_bounds__(256) void l1_pairs_bwd_kernel(L1Pairs P, const floa
   }
 }
 
+
+// Column sums of a tall, skinny row-major matrix (rows x cols, cols <= 64): the bias gradient of the layers with a handful of
+// output channels (conv_img 64 -> 3 at full resolution, the discriminators' heads) -- ATen's sum(0) runs such a shape on a few
+// workgroups (0.34 ms for 1 M x 3).  Flat walk with a stride that is a multiple of cols (a thread stays on its column),
+// f64 partials per workgroup, fixed-order fold: deterministic.
+constexpr int kColGrid = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long n, int cols, long stride,
+                                                             double* __restrict__ partial /*[kColGrid][cols]*/) {
+  __shared__ double red[256];
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.;
+  if (g < stride)
+    for (long e = g; e < n; e += stride) acc += (double)x[e];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < cols) {
+    // threads of this workgroup on column c: those with (blockIdx.x * 256 + t) % cols == c
+    const int first = (int)((threadIdx.x + cols - (int)(((long)blockIdx.x * 256) % cols)) % cols);
+    double s = 0.;
+    for (int t = first; t < 256; t += cols) s += red[t];
+    partial[(size_t)blockIdx.x * cols + threadIdx.x] = s;
+  }
+}
+__global__ __launch_bounds__(64) void colsum_fold_kernel(const double* __restrict__ partial, int nblk, int cols, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * cols + c];
+  out[c] = (float)s;
+}
+
 int pack(const char* what, int n, const float* const* f, const float* const* r, const float* const* w, const long* rows,
          const int* C, const float* scale, L1Pairs* P) {
   if (n < 1 || n > kMaxPairs) return eml::fail(EML_EINVAL, "%s: 1 <= pairs <= %d (got %d)", what, kMaxPairs, n);
@@ -175,4 +206,19 @@ extern "C" int eml_l1_pairs_bwd_f32(int npairs, const float* const* f, const flo
   }
   hipLaunchKernelGGL(l1_pairs_bwd_kernel, dim3(kGrid, npairs), dim3(256), 0, (hipStream_t)stream, P, gout);
   return eml::check_launch("eml_l1_pairs_bwd_f32");
+}
+
+extern "C" size_t eml_colsum_partial_doubles(int cols) { return cols > 0 ? (size_t)kColGrid * cols : 0; }
+
+extern "C" int eml_colsum_f32(const float* x, long rows, int cols, double* partial, float* out, eml_stream_t stream) {
+  if (!x || !partial || !out || rows < 0 || cols < 1 || cols > 64)
+    return eml::fail(EML_EINVAL, "eml_colsum_f32: null pointer, negative rows or cols outside [1, 64] (cols=%d)", cols);
+  const long n = rows * cols;
+  // every workgroup takes part (its partial row must be written); the stride is the largest multiple of cols <= the grid
+  const long threads = (long)kColGrid * 256;
+  const long stride = threads / cols * cols;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(kColGrid), dim3(256), 0, st, x, n, cols, stride, partial);
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(1), dim3(64), 0, st, partial, kColGrid, cols, out);
+  return eml::check_launch("eml_colsum_f32");
 }

@@ -126,15 +126,11 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(const float* __restrict__
 constexpr int kCC = 256;
 constexpr int kTile = kCC * 9 + kCC / 4;
 
-// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma
-__global__ __launch_bounds__(256) void sn_relayout_kernel(const float* __restrict__ W, const float* __restrict__ sigma,
-                                                          float* __restrict__ W2, int C) {
-  __shared__ float tile[kTile];
-  const int K = 9 * C, o = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0), tid = threadIdx.x;
-  const float inv = 1.f / *sigma;
-  const float* src = W + (size_t)o * K + (size_t)c0 * 9;
-  float* dst = W2 + (size_t)o * K + c0;
-  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0) {
+// one chunk: dst[tap*C + c] = src[c*9 + tap] * inv for the cc channels of the chunk (src / dst already point at the chunk)
+__device__ __forceinline__ void relayout_chunk(const float* __restrict__ src, float* __restrict__ dst, int C, int cc, float inv,
+                                               bool vec, float* tile) {
+  const int tid = threadIdx.x;
+  if (vec) {
     const float4* src4 = reinterpret_cast<const float4*>(src);
     for (int j = tid; j < (cc * 9) / 4; j += 256) {       // elements 4j .. 4j+3 of the chunk: 36 | 4j' boundaries only
       const float4 w = src4[j];
@@ -157,6 +153,40 @@ __global__ __launch_bounds__(256) void sn_relayout_kernel(const float* __restric
       dst[(size_t)tap * C + c] = tile[9 * c + tap + (c >> 2)] * inv;
     }
   }
+}
+
+// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma
+__global__ __launch_bounds__(256) void sn_relayout_kernel(const float* __restrict__ W, const float* __restrict__ sigma,
+                                                          float* __restrict__ W2, int C) {
+  __shared__ float tile[kTile];
+  const int K = 9 * C, o = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0);
+  const bool vec = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0;
+  relayout_chunk(W + (size_t)o * K + (size_t)c0 * 9, W2 + (size_t)o * K + c0, C, cc, 1.f / *sigma, vec, tile);
+}
+
+// SPADE's two heads (normalization.py:96-98: mlp_gamma, mlp_beta, each (Cn, C, 3, 3) + bias) as ONE (2 Cn, 9 C) operand in the
+// (tap, c) column order of the gather-GEMM kernels -- one launch instead of cat(weights), cat(biases) and the re-layout copy.
+// reorder != 0: rows in the order of eml_sphere_conv_spade_fwd_f32 (position p holds head `half`, channel c with
+// c = 64 (p / 128) + 32 ((p % 128) / 64) + p % 32, half = (p % 64) / 32); else cat order (gamma rows, then beta rows).
+__global__ __launch_bounds__(256) void spade_heads_kernel(const float* __restrict__ Wg, const float* __restrict__ Wb,
+                                                          const float* __restrict__ bg, const float* __restrict__ bb,
+                                                          float* __restrict__ W2, float* __restrict__ b2, int Cn, int C,
+                                                          int reorder) {
+  __shared__ float tile[kTile];
+  const int K = 9 * C, p = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0);
+  int half, c;
+  if (reorder) {
+    c = 64 * (p / 128) + 32 * ((p % 128) / 64) + p % 32;
+    half = (p % 64) / 32;
+  } else {
+    half = p >= Cn;
+    c = p - half * Cn;
+  }
+  const float* W = half ? Wb : Wg;
+  if (b2 && blockIdx.y == 0 && threadIdx.x == 0) b2[p] = (half ? bb : bg)[c];
+  const bool vec = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(Wg) | reinterpret_cast<uintptr_t>(Wb) |
+                                     reinterpret_cast<uintptr_t>(W2)) & 15) == 0;
+  relayout_chunk(W + (size_t)c * K + (size_t)c0 * 9, W2 + (size_t)p * K + c0, C, cc, 1.f, vec, tile);
 }
 
 // partial[b] = sum over this workgroup's elements of dW2 * W2
@@ -268,4 +298,14 @@ extern "C" int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, c
   hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(O, (C + kCC - 1) / kCC), dim3(256), 0, st, dW2, partial, grid, u_used, v, sigma, dW,
                      C);
   return eml::check_launch("eml_spectral_norm_w2_bwd_f32");
+}
+
+extern "C" int eml_spade_heads_w2_f32(const float* Wg, const float* Wb, const float* bg, const float* bb, float* W2, float* b2,
+                                      int Cn, int C, int reorder, eml_stream_t stream) {
+  if (!Wg || !Wb || !W2 || Cn < 1 || C < 1) return eml::fail(EML_EINVAL, "eml_spade_heads_w2_f32: null pointer or empty shape");
+  if (b2 && (!bg || !bb)) return eml::fail(EML_EINVAL, "eml_spade_heads_w2_f32: b2 needs both head biases");
+  if (reorder && Cn % 64) return eml::fail(EML_EINVAL, "eml_spade_heads_w2_f32: the one-launch SPADE's row order needs Cn %% 64 == 0 (Cn=%d)", Cn);
+  hipLaunchKernelGGL(spade_heads_kernel, dim3(2 * Cn, (C + kCC - 1) / kCC), dim3(256), 0, (hipStream_t)stream, Wg, Wb, bg, bb, W2,
+                     b2, Cn, C, reorder ? 1 : 0);
+  return eml::check_launch("eml_spade_heads_w2_f32");
 }

@@ -418,9 +418,10 @@ int eml_sphere_conv_fwd_fused_f32(const float* X, const int* idx, const float* w
  * convolution (generator.py:84).  eml_sphere_conv_fwd_fused_f32 is this entry with (NULL, 1). */
 /* table_flags: EML_TAP_ROWSHARE -- the caller vouches that the table has the row structure of a stride-1 sphere grid
  * (sphere_cnn.py:31-58: a tap samples source column c + const(row, tap) of two adjacent source rows): for every destination
- * pixel p with p % 4 != 3 and every tap, idx[p][tap][1] == idx[p+1][tap][0] and idx[p][tap][3] == idx[p+1][tap][2]
- * (north-east of p = north-west of its right neighbour, likewise south), and Po % 4 == 0.  The kernel then fetches 2 x 5 lines
- * per 4 pixels instead of 4 x 4 (same values, same summation order: bit-identical results).  Honoured for ke == 4 only. */
+ * pixel p with p % 4 != 3 and every tap, entries 1 of p and 0 of p + 1 (north-east of p / north-west of its right neighbour)
+ * are the SAME source pixel unless one of them is -1 (the zero-padded wrap-around column; its weight is 0), likewise entries
+ * 3 and 2; every -1 entry has weight 0; Po % 4 == 0.  The kernel then fetches 2 x 5 lines per 4 pixels instead of 4 x 4 (same
+ * values, same summation order: identical results).  Honoured for ke == 4 only. */
 #define EML_TAP_ROWSHARE 1
 int eml_sphere_conv_fwd_fused_ex_f32(const float* X, const int* idx, const float* wgt, const float* W2,
                                      const float* bias, float* Y, int B, int HW, int Po, int C, int O, int ke,
@@ -564,6 +565,14 @@ int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, fl
 int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, const float* u_used, const float* v_used,
                                  const float* sigma, double* partial, float* dW, int O, int C, eml_stream_t stream);
 
+/* SPADE's two heads (normalization.py:96-98: mlp_gamma, mlp_beta -- SphereConv2D(nhidden, Cn) each) as the ONE (2 Cn, 9 C)
+ * operand of the gamma | beta product, columns (tap, c): W2[p][tap*C + c] = W_head(p)[c(p)][c][tap], b2[p] = b_head(p)[c(p)]
+ * (b2 / bg / bb may be NULL).  reorder = 0: cat order (p < Cn: gamma row p, else beta row p - Cn) -- what
+ * eml_sphere_conv_fwd_fused_f32 / the im2col GEMM take; reorder != 0: the row order of eml_sphere_conv_spade_fwd_f32
+ * (Cn % 64 == 0).  One launch instead of cat(weights), cat(biases) and a re-layout copy per SPADE and pass. */
+int eml_spade_heads_w2_f32(const float* Wg, const float* Wb, const float* bg, const float* bb, float* W2, float* b2, int Cn,
+                           int C, int reorder, eml_stream_t stream);
+
 /* nn.InstanceNorm2d(affine=False) + the LeakyReLU that follows it in the PatchGAN discriminator and the crop encoder
  * (normalization.py:44-45 'instance'; discriminator.py:84-98; generator.py:113-122): y = leaky_relu((x - mean) * istd, slope),
  * mean / biased variance per (sample, channel) over the HW pixels (f64 accumulation), istd = 1/sqrt(var + eps).
@@ -592,6 +601,12 @@ int eml_l1_pairs_fwd_f32(int npairs, const float* const* f, const float* const* 
 int eml_l1_pairs_bwd_f32(int npairs, const float* const* f, const float* const* r, const float* const* w, const long* rows,
                          const int* C, const float* scale, const float* gout, float* const* g, float* const* gzero,
                          const long* nzero, eml_stream_t stream);
+
+/* out[c] = sum_r x[r][c] for a tall row-major (rows, cols) matrix with cols <= 64: the bias gradient of the few-output-channel
+ * layers (autograd of sphere_cnn.py:124's bias for conv_img / the discriminators' heads).  partial:
+ * eml_colsum_partial_doubles(cols) f64 of scratch; deterministic. */
+size_t eml_colsum_partial_doubles(int cols);
+int eml_colsum_f32(const float* x, long rows, int cols, double* partial, float* out, eml_stream_t stream);
 
 /* ---------------------------------------------------------------- ground-truth parametrisation (data preparation)
  * representation/distribution_representation.py:65-120 (`extract_mesh`), the inverse of the rasteriser.

@@ -174,9 +174,9 @@ def test_ngf64_shape_list_is_what_the_networks_run(monkeypatch):
     monkeypatch.setattr(spherenet, "sphere_conv", spy)
     real_spade = spherenet.spade_conv_modulate
 
-    def spy_spade(x, actv, weight, *more):   # the gamma | beta SphereConvs that run with SPADE's modulation as their epilogue
-        seen.add((actv.shape[0], actv.shape[1], weight.shape[0], actv.shape[2], actv.shape[3], 1))
-        return real_spade(x, actv, weight, *more)
+    def spy_spade(x, actv, wg, *more):   # the gamma | beta SphereConvs that run with SPADE's modulation as their epilogue
+        seen.add((actv.shape[0], actv.shape[1], 2 * wg.shape[0], actv.shape[2], actv.shape[3], 1))   # the two heads: O = 2 Cn
+        return real_spade(x, actv, wg, *more)
     monkeypatch.setattr(spherenet, "spade_conv_modulate", spy_spade)
     torch.manual_seed(0)
     pm = Pix2PixModel(networks.default_options()).cuda()
@@ -1050,10 +1050,15 @@ def test_row_shared_corners_gather_is_bit_identical(B, C, O, H, W):
     torch.manual_seed(C + O + H)
     geo = spherenet.sphere_geometry(H, W, 1, torch.device("cuda"))
     po = H * W
-    idx = geo.idx.view(po, 9, 4)
+    idx, wgt = geo.idx.view(po, 9, 4), geo.wgt.view(po, 9, 4)
     same_row = (torch.arange(po, device="cuda") % 4 != 3)[:-1]
-    want = bool(((idx[:-1, :, 1] == idx[1:, :, 0]) & (idx[:-1, :, 3] == idx[1:, :, 2]))[same_row].all())
-    assert want and geo.rowshare == 1          # W % 4 == 0: four consecutive pixels never straddle two rows
+
+    def shared(a, b):   # the same source pixel, or one side is grid_sample's zero-padded wrap-around column
+        return (a == b) | (a < 0) | (b < 0)
+    want = bool((shared(idx[:-1, :, 1], idx[1:, :, 0]) & shared(idx[:-1, :, 3], idx[1:, :, 2]))[same_row].all())
+    assert want and bool((wgt[idx < 0] == 0).all()) and geo.rowshare == 1   # W % 4 == 0: 4 consecutive pixels share a row
+    seams = int(((idx[:-1, :, 1] != idx[1:, :, 0]) & (idx[:-1, :, 1] >= 0) & (idx[1:, :, 0] >= 0))[same_row].sum())
+    assert seams == 0
     assert spherenet.sphere_geometry(H, W, 2, torch.device("cuda")).rowshare == 0   # stride 2: neighbours sample 2 columns apart
     x = torch.randn(B * po, C, device="cuda")
     w2 = torch.randn(O, 9 * C, device="cuda") * 0.05

@@ -81,6 +81,25 @@ for name, C, O, H, W, role in LAYERS:
         row["bit_identical"] = bool(torch.equal(outs[0], outs[1]))
     print(json.dumps(row), flush=True)
 
+# what do the gathered loads cost when they cannot miss?  The same kernels on a table whose every entry is pixel 0 of the sample
+# (one 512-byte line per sample: L1 hits): if the rate jumps, the gather is bound by memory latency / L2 traffic, not by issue
+for name, C, O, H, W in (("128->128 @128x256, all taps -> pixel 0", 128, 128, 128, 256), ("256->128 @64x128, all taps -> pixel 0", 256, 128, 64, 128)):
+    geo = spherenet.sphere_geometry(H, W, 1, dev)
+    po = H * W
+    M = B * po
+    gflop = 2.0 * M * 9 * C * O / 1e9
+    idx0 = torch.zeros_like(geo.idx)
+    x = torch.randn(M, C, device=dev)
+    w2 = torch.randn(O, 9 * C, device=dev) * 0.05
+    y = torch.empty(M, O, device=dev)
+    row = {"layer": name, "role": "fwd-local", "B": B, "gflop": round(gflop, 1)}
+    for flags in (0, 1):
+        fn = lambda: _lib.check(L.eml_sphere_conv_fwd_fused_ex_f32(p(x), p(idx0), p(geo.wgt), p(w2), None, p(y), B, po, po, C, O, 4,
+                                                                   None, 1.0, flags, st), "fwd")
+        t = events(fn)
+        row["flags%d" % flags] = {"ms": round(t, 4), "tflops": round(gflop / t, 1)}
+    print(json.dumps(row), flush=True)
+
 # spectral norm: the forward's five launches for the generator's weight shapes (training mode: one power iteration)
 for O, C in ((1024, 1024), (512, 1024), (512, 512), (256, 512), (256, 256), (128, 256), (128, 128), (64, 128), (64, 64)):
     w = torch.randn(O, C, 3, 3, device=dev) * 0.02
