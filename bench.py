@@ -797,6 +797,24 @@ def main():
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.anchors, crop_hw, args.blur)
+        # the headline numbers of EVERY leg in one compact object: inside `roofline` (an object the driver's record keeps
+        # whole) and once more as the LAST key of the line (what a truncated stdout tail still shows)
+        legs_summary = {"regression": {"value": out["value"], "ms_per_step": out["ms_per_step"],
+                                       "step_frac_of_f32_mfma_peak": out["step_frac_of_f32_mfma_peak"]}}
+        for k in ("projector", "joint"):
+            if k in out:
+                legs_summary[k] = {"value": out[k]["value"], "ms_per_step": out[k]["ms_per_step"],
+                                   "step_frac_of_f32_mfma_peak": out[k].get("step_frac_of_f32_mfma_peak",
+                                                                            out[k].get("roofline", {}).get("frac")),
+                                   "dominant_kernel_frac": out[k].get("roofline", {}).get("frac"),
+                                   "without_vgg": out[k].get("without_vgg", {}).get("value")}
+        for k in ("sinkhorn", "sinkhorn_n256"):
+            if k in out and isinstance(out[k], dict):
+                legs_summary[k] = {kk: out[k][kk] for kk in ("ms_per_loss_call", "ms_per_eps_step", "n_eps",
+                                                             "frac_of_hbm_peak_8TBps") if kk in out[k]}
+        if "roofline" in out:
+            out["roofline"]["legs"] = legs_summary
+        out["legs_summary"] = legs_summary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -13,6 +13,7 @@ from emlight_amd import _lib
 from emlight_amd.GenProjector import spherenet
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PROBE = len(sys.argv) > 2 and sys.argv[2] == "probe"   # counters run: one layer, 16-load / 10-load / all-taps-to-pixel-0 only
 dev = torch.device("cuda")
 L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
 
@@ -36,6 +37,8 @@ LAYERS = [("up_3 gamma|beta 128->256 @128x256", 128, 256, 128, 256, "spade"), ("
           ("up_2 conv_1 128->128 @64x128", 128, 128, 64, 128, "fwd"), ("up_1 conv_0 512->256 @32x64", 512, 256, 32, 64, "fwd"),
           ("up_3 conv_0 dgrad 128<-64 @128x256", 128, 64, 128, 256, "dgrad"), ("up_2 conv_0 dgrad 256<-128 @64x128", 256, 128, 64, 128, "dgrad"),
           ("up_3 gamma|beta dgrad 128<-256 @128x256", 128, 256, 128, 256, "dgrad")]
+if PROBE:
+    LAYERS = [("up_3 gamma|beta 128->128 @128x256", 128, 128, 128, 256, "fwd")]
 for name, C, O, H, W, role in LAYERS:
     geo = spherenet.sphere_geometry(H, W, 1, dev)
     po = H * W
@@ -65,8 +68,9 @@ for name, C, O, H, W, role in LAYERS:
         for flags in (0, 1):
             if role == "spade":
                 Cn = O // 2
-                xn = torch.randn(M, Cn, device=dev)
-                mean, istd = torch.randn(Cn, device=dev), torch.rand(Cn, device=dev) + 0.5
+                g_ = torch.Generator(device=dev).manual_seed(5)   # the same operands for both kernels
+                xn = torch.randn(M, Cn, device=dev, generator=g_)
+                mean, istd = torch.randn(Cn, device=dev, generator=g_), torch.rand(Cn, device=dev, generator=g_) + 0.5
                 y = torch.empty(M, Cn, device=dev)
                 g = torch.empty(M, Cn, device=dev)
                 fn = lambda: _lib.check(L.eml_sphere_conv_spade_fwd_f32(p(x), p(geo.idx), p(geo.wgt), p(w2), p(bias), p(xn), p(mean),
@@ -83,7 +87,7 @@ for name, C, O, H, W, role in LAYERS:
 
 # what do the gathered loads cost when they cannot miss?  The same kernels on a table whose every entry is pixel 0 of the sample
 # (one 512-byte line per sample: L1 hits): if the rate jumps, the gather is bound by memory latency / L2 traffic, not by issue
-for name, C, O, H, W in (("128->128 @128x256, all taps -> pixel 0", 128, 128, 128, 256), ("256->128 @64x128, all taps -> pixel 0", 256, 128, 64, 128)):
+for name, C, O, H, W in (("128->128 @128x256, all taps -> pixel 0", 128, 128, 128, 256), ("256->128 @64x128, all taps -> pixel 0", 256, 128, 64, 128))[:1 if PROBE else 2]:
     geo = spherenet.sphere_geometry(H, W, 1, dev)
     po = H * W
     M = B * po
@@ -101,7 +105,7 @@ for name, C, O, H, W in (("128->128 @128x256, all taps -> pixel 0", 128, 128, 12
     print(json.dumps(row), flush=True)
 
 # spectral norm: the forward's five launches for the generator's weight shapes (training mode: one power iteration)
-for O, C in ((1024, 1024), (512, 1024), (512, 512), (256, 512), (256, 256), (128, 256), (128, 128), (64, 128), (64, 64)):
+for O, C in () if PROBE else ((1024, 1024), (512, 1024), (512, 512), (256, 512), (256, 256), (128, 256), (128, 128), (64, 128), (64, 64)):
     w = torch.randn(O, C, 3, 3, device=dev) * 0.02
     u, v = torch.randn(O, device=dev), torch.randn(9 * C, device=dev)
     w2 = torch.empty(O, 9 * C, device=dev)
