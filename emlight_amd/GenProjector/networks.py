@@ -78,7 +78,12 @@ def nonspade_norm(norm_type):
     def wrap(layer):
         sub = norm_type
         if sub.startswith("spectral"):
-            layer = spherenet.fused_spectral_norm(layer) if isinstance(layer, SphereConv2D) else spectral_norm(layer)
+            # the fused hook (csrc/spectral.hip: 5 launches instead of torch's ~15 per forward) serves every 3x3 convolution:
+            # its result is the (O, C, 3, 3) weight in channels-last memory, which SphereConv2D's kernels AND MIOpen's NHWC
+            # convolutions (the crop encoder's stride-2 nn.Conv2d layers) take as it is
+            k3 = isinstance(layer, SphereConv2D) or (isinstance(layer, nn.Conv2d) and tuple(layer.kernel_size) == (3, 3)
+                                                     and layer.groups == 1)
+            layer = spherenet.fused_spectral_norm(layer) if k3 else spectral_norm(layer)
             sub = sub[len("spectral"):]
         if sub in ("none", ""):
             return layer

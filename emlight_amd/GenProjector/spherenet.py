@@ -358,7 +358,7 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             bmo = 128 if (O % 128 == 0 or O > 192) else 64
             tiles = 9 * (C // bn) * ((O + bmo - 1) // bmo)
             nchunks = (B * po + 31) // 32
-            split = max(1, min(nchunks, 2048 // tiles, (512 << 20) // (O * 9 * C * 4)))
+            split = max(1, min(nchunks, SphereConv2D.wgrad_workgroups // tiles, (512 << 20) // (O * 9 * C * 4)))
             part = torch.empty(L.eml_sphere_conv_wgrad_partial_floats(C, O, split), dtype=torch.float32, device=gy.device)
             gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
             _lib.check(L.eml_sphere_conv_wgrad_fused_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B,
@@ -936,6 +936,8 @@ class SphereConv2D(nn.Module):
     narrow_kernels = knob_flag("EML_NARROW", True)
     # input gradient of the 3-channel input layers through eml_sphere_conv_small_da9_f32; EML_SMALL_DA9=0: A/B knob (general path)
     small_input_grad = knob_flag("EML_SMALL_DA9", True)
+    # split-K of the fused weight gradient: workgroups per launch (tiles x K-splits); EML_WGRAD_WGS: A/B knob
+    wgrad_workgroups = knob_int("EML_WGRAD_WGS", 2048, lo=256)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()
