@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 from . import spherenet
+from .._knobs import knob_flag
 from .spherenet import SphereConv2D
 
 
@@ -82,7 +83,7 @@ def nonspade_norm(norm_type):
             # its result is the (O, C, 3, 3) weight in channels-last memory, which SphereConv2D's kernels AND MIOpen's NHWC
             # convolutions (the crop encoder's stride-2 nn.Conv2d layers) take as it is
             k3 = isinstance(layer, SphereConv2D) or (isinstance(layer, nn.Conv2d) and tuple(layer.kernel_size) == (3, 3)
-                                                     and layer.groups == 1)
+                                                     and layer.groups == 1 and knob_flag("EML_SN_CONV2D", True))
             layer = spherenet.fused_spectral_norm(layer) if k3 else spectral_norm(layer)
             sub = sub[len("spectral"):]
         if sub in ("none", ""):

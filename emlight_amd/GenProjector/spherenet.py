@@ -862,7 +862,13 @@ class _FusedSpectralNormHook:
             u, v = getattr(module, sn.name + "_u"), getattr(module, sn.name + "_v")
             O, C = w.shape[0], w.shape[1]
             w2 = _SpectralW2Fn.apply(w, u, v, module.training, sn.eps)
-            setattr(module, sn.name, w2.view(O, 3, 3, C).permute(0, 3, 1, 2))
+            wn = w2.view(O, 3, 3, C).permute(0, 3, 1, 2)
+            if not isinstance(module, SphereConv2D):
+                # an nn.Conv2d (the crop encoder's stride-2 layers) runs on MIOpen, which takes a channels-last WEIGHT down a
+                # path 20x slower than its NCHW one (measured: 25.4 against 1.1 ms per joint step, profiles/r05_ab_sn_conv2d.txt):
+                # one small copy back to the parameter's own layout
+                wn = wn.contiguous()
+            setattr(module, sn.name, wn)
         else:
             sn(module, inputs)
 
@@ -936,8 +942,10 @@ class SphereConv2D(nn.Module):
     narrow_kernels = knob_flag("EML_NARROW", True)
     # input gradient of the 3-channel input layers through eml_sphere_conv_small_da9_f32; EML_SMALL_DA9=0: A/B knob (general path)
     small_input_grad = knob_flag("EML_SMALL_DA9", True)
-    # split-K of the fused weight gradient: workgroups per launch (tiles x K-splits); EML_WGRAD_WGS: A/B knob
-    wgrad_workgroups = knob_int("EML_WGRAD_WGS", 2048, lo=256)
+    # split-K of the fused weight gradient: workgroups per launch (tiles x K-splits).  Two resident workgroups per CU: 1024 is
+    # two full waves of them; round 4's 2048 wrote and re-read twice the partial sums for nothing (same-box A/B of the joint
+    # step: 2048 -> 1024 -1.6 ms, 4096 +3 ms; profiles/r05_ab_wgrad_split.txt).  EML_WGRAD_WGS: A/B knob
+    wgrad_workgroups = knob_int("EML_WGRAD_WGS", 1024, lo=256)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()
