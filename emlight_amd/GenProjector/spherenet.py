@@ -344,6 +344,10 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             _lib.check(L.eml_colsum_f32(p(gyr), B * po, O, p(part), p(gb), st), "eml_colsum_f32")
         else:
             gb = gyr.sum(0)
+        if gres is not None and gb is not None:
+            # the residual branch's gradient IS this (masked) dY: a learned shortcut's bias gradient (conv_s, architecture.py:60)
+            # is the same column sum -- handed over on the tensor, under the same storage / version check as above
+            gres._eml_colsum = (gb, gres.data_ptr(), gres._version)
     narrow = getattr(ctx, "narrow", False)
     if needs[1] and not small_w:
         if narrow:

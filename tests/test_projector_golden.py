@@ -152,7 +152,7 @@ def test_generator_step_leaves_the_discriminator_out_of_its_graph():
     for literal in (False, True):
         m = _model()
         if literal:   # the reference's graph: D's parameters take part
-            m.discriminate = lambda a, b, c, for_generator=False, _d=type(m).discriminate, _m=m: _d(_m, a, b, c, False)
+            m.discriminate_raw = lambda a, b, c, for_generator=False, _d=type(m).discriminate_raw, _m=m: _d(_m, a, b, c, False)
         losses, _ = m(data, "generator")
         sum(losses.values()).mean().backward()
         grads.append({k: q.grad.clone() for k, q in m.netG.named_parameters()})
