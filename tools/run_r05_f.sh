@@ -1,6 +1,8 @@
 #!/bin/bash
 # round-5 GPU call F: same-box A/B of the whole round (the round-4 tree, build_exp/r04_tree, against this tree) on the
-# regression / projector / joint legs, and SQ counters of the gather-GEMM with 16 loads, 10 loads and loads that cannot miss
+# regression / projector / joint legs (the round-4 tree is not in the history of this one -- it IS its history:
+#   mkdir -p build_exp/r04_tree && git archive e9fe561 | tar -x -C build_exp/r04_tree && make -C build_exp/r04_tree/emlight_amd/csrc
+# build_exp/ is git-ignored and travels to the GPU box with the snapshot), and SQ counters of the gather-GEMM with 16 loads, 10 loads and loads that cannot miss
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
