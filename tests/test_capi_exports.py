@@ -155,3 +155,38 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_knobs_are_validated_and_follow_the_environment(monkeypatch, capsys):
+    """A/B knobs go through one parser -- a malformed value is reported and ignored (it must not break the
+    import), a non-default one is announced, and a change made in-process (tests, A/B drivers) is honoured."""
+    from emlight_amd import _knobs
+    monkeypatch.setenv("EML_TEST_KNOB", "banana")
+    assert _knobs.knob_int("EML_TEST_KNOB", 64, lo=0) == 64 and _knobs.knob_flag("EML_TEST_KNOB", True) is True
+    assert "ignoring EML_TEST_KNOB" in capsys.readouterr().err
+    monkeypatch.setenv("EML_TEST_KNOB", "0")
+    assert _knobs.knob_int("EML_TEST_KNOB", 64, lo=0) == 0 and _knobs.knob_flag("EML_TEST_KNOB", True) is False
+    assert "A/B knob EML_TEST_KNOB" in capsys.readouterr().err
+    monkeypatch.setenv("EML_TEST_KNOB", "-3")
+    assert _knobs.knob_int("EML_TEST_KNOB", 64, lo=0) == 64 and "ignoring" in capsys.readouterr().err   # out of range
+    monkeypatch.delenv("EML_TEST_KNOB")
+    assert _knobs.knob_int("EML_TEST_KNOB", 64, lo=0) == 64 and _knobs.knob_choice("EML_TEST_KNOB", "a", ("a", "b")) == "a"
+    assert capsys.readouterr().err == ""
+
+
+def test_guide_map_resizes_are_computed_once_per_map_and_size():
+    """``networks.resized_guide`` = F.interpolate(nearest) (normalization.py:106), cached on the tensor: same object for the same
+    size, the map itself at its own size, a fresh entry after an in-place change, gradients accumulate through the shared node."""
+    import torch
+    import torch.nn.functional as F
+    from emlight_amd.GenProjector.networks import resized_guide
+    x = torch.rand(2, 3, 8, 16, requires_grad=True)
+    a, b = resized_guide(x, (4, 8)), resized_guide(x, (4, 8))
+    assert a is b and resized_guide(x, (8, 16)) is x and torch.equal(a, F.interpolate(x, size=(4, 8), mode="nearest"))
+    (a.sum() + 2 * b.sum()).backward()
+    want = torch.autograd.grad(3 * F.interpolate(x, size=(4, 8), mode="nearest").sum(), x)[0]
+    assert torch.equal(x.grad, want)
+    y = torch.rand(1, 3, 8, 16)
+    first = resized_guide(y, (2, 4))
+    y.mul_(2.0)
+    assert resized_guide(y, (2, 4)) is not first and torch.equal(resized_guide(y, (2, 4)), F.interpolate(y, size=(2, 4), mode="nearest"))

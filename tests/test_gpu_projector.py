@@ -1100,3 +1100,60 @@ def test_row_shared_corners_gather_is_bit_identical(B, C, O, H, W):
                                                          flags, st), "dgrad")
             gs.append(gx)
         assert torch.equal(gs[0], gs[1])
+
+
+@pytest.mark.parametrize("rows,cols", [(1048576, 3), (100003, 1), (4097, 8), (5, 64), (0, 3)])
+def test_colsum_of_a_tall_skinny_matrix(rows, cols):
+    """``eml_colsum_f32`` (the bias gradient of the few-output-channel layers) against an f64 column sum; run-to-run equal."""
+    from emlight_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    x = torch.randn(max(rows, 1), cols, device="cuda")[:rows].contiguous()
+    outs = []
+    for _ in range(2):
+        part = torch.empty(L.eml_colsum_partial_doubles(cols), dtype=torch.float64, device="cuda")
+        out = torch.full((cols,), float("nan"), device="cuda")
+        _lib.check(L.eml_colsum_f32(p(x) if rows else p(torch.empty(1, device="cuda")), rows, cols, p(part), p(out), st), "colsum")
+        outs.append(out)
+    want = x.double().sum(0)
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6 * np.sqrt(max(rows, 1)))
+
+
+@pytest.mark.parametrize("Cn,Cin", [(64, 128), (128, 128), (16, 64), (64, 6)])
+def test_spade_heads_as_one_operand(Cn, Cin):
+    """``eml_spade_heads_w2_f32``: cat(gamma head, beta head) in the (tap, c) column order of the gather-GEMM kernels, in cat
+    order and -- for the one-launch SPADE -- in that kernel's row order: bitwise what cat + permute (+ row gather) produce."""
+    from emlight_amd.GenProjector import spherenet
+    torch.manual_seed(Cn + Cin)
+    wg, wb = torch.randn(Cn, Cin, 3, 3, device="cuda"), torch.randn(Cn, Cin, 3, 3, device="cuda")
+    bg, bb = torch.randn(Cn, device="cuda"), torch.randn(Cn, device="cuda")
+    w_cat = torch.cat([wg, wb], 0).permute(0, 2, 3, 1).reshape(2 * Cn, 9 * Cin)
+    b_cat = torch.cat([bg, bb], 0)
+    w2, b2 = spherenet.spade_heads_w2(wg, wb, bg, bb, False)
+    assert torch.equal(w2, w_cat) and torch.equal(b2, b_cat)
+    if Cn % 64 == 0:
+        order = spherenet.spade_row_order(Cn, wg.device)
+        w2r, br = spherenet.spade_heads_w2(wg, wb, bg, bb, True)
+        assert torch.equal(w2r, w_cat[order]) and torch.equal(br, b_cat[order])
+    # through autograd: the (2 Cn, Cin, 3, 3) VIEW the convolutions take, gradients = the two halves
+    wg.requires_grad_(), wb.requires_grad_(), bg.requires_grad_(), bb.requires_grad_()
+    w, b = spherenet._SpadeHeadsFn.apply(wg, wb, bg, bb)
+    assert w.shape == (2 * Cn, Cin, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    gw, gbias = torch.randn_like(w), torch.randn_like(b)
+    ((w * gw).sum() + (b * gbias).sum()).backward()
+    assert torch.equal(wg.grad, gw[:Cn]) and torch.equal(wb.grad, gw[Cn:]) and torch.equal(bg.grad, gbias[:Cn]) and torch.equal(bb.grad, gbias[Cn:])
+
+
+@pytest.mark.parametrize("O,slope,M", [(128, 0.0, 4099), (64, 0.0, 512), (128, 1.0, 33), (64, 0.2, 70000)])
+def test_small_layer_input_gradient_first_half(O, slope, M):
+    """``eml_sphere_conv_small_da9_f32``: dA9 = (dY * act'(Y)) W2 for the 3-channel input layers, against the two stock steps."""
+    from emlight_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    torch.manual_seed(O + M)
+    gy, y = torch.randn(M, O, device="cuda"), torch.randn(M, O, device="cuda")
+    w2 = torch.randn(O, 27, device="cuda") * 0.2
+    da9 = torch.full((M, 27), float("nan"), device="cuda")
+    _lib.check(L.eml_sphere_conv_small_da9_f32(p(gy), p(y) if slope != 1.0 else None, slope, p(w2), p(da9), M, 3, O, st), "da9")
+    g = gy if slope == 1.0 else torch.where(y > 0, gy, gy * slope)
+    want = g.double() @ w2.double()
+    np.testing.assert_allclose(da9.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(want.abs().max()))
