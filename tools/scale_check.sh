@@ -5,6 +5,12 @@
 # whole-job img/s, the per-GPU img/s and the efficiency against N x the 1-GPU value, for the headline regression step and
 # for every leg object asked for.
 REPO=$(cd "$(dirname "$0")/.." && pwd)
+# `tools/scale_check.sh dry`: no node needed -- two ranks on ONE GPU (gloo transport) run a projector iteration and the test
+# asserts what it puts on the wire besides the gradient buckets: 14 sync-BN all-reduces per generator forward, 18 per backward,
+# 14 for the discriminator step's no-grad generator pass, (2C+1) f64 each; no D buckets in the G step, no G buckets in the D step
+if [ "$1" = dry ]; then
+  cd $REPO && exec python -m pytest tests/test_gpu_ddp_two_ranks.py -q -m gpu -k "collective_counts or sync_bn_two_ranks"
+fi
 LEGS=${1:-joint}
 shift
 NS=${@:-1 2 4 8}
