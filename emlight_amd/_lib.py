@@ -139,6 +139,10 @@ SIGNATURES = {
                                                 _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_narrow_f32": (_int, [_f32p, _f32p, _int, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
                                                 ctypes.c_long, _f32p, _int, _f32p, _f32p, _int, _int, _stream]),
+    "eml_dense_conv1x1_bwd_narrow2_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _f32p, _int,
+                                                 _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _f32p, _int, _f32p, _f64p, _int, _int,
+                                                 _stream]),
+    "eml_dense_conv1x1_bwd_pair_f32": (_int, [ctypes.c_void_p] * 14 + [_f32p, _int, ctypes.c_long, _f32p, _int, _int, _stream]),
     "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
