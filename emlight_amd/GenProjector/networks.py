@@ -256,6 +256,7 @@ class SPADEGenerator(nn.Module):
         return sw, round(sw / opt.aspect_ratio)
 
     def forward(self, input, crop):
+        spherenet.spectral_precompute(self)   # all 23 spectrally normalised weights of this pass in five launches
         guide = input
         x = self.netE(crop).view(-1, 16 * self.opt.ngf, 1, 2)
         x = F.interpolate(x, size=(self.sh, self.sw))
@@ -314,6 +315,7 @@ class MultiscaleDiscriminator(nn.Module):
         return F.avg_pool2d(x, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
 
     def forward(self, input):
+        spherenet.spectral_precompute(self)
         result = []
         for _, D in self.named_children():
             out = D(input)

@@ -820,17 +820,20 @@ class _SpectralW2Fn(torch.autograd.Function):
     memory order of the gather-GEMM kernels: ``csrc/spectral.hip``, 4 launches forward and 2 backward."""
 
     @staticmethod
-    def forward(ctx, w, u, v, iterate, eps):
+    def forward(ctx, w, u, v, iterate, eps, pre=None):
         from .. import _lib
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
         O, C = w.shape[0], w.shape[1]
-        w = w.contiguous()
-        w2 = torch.empty(O, 9 * C, dtype=torch.float32, device=w.device)
-        sigma = torch.empty(1, dtype=torch.float32, device=w.device)
-        uv = torch.empty(O + 9 * C, dtype=torch.float32, device=w.device)
-        scratch = torch.empty(L.eml_spectral_norm_scratch_floats(O, C), dtype=torch.float32, device=w.device)
-        _lib.check(L.eml_spectral_norm_w2_f32(p(w), p(u), p(v), int(bool(iterate)), float(eps), p(w2), p(sigma), p(uv),
-                                              p(scratch), O, C, st), "eml_spectral_norm_w2_f32")
+        if pre is not None:   # already computed, with every other weight of the network, by spectral_precompute
+            w2, uv, sigma = pre
+        else:
+            w = w.contiguous()
+            w2 = torch.empty(O, 9 * C, dtype=torch.float32, device=w.device)
+            sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+            uv = torch.empty(O + 9 * C, dtype=torch.float32, device=w.device)
+            scratch = torch.empty(L.eml_spectral_norm_scratch_floats(O, C), dtype=torch.float32, device=w.device)
+            _lib.check(L.eml_spectral_norm_w2_f32(p(w), p(u), p(v), int(bool(iterate)), float(eps), p(w2), p(sigma), p(uv),
+                                                  p(scratch), O, C, st), "eml_spectral_norm_w2_f32")
         ctx.save_for_backward(w2, uv, sigma)
         ctx.shape = (O, C)
         return w2
@@ -846,7 +849,7 @@ class _SpectralW2Fn(torch.autograd.Function):
         dw = torch.empty(O, C, 3, 3, dtype=torch.float32, device=gw2.device)
         _lib.check(L.eml_spectral_norm_w2_bwd_f32(p(gw2), p(w2), p(uv[:O]), p(uv[O:]), p(sigma), p(partial), p(dw), O, C, st),
                    "eml_spectral_norm_w2_bwd_f32")
-        return dw, None, None, None, None
+        return dw, None, None, None, None, None
 
 
 class _FusedSpectralNormHook:
@@ -857,15 +860,29 @@ class _FusedSpectralNormHook:
 
     def __init__(self, inner):
         self.inner = inner
+        self.pre = None   # (key, (w2, uv, sigma)) left by spectral_precompute for this module's NEXT call
+
+    @staticmethod
+    def eligible(sn, w):
+        return (w.is_cuda and w.dtype == torch.float32 and sn.dim == 0 and sn.n_power_iterations == 1 and w.dim() == 4
+                and tuple(w.shape[2:]) == (3, 3))
+
+    @staticmethod
+    def key(module, w, u, v):
+        # what a precomputed result was formed from: the parameter and the buffers AS THEY WERE LEFT by the batch (a load_state_dict,
+        # an optimizer step or another forward in between changes a version and the result is dropped)
+        return (id(w), w._version, id(u), u._version, id(v), v._version, bool(module.training), torch.is_grad_enabled())
 
     def __call__(self, module, inputs):
         sn = self.inner
         w = getattr(module, sn.name + "_orig")
-        if (w.is_cuda and w.dtype == torch.float32 and sn.dim == 0 and sn.n_power_iterations == 1 and w.dim() == 4
-                and tuple(w.shape[2:]) == (3, 3)):
+        if self.eligible(sn, w):
             u, v = getattr(module, sn.name + "_u"), getattr(module, sn.name + "_v")
             O, C = w.shape[0], w.shape[1]
-            w2 = _SpectralW2Fn.apply(w, u, v, module.training, sn.eps)
+            pre, self.pre = self.pre, None
+            if pre is not None and pre[0] != self.key(module, w, u, v):
+                pre = None
+            w2 = _SpectralW2Fn.apply(w, u, v, module.training, sn.eps, None if pre is None else pre[1])
             wn = w2.view(O, 3, 3, C).permute(0, 3, 1, 2)
             if not isinstance(module, SphereConv2D):
                 # an nn.Conv2d (the crop encoder's stride-2 layers) runs on MIOpen, which takes a channels-last WEIGHT down a
@@ -875,6 +892,64 @@ class _FusedSpectralNormHook:
             setattr(module, sn.name, wn)
         else:
             sn(module, inputs)
+
+
+# EML_SN_BATCH=0: A/B knob -- every hook launches its own five kernels again
+_sn_batch = knob_flag("EML_SN_BATCH", True)
+
+
+def spectral_precompute(root):
+    """Spectral normalisation of EVERY fused-hook convolution under ``root`` in five launches (``eml_spectral_norm_w2_batch_f32``),
+    called at the top of a network's forward: torch's hook -- and round 4's fused one -- run in front of each convolution
+    (architecture.py:41-45), 5 launches of 5-10 us each for 23 + 6 weights, twice per iteration.  The power iteration updates
+    each module's ``weight_u`` / ``weight_v`` exactly as its own call would (same kernels, same buffers); every hook then
+    picks its result up on the module's next call, provided nothing it was formed from has changed (``_FusedSpectralNormHook.key``),
+    and falls back to its own launches otherwise -- a module called twice in one forward iterates twice, as the reference's."""
+    if not _sn_batch:
+        return
+    plan = root.__dict__.get("_eml_sn_plan")
+    if plan is None:
+        plan = [(m, h) for m in root.modules() for h in m._forward_pre_hooks.values() if isinstance(h, _FusedSpectralNormHook)]
+        root.__dict__["_eml_sn_plan"] = plan
+    groups = {}
+    for m, h in plan:
+        sn = h.inner
+        w = getattr(m, sn.name + "_orig", None)
+        if w is None or not h.eligible(sn, w) or not w.is_contiguous():
+            continue
+        groups.setdefault((bool(m.training), float(sn.eps), w.device), []).append((m, h, w))
+    if not groups:
+        return
+    import ctypes
+    from .. import _lib
+    L, st = _lib.lib(), _lib.current_stream()
+    for (iterate, eps, dev), items in groups.items():
+        n = len(items)
+        if n < 2:
+            continue
+        shapes = [(w.shape[0], w.shape[1]) for _, _, w in items]
+        # one allocation for the small per-weight buffers (sigma | uv | scratch, each 8-byte aligned), one per W2 (kept for the
+        # backward one by one)
+        sizes = [(2, O + 9 * C + ((O + 9 * C) & 1), (L.eml_spectral_norm_scratch_floats(O, C) + 1) & ~1) for O, C in shapes]
+        flat = torch.empty(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
+        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+        us, vs, w2s, sigmas, uvs, scr, off = [], [], [], [], [], [], 0
+        for (m, h, w), (O, C), (a, b, c) in zip(items, shapes, sizes):
+            us.append(getattr(m, h.inner.name + "_u"))
+            vs.append(getattr(m, h.inner.name + "_v"))
+            w2s.append(torch.empty(O, 9 * C, dtype=torch.float32, device=dev))
+            sigmas.append(flat[off:off + 1])
+            uvs.append(flat[off + a:off + a + O + 9 * C])
+            scr.append(flat[off + a + b:off + a + b + c])
+            off += a + b + c
+        ptrs = lambda ts: arr([t.data_ptr() for t in ts])
+        Os, Cs = (ctypes.c_int * n)(*[o for o, _ in shapes]), (ctypes.c_int * n)(*[c for _, c in shapes])
+        with torch.no_grad():
+            _lib.check(L.eml_spectral_norm_w2_batch_f32(n, ptrs([w for _, _, w in items]), ptrs(us), ptrs(vs), int(iterate), eps,
+                                                        ptrs(w2s), ptrs(sigmas), ptrs(uvs), ptrs(scr), Os, Cs, st),
+                       "eml_spectral_norm_w2_batch_f32")
+        for (m, h, w), u, v, w2, sigma, uv in zip(items, us, vs, w2s, sigmas, uvs):
+            h.pre = (h.key(m, w, u, v), (w2, uv, sigma))
 
 
 def fused_spectral_norm(module):

@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 21   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 22   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -83,6 +83,9 @@ SIGNATURES = {
     "eml_spectral_norm_w2_f32": (_int, [_f32p, _f32p, _f32p, _int, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                         _stream]),
     "eml_spectral_norm_w2_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _stream]),
+    "eml_spectral_norm_w2_batch_f32": (_int, [_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, ctypes.c_float,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, _stream]),
     "eml_spade_heads_w2_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream]),
     "eml_instance_norm_act_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, ctypes.c_float,
                                              _stream]),

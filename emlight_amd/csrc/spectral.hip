@@ -30,12 +30,15 @@ __device__ __forceinline__ double block_sum(double v, double* red /*[16]*/) {
   return s;
 }
 
+// The five forward phases are written as device functions of (operands, block coordinates): the launches below run them for a
+// BATCH of weights at once (SnBatch), each workgroup looking up its weight and its block within it.
+
 // t_part[slice][k] = sum_{o in slice} W[o][k] * u[o]
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u,
-                                                      float* __restrict__ t_part, int O, int K, int rows_per_slice) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sn_wt_u(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t_part, int O,
+                                        int K, int rows_per_slice, int bx, int by) {
+  const int k = bx * 256 + threadIdx.x;
   if (k >= K) return;
-  const int o0 = blockIdx.y * rows_per_slice, o1 = min(O, o0 + rows_per_slice);
+  const int o0 = by * rows_per_slice, o1 = min(O, o0 + rows_per_slice);
   float a0 = 0.f, a1 = 0.f;
   int o = o0;
   for (; o + 1 < o1; o += 2) {
@@ -43,21 +46,20 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ 
     a1 = fmaf(W[(size_t)(o + 1) * K + k], u[o + 1], a1);
   }
   if (o < o1) a0 = fmaf(W[(size_t)o * K + k], u[o], a0);
-  t_part[(size_t)blockIdx.y * K + k] = a0 + a1;
+  t_part[(size_t)by * K + k] = a0 + a1;
 }
 
 // t = sum of the slices, and this workgroup's share of |t|^2 (the norm is finished by its consumers: 36 values at most)
-__global__ __launch_bounds__(256) void sn_fold_t_kernel(const float* __restrict__ t_part, int S, int K, float* __restrict__ t,
-                                                        double* __restrict__ tnorm_part) {
-  __shared__ double red[16];
-  const int k = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sn_fold_t(const float* __restrict__ t_part, int S, int K, float* __restrict__ t,
+                                          double* __restrict__ tnorm_part, int bx, double* red) {
+  const int k = bx * 256 + threadIdx.x;
   float a = 0.f;
   if (k < K) {
     for (int s = 0; s < S; ++s) a += t_part[(size_t)s * K + k];
     t[k] = a;
   }
   const double tot = block_sum((double)a * a, red);
-  if (threadIdx.x == 0) tnorm_part[blockIdx.x] = tot;
+  if (threadIdx.x == 0) tnorm_part[bx] = tot;
 }
 
 __device__ __forceinline__ float inv_norm(const double* __restrict__ part, int n, float eps) {
@@ -67,10 +69,9 @@ __device__ __forceinline__ float inv_norm(const double* __restrict__ part, int n
 }
 
 // s[o] = sum_k W[o][k] v[k], v = t * vscale (vscale = 1 / max(|t|, eps) from the partials when tnorm_part != NULL): one wave per row
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
-                                                     const double* __restrict__ tnorm_part, int np, float eps,
-                                                     float* __restrict__ s, int O, int K) {
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void sn_w_v(const float* __restrict__ W, const float* __restrict__ v, const double* __restrict__ tnorm_part,
+                                       int np, float eps, float* __restrict__ s, int O, int K, int bx) {
+  const int o = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= O) return;
   const float vscale = tnorm_part ? inv_norm(tnorm_part, np, eps) : 1.f;
   const float* row = W + (size_t)o * K;
@@ -89,11 +90,10 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W
 
 // sigma, u and v of this forward, by ONE workgroup (the O-vector s is at most a few KB): sigma = u . (W v), u = s / max(|s|, eps)
 // when `iterate`, the stored u otherwise; the (u | v) actually used are kept for the backward.
-__global__ __launch_bounds__(256) void sn_sigma_kernel(const float* __restrict__ s, float* __restrict__ u, float* __restrict__ v,
-                                                       const float* __restrict__ t, const double* __restrict__ tnorm_part,
-                                                       int np, int iterate, float eps, float* __restrict__ sigma_out,
-                                                       float* __restrict__ u_used, int O, int K) {
-  __shared__ double red[16];
+__device__ __forceinline__ void sn_sigma(const float* __restrict__ s, float* __restrict__ u, float* __restrict__ v,
+                                         const float* __restrict__ t, const double* __restrict__ tnorm_part, int np, int iterate,
+                                         float eps, float* __restrict__ sigma_out, float* __restrict__ u_used, int O, int K,
+                                         double* red) {
   double q = 0.;
   for (int i = threadIdx.x; i < O; i += 256) q += iterate ? (double)s[i] * s[i] : (double)s[i] * u[i];
   const double tot = block_sum(q, red);
@@ -155,13 +155,72 @@ __device__ __forceinline__ void relayout_chunk(const float* __restrict__ src, fl
   }
 }
 
-// W2[o][tap*C + c] = W[o][c*9 + tap] / sigma
-__global__ __launch_bounds__(256) void sn_relayout_kernel(const float* __restrict__ W, const float* __restrict__ sigma,
-                                                          float* __restrict__ W2, int C) {
-  __shared__ float tile[kTile];
-  const int K = 9 * C, o = blockIdx.x, c0 = blockIdx.y * kCC, cc = min(kCC, C - c0);
-  const bool vec = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0;
-  relayout_chunk(W + (size_t)o * K + (size_t)c0 * 9, W2 + (size_t)o * K + c0, C, cc, 1.f / *sigma, vec, tile);
+// ---- the batch: up to kMaxItems weights per launch, passed by value (2.3 KB of kernel arguments)
+constexpr int kMaxItems = 32;
+struct SnItem {
+  const float* W;   // (O, 9C): the parameter
+  float *u, *v;     // the module's buffers
+  float *W2, *sigma, *uv, *scratch;
+  int O, C;
+};
+struct SnBatch {
+  SnItem it[kMaxItems];
+  int n, iterate;
+  float eps;
+};
+__host__ __device__ inline int sn_np(int K) { return (K + 255) / 256; }
+__host__ __device__ inline int sn_slices(int O) { return O / 32 < 1 ? 1 : (O / 32 > kMaxSlices ? kMaxSlices : O / 32); }
+// workgroups of one weight in phase PH: 0 W^T u partials, 1 fold, 2 W v, 3 sigma, 4 re-layout
+template <int PH>
+__host__ __device__ inline int sn_blocks(int O, int C) {
+  const int K = 9 * C;
+  return PH == 0 ? sn_np(K) * sn_slices(O) : PH == 1 ? sn_np(K) : PH == 2 ? (O + 3) / 4 : PH == 3 ? 1 : O * ((C + kCC - 1) / kCC);
+}
+// scratch of one weight: t partials | t | s | (8-byte aligned) |t|^2 partials
+struct SnScratch {
+  float *t_part, *t, *s;
+  double* tnorm_part;
+};
+__host__ __device__ inline SnScratch sn_scratch(float* scratch, int O, int K) {
+  SnScratch r;
+  r.t_part = scratch;
+  r.t = scratch + (size_t)kMaxSlices * K;
+  r.s = r.t + K;
+  r.tnorm_part = reinterpret_cast<double*>(scratch + (((size_t)(kMaxSlices + 1) * K + O + 1) & ~(size_t)1));
+  return r;
+}
+
+template <int PH>
+__global__ __launch_bounds__(256) void sn_phase_kernel(SnBatch b) {
+  __shared__ double red[16];
+  __shared__ float tile[PH == 4 ? kTile : 1];
+  // which weight, which of its blocks (a scalar walk over at most 32 entries of the kernel arguments)
+  int item = 0, local = (int)blockIdx.x;
+  for (; item < b.n; ++item) {
+    const int cnt = sn_blocks<PH>(b.it[item].O, b.it[item].C);
+    if (local < cnt) break;
+    local -= cnt;
+  }
+  if (item >= b.n) return;
+  const SnItem& w = b.it[item];
+  const int O = w.O, C = w.C, K = 9 * C, np = sn_np(K);
+  const SnScratch sc = sn_scratch(w.scratch, O, K);
+  if constexpr (PH == 0) {
+    const int slices = sn_slices(O), rps = (O + slices - 1) / slices;
+    sn_wt_u(w.W, w.u, sc.t_part, O, K, rps, local % np, local / np);
+  } else if constexpr (PH == 1) {
+    sn_fold_t(sc.t_part, sn_slices(O), K, sc.t, sc.tnorm_part, local, red);
+  } else if constexpr (PH == 2) {
+    if (b.iterate) sn_w_v(w.W, sc.t, sc.tnorm_part, np, b.eps, sc.s, O, K, local);
+    else sn_w_v(w.W, w.v, nullptr, 0, b.eps, sc.s, O, K, local);
+  } else if constexpr (PH == 3) {
+    sn_sigma(sc.s, w.u, w.v, sc.t, sc.tnorm_part, np, b.iterate, b.eps, w.sigma, w.uv, O, K, red);
+  } else {
+    // W2[o][tap*C + c] = W[o][c*9 + tap] / sigma
+    const int o = local % O, c0 = (local / O) * kCC, cc = min(kCC, C - c0);
+    const bool vec = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(w.W) | reinterpret_cast<uintptr_t>(w.W2)) & 15) == 0;
+    relayout_chunk(w.W + (size_t)o * K + (size_t)c0 * 9, w.W2 + (size_t)o * K + c0, C, cc, 1.f / *w.sigma, vec, tile);
+  }
 }
 
 // SPADE's two heads (normalization.py:96-98: mlp_gamma, mlp_beta, each (Cn, C, 3, 3) + bias) as ONE (2 Cn, 9 C) operand in the
@@ -255,33 +314,68 @@ extern "C" size_t eml_spectral_norm_scratch_floats(int O, int C) {
   return (size_t)(kMaxSlices + 1) * 9 * C + O + 2 * ((9 * C + 255) / 256 + 1);   // t partials, t, s, |t|^2 partials (doubles)
 }
 
+namespace {
+template <int PH>
+void sn_launch_phase(const SnBatch& b, hipStream_t st) {
+  long blocks = 0;
+  for (int i = 0; i < b.n; ++i) blocks += sn_blocks<PH>(b.it[i].O, b.it[i].C);
+  hipLaunchKernelGGL(sn_phase_kernel<PH>, dim3((unsigned)blocks), dim3(256), 0, st, b);
+}
+void sn_launch(const SnBatch& b, hipStream_t st) {
+  if (b.iterate) {
+    sn_launch_phase<0>(b, st);
+    sn_launch_phase<1>(b, st);
+  }
+  sn_launch_phase<2>(b, st);
+  sn_launch_phase<3>(b, st);
+  sn_launch_phase<4>(b, st);
+}
+const char* sn_check_item(const float* W, const float* u, const float* v, const float* W2, const float* sigma, const float* uv,
+                          const float* scratch, int O, int C) {
+  if (!W || !u || !v || !W2 || !sigma || !uv || !scratch || O < 1 || C < 1) return "null pointer or empty shape";
+  if ((size_t)9 * C * sizeof(float) > 160 * 1024) return "C too wide";
+  return nullptr;
+}
+}  // namespace
+
 extern "C" int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, float eps, float* W2, float* sigma,
                                         float* uv_used /*[O + 9C]*/, float* scratch, int O, int C, eml_stream_t stream) {
-  if (!W || !u || !v || !W2 || !sigma || !uv_used || !scratch || O < 1 || C < 1)
-    return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: null pointer or empty shape");
+  if (const char* why = sn_check_item(W, u, v, W2, sigma, uv_used, scratch, O, C))
+    return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: %s (O=%d, C=%d)", why, O, C);
   if (!(eps > 0.f)) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: eps must be positive");
-  const int K = 9 * C;
-  if ((size_t)K * sizeof(float) > 160 * 1024) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_f32: C = %d too wide", C);
-  hipStream_t st = (hipStream_t)stream;
-  float* t_part = scratch;
-  float* t = scratch + (size_t)kMaxSlices * K;
-  float* s = t + K;
-  // the doubles sit behind the floats, 8-byte aligned
-  double* tnorm_part = reinterpret_cast<double*>(scratch + (((size_t)(kMaxSlices + 1) * K + O + 1) & ~(size_t)1));
-  const int np = (K + 255) / 256;
-  if (iterate) {
-    const int slices = std::max(1, std::min(kMaxSlices, O / 32));
-    const int rps = (O + slices - 1) / slices;
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(np, slices), dim3(256), 0, st, W, u, t_part, O, K, rps);
-    hipLaunchKernelGGL(sn_fold_t_kernel, dim3(np), dim3(256), 0, st, t_part, slices, K, t, tnorm_part);
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, t, tnorm_part, np, eps, s, O, K);
-  } else {
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3((O + 3) / 4), dim3(256), 0, st, W, v, nullptr, 0, eps, s, O, K);
-  }
-  hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, s, u, v, t, tnorm_part, np, iterate ? 1 : 0, eps, sigma, uv_used,
-                     O, K);
-  hipLaunchKernelGGL(sn_relayout_kernel, dim3(O, (C + kCC - 1) / kCC), dim3(256), 0, st, W, sigma, W2, C);
+  SnBatch b;
+  b.it[0] = SnItem{W, u, v, W2, sigma, uv_used, scratch, O, C};
+  b.n = 1;
+  b.iterate = iterate ? 1 : 0;
+  b.eps = eps;
+  sn_launch(b, (hipStream_t)stream);
   return eml::check_launch("eml_spectral_norm_w2_f32");
+}
+
+// The same for n weights in 5 launches altogether (ceil(n / 32) x 5): every weight of a network that is spectrally normalised
+// at the top of its forward, instead of 5 launches of 5-10 us in front of each convolution.  All weights share `iterate` and
+// `eps`; item i uses its own buffers exactly as eml_spectral_norm_w2_f32 does (the results are bit-identical to n such calls).
+extern "C" int eml_spectral_norm_w2_batch_f32(int n, const float* const* W, float* const* u, float* const* v, int iterate, float eps,
+                                              float* const* W2, float* const* sigma, float* const* uv_used,
+                                              float* const* scratch, const int* O, const int* C, eml_stream_t stream) {
+  if (n < 0 || (n > 0 && (!W || !u || !v || !W2 || !sigma || !uv_used || !scratch || !O || !C)))
+    return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_batch_f32: null array or negative count");
+  if (!(eps > 0.f)) return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_batch_f32: eps must be positive");
+  for (int i = 0; i < n; ++i)
+    if (const char* why = sn_check_item(W[i], u[i], v[i], W2[i], sigma[i], uv_used[i], scratch[i], O[i], C[i]))
+      return eml::fail(EML_EINVAL, "eml_spectral_norm_w2_batch_f32: item %d: %s (O=%d, C=%d)", i, why, O[i], C[i]);
+  for (int i0 = 0; i0 < n; i0 += kMaxItems) {
+    SnBatch b;
+    b.n = std::min(kMaxItems, n - i0);
+    b.iterate = iterate ? 1 : 0;
+    b.eps = eps;
+    for (int j = 0; j < b.n; ++j) {
+      const int i = i0 + j;
+      b.it[j] = SnItem{W[i], u[i], v[i], W2[i], sigma[i], uv_used[i], scratch[i], O[i], C[i]};
+    }
+    sn_launch(b, (hipStream_t)stream);
+  }
+  return eml::check_launch("eml_spectral_norm_w2_batch_f32");
 }
 
 extern "C" int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, const float* u_used, const float* v,

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 21
+#define EML_ABI_VERSION 22
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -587,6 +587,13 @@ int eml_spectral_norm_w2_f32(const float* W, float* u, float* v, int iterate, fl
                              float* uv_used, float* scratch, int O, int C, eml_stream_t stream);
 int eml_spectral_norm_w2_bwd_f32(const float* dW2, const float* W2, const float* u_used, const float* v_used,
                                  const float* sigma, double* partial, float* dW, int O, int C, eml_stream_t stream);
+/* eml_spectral_norm_w2_f32 for n weights at once (host arrays of n device pointers / shapes; one `iterate` and `eps` for all):
+ * 5 launches for every spectrally normalised convolution of a network (the generator: 23, the discriminators: 6) at the top
+ * of its forward, where torch's per-module hook (architecture.py:41-45 wraps each convolution) puts them in front of each
+ * layer.  Item i is computed from and into its own buffers exactly as by the single call: bit-identical results. */
+int eml_spectral_norm_w2_batch_f32(int n, const float* const* W, float* const* u, float* const* v, int iterate, float eps,
+                                   float* const* W2, float* const* sigma, float* const* uv_used, float* const* scratch,
+                                   const int* O, const int* C, eml_stream_t stream);
 
 /* SPADE's two heads (normalization.py:96-98: mlp_gamma, mlp_beta -- SphereConv2D(nhidden, Cn) each) as the ONE (2 Cn, 9 C)
  * operand of the gamma | beta product, columns (tap, c): W2[p][tap*C + c] = W_head(p)[c(p)][c][tap], b2[p] = b_head(p)[c(p)]

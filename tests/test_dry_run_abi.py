@@ -214,3 +214,38 @@ def test_one_launch_spade_and_few_output_channel_calls_match_the_abi(recorder, m
         assert name in recorder.calls[n:], name
     assert "eml_sphere_im2col_f32" not in recorder.calls[n:] and "eml_sphere_col2im_f32" not in recorder.calls[n:]
     assert xi.grad.shape == xi.shape and conv.weight.grad.shape == conv.weight.shape
+
+
+def test_batched_spectral_norm_calls_match_the_abi(recorder, monkeypatch):
+    """Round 5: ``spectral_precompute`` normalises every fused-hook weight under a root in one batch call; each hook then
+    picks its result up once, and falls back to its own launches when the weight changed in between."""
+    from emlight_amd.GenProjector import spherenet
+    hook_t = spherenet._FusedSpectralNormHook
+    monkeypatch.setattr(hook_t, "eligible", staticmethod(lambda sn, w: w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)))
+    root = torch.nn.Sequential(spherenet.fused_spectral_norm(spherenet.SphereConv2D(8, 16)),
+                               spherenet.fused_spectral_norm(spherenet.SphereConv2D(16, 4)),
+                               spherenet.fused_spectral_norm(torch.nn.Conv2d(4, 4, 3)))
+    hooks = [h for m in root for h in m._forward_pre_hooks.values()]
+    assert all(isinstance(h, hook_t) for h in hooks) and len(hooks) == 3
+    spherenet.spectral_precompute(root)
+    assert recorder.calls.count("eml_spectral_norm_w2_batch_f32") == 1
+    name, args = recorder.args[-1]
+    assert args[0] == 3 and list(args[10]) == [16, 4, 4] and list(args[11]) == [8, 16, 4] and args[4] == 1   # n, O[], C[], iterate
+    assert all(h.pre is not None for h in hooks)
+    n = len(recorder.calls)
+    hooks[0](root[0], ())
+    assert hooks[0].pre is None and "eml_spectral_norm_w2_f32" not in recorder.calls[n:]     # picked up, once
+    assert tuple(root[0].weight.shape) == (16, 8, 3, 3)
+    hooks[0](root[0], ())
+    assert recorder.calls[n:].count("eml_spectral_norm_w2_f32") == 1                         # a second call iterates itself
+    with torch.no_grad():
+        root[1].weight_orig.mul_(2.0)                                                        # e.g. an optimizer step in between
+    hooks[1](root[1], ())
+    assert recorder.calls[n:].count("eml_spectral_norm_w2_f32") == 2 and hooks[1].pre is None
+    root.eval()
+    spherenet.spectral_precompute(root)
+    assert recorder.args[-1][1][4] == 0                                                      # eval: stored u, v
+    monkeypatch.setattr(spherenet, "_sn_batch", False)
+    n = len(recorder.calls)
+    spherenet.spectral_precompute(root)
+    assert len(recorder.calls) == n

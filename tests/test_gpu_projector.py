@@ -826,6 +826,90 @@ def test_fused_spectral_norm_vs_torch_hook(O, C):
     assert w2.is_contiguous()
 
 
+@pytest.mark.parametrize("iterate", [1, 0])
+def test_batched_spectral_norm_is_bit_identical_to_single_calls(iterate):
+    """``eml_spectral_norm_w2_batch_f32`` (round 5: every normalised weight of a network in five launches) against one
+    ``eml_spectral_norm_w2_f32`` per weight on copies of the same operands: W2, sigma, the (u | v) record and the updated
+    buffers, bit for bit -- 37 weights (two chunks of the 32-entry batch), wide, narrow, non-multiple-of-4 channel counts."""
+    import ctypes
+    from emlight_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    g = torch.Generator(device="cuda").manual_seed(17 + iterate)
+    shapes = [(64, 64), (128, 256), (1024, 1024), (32, 3), (8, 5), (512, 1024), (3, 64)] + [(16 + 8 * i, 12 + 4 * i) for i in range(30)]
+
+    def operands():
+        out = []
+        for O, C in shapes:
+            out.append(dict(O=O, C=C, W=torch.randn(O, C, 3, 3, device="cuda", generator=g) * 0.05,
+                            u=torch.nn.functional.normalize(torch.randn(O, device="cuda", generator=g), dim=0),
+                            v=torch.nn.functional.normalize(torch.randn(9 * C, device="cuda", generator=g), dim=0)))
+        return out
+    ops = operands()
+    res = {}
+    for mode in ("single", "batch"):
+        items = [dict(o, u=o["u"].clone(), v=o["v"].clone(), W2=torch.full((o["O"], 9 * o["C"]), float("nan"), device="cuda"),
+                      sigma=torch.zeros(1, device="cuda"), uv=torch.zeros(o["O"] + 9 * o["C"], device="cuda"),
+                      scratch=torch.empty(L.eml_spectral_norm_scratch_floats(o["O"], o["C"]), device="cuda")) for o in ops]
+        if mode == "single":
+            for it in items:
+                _lib.check(L.eml_spectral_norm_w2_f32(p(it["W"]), p(it["u"]), p(it["v"]), iterate, 1e-12, p(it["W2"]), p(it["sigma"]),
+                                                      p(it["uv"]), p(it["scratch"]), it["O"], it["C"], st), "single")
+        else:
+            n = len(items)
+            arr = lambda key: (ctypes.c_void_p * n)(*[it[key].data_ptr() for it in items])
+            ints = lambda key: (ctypes.c_int * n)(*[it[key] for it in items])
+            _lib.check(L.eml_spectral_norm_w2_batch_f32(n, arr("W"), arr("u"), arr("v"), iterate, 1e-12, arr("W2"), arr("sigma"),
+                                                        arr("uv"), arr("scratch"), ints("O"), ints("C"), st), "batch")
+        torch.cuda.synchronize()
+        res[mode] = items
+    for a, b in zip(res["single"], res["batch"]):
+        for key in ("W2", "sigma", "uv", "u", "v"):
+            assert torch.equal(a[key], b[key]), (a["O"], a["C"], key)
+        assert bool(torch.isfinite(b["W2"]).all())
+    assert L.eml_spectral_norm_w2_batch_f32(0, None, None, None, 1, 1e-12, None, None, None, None, None, None, st) == 0   # empty batch
+
+
+def test_generator_with_batched_spectral_norm_equals_per_module_hooks(monkeypatch):
+    """The generator's forward + backward with ``spectral_precompute`` (default) and with every hook launching for itself
+    (EML_SN_BATCH=0): the image, the power-iteration buffers and every parameter gradient of this repo's kernels, bit for bit."""
+    import copy
+    from emlight_amd.GenProjector import networks, spherenet
+    torch.manual_seed(3)
+    opt = networks.default_options()
+    opt.ngf = 8
+    a = networks.SPADEGenerator(opt).cuda()
+    networks.init_weights(a, "xavier", 0.02)
+    b = copy.deepcopy(a)
+    guide = torch.rand(2, 3, 128, 256, device="cuda")
+    crop = torch.rand(2, 3, 96, 128, device="cuda")
+    outs = []
+    for net, flag in ((a, True), (b, False)):
+        monkeypatch.setattr(spherenet, "_sn_batch", flag)
+        net.train()
+        for _ in range(2):   # two passes: the second starts from the buffers the first one left
+            net.zero_grad(set_to_none=True)
+            y = net(guide, crop)
+            y.square().mean().backward()
+        with torch.no_grad():
+            net.eval()
+            ye = net(guide, crop)
+        outs.append((y.detach(), ye, {n: q.grad for n, q in net.named_parameters()}, dict(net.named_buffers())))
+    (ya, yea, ga, ba), (yb, yeb, gb, bb) = outs
+    assert torch.equal(ya, yb) and torch.equal(yea, yeb)
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None), n
+        if ga[n] is None:
+            continue
+        if n.startswith("netE."):   # the crop encoder's nn.Conv2d / Linear run on MIOpen / the BLAS library: their weight
+            torch.testing.assert_close(ga[n], gb[n], rtol=1e-3, atol=1e-4 * float(gb[n].abs().max()))   # gradients are not run-to-run exact
+        else:
+            assert torch.equal(ga[n], gb[n]), n
+    for n in ba:
+        assert torch.equal(ba[n], bb[n]), n
+    plan = a.__dict__["_eml_sn_plan"]
+    assert len(plan) == 23 and all(h.pre is None for _, h in plan)   # 18 SphereConvs of the blocks + the crop encoder's 5; all consumed
+
+
 @pytest.mark.parametrize("fin,fout,H,W,train", [(64, 32, 8, 16, True), (128, 64, 16, 32, True), (32, 16, 4, 8, False)])
 def test_spade_block_with_the_upsample_folded_in(fin, fout, H, W, train):
     """``blk(x, seg, up2=True)`` (the nearest x2 upsample of generator.py:70-82 folded into the SPADE kernels: statistics from the
