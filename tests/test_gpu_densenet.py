@@ -386,7 +386,7 @@ def test_pair_pass_of_the_1x1_backward_matches_the_default_path(monkeypatch):
     x / G rows (csrc/dense_bwd_pair.hip: both weight gradients + both data gradients + BN1's statistics; the narrow pass
     that unblocks the lower layer's 3x3 backward is its own small kernel).  It is an A/B build (measured slower than the
     separate kernels), kept correct: every parameter gradient against the default path
-    on the same network, to the f32-reassociation bound the default path itself meets against the f64 oracle."""
+    on the same network, to the bounds the default path itself meets against the oracle (_grad_check)."""
     anchors, crop, B = 32, (64, 96), 2
     _, net = _pair(anchors, crop, seed=11)
     net.train()
@@ -403,9 +403,13 @@ def test_pair_pass_of_the_1x1_backward_matches_the_default_path(monkeypatch):
         torch.cuda.synchronize()
         return {n: q.grad.double().cpu().numpy() for n, q in net.named_parameters()}
     base, pair = run("0"), run("1")
-    worst = 0.0
-    for n, t in base.items():
-        rms = float(np.sqrt(np.mean(np.square(t)))) + 1e-30
-        worst = max(worst, float(np.abs(pair[n] - t).max() / rms))
-    print("pair pass vs default path: worst |diff| / rms(grad) = %.2e over %d tensors" % (worst, len(base)))
-    assert worst < 2e-3   # measured ~1e-4: different summation orders of the same f32 products
+    # the metric of _grad_check: relative L2 per tensor with a floor for the analytically-zero gradients (a max-norm ratio
+    # blows up on last_norm*.bias, whose true gradient is 0, and on the one element a flipped ReLU bit moves)
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a))))
+    floor = 1e-3 * np.median([rms(t) for t in base.values()])
+    errs = sorted(((rms(pair[n] - t) / max(rms(t), floor), n) for n, t in base.items()), reverse=True)
+    print("pair pass vs default path: max rel-L2 %.2e (%s), median %.2e over %d tensors"
+          % (errs[0][0], errs[0][1], np.median([e for e, _ in errs]), len(errs)))
+    assert all(np.isfinite(t).all() for t in pair.values())
+    assert errs[0][0] < GRAD_L2_MAX, errs[:8]
+    assert np.median([e for e, _ in errs]) < GRAD_L2_MEDIAN
