@@ -545,6 +545,12 @@ def _free_gpu():
     torch.cuda.reset_peak_memory_stats()
 
 
+def _gemm_selection_status():
+    """Whether the plain library GEMMs of this run used the recorded selection (emlight_amd/_gemm_selection.py)."""
+    from emlight_amd import _gemm_selection
+    return _gemm_selection.status()
+
+
 def leg_projector(args, rank, world, dev, steps, warmup):
     """SURVEY 8d metric (ii): GenProjector training images/sec, one G step + one D step (GenProjector/train.py:33-37)
     at BASELINE configs[2] (B=32 per GPU, 128x256 panoramas).  SphereConv2D and SPADE's modulation run on the HIP
@@ -583,7 +589,8 @@ def leg_projector(args, rank, world, dev, steps, warmup):
            "config": {"workload": "GenProjector train step (G+D), BASELINE configs[2]", "per_gpu_batch": B,
                       "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
                       "vgg": "VGG19 to relu5_1 on fake and real, seeded random weights (pretrained ones are not obtainable "
-                             "offline; injectable via opt.vgg_weights)"},
+                             "offline; injectable via opt.vgg_weights)",
+                      "library_gemm_selection": _gemm_selection_status()},
            "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
                            "frac_of_f32_mfma_peak": round(PROJECTOR_STEP_GFLOP * value0 / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
                            "note": "the round-1/2 configuration (no_vgg_loss=True): a step lighter than the reference's"},
@@ -643,7 +650,8 @@ def leg_joint(args, rank, world, dev, steps, warmup):
            "ms_per_step": round(dt / steps * 1e3, 3),
            "config": {"workload": "joint regression+projector train step, BASELINE configs[3] (256 over 8 GPUs)",
                       "per_gpu_batch": B, "global_batch": B * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
-                      "pano_hw": [128, 256], "ngf": 64, "ndf": 64, "vgg": "VGG19 perceptual term on, seeded random weights"},
+                      "pano_hw": [128, 256], "ngf": 64, "ndf": 64, "vgg": "VGG19 perceptual term on, seeded random weights",
+                      "library_gemm_selection": _gemm_selection_status()},
            "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
                            "frac_of_f32_mfma_peak": round((enc_gflop + PROJECTOR_STEP_GFLOP) * value0 / world / 1e3
                                                           / F32_MFMA_PEAK_TFLOPS, 4)},

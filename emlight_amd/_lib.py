@@ -195,6 +195,9 @@ def lib():
             raise EmlightHipError("libemlight_hip.so has ABI version %d, this binding expects %d -- rebuild it "
                                   "(make -C emlight_amd/csrc)" % (got, ABI_VERSION))
         _lib = handle
+    # one-time initialisation that belongs to "the GPU path is now in use": the recorded library-GEMM selection
+    from . import _gemm_selection
+    _gemm_selection.ensure()
     return _lib
 
 

@@ -1,0 +1,82 @@
+"""The recorded library-GEMM selection (emlight_amd/_gemm_selection.py, tuned_gemms_gfx950.csv): the record is well formed and
+the switch is inert without a GPU (CPU); on the MI355X it is in effect, deterministic and numerically a plain f32 GEMM."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def _fresh():
+    from emlight_amd import _gemm_selection as gs
+    gs._state.update(done=False, active=False, why="not initialised", entries=0)
+    return gs
+
+
+def test_record_is_well_formed():
+    from emlight_amd import _gemm_selection as gs
+    lines = [l.rstrip("\n") for l in open(gs.CSV)]
+    validators = {l.split(",")[1]: l.split(",")[2] for l in lines if l.startswith("Validator,")}
+    assert set(validators) == {"PT_VERSION", "HIP_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME", "ROCBLAS_VERSION"}
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    entries = [l.split(",") for l in lines if l and not l.startswith("Validator,")]
+    assert len(entries) >= 60
+    keys = set()
+    for op, key, solution, ms in entries:
+        assert re.fullmatch(r"Gemm(AndBias|Strided)?(Batched)?TunableOp_float_[NT][NT]", op), op
+        assert re.fullmatch(r"[nt][nt]_\d+_\d+_\d+(_B_\d+)?_ld_\d+_\d+_\d+", key), key
+        assert re.fullmatch(r"Default|Gemm_(Hipblaslt|Rocblas)_-?\d+", solution), solution
+        assert float(ms) > 0
+        assert (op, key) not in keys
+        keys.add((op, key))
+    # the products the record is for: the 1024 x 1024 x 3 x 3 layers of the generator at 8 x 16, 32 per GPU (forward, weight
+    # and input gradient)
+    assert any("_1024_4096_9216_" in k or "_4096_1024_9216_" in k for _, k in keys)
+    assert any("_9216_" in k and "_4096_" in k for _, k in keys)
+
+
+def test_switch_is_inert_without_a_gpu_and_obeys_its_knobs(monkeypatch):
+    gs = _fresh()
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side behaviour")
+    assert gs.ensure() is False and gs.status() == {"active": False, "why": "no GPU", "entries": 0}
+    gs = _fresh()
+    monkeypatch.setenv("EML_TUNED_GEMMS", "0")
+    assert gs.ensure() is False and gs.status()["why"] == "EML_TUNED_GEMMS=0"
+    monkeypatch.delenv("EML_TUNED_GEMMS")
+    gs = _fresh()
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_TUNING", "1")   # the process that MAKES the record must not be steered by the old one
+    assert gs.ensure() is False and "PYTORCH_TUNABLEOP" in gs.status()["why"]
+    assert gs.ensure() is False   # idempotent
+    _fresh()
+
+
+@pytest.mark.gpu
+def test_recorded_selection_is_in_effect_deterministic_and_a_plain_f32_gemm():
+    from emlight_amd import _gemm_selection as gs, _lib
+    _lib.lib()
+    st = gs.status()
+    if not st["active"]:
+        assert "validators" in st["why"] or "TUNED_GEMMS" in st["why"] or "PYTORCH_TUNABLEOP" in st["why"], st
+        pytest.skip("recorded selection not in effect here: %s" % st["why"])
+    import torch.cuda.tunable as tn
+    assert tn.is_enabled() and not tn.tuning_is_enabled() and st["entries"] >= 60
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, C, O = 4096, 1024, 1024   # G_middle's convolutions at 8 x 16, B = 32
+    a9 = torch.randn(M, 9 * C, device="cuda", generator=g)
+    w2 = torch.randn(O, 9 * C, device="cuda", generator=g) * 0.02
+    gy = torch.randn(M, O, device="cuda", generator=g)
+    bias = torch.randn(O, device="cuda", generator=g)
+    prods = {"forward": lambda: torch.addmm(bias, a9, w2.t()), "weight gradient": lambda: a9.t() @ gy, "input gradient": lambda: gy @ w2}
+    refs = {"forward": lambda: bias.double() + a9.double() @ w2.double().t(), "weight gradient": lambda: a9.double().t() @ gy.double(),
+            "input gradient": lambda: gy.double() @ w2.double()}
+    for name, f in prods.items():
+        y0, y1, y2 = f(), f(), f()
+        assert torch.equal(y0, y1) and torch.equal(y0, y2), name            # no atomics in the recorded solutions
+        ref = refs[name]()
+        err = float((y0.double() - ref).norm() / ref.norm())
+        assert err < 2e-6, (name, err)                                      # f32 accumulation over K = 9216 / 4096: ~3e-7
+    n_before = len(tn.get_results())
+    torch.randn(37, 53, device="cuda") @ torch.randn(53, 29, device="cuda")   # a shape not in the record: library default,
+    assert len(tn.get_results()) == n_before                                  # nothing tuned, nothing recorded
