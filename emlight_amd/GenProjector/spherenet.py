@@ -254,6 +254,11 @@ class _SphereConvFn(torch.autograd.Function):
                 y += res
             if slope != 1.0:
                 y = torch.relu_(y) if slope == 0.0 else nn.functional.leaky_relu_(y, slope)
+        # A9 exists (the forward ran as im2col + library GEMM: wide heads, O >= 512): the weight gradient is then ONE long-K
+        # library GEMM on it -- 145-152 TF/s on the recorded selection (_gemm_selection.py) against the fused kernel's 110,
+        # with no gather pass of its own.  (Round 5; before the GEMMs were tuned the fused kernel won above 256 MB of operand.)
+        if a9 is not None and SphereConv2D.lib_wgrad_on_kept_operand and SphereConv2D.keep_operand and weight.requires_grad:
+            ctx.fused_wgrad = False
         # the library weight gradient needs A9 again: keep it (9x the input) or rebuild it from x; the fused one never does
         ctx.keep = (a9 is not None and not ctx.fused_wgrad and SphereConv2D.keep_operand and weight.requires_grad)
         ctx.slope = slope
@@ -383,11 +388,13 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             if split > 1:
                 gw2 = torch.bmm(a9.view(split, m_rows // split, 9 * C).transpose(1, 2),
                                 gyr.view(split, m_rows // split, O)).sum(0)
+                gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
             else:
-                # (9C, O) = A9^T gy: the orientation rocBLAS runs 3-8 % faster for these long-K products (tools/gemm_shapes.py)
+                # (9C, O) = A9^T gy, then one transposing copy into the (O, tap, c) layout of every other weight gradient.
+                # (gy^T A9 gives that layout directly: measured in round 5 on the recorded GEMM selection -- the copies it saves,
+                # 0.5 ms per joint step, are what that orientation's GEMMs lose: profiles/r05_ab_dispatch_late.txt)
                 gw2 = a9.t() @ gyr
-            # (O, tap, c) in memory like the fused kernels' result: the one copy this gradient needs either way
-            gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
+                gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
             del a9
     if needs[0] and not small_x:
         gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
@@ -779,6 +786,9 @@ def _spade_conv_fusable(x, actv, C, up2):
         return False
     lim = SphereConv2D.fused_min_bytes
     a9_bytes = B * H * W * 9 * Cin * 4
+    # (round 5, with the library GEMMs on their recorded selection: sending the 2C = 512 SPADEs down the two-launch path when a
+    # backward follows -- so that their weight gradient becomes a library GEMM on the kept operand -- wins 0.36 ms per weight
+    # gradient and loses 0.42 ms per forward, the one-launch kernel runs these at 133 TF/s: measured, not adopted)
     return a9_bytes >= 32 * lim or (2 * C <= 256 and a9_bytes >= lim) or (2 * C <= 512 and a9_bytes >= 8 * lim)
 
 
@@ -1025,6 +1035,9 @@ class SphereConv2D(nn.Module):
     # two full waves of them; round 4's 2048 wrote and re-read twice the partial sums for nothing (same-box A/B of the joint
     # step: 2048 -> 1024 -1.6 ms, 4096 +3 ms; profiles/r05_ab_wgrad_split.txt).  EML_WGRAD_WGS: A/B knob
     wgrad_workgroups = knob_int("EML_WGRAD_WGS", 1024, lo=256)
+    # layers whose forward left the im2col operand behind take the library's long-K GEMM for the weight gradient;
+    # EML_WGRAD_LIB_KEPT=0: A/B knob (round 4's rule: fused above 256 MB of operand and 32 k pixels)
+    lib_wgrad_on_kept_operand = knob_flag("EML_WGRAD_LIB_KEPT", True)
 
     def __init__(self, in_c, out_c, stride=1, bias=True, mode="bilinear"):
         super().__init__()

@@ -7,6 +7,8 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
 rm -f $OUT/tunableop_results*.csv
+# EXTEND=1: start from the committed record and time only the shapes it lacks (a dispatch change added a few products)
+[ -n "$EXTEND" ] && cp emlight_amd/tuned_gemms_gfx950.csv $OUT/tunableop_results0.csv
 T0=$(date +%s)
 PYTORCH_TUNABLEOP_FILENAME=$OUT/tunableop_results.csv PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 \
 PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=${1:-30} PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS=${2:-30} PYTORCH_TUNABLEOP_VERBOSE=0 \
