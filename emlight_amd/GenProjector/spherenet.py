@@ -938,9 +938,10 @@ def spectral_precompute(root):
         if n < 2:
             continue
         shapes = [(w.shape[0], w.shape[1]) for _, _, w in items]
-        # one allocation for the small per-weight buffers (sigma | uv | scratch, each 8-byte aligned), one per W2 (kept for the
-        # backward one by one)
-        sizes = [(2, O + 9 * C + ((O + 9 * C) & 1), (L.eml_spectral_norm_scratch_floats(O, C) + 1) & ~1) for O, C in shapes]
+        # one allocation for the small per-weight buffers (sigma | uv | scratch, each 16-byte aligned: the backward reads u and
+        # v as float4 where their addresses allow), one per W2 (kept for the backward one by one)
+        up4 = lambda k: (k + 3) & ~3
+        sizes = [(4, up4(O + 9 * C), up4(L.eml_spectral_norm_scratch_floats(O, C))) for O, C in shapes]
         flat = torch.empty(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
         arr = lambda vals: (ctypes.c_void_p * n)(*vals)
         us, vs, w2s, sigmas, uvs, scr, off = [], [], [], [], [], [], 0
