@@ -80,3 +80,62 @@ def test_recorded_selection_is_in_effect_deterministic_and_a_plain_f32_gemm():
     n_before = len(tn.get_results())
     torch.randn(37, 53, device="cuda") @ torch.randn(53, 29, device="cuda")   # a shape not in the record: library default,
     assert len(tn.get_results()) == n_before                                  # nothing tuned, nothing recorded
+
+
+class _FakeTunable:
+    """Stands in for torch.cuda.tunable: records the switches, answers read_file / get_results as told."""
+
+    def __init__(self, read_ok=True, n=82, boom=None):
+        self.read_ok, self.n, self.boom, self.calls, self.on = read_ok, n, boom, [], False
+
+    def enable(self, v=True):
+        self.calls.append(("enable", v))
+        self.on = bool(v)
+
+    def tuning_enable(self, v=True):
+        self.calls.append(("tuning_enable", v))
+
+    def record_untuned_enable(self, v=True):
+        self.calls.append(("record_untuned_enable", v))
+
+    def set_filename(self, name, insert_device_ordinal=False):
+        self.calls.append(("set_filename", os.path.basename(name), insert_device_ordinal))
+
+    def read_file(self, name=None):
+        if self.boom:
+            raise RuntimeError(self.boom)
+        return self.read_ok
+
+    def get_results(self):
+        return [()] * self.n
+
+
+@pytest.mark.parametrize("case", ["ok", "other stack", "empty", "raises"])
+def test_switch_falls_back_to_library_defaults_when_the_record_is_refused(monkeypatch, case):
+    """On a GPU whose software stack is not the one the record was made with TunableOp refuses the file (read_file False),
+    an API drift may raise: in every such case TunableOp ends up OFF and the reason is reported -- never a half-enabled state
+    that would start tuning inside a training step."""
+    import sys
+    import types
+    gs = _fresh()
+    for k in [k for k in os.environ if k.startswith("PYTORCH_TUNABLEOP_")]:
+        monkeypatch.delenv(k)
+    monkeypatch.delenv("EML_TUNED_GEMMS", raising=False)
+    fake = {"ok": _FakeTunable(), "other stack": _FakeTunable(read_ok=False), "empty": _FakeTunable(n=0),
+            "raises": _FakeTunable(boom="no such attribute")}[case]
+    mod = types.ModuleType("torch.cuda.tunable")
+    for name in ("enable", "tuning_enable", "record_untuned_enable", "set_filename", "read_file", "get_results"):
+        setattr(mod, name, getattr(fake, name))
+    monkeypatch.setitem(sys.modules, "torch.cuda.tunable", mod)
+    monkeypatch.setattr(torch.cuda, "tunable", mod, raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    active = gs.ensure()
+    st = gs.status()
+    assert ("tuning_enable", False) in fake.calls and ("record_untuned_enable", False) in fake.calls
+    assert ("set_filename", "tuned_gemms_gfx950.csv", False) in fake.calls   # one file for every rank: no device ordinal
+    if case == "ok":
+        assert active and fake.on and st["entries"] == 82
+    else:
+        assert not active and not fake.on and st["entries"] == 0, st
+        assert ("validators" in st["why"]) if case != "raises" else ("refused" in st["why"])
+    _fresh()
