@@ -448,10 +448,6 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
     for k in FAM:
         setattr(L, k, timed(k))
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # the instrumented iteration runs the discriminator step's generator pass eagerly: a replayed graph launches nothing
-    # through these wrappers, and the table is meant to hold every launch of a step
-    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
-    graph_was, Pix2PixModel.graph_dstep = Pix2PixModel.graph_dstep, False
     try:
         torch.cuda.synchronize()
         t0.record()
@@ -460,7 +456,6 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
         t1.record()
         torch.cuda.synchronize()
     finally:
-        Pix2PixModel.graph_dstep = graph_was
         for k in FAM:
             setattr(L, k, orig[k])
     total = t0.elapsed_time(t1) / steps
@@ -490,14 +485,9 @@ def other_breakdown(step_fn, world):
     profiled step's HOST side is slower; its kernels are not).  Returns a list of rows, or None when profiling fails."""
     try:
         from torch.profiler import ProfilerActivity, profile
-        from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
-        graph_was, Pix2PixModel.graph_dstep = Pix2PixModel.graph_dstep, False   # op shapes come from eager launches only
-        try:
-            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-                step_fn()
-                torch.cuda.synchronize()
-        finally:
-            Pix2PixModel.graph_dstep = graph_was
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step_fn()
+            torch.cuda.synchronize()
         rows = prof.key_averages(group_by_input_shape=True)
     except Exception as e:   # noqa: BLE001 -- evidence, not the product: never fail the bench line over it
         return [{"error": repr(e)[:200]}]
@@ -558,15 +548,6 @@ def _free_gpu():
     torch.cuda.reset_peak_memory_stats()
 
 
-_DSTEP_PASS = {}
-
-
-def _note_dstep_pass(leg, model):
-    """How the discriminator step's generator pass ran in the timed loop of `leg`: 'graph' (captured once, replayed) or 'eager'."""
-    g = getattr(model, "_dstep_graph", None)
-    _DSTEP_PASS[leg] = "graph" if (g is not None and g.graph is not None and not g.failed) else "eager"
-
-
 def _gemm_selection_status():
     """Whether the plain library GEMMs of this run used the recorded selection (emlight_amd/_gemm_selection.py)."""
     from emlight_amd import _gemm_selection
@@ -590,8 +571,6 @@ def leg_projector(args, rank, world, dev, steps, warmup):
             warnings.simplefilter("ignore")   # "random VGG features": stated in the JSON instead
             tr = Trainer(default_options(no_vgg_loss=no_vgg, vgg_random=True), device=dev, world=world)
         dt = run_timed(lambda: tr.step(data), steps, warmup, world, dev)
-        if not no_vgg:
-            _note_dstep_pass("projector", tr.model)
         # EVERY rank runs the instrumented step (it contains DDP's all-reduces and SPADE's statistics all-reduce); rank 0 reports
         fams = time_projector_families(tr, data, 1) if not no_vgg else None
         other = other_breakdown(lambda: tr.step(data), world) if not no_vgg else None
@@ -614,8 +593,7 @@ def leg_projector(args, rank, world, dev, steps, warmup):
                       "global_batch": B * world, "pano_hw": [128, 256], "ngf": 64, "ndf": 64,
                       "vgg": "VGG19 to relu5_1 on fake and real, seeded random weights (pretrained ones are not obtainable "
                              "offline; injectable via opt.vgg_weights)",
-                      "library_gemm_selection": _gemm_selection_status(),
-                      "dstep_generator_pass": _DSTEP_PASS.get("projector")},
+                      "library_gemm_selection": _gemm_selection_status()},
            "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
                            "frac_of_f32_mfma_peak": round(PROJECTOR_STEP_GFLOP * value0 / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
                            "note": "the round-1/2 configuration (no_vgg_loss=True): a step lighter than the reference's"},
@@ -654,8 +632,6 @@ def leg_joint(args, rank, world, dev, steps, warmup):
             tr = JointTrainer(default_options(no_vgg_loss=no_vgg, vgg_random=True), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
                               device=dev, world=world)
         dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
-        if not no_vgg:
-            _note_dstep_pass("joint", tr.proj.model)
         # every rank runs the instrumented iteration (collectives inside); rank 0 reports
         fams = None if no_vgg else time_projector_families(
             tr, batch, 1, {**ENCODER_FAMILIES, **PROJECTOR_FAMILIES},
@@ -678,7 +654,7 @@ def leg_joint(args, rank, world, dev, steps, warmup):
            "config": {"workload": "joint regression+projector train step, BASELINE configs[3] (256 over 8 GPUs)",
                       "per_gpu_batch": B, "global_batch": B * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
                       "pano_hw": [128, 256], "ngf": 64, "ndf": 64, "vgg": "VGG19 perceptual term on, seeded random weights",
-                      "library_gemm_selection": _gemm_selection_status(), "dstep_generator_pass": _DSTEP_PASS.get("joint")},
+                      "library_gemm_selection": _gemm_selection_status()},
            "without_vgg": {"value": round(value0, 2), "ms_per_step": round(dt0 / steps * 1e3, 3),
                            "frac_of_f32_mfma_peak": round((enc_gflop + PROJECTOR_STEP_GFLOP) * value0 / world / 1e3
                                                           / F32_MFMA_PEAK_TFLOPS, 4)},
