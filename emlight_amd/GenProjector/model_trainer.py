@@ -19,7 +19,8 @@ class Trainer:
         self.opt = opt
         self.model = Pix2PixModel(opt, vgg_features=vgg_features).to(device)
         self.world = world
-        if world > 1:
+        from .._dist import dp_wrap
+        if dp_wrap(world):
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
             self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
             self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)

@@ -490,8 +490,8 @@ def _stats_grid(rows, C):
 def _bn_sync():
     """SPADE's norm is SYNCHRONISED batch norm in the reference (sync_batchnorm/batchnorm.py:105-126, across the
     DataParallel replicas); here replicas are processes: the (2C+1)-float sums are all-reduced over RCCL."""
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    from .._dist import dp_active
+    return dp_active()
 
 
 def _reduce_sums(partials, rows, C, repeat=1):

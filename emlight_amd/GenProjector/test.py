@@ -6,28 +6,31 @@ import os
 import numpy as np
 import torch
 
-from . import data, networks
+from . import data, networks, options
 from .pix2pix_model import Pix2PixModel
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--name", default="laval")
-    ap.add_argument("--checkpoints_dir", default="./checkpoints")
-    ap.add_argument("--which_epoch", default="latest")
-    ap.add_argument("--results_dir", default="./results")
-    ap.add_argument("--ngf", type=int, default=64)
-    ap.add_argument("--batchSize", type=int, default=1)
-    ap.add_argument("--how_many", type=int, default=10)
+def parse_args(argv=None):
+    """The reference's flags (``options/test_options.py`` over ``base_options.py``: ``test.sh`` runs unchanged) + ``--synthetic``."""
+    ap = options.test_parser()
     args = ap.parse_args(argv)
-    dev = "cuda"
-    opt = networks.default_options(ngf=args.ngf, isTrain=False)
+    args.gpu_id_list = options.resolve_gpu_ids(args.gpu_ids, 1)
+    args.ignored_reference_flags = options.check_data_flags(args, ap, args.synthetic)
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    dev = "cuda:%d" % args.gpu_id_list[0]
+    opt = options.network_options(args, False)
     model = Pix2PixModel(opt).to(dev).eval()
     path = os.path.join(args.checkpoints_dir, args.name, "%s_net_G.pth" % args.which_epoch)
     if os.path.exists(path):
         model.netG.load_state_dict(torch.load(path, map_location=dev))
     os.makedirs(args.results_dir, exist_ok=True)
-    for i in range(args.how_many):
+    # the reference stops after 1000 samples (test.py:23-25); the synthetic stream is endless, so --how_many bounds it (default 10)
+    how_many = 10 if args.how_many == float("inf") else int(args.how_many)
+    for i in range(how_many):
         batch = data.projector_batch(args.batchSize, dev, seed=4321 + i)
         fake = model(batch, mode="inference")
         np.save(os.path.join(args.results_dir, "pred_%04d.npy" % i), fake.cpu().numpy())

@@ -2,6 +2,8 @@
 (``train.py:28-37``), torchrun-aware.  ``--synthetic`` batches replace the licence-restricted Laval dataset.
 
     python -m emlight_amd.GenProjector.train --synthetic --batchSize 8 --max_iters 10
+    python -m emlight_amd.GenProjector.train --synthetic --name lavalindoor --dataset_mode lavalindoor --dataroot /data/laval \
+        --display_freq 1000 --batchSize 16 --niter 100 --niter_decay 100 --gpu_ids 0 --continue_train      # train_laval.sh's flags
     python -m emlight_amd.GenProjector.train --synthetic --continue_train --which_epoch latest     # resume (iter.txt)
     torchrun --nproc-per-node 8 -m emlight_amd.GenProjector.train --synthetic
 """
@@ -11,36 +13,29 @@ import os
 import torch
 
 from ..RegressionNetwork.engine import init_distributed
-from . import data, networks
+from . import data, networks, options
 from .iter_counter import IterationCounter
 from .model_trainer import Trainer
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--name", default="laval")
-    ap.add_argument("--checkpoints_dir", default="./checkpoints")
-    ap.add_argument("--batchSize", type=int, default=16, help="per-GPU batch (reference: 16 over 2 GPUs)")
-    ap.add_argument("--ngf", type=int, default=64)
-    ap.add_argument("--ndf", type=int, default=64)
-    ap.add_argument("--niter", type=int, default=50)
-    ap.add_argument("--niter_decay", type=int, default=0)
-    ap.add_argument("--lr", type=float, default=2e-4)
-    ap.add_argument("--no_TTUR", action="store_true")
-    ap.add_argument("--synthetic", action="store_true")
-    ap.add_argument("--iters_per_epoch", type=int, default=100)
-    ap.add_argument("--max_iters", type=int, default=0)
-    ap.add_argument("--save_epoch_freq", type=int, default=10)
-    ap.add_argument("--save_latest_freq", type=int, default=5000, help="in samples, like the reference")
-    ap.add_argument("--print_freq", type=int, default=100, help="in samples, like the reference")
-    ap.add_argument("--continue_train", action="store_true", help="resume from <which_epoch>_net_{G,D}.pth and iter.txt")
-    ap.add_argument("--which_epoch", default="latest")
+def parse_args(argv=None):
+    """The reference's flags (``options/train_options.py`` over ``base_options.py``: ``train_laval.sh`` runs unchanged --
+    see ``options.py`` for what each one means here) plus ``--synthetic --iters_per_epoch --max_iters`` and the VGG switches.
+    Needs no GPU: a launch that disagrees with ``--gpu_ids``, or a dataset the package cannot read, exits here."""
+    ap = options.train_parser()
     networks.add_vgg_arguments(ap)
     args = ap.parse_args(argv)
+    options.resolve_gpu_ids(args.gpu_ids, options.world_from_env())
+    args.ignored_reference_flags = options.check_data_flags(args, ap, args.synthetic,
+                                                            verbose=int(os.environ.get("RANK", "0")) == 0)
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)       # before any process group exists: a wrong launch exits at once
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local
-    opt = networks.default_options(ngf=args.ngf, ndf=args.ndf, lr=args.lr, no_TTUR=args.no_TTUR,
-                                   **networks.vgg_options(args, verbose=rank == 0))
+    opt = options.network_options(args, True, **networks.vgg_options(args, verbose=rank == 0))
     tr = Trainer(opt, device=dev, world=world)
     save_dir = os.path.join(args.checkpoints_dir, args.name)
     if rank == 0:
@@ -59,7 +54,9 @@ def main(argv=None):
         for i in range(counter.epoch_iter // global_batch, args.iters_per_epoch):
             counter.record_one_iteration()
             batch = data.projector_batch(args.batchSize, dev, seed=1234 + rank + 977 * (counter.total_steps_so_far // global_batch))
-            tr.step(batch)
+            if i % args.D_steps_per_G == 0:          # train.py:33-37
+                tr.run_generator_one_step(batch)
+            tr.run_discriminator_one_step(batch)
             it += 1
             if rank == 0 and counter.needs_printing():   # the only host syncs
                 print("(epoch: %d, iters: %d, time: %.3f) " % (epoch, counter.epoch_iter, counter.time_per_iter)

@@ -39,11 +39,19 @@ def init_distributed():
             raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: one process per GPU (set EML_DIST_BACKEND=gloo "
                                "or EML_SHARE_GPUS=1 to let ranks share a device in tests)" % (local, torch.cuda.device_count()))
         local %= torch.cuda.device_count()
-    if world > 1 and not dist.is_initialized():
-        # 'nccl' is RCCL on ROCm; EML_DIST_BACKEND=gloo lets two ranks share one GPU in tests
+    from .._dist import single_rank_dry_run
+    if (world > 1 or single_rank_dry_run()) and not dist.is_initialized():
+        # 'nccl' is RCCL on ROCm; EML_DIST_BACKEND=gloo lets two ranks share one GPU in tests.  EML_DIST_SINGLE=1: the
+        # one-rank dry run of the multi-GPU path (_dist.py) -- the group is initialised with a single rank as well
         backend = os.environ.get("EML_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
+        if world == 1 and "MASTER_ADDR" not in os.environ:   # no launcher: rendezvous with ourselves on a free local port
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s.getsockname()[1])
+            s.close()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
@@ -61,8 +69,9 @@ class RegressionTrainer:
         ``sync_diameter``: derive the Sinkhorn eps-schedule from the range of the GLOBAL batch (2-float all-reduce per
         step) so that N ranks x B reproduce the single-process run with N*B samples (sinkhorn_divergence.py:9-18);
         default: on when world > 1 and no fixed ``diameter`` is given."""
+        from .._dist import dp_wrap
         if sync_diameter is None:
-            sync_diameter = world > 1 and diameter is None
+            sync_diameter = dp_wrap(world) and diameter is None
         self.ln = anchors
         self.device = torch.device(device)
         self.model = (DenseNet(anchors=anchors, crop_hw=crop_hw) if model is None else model).to(self.device)
@@ -70,7 +79,7 @@ class RegressionTrainer:
         self.sam_loss = sam_loss or SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors,
                                                 sync_diameter=sync_diameter)
         self.ddp = None
-        if world > 1:
+        if dp_wrap(world):
             # DenseNet BN stays per-rank (plain nn.BatchNorm2d in the reference); only the
             # 37.3 MB of f32 gradients cross xGMI, in one bucket overlapped with backward.
             self.ddp = torch.nn.parallel.DistributedDataParallel(

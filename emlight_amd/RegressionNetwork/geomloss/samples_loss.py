@@ -109,7 +109,8 @@ def global_range(x, y):
     lo = torch.minimum(x.detach().amin(), y.detach().amin())
     hi = torch.maximum(x.detach().amax(), y.detach().amax())
     r = torch.stack([lo, -hi]).float()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    from ..._dist import dp_active
+    if dp_active():
         dist.all_reduce(r, op=dist.ReduceOp.MIN)
     return torch.stack([r[0], -r[1]])
 
