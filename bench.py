@@ -26,8 +26,11 @@ import os
 import sys
 import time
 
-# read by the HIP runtime when it initialises (see emlight_amd/__init__.py, which sets the same default for any other entry point)
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# kernel arguments in device memory: read by the HIP runtime when it initialises, so chosen here, before torch touches the GPU
+# (emlight_amd/_runtime.py: an entry point's choice, never a side effect of importing the package)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from emlight_amd import _runtime  # noqa: E402
+_runtime.entry_point_defaults()
 
 import glob
 import socket
@@ -762,7 +765,7 @@ def main():
             "config": {"workload": "RegressionNetwork train step, BASELINE configs[1]", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "crop_hw": list(crop_hw), "anchors": args.anchors,
                        "sinkhorn_blur": args.blur, "parallelism": par,
-                       "runtime_env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")}},
+                       "runtime_env": _runtime.status()},
             "peak_hbm_GB": peak_gb,
             "step_tflops": round(STEP_GFLOP_240x320 * value / 1e3, 2) if crop_hw == (240, 320) else None,
             "step_frac_of_f32_mfma_peak": round(STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)

@@ -99,9 +99,26 @@ class _L1PairsFn(torch.autograd.Function):
         return (None, *grads)
 
 
+MAX_PAIRS = 16   # pairs per launch: the kernels take their pair table by value in the kernel arguments (csrc/losses.hip)
+
+
 def l1_pairs(spec, tensors):
-    """See ``_L1PairsFn``; returns a 0-dim tensor."""
-    return _L1PairsFn.apply(tuple(spec), *tensors).reshape(())
+    """See ``_L1PairsFn``; returns a 0-dim tensor.  Any number of pairs: a launch takes up to ``MAX_PAIRS`` (the reference's
+    defaults make 8 feature-matching and 5 VGG terms; ``--num_D 3 --n_layers_D 6`` makes 18), more run as further launches
+    whose results are summed; none (``--n_layers_D 1``: no intermediate maps) is the reference's zero loss."""
+    spec, tensors = tuple(spec), list(tensors)
+    if not spec:
+        like = next((t for t in tensors if isinstance(t, torch.Tensor)), None)
+        return torch.zeros((), dtype=torch.float32, device=like.device if like is not None else "cuda")
+    width = [2 if kind == "halves" else 3 for kind, _ in spec]
+    total, k, off = None, 0, 0
+    while k < len(spec):
+        n = min(MAX_PAIRS, len(spec) - k)
+        m = sum(width[k:k + n])
+        part = _L1PairsFn.apply(spec[k:k + n], *tensors[off:off + m]).reshape(())
+        total = part if total is None else total + part
+        k, off = k + n, off + m
+    return total
 
 
 def feature_matching(feats, masks, num_D):

@@ -110,9 +110,12 @@ def resized_guide(segmap, size):
     size = (int(size[0]), int(size[1]))
     if tuple(segmap.shape[2:]) == size:
         return segmap
+    # a resize made under no_grad has no grad_fn: it must never serve a later pass that differentiates through the map
+    #  -- the key carries whether this pass records a graph for the map
+    key = (segmap._version, bool(torch.is_grad_enabled() and segmap.requires_grad))
     cache = getattr(segmap, "_eml_resized", None)
-    if cache is None or cache[0] != segmap._version:
-        cache = (segmap._version, {})
+    if cache is None or cache[0] != key:
+        cache = (key, {})
         segmap._eml_resized = cache
     if size not in cache[1]:
         cache[1][size] = F.interpolate(segmap, size=size, mode="nearest")

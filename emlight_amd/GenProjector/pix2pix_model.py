@@ -105,7 +105,7 @@ class Pix2PixModel(torch.nn.Module):
             # reference: L1(f*m + f*(1-m)*50, r*m + r*(1-m)*50) -- both sides carry the same per-pixel weight
             # m + 50(1-m) = 50 - 49m, so a term is mean(|(f - r) * (50 - 49m)|); differs from the literal form by f32 rounding only
             from . import l1_terms
-            if fake.is_cuda and l1_terms.ENABLED:
+            if fake.is_cuda and l1_terms.ENABLED and feats:   # (no intermediate maps, --n_layers_D 1: the zero below)
                 # all (discriminator, stage) terms in one launch each way, straight on the maps of cat(fake, real)
                 losses["GAN_Feat"] = l1_terms.feature_matching(feats, masks, num_D).reshape(1)
             else:

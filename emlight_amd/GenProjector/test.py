@@ -20,6 +20,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()   # kernel arguments in device memory, recorded library-GEMM selection: an entry point's choice
     args = parse_args(argv)
     dev = "cuda:%d" % args.gpu_id_list[0]
     opt = options.network_options(args, False)

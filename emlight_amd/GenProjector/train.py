@@ -32,6 +32,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()   # kernel arguments in device memory, recorded library-GEMM selection: an entry point's choice
     args = parse_args(argv)       # before any process group exists: a wrong launch exits at once
     rank, local, world = init_distributed()
     dev = "cuda:%d" % local

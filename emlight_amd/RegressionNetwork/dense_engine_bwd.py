@@ -75,7 +75,6 @@ class _BwdBuffers:
         self.part2 = torch.zeros(2, g * kp * 2, dtype=torch.float64, device=dev)
         # weight-gradient partials: conv1x1 [grid][Kp][48], conv3x3 [2*grid][27*256], conv0 [4*grid][1024]
         self.partW = torch.empty(g * max(kp * 48, 2 * 27 * 256, 4 * 1024), **f32)
-        self.partW_b = None   # second weight-gradient partial buffer of the pair pass (allocated on first use)
         # BN1 / transition-norm dgamma: channels whose weight-gradient identity is ill-conditioned (small |gamma|) are flagged
         # by the finalize kernel and recomputed directly (eml_dense_bn_dgamma_direct_f32; gated on the device by the
         # flags of the SAME backward -- no host-side report).
@@ -170,7 +169,6 @@ def _run_backward(enc, ws, x, gpooled):
     # EML_DGAMMA_DIRECT=never exists for A/B timing only.
     direct = knob_choice("EML_DGAMMA_DIRECT", "always", ("always", "never")) != "never"
     c3_fold = knob_flag("EML_C3_FOLD", True)   # read once, not per layer
-    pair_on = knob_flag("EML_PAIR_PASS", False)   # round 5: the 1x1 backward of a layer pair in one pass (A/B knob)
     bw.any_ill.zero_()
 
     def dgamma_direct(blk, X_ld, Pin, Hin, Win, pool, DY, ld_dy, Zr, ld_z, co, Cout, conv, Cin, scale1, shift1, cond, bn):
@@ -239,7 +237,7 @@ def _run_backward(enc, ws, x, gpooled):
                       bw.condT[bi], T.norm)   # before the dense layers reuse coefficient set 0
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
-        def conv2_backward(l, slot, n12=False, narrow_lo=None, wgrad=True):
+        def conv2_backward(l, slot, n12=False, narrow_lo=None):
             """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad, which
             also materialises dz = cA*dzn + cB*z + cC in place over DZ[slot] for the data-gradient passes.
             n12: the layer above left the finished gradient of this layer's channels in the compact bw.N12.
@@ -288,8 +286,6 @@ def _run_backward(enc, ws, x, gpooled):
                     bw.ev_done[r] = torch.cuda.Event()
                 bw.ev_done[r].record(bw.side)
             finalize(G3d, 96, P, Lm.norm2, lay["zmean"], lay["zistd"], 48, 48, coef=slot)
-            if not wgrad:   # the pair pass: DZ[slot] keeps dzn, the weight gradient comes later
-                return Lm
             a, b, c = coefs[slot]
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
@@ -322,48 +318,9 @@ def _run_backward(enc, ws, x, gpooled):
             dgamma_direct(blk, ld, P, Hb, Wb, 0, bw.DZ[slot], 48, None, 0, None, 48, Lm.conv1, lay["Cin"], lay["scale1"],
                           lay["shift1"], bw.cond[bi][l], Lm.norm1)
 
-        def pair_pass(la, lb):
-            """Round 5 (csrc/dense_bwd_pair.hip): layers la / lb = la - 1 with 22 % fewer bytes.  The narrow pass
-            runs on its own (dz_a rebuilt from dzn_a / z_a and materialised in place, S1 AND S2 of the 12 channels directly),
-            layer a's weight gradient is postponed, and ONE kernel then computes both weight gradients and the two-layer data
-            gradient: x is read once, neither dz is written."""
-            lay_a, lay_b = blk["layers"][la], blk["layers"][lb]
-            cin_a, cin_b = lay_a["Cin"], lay_b["Cin"]
-            Lma = conv2_backward(la, 0, wgrad=False)
-            a, b, c = coefs[0]
-            _lib.check(L.eml_dense_conv1x1_bwd_narrow2_f32(
-                p(bw.DZ[0]), p(blk["Z"][la]), p(a), p(b), p(c), p(bw.DZ[0]), p(Lma.conv1.weight), cin_a, cin_b, p(blk["X"]), ld,
-                p(lay_a["scale1"]), p(lay_a["shift1"]), p(blk["mean"]), p(blk["istd"]), P, p(Gbuf), ld, p(bw.N12),
-                p(bw.part2[0]), lay_a["Kp"], Gw, st), "eml_dense_conv1x1_bwd_narrow2_f32")
-            # BN1 of layer a over the lower layer's 12 output channels: (S1, S2) straight from the narrow pass
-            finalize(Gw, 2 * lay_a["Kp"], P, Lma.norm1, blk["mean"], blk["istd"], cin_a, lay_a["Kp"], coef=None, s_acc=True,
-                     src=bw.part2[0], c_lo=cin_b, c_hi=cin_a)
-            Lmb = conv2_backward(lb, 1, n12=True, wgrad=False)
-            if bw.partW_b is None:
-                bw.partW_b = torch.empty_like(bw.partW)
-            Gp = min(enc.grid_max, enc._cu)   # one 4-wave workgroup per CU (397 registers per lane)
-            a1, b1, c1 = coefs[1]
-            _lib.check(L.eml_dense_conv1x1_bwd_pair_f32(
-                parr([bw.DZ[0], bw.DZ[1]]), (ctypes.c_void_p * 2)(None, blk["Z"][lb].data_ptr()),
-                (ctypes.c_void_p * 2)(None, a1.data_ptr()), (ctypes.c_void_p * 2)(None, b1.data_ptr()),
-                (ctypes.c_void_p * 2)(None, c1.data_ptr()), parr([bw.Wd[bi][la], bw.Wd[bi][lb]]),
-                parr([lay_a["scale1"], lay_b["scale1"]]), parr([lay_a["shift1"], lay_b["shift1"]]),
-                parr([bw.part2[0], bw.part2[1]]), parr([bw.partW, bw.partW_b]),
-                parr([grads[id(Lma.conv1.weight)], grads[id(Lmb.conv1.weight)]]),
-                (ctypes.c_int * 2)(lay_a["Kp"], lay_b["Kp"]), (ctypes.c_int * 2)(cin_a, cin_b),
-                parr([lay_a["mask"], lay_b["mask"]]), p(blk["X"]), ld, P, p(Gbuf), ld, Gp, st), "eml_dense_conv1x1_bwd_pair_f32")
-            bn1_finalize(la, Lma, 0, 0, cin_b, rows=Gp)
-            bn1_finalize(lb, Lmb, 1, 0, lay_b["Kp"], rows=Gp)
-            bn1_direct(la, Lma, 0)                       # DZ[0] holds the materialised dz_a
-            dgamma_direct(blk, ld, P, Hb, Wb, 0, bw.DZ[1], 48, blk["Z"][lb], 48, coefs[1], 48, Lmb.conv1, cin_b,
-                          lay_b["scale1"], lay_b["shift1"], bw.cond[bi][lb], Lmb.norm1)   # dz_b from (dzn_b, z_b, coefficients)
-
         l = len(blk["layers"]) - 1
         while l >= 0:
-            if l >= 1 and pair_on and bw.side is None:
-                pair_pass(l, l - 1)
-                l -= 2
-            elif l >= 1:
+            if l >= 1:
                 la, lb = l, l - 1
                 cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
                 Lma = conv2_backward(la, 0, narrow_lo=cin_b)   # + narrow pass: layer lb's output channels only -> N12

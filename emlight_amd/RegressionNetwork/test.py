@@ -15,6 +15,8 @@ from .DenseNet import DenseNet
 
 
 def main(argv=None):
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()   # kernel arguments in device memory, recorded library-GEMM selection: an entry point's choice
     ap = argparse.ArgumentParser()
     ap.add_argument("--test_dir", default=None)
     ap.add_argument("--synthetic", action="store_true")

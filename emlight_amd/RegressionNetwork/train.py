@@ -37,6 +37,8 @@ def save_visual(path, crop, pred, gt, ln, tone):
 
 
 def main(argv=None):
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()   # kernel arguments in device memory, recorded library-GEMM selection: an entry point's choice
     ap = argparse.ArgumentParser()
     ap.add_argument("--train_dir", default=None, help="directory in PickleParameterDataset format")
     ap.add_argument("--synthetic", action="store_true")

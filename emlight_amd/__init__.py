@@ -6,14 +6,8 @@ Host side: Python on PyTorch-ROCm mirroring the reference's own modules
 ``csrc/`` behind the C ABI of ``include/emlight_hip.h`` (``libemlight_hip.so``, loaded
 with ctypes by ``_lib``).  There is no CPU fallback: ops raise if the library is missing.
 """
-import os as _os
-
-# Kernel arguments in device memory instead of host-coherent memory (a HIP runtime switch, read when the runtime initialises:
-# effective when this package is imported before the process first touches the GPU; a value set by the user wins).  A training
-# step here is 800-2 500 launches, many of them 5-10 us kernels whose first wavefront otherwise starts by fetching its arguments
-# over the host link: measured on the MI355X, same box, alternating runs -- regression step 530.1 / 530.4 -> 534.0 / 533.5 img/s,
-# joint step 291.3 / 289.0 -> 288.7 / 287.8 ms, kernel time of one traced joint iteration 285.8 -> 282.5 ms
-# (profiles/r05_ab_dev_kernarg.txt).
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Importing this package changes nothing in the host process (ADVICE round 5): the runtime settings an entry point may choose
+# (kernel arguments in device memory, HIP_FORCE_DEV_KERNARG) live in ``_runtime.entry_point_defaults()``, called by bench.py and
+# the train / test / joint mains; the recorded library-GEMM selection is opt-in (``_gemm_selection``).
 
 __version__ = "0.1.0"

@@ -142,10 +142,6 @@ SIGNATURES = {
                                                 _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_narrow_f32": (_int, [_f32p, _f32p, _int, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
                                                 ctypes.c_long, _f32p, _int, _f32p, _f32p, _int, _int, _stream]),
-    "eml_dense_conv1x1_bwd_narrow2_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _f32p, _int,
-                                                 _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _f32p, _int, _f32p, _f64p, _int, _int,
-                                                 _stream]),
-    "eml_dense_conv1x1_bwd_pair_f32": (_int, [ctypes.c_void_p] * 14 + [_f32p, _int, ctypes.c_long, _f32p, _int, _int, _stream]),
     "eml_dense_permute_w1_bwd_f32": (_int, [_f32p, _int, _int, _int, _int, _f32p, _stream]),
     "eml_dense_conv1x1_bwd_data_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
                                               _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_long, _int, _int, _int,
@@ -195,9 +191,11 @@ def lib():
             raise EmlightHipError("libemlight_hip.so has ABI version %d, this binding expects %d -- rebuild it "
                                   "(make -C emlight_amd/csrc)" % (got, ABI_VERSION))
         _lib = handle
-    # one-time initialisation that belongs to "the GPU path is now in use": the recorded library-GEMM selection
+    # Loading the library changes nothing else in the process unless an ENTRY POINT asked for it
+    # (_runtime.entry_point_defaults(): bench.py, the train / test / joint mains, the test session): the recorded library-GEMM
+    # selection -- TunableOp in look-up mode, process-wide -- is then switched on here, once the rank's device is chosen
     from . import _gemm_selection
-    _gemm_selection.ensure()
+    _gemm_selection.ensure_if_requested()
     return _lib
 
 

@@ -108,6 +108,8 @@ def joint_batch(batch, device, anchors=128, crop_hw=(240, 320), pano_hw=(128, 25
 
 
 def main(argv=None):
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()   # kernel arguments in device memory, recorded library-GEMM selection: an entry point's choice
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[3]: 256 over 8 GPUs)")
     ap.add_argument("--anchors", type=int, default=128)

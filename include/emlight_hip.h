@@ -354,29 +354,6 @@ int eml_dense_conv1x1_bwd_narrow_f32(const float* DZ, const float* W1, int Cin, 
                                      const float* mean, const float* istd, long P, const float* G, int ldg,
                                      float* N12, double* partials, int Kp, int grid, eml_stream_t stream);
 
-/* ROUND 5: the 1x1 backward of a PAIR of dense layers with 22 % fewer bytes -- autograd backward of conv1 / norm1 of
- * two consecutive _DenseLayers (RegressionNetwork/DenseNet.py:26-55).  [0] = the upper layer a (Cin_a = Cin_b + 12), [1] = b.
- *   eml_dense_conv1x1_bwd_narrow2_f32   eml_dense_conv1x1_bwd_narrow_f32 from the UN-materialised operands: dz = cA*DZ + cB*Zr +
- *       cC is rebuilt in registers and written to dz_out (P,48; may alias DZ); N12 / partials (S1 AND S2, accumulated per
- *       element: the lower layer's 3x3 backward needs this range's BN1 backward before the postponed weight gradient exists).
- *   eml_dense_conv1x1_bwd_pair_f32      both weight gradients dW_j (48, Cin_j) = sum_p relu(bn1_j(x))[p] (x) dz_j[p] and the
- *       two-layer data gradient G[:, 0:Cin_b) += sum_j scale1_j * relu'_j * (dz_j W1_j) in ONE pass: x[:Cin_a] is read once,
- *       neither dz is written.  Per layer: DZ / Zr / cA / cB / cC (Zr[j] == NULL: DZ[j] is the materialised dz), Wd
- *       (eml_dense_permute_w1_bwd_f32), scale1 / shift1 (Kp_j, zero-padded), stats [grid][Kp_j][2] f64 (S1; slot 1 = 0: S2
- *       follows from W and dW in eml_dense_bn_bwd_finalize_f32), wpartial [grid][Kp_j][48] scratch, relu_masks = the forward's
- *       ReLU bits (eml_dense_conv1x1_fwd_f32's relu_mask: the data gradient's mask without a second read of x).  Kp_j <= 384.
- * Deterministic (per-workgroup partials, fixed-order reduction). */
-int eml_dense_conv1x1_bwd_narrow2_f32(const float* DZ, const float* Zr, const float* cA, const float* cB, const float* cC,
-                                      float* dz_out, const float* W1, int Cin, int k_lo, const float* X, int ldx,
-                                      const float* scale1, const float* shift1, const float* mean, const float* istd, long P,
-                                      const float* G, int ldg, float* N12, double* partials, int Kp, int grid,
-                                      eml_stream_t stream);
-int eml_dense_conv1x1_bwd_pair_f32(const float* const* DZ, const float* const* Zr, const float* const* cA,
-                                   const float* const* cB, const float* const* cC, const float* const* Wd,
-                                   const float* const* scale1, const float* const* shift1, double* const* stats,
-                                   float* const* wpartial, float* const* dW, const int* Kp, const int* Cin,
-                                   const unsigned long long* const* relu_masks, const float* X, int ldx, long P, float* G,
-                                   int ldg, int grid, eml_stream_t stream);
 /* G[p][c] += sB[c]*X[p][c] + sC[c] for c in [c0, c0+n): applies the deferred BN1-backward affine once
  * the gradient of those channels is complete. */
 int eml_dense_grad_materialize_f32(float* G, int ldg, const float* X, int ldx, const float* sB,

@@ -15,6 +15,10 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the test session is an entry point: on the GPU box it runs the configuration bench.py and the train mains run (kernel
+    # arguments in device memory, the recorded library-GEMM selection) -- chosen here, before anything touches the GPU
+    from emlight_amd import _runtime
+    _runtime.entry_point_defaults()
 
 
 def pytest_collection_modifyitems(config, items):

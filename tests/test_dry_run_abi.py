@@ -66,25 +66,6 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     assert all(p.grad is not None for p in net.parameters())
 
 
-def test_densenet_engine_pair_pass_calls_match_the_abi(recorder, monkeypatch):
-    """Round 5's schedule of the 1x1 backward (EML_PAIR_PASS=1, csrc/dense_bwd_pair.hip): per layer pair one stand-alone narrow
-    pass from the un-materialised operands and ONE launch for both weight gradients + the two-layer data gradient."""
-    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
-    from emlight_amd.RegressionNetwork.dense_engine import HipDenseEncoder
-    monkeypatch.setenv("EML_PAIR_PASS", "1")
-    net = DenseNet(anchors=8, crop_hw=(32, 32)).train()
-    net._hip = HipDenseEncoder(net)
-    net._hip._cu = 256
-    out = net(torch.rand(2, 3, 32, 32))
-    sum(v.sum() for v in out.values()).backward()
-    assert recorder.calls.count("eml_dense_conv1x1_bwd_pair_f32") == 24 and recorder.calls.count("eml_dense_conv1x1_bwd_narrow2_f32") == 24
-    assert "eml_dense_conv1x1_bwd_data_multi_f32" not in recorder.calls      # 16 layers per block: every layer is in a pair
-    assert "eml_dense_conv1x1_bwd_weight_f32" in recorder.calls              # the transitions keep theirs
-    pair = [a for n, a in recorder.args if n == "eml_dense_conv1x1_bwd_pair_f32"][0]
-    assert pair[12][0] == pair[12][1] + 12                                   # Cin of (upper, lower)
-    assert all(p.grad is not None for p in net.parameters())
-
-
 def test_permute_table_is_rebuilt_only_when_a_pointer_moves(recorder):
     """One batched re-layout launch per pass; its device descriptor table follows the weights' data pointers."""
     import numpy as np

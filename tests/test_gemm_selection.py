@@ -10,7 +10,7 @@ import torch
 
 def _fresh():
     from emlight_amd import _gemm_selection as gs
-    gs._state.update(done=False, active=False, why="not initialised", entries=0)
+    gs._state.update(done=False, active=False, why="not initialised", entries=0, requested=False)
     return gs
 
 
@@ -54,8 +54,10 @@ def test_switch_is_inert_without_a_gpu_and_obeys_its_knobs(monkeypatch):
 
 @pytest.mark.gpu
 def test_recorded_selection_is_in_effect_deterministic_and_a_plain_f32_gemm():
-    from emlight_amd import _gemm_selection as gs, _lib
+    from emlight_amd import _gemm_selection as gs, _lib, _runtime
+    _runtime.entry_point_defaults()   # what bench.py / the train mains / this test session do (tests/conftest.py)
     _lib.lib()
+    gs.ensure_if_requested()          # (a library loaded before the request switches on here)
     st = gs.status()
     if not st["active"]:
         assert "validators" in st["why"] or "TUNED_GEMMS" in st["why"] or "PYTORCH_TUNABLEOP" in st["why"], st
@@ -98,6 +100,9 @@ class _FakeTunable:
     def record_untuned_enable(self, v=True):
         self.calls.append(("record_untuned_enable", v))
 
+    def write_file_on_exit(self, v):
+        self.calls.append(("write_file_on_exit", v))
+
     def set_filename(self, name, insert_device_ordinal=False):
         self.calls.append(("set_filename", os.path.basename(name), insert_device_ordinal))
 
@@ -124,7 +129,7 @@ def test_switch_falls_back_to_library_defaults_when_the_record_is_refused(monkey
     fake = {"ok": _FakeTunable(), "other stack": _FakeTunable(read_ok=False), "empty": _FakeTunable(n=0),
             "raises": _FakeTunable(boom="no such attribute")}[case]
     mod = types.ModuleType("torch.cuda.tunable")
-    for name in ("enable", "tuning_enable", "record_untuned_enable", "set_filename", "read_file", "get_results"):
+    for name in ("enable", "tuning_enable", "record_untuned_enable", "set_filename", "read_file", "get_results", "write_file_on_exit"):
         setattr(mod, name, getattr(fake, name))
     monkeypatch.setitem(sys.modules, "torch.cuda.tunable", mod)
     monkeypatch.setattr(torch.cuda, "tunable", mod, raising=False)
@@ -133,6 +138,7 @@ def test_switch_falls_back_to_library_defaults_when_the_record_is_refused(monkey
     st = gs.status()
     assert ("tuning_enable", False) in fake.calls and ("record_untuned_enable", False) in fake.calls
     assert ("set_filename", "tuned_gemms_gfx950.csv", False) in fake.calls   # one file for every rank: no device ordinal
+    assert ("write_file_on_exit", False) in fake.calls                        # the packaged record is never rewritten
     if case == "ok":
         assert active and fake.on and st["entries"] == 82
     else:

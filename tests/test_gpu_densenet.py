@@ -379,37 +379,3 @@ def test_dgamma_of_small_and_negative_gammas_is_recomputed_directly(monkeypatch)
     # the same bound the well-conditioned channels of this network meet against f64 (test_gradient_error_is_f32_conditioning)
     assert e_auto < 5e-2 and e_always < 5e-2
     assert e_never > 3 * max(e_auto, 1e-3), "the identity alone should be visibly worse on these channels (else the test is blind)"
-
-
-def test_pair_pass_of_the_1x1_backward_matches_the_default_path(monkeypatch):
-    """Round 5: EML_PAIR_PASS=1 runs the 1x1 backward of two dense layers as one pass over the block's
-    x / G rows (csrc/dense_bwd_pair.hip: both weight gradients + both data gradients + BN1's statistics; the narrow pass
-    that unblocks the lower layer's 3x3 backward is its own small kernel).  It is an A/B build (measured slower than the
-    separate kernels), kept correct: every parameter gradient against the default path
-    on the same network, to the bounds the default path itself meets against the oracle (_grad_check)."""
-    anchors, crop, B = 32, (64, 96), 2
-    _, net = _pair(anchors, crop, seed=11)
-    net.train()
-    g = np.random.default_rng(9)
-    x = torch.from_numpy(g.random((B, 3) + crop, dtype=np.float32)).cuda()
-    w = {k: torch.from_numpy(g.standard_normal(s).astype(np.float32)).cuda()
-         for k, s in (("distribution", (B, anchors)), ("intensity", (B, 1)), ("rgb_ratio", (B, 3)), ("ambient", (B, 3)))}
-
-    def run(flag):
-        monkeypatch.setenv("EML_PAIR_PASS", flag)
-        net.zero_grad(set_to_none=True)
-        o = net(x)
-        sum((o[k] * w[k]).sum() for k in KEYS).backward()
-        torch.cuda.synchronize()
-        return {n: q.grad.double().cpu().numpy() for n, q in net.named_parameters()}
-    base, pair = run("0"), run("1")
-    # the metric of _grad_check: relative L2 per tensor with a floor for the analytically-zero gradients (a max-norm ratio
-    # blows up on last_norm*.bias, whose true gradient is 0, and on the one element a flipped ReLU bit moves)
-    rms = lambda a: float(np.sqrt(np.mean(np.square(a))))
-    floor = 1e-3 * np.median([rms(t) for t in base.values()])
-    errs = sorted(((rms(pair[n] - t) / max(rms(t), floor), n) for n, t in base.items()), reverse=True)
-    print("pair pass vs default path: max rel-L2 %.2e (%s), median %.2e over %d tensors"
-          % (errs[0][0], errs[0][1], np.median([e for e, _ in errs]), len(errs)))
-    assert all(np.isfinite(t).all() for t in pair.values())
-    assert errs[0][0] < GRAD_L2_MAX, errs[:8]
-    assert np.median([e for e, _ in errs]) < GRAD_L2_MEDIAN

@@ -1121,6 +1121,48 @@ def test_fused_l1_terms_vs_stock_formulas():
         np.testing.assert_allclose(t.grad.cpu().numpy(), rt.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_fused_l1_terms_with_more_pairs_than_one_launch_takes_and_with_none():
+    """``--num_D 3 --n_layers_D 6`` makes 18 feature-matching pairs, ``--num_D 5`` 20 -- more than the
+    16 a launch of ``eml_l1_pairs_*`` takes: they run as two launches whose sums add up; ``--n_layers_D 1`` makes none, which
+    is the reference's zero loss (pix2pix_model.py:101-117), not an error.  Then the same through the model's own loss."""
+    from emlight_amd.GenProjector import l1_terms
+    torch.manual_seed(5)
+    B, num_D = 2, 5
+    shapes = [(8 + 4 * (i % 3), 4 + (i % 2) * 4, 8) for i in range(20)]
+    feats = [torch.randn(2 * B, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_()
+             for c, h, w in shapes]
+    masks = [(torch.rand(B, 1, h, w, device="cuda") > 0.5).float() for _, h, w in shapes]
+    got = l1_terms.feature_matching(feats, masks, num_D)
+    got.backward()
+    refs = [t.detach().double().requires_grad_() for t in feats]
+    want = 0
+    for t, m in zip(refs, masks):
+        f, r, m = t[:B], t[B:].detach(), m.double()
+        want = want + torch.nn.functional.l1_loss(f * m + f * (1 - m) * 50, r * m + r * (1 - m) * 50) / num_D
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    for t, rt in zip(feats, refs):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), rt.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
+    a = [torch.randn(B, 8, 4, 8, device="cuda", requires_grad=True) for _ in range(17)]
+    b = [torch.randn(B, 8, 4, 8, device="cuda") for _ in range(17)]
+    got = l1_terms.l1_sum((0.5 + i, x, y) for i, (x, y) in enumerate(zip(a, b)))
+    want = sum((0.5 + i) * torch.nn.functional.l1_loss(x.double(), y.double()) for i, (x, y) in enumerate(zip(a, b)))
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    zero = l1_terms.feature_matching([], [], 2)
+    assert zero.shape == () and float(zero) == 0.0 and zero.is_cuda
+    # the model's generator loss at those settings: 18 pairs, and none
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.data import projector_batch
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    for num_d, n_layers, pairs in ((3, 6, 18), (2, 1, 0)):
+        model = Pix2PixModel(networks.default_options(ngf=4, ndf=4, num_D=num_d, n_layers_D=n_layers)).cuda()
+        losses, _ = model(projector_batch(2, "cuda:0"), mode="generator")
+        assert bool(torch.isfinite(losses["GAN_Feat"]).all()) and losses["GAN_Feat"].shape == (1,)
+        assert (float(losses["GAN_Feat"]) == 0.0) == (pairs == 0)
+        sum(losses.values()).mean().backward()
+
+
 @pytest.mark.parametrize("B,C,O,H,W", [(2, 64, 64, 16, 32), (3, 128, 128, 32, 64), (1, 128, 256, 8, 16), (2, 64, 128, 12, 20)])
 def test_row_shared_corners_gather_is_bit_identical(B, C, O, H, W):
     """EML_TAP_ROWSHARE (include/emlight_hip.h): on a stride-1 sphere table a pixel's east corners are its right neighbour's
