@@ -44,6 +44,12 @@ sys.path.insert(0, ROOT)
 
 FWD_GFLOP_240x320 = 43.775      # algorithmic conv FLOPs per image, forward
 STEP_GFLOP_240x320 = 131.2      # forward + dgrad + wgrad (minus conv0 dgrad)
+# The engine pools BEFORE the three transition convolutions (pool_act_kernel: the 1x1 convolution commutes with the 2x2 mean),
+# so a quarter of their algorithmic FLOPs (DenseNet.py:14-21 counts them at the pre-pool resolution: 5.87 G forward, x3 in a
+# step) is what the matrix pipe executes.  `value * STEP` is the algorithmic credit SURVEY 8d defines; `EXECUTED` is the honest
+# utilisation of the pipe -- both are on the line.
+TRANSITION_FWD_GFLOP_240x320 = 2.0 * (216 * 108 * 120 * 160 + 300 * 150 * 60 * 80 + 342 * 171 * 30 * 40) * 4 / 1e9   # at pre-pool pixels
+EXECUTED_STEP_GFLOP_240x320 = STEP_GFLOP_240x320 - 3 * 0.75 * TRANSITION_FWD_GFLOP_240x320
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 stacks
 
@@ -94,6 +100,21 @@ def family_bytes(B, crop_hw):
         by["eml_dense_conv1x1_bwd_data_f32"] += ((ct + ct // 8) * 4 + ct / 8) * P   # dY(pooled), ReLU bits in, G out (no X)
         c, h, w = ct // 2, h // 2, w // 2
     return by
+
+
+def wgrad_operand_minimal_bytes(B, crop_hw):
+    """What a 1x1 weight gradient needs at the very least: x and dz once.  `family_bytes` books the
+    BN2-backward rebuild that is fused into the kernel (dzn and Z in, dz out) to it as well: (k + 144) floats per pixel against
+    the (k + 48) counted here -- the bench line carries the fraction of the HBM roof on BOTH counts."""
+    h, w = crop_hw
+    c, tot = 24, 0.0
+    for _ in range(3):
+        P = float(B * h * w)
+        tot += sum((c + 12 * l + 48) * 4 * P for l in range(16))
+        ct = c + 192
+        tot += (ct // 4 + ct // 8) * 4 * P       # transition: pooled activation A in, pooled dY in
+        c, h, w = ct // 2, h // 2, w // 2
+    return tot
 
 
 # launcher -> (kernel family, which algorithmic FLOP count one pass over its launches performs)
@@ -167,6 +188,10 @@ def time_kernel_families(trainer, batch, steps, B, crop_hw):
                      "tflops": round(flops[which] / (ms * 1e-3) / 1e12, 2) if ms > 0 and flops[which] else None,
                      "algorithmic_GB_per_step": round(nbytes[k] / 1e9, 2),
                      "algorithmic_GBps": round(nbytes[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        if k == "eml_dense_conv1x1_bwd_weight_f32":
+            mb = wgrad_operand_minimal_bytes(B, crop_hw)
+            rows[-1]["operand_minimal_GB_per_step"] = round(mb / 1e9, 2)
+            rows[-1]["operand_minimal_GBps"] = round(mb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
 
@@ -500,6 +525,7 @@ def other_breakdown(step_fn, world):
                "MIOpen (the crop encoder's / discriminator's stock convolutions)": 0.0, "fused Adam": 0.0,
                "runtime copies / memsets": 0.0, "RCCL": 0.0, "this repo's kernels (for reference)": 0.0, "unclassified": 0.0}
     counts = {k: 0 for k in buckets}
+    unknown = []
     for e in rows:
         if not is_kernel(e):
             continue
@@ -514,12 +540,13 @@ def other_breakdown(step_fn, world):
             k = "ATen (elementwise, reductions, layout copies)"
         elif "rocclr" in n or "copyBuffer" in n or "fillBuffer" in n or n.lower().startswith("memcpy") or n.lower().startswith("memset"):
             k = "runtime copies / memsets"
-        elif "nccl" in n.lower() or "rccl" in n.lower():
+        elif "nccl" in n.lower() or "rccl" in n.lower() or "AllReduce" in n or "Broadcast" in n or "msccl" in n.lower():
             k = "RCCL"
         elif "(anonymous namespace)::" in n or "gg2::" in n or "_kernel" in n and "void " in n and "at::" not in n:
             k = "this repo's kernels (for reference)"
         else:
             k = "unclassified"
+            unknown.append((us / 1e3, n[:60]))
         buckets[k] += us / 1e3
         counts[k] += e.count
     gemm_flops = 0.0
@@ -540,7 +567,43 @@ def other_breakdown(step_fn, world):
         if k.startswith("library GEMM") and gemm_flops:
             row["tflops"] = round(gemm_flops / (ms * 1e-3) / 1e12, 1)
             row["gflop_per_step"] = round(gemm_flops / 1e9, 1)
+        if k == "unclassified" and unknown:
+            row["largest"] = ["%.3f ms %s" % u for u in sorted(unknown, reverse=True)[:3]]
         out.append(row)
+    return out
+
+
+def collectives_of_a_step(step_fn, ddps):
+    """What ONE iteration puts on the wire, observed in this run: the ranks RCCL sees, every explicit
+    ``dist.all_reduce`` of the step (SPADE's synchronised BatchNorm sums, the Sinkhorn diameter: count and bytes) and DDP's gradient
+    buckets per wrapped network (count and bytes from the reducer's own record).  None without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    seen = {"calls": 0, "bytes": 0}
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        seen["calls"] += 1
+        seen["bytes"] += t.numel() * t.element_size()
+        return orig(t, *a, **k)
+    dist.all_reduce = counting
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        dist.all_reduce = orig
+    out = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(),
+           "explicit_all_reduces_per_step": seen["calls"], "explicit_all_reduce_bytes_per_step": seen["bytes"], "ddp": {}}
+    for name, d in ddps:
+        if d is None:
+            continue
+        try:
+            info = d._get_ddp_logging_data()
+            sizes = [int(x) for x in str(info.get("rebuilt_bucket_sizes") or info.get("bucket_sizes") or "").replace(",", " ").split()]
+            out["ddp"][name] = {"buckets": len(sizes), "bytes": sum(sizes), "backend": info.get("backend_name"),
+                                "world_size": info.get("world_size")}
+        except Exception as e:   # noqa: BLE001 -- evidence only
+            out["ddp"][name] = {"error": repr(e)[:120]}
     return out
 
 
@@ -640,15 +703,20 @@ def leg_joint(args, rank, world, dev, steps, warmup):
             tr, batch, 1, {**ENCODER_FAMILIES, **PROJECTOR_FAMILIES},
             "other (encoder BN / pooling / head passes, Sinkhorn, rasteriser, library GEMMs of the unfused layers, ATen glue, Adam)")
         other = None if no_vgg else other_breakdown(lambda: tr.step(batch), world)
+        coll = None if no_vgg else collectives_of_a_step(
+            lambda: tr.step(batch), [("encoder", tr.reg.ddp), ("generator", getattr(tr.proj, "_ddpG", None)),
+                                     ("discriminator", getattr(tr.proj, "_ddpD", None))])
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
-        return dt, peak, fams, other
-    dt, peak, fams, other = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
-    dt0, _, _, _ = run(True)
+        return dt, peak, fams, other, coll
+    dt, peak, fams, other, coll = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
+    dt0 = run(True)[0]
     value, value0 = B * world * steps / dt, B * world * steps / dt0
     enc_gflop = STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
+    enc_exec = EXECUTED_STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
     gflop = enc_gflop + PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
+    gflop_exec = enc_exec + PROJECTOR_STEP_GFLOP + VGG_STEP_GFLOP
     tf = gflop * value / world / 1e3
     out = {"metric": "training images/sec (joint step: DenseNet -> SG rasteriser -> SPADE generator + PatchGAN, "
                      "encoder+G step and D step)",
@@ -662,6 +730,9 @@ def leg_joint(args, rank, world, dev, steps, warmup):
                            "frac_of_f32_mfma_peak": round((enc_gflop + PROJECTOR_STEP_GFLOP) * value0 / world / 1e3
                                                           / F32_MFMA_PEAK_TFLOPS, 4)},
            "peak_hbm_GB": peak,
+           "algorithmic_gflop_per_image": round(gflop, 1), "executed_gflop_per_image": round(gflop_exec, 1),
+           "step_frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+           "step_frac_executed": round(gflop_exec * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
            "roofline": {"kernel": "whole step", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "note": "algorithmic conv FLOPs per image = %.1f (encoder train step) + %.1f (projector G+D step) + "
@@ -670,6 +741,8 @@ def leg_joint(args, rank, world, dev, steps, warmup):
     if fams and rank == 0:
         out["kernel_families"] = fams
         out["other_breakdown"] = other
+    if coll is not None:
+        out["collectives"] = coll
     del batch
     _free_gpu()
     return out
@@ -744,6 +817,7 @@ def main():
     # live per-kernel timing: EVERY rank runs the instrumented steps (they contain DDP's all-reduce)
     fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) if "families" in legs else None
     peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+    reg_coll = collectives_of_a_step(lambda: tr.step(batch), [("encoder", tr.ddp)])   # every rank steps; rank 0 reports
     del tr, batch
     _free_gpu()
     # the other legs of BASELINE's metric; every rank takes part (DDP collectives inside), rank 0 reports
@@ -767,8 +841,15 @@ def main():
                        "sinkhorn_blur": args.blur, "parallelism": par,
                        "runtime_env": _runtime.status()},
             "peak_hbm_GB": peak_gb,
+            "rccl_ranks_seen": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+            "collectives": reg_coll,
             "step_tflops": round(STEP_GFLOP_240x320 * value / 1e3, 2) if crop_hw == (240, 320) else None,
             "step_frac_of_f32_mfma_peak": round(STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
+            if crop_hw == (240, 320) else None,
+            # the same with the FLOPs the matrix pipe really executes (transition convolutions at the pooled resolution)
+            "algorithmic_gflop_per_image": STEP_GFLOP_240x320 if crop_hw == (240, 320) else None,
+            "executed_gflop_per_image": round(EXECUTED_STEP_GFLOP_240x320, 1) if crop_hw == (240, 320) else None,
+            "step_frac_executed": round(EXECUTED_STEP_GFLOP_240x320 * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
             if crop_hw == (240, 320) else None,
         }
         if fams:
@@ -795,6 +876,13 @@ def main():
                                                                              max(dom["dispatches_per_step"], 1)), 3)
                                                             if traffic else None),
                                "dispatches_per_step": dom["dispatches_per_step"],
+                               # the strict count: only what the family's arithmetic needs (for the 1x1 weight gradient x and
+                               # dz once, without the BN2-backward rebuild fused into it), and the fraction of the roof on it
+                               "operand_minimal_bytes_per_dispatch": (round(dom["operand_minimal_GB_per_step"] * 1e9 /
+                                                                            max(dom["dispatches_per_step"], 1))
+                                                                      if dom.get("operand_minimal_GB_per_step") else None),
+                               "frac_operand_minimal": (round(dom["operand_minimal_GBps"] / HBM_PEAK_GBPS, 4)
+                                                        if dom.get("operand_minimal_GBps") else None),
                                "other_roof_frac": round(min(f_hbm, f_mfma), 4),
                                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
                                "note": "achieved = algorithmic bytes (or conv FLOPs) of the family's launches / their "
@@ -815,12 +903,14 @@ def main():
         # the headline numbers of EVERY leg in one compact object: inside `roofline` (an object the driver's record keeps
         # whole) and once more as the LAST key of the line (what a truncated stdout tail still shows)
         legs_summary = {"regression": {"value": out["value"], "ms_per_step": out["ms_per_step"],
-                                       "step_frac_of_f32_mfma_peak": out["step_frac_of_f32_mfma_peak"]}}
+                                       "step_frac_of_f32_mfma_peak": out["step_frac_of_f32_mfma_peak"],
+                                       "step_frac_executed": out["step_frac_executed"]}}
         for k in ("projector", "joint"):
             if k in out:
                 legs_summary[k] = {"value": out[k]["value"], "ms_per_step": out[k]["ms_per_step"],
                                    "step_frac_of_f32_mfma_peak": out[k].get("step_frac_of_f32_mfma_peak",
                                                                             out[k].get("roofline", {}).get("frac")),
+                                   "step_frac_executed": out[k].get("step_frac_executed"),
                                    "dominant_kernel_frac": out[k].get("roofline", {}).get("frac"),
                                    "without_vgg": out[k].get("without_vgg", {}).get("value")}
         for k in ("sinkhorn", "sinkhorn_n256"):

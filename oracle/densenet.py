@@ -56,6 +56,9 @@ class OracleDenseNet(nn.Module):
         super().__init__()
         self.block_config = tuple(block_config)
         self.avgpool_size = avgpool_size
+        # tests at BASELINE's full batch (64 x 240 x 320) set this: every dense layer is re-run in the backward instead of
+        # keeping its intermediates (same arithmetic; 4x less memory, which is what lets the f64 yardstick fit next to it)
+        self.checkpoint_layers = False
         f = nn.Module()
         f.conv0 = nn.Conv2d(3, num_init_features, 3, padding=1, bias=False)
         f.norm0 = _Norm(num_init_features)
@@ -89,9 +92,16 @@ class OracleDenseNet(nn.Module):
             blk = getattr(f, "denseblock%d" % b)
             for l in range(n_layers):
                 L = getattr(blk, "denselayer%d" % (l + 1))
-                # DenseNet.py:30-43: BN1 -> ReLU -> 1x1 -> BN2 -> (no ReLU) -> 3x3 -> cat
-                z = F.conv2d(F.relu(_bn(x, L.norm1, tr)), L.conv1.weight)
-                new = F.conv2d(_bn(z, L.norm2, tr), L.conv2.weight, padding=1)
+
+                def layer(x, L=L):
+                    # DenseNet.py:30-43: BN1 -> ReLU -> 1x1 -> BN2 -> (no ReLU) -> 3x3 -> cat
+                    z = F.conv2d(F.relu(_bn(x, L.norm1, tr)), L.conv1.weight)
+                    return F.conv2d(_bn(z, L.norm2, tr), L.conv2.weight, padding=1)
+                if self.checkpoint_layers and torch.is_grad_enabled():
+                    from torch.utils.checkpoint import checkpoint
+                    new = checkpoint(layer, x, use_reentrant=False)
+                else:
+                    new = layer(x)
                 x = torch.cat([x, new], 1)
             T = getattr(f, "transition%d" % b)
             # DenseNet.py:14-21: BN -> ReLU -> 1x1 -> avgpool2

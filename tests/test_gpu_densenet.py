@@ -296,6 +296,67 @@ def test_properties_at_full_baseline_size():
     assert all(bool(torch.isfinite(g).all()) for g in g1)
 
 
+def test_cfg2_full_batch_values_against_the_stock_op_graph():
+    """BASELINE configs[1] at its FULL size (B = 64, 240 x 320 crops, 128 anchors, train-mode BatchNorm) against the oracle's
+    stock-op graph -- the reference's arithmetic (RegressionNetwork/train.py:81-102, DenseNet.py:135-157) -- run on the GPU in
+    f32 and, as the yardstick for the gradients, in f64, on the same weights, input and targets (VERDICT round 5, item 7:
+    the full-size test above checks properties, values were pinned at B = 2 only).  Bounds: the four regressed tensors 1e-4
+    abs (north_star), the loss terms 1e-4 rel, every parameter's gradient as close to the f64 gradient as the stock f32 graph
+    is (relative L2 within 3x, like test_gradient_error_is_f32_conditioning).  The oracle re-runs each dense layer in its
+    backward (``checkpoint_layers``: same values) so that the f64 graph fits in HBM."""
+    import gc
+    from emlight_amd.RegressionNetwork.data import synthetic_batch
+    from emlight_amd.RegressionNetwork.engine import regression_loss as hip_loss
+    from emlight_amd.RegressionNetwork.geomloss import SamplesLoss
+    B, anchors, crop_hw = 64, 128, (240, 320)
+    ref32, net = _pair(anchors, crop_hw, seed=4)
+    sd = ref32.state_dict()
+    batch = synthetic_batch(B, anchors, crop_hw, seed=77, device="cuda")
+    M = oracle.anchor_cost_matrix(anchors)      # the oracle's Sinkhorn is a CPU restatement: the loss is taken on host copies
+
+    def stock(dtype):
+        m = oracle.OracleDenseNet(anchors=anchors, crop_hw=crop_hw).to(dtype)
+        m.load_state_dict({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()})
+        m = m.cuda().train()
+        m.checkpoint_layers = True
+        gt = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+        pred = m(gt["crop"])
+        pred_h = {k: v.cpu() for k, v in pred.items()}          # differentiable copies: the gradient flows back to the GPU graph
+        gt_h = {k: v.cpu() for k, v in gt.items() if k != "crop"}
+        loss, terms = oracle.regression_loss(pred_h, gt_h, lambda a, b: oracle.samples_loss(a, b, M.to(dtype), blur=.05), anchors)
+        loss.backward()
+        out = ({k: pred[k].detach().double().cpu() for k in KEYS}, {k: float(v) for k, v in terms.items()},
+               {n: q.grad.detach().double().cpu() for n, q in m.named_parameters()})
+        del m, pred, pred_h, gt_h, loss, terms, gt
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+    o32, t32, g32 = stock(torch.float32)
+    o64, t64, g64 = stock(torch.float64)
+    net.train()
+    pred = net(batch["crop"])
+    loss, terms = hip_loss(pred, batch, SamplesLoss("sinkhorn", p=2, blur=.05, anchors=anchors), anchors)
+    loss.backward()
+    for k in KEYS:   # north_star: regressed tensors within 1e-4 abs -- against the f64 values and against the stock f32 graph
+        got = pred[k].detach().double().cpu()
+        assert float((got - o64[k]).abs().max()) <= OUT_ATOL, (k, float((got - o64[k]).abs().max()))
+        assert float((got - o32[k]).abs().max()) <= OUT_ATOL, (k, float((got - o32[k]).abs().max()))
+    for k, v in terms.items():
+        assert abs(float(v) - t64[k]) <= 1e-4 * abs(t64[k]) + 1e-9, (k, float(v), t64[k], t32[k])
+    rms = lambda a: float(a.square().mean().sqrt())
+    e_hip, e_o32 = [], []
+    for name, q in net.named_parameters():
+        if name in ("features.last_norm1.bias", "features.last_norm2.bias"):   # analytically zero (feed train-mode BNs only)
+            continue
+        t = g64[name]
+        e_hip.append(rms(q.grad.detach().double().cpu() - t) / rms(t))
+        e_o32.append(rms(g32[name] - t) / rms(t))
+    print("B=64 240x320: gradient rel-L2 vs f64: HIP median %.2e max %.2e | stock f32 median %.2e max %.2e"
+          % (np.median(e_hip), max(e_hip), np.median(e_o32), max(e_o32)))
+    assert np.median(e_hip) <= 3.0 * np.median(e_o32) + 5e-4
+    assert max(e_hip) <= 3.0 * max(e_o32) + 5e-4
+
+
 def test_training_curve_tracks_stock_op_oracle():
     """24 Adam steps (10x the reference learning rate) with the HIP engine and with the oracle's stock-op encoder (run
     on the same GPU) from the same initial weights and batches: the loss curves stay together.  (Element-wise agreement is impossible across two f32
