@@ -530,6 +530,8 @@ def other_breakdown(step_fn, world):
         if not is_kernel(e):
             continue
         n, us = e.key, dev_us(e)
+        if "DistributedDataParallel" in n or n.startswith("Optimizer.") or n.startswith("ProfilerStep"):
+            continue   # user annotations mirrored on the device track (their span covers kernels counted below), not kernels
         if n.startswith("Cijk_") or "Tensile" in n or "rocblas" in n.lower():
             k = "library GEMM (rocBLAS / Tensile Cijk_*)"
         elif "multi_tensor_apply" in n or "FusedAdam" in n or "fused_adam" in n.lower():

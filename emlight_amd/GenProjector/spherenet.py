@@ -500,7 +500,7 @@ def _reduce_sums(partials, rows, C, repeat=1):
     from .. import _lib
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
     sums = torch.empty(2 * C + 1, dtype=torch.float64, device=partials.device)
-    sums[2 * C] = float(rows)
+    sums[2 * C:].fill_(float(rows))   # (a fill kernel: `t[i] = python_float` is a host->device copy, which a stream capture refuses)
     _lib.check(L.eml_bn_fold_f64(p(partials), partials.shape[0], 2 * C, p(sums), st), "eml_bn_fold_f64")
     if repeat != 1:
         sums *= float(repeat)
@@ -600,7 +600,7 @@ class _SpadeNormModulateFn(torch.autograd.Function):
         sums = None
         if ctx.training:
             sums = folded[:2 * C + 1]
-            sums[2 * C] = float(rows)
+            sums[2 * C:].fill_(float(rows))
             if _bn_sync():
                 import torch.distributed as dist
                 dist.all_reduce(sums)
@@ -732,7 +732,7 @@ class _SpadeConvModulateFn(torch.autograd.Function):
         sums = None
         if ctx.training:
             sums = folded[:2 * C + 1]
-            sums[2 * C] = float(rows)
+            sums[2 * C:].fill_(float(rows))
             if _bn_sync():
                 import torch.distributed as dist
                 dist.all_reduce(sums)

@@ -1124,8 +1124,8 @@ def test_fused_l1_terms_vs_stock_formulas():
 @pytest.mark.gpu
 def test_fused_l1_terms_with_more_pairs_than_one_launch_takes_and_with_none():
     """``--num_D 3 --n_layers_D 6`` makes 18 feature-matching pairs, ``--num_D 5`` 20 -- more than the
-    16 a launch of ``eml_l1_pairs_*`` takes: they run as two launches whose sums add up; ``--n_layers_D 1`` makes none, which
-    is the reference's zero loss (pix2pix_model.py:101-117), not an error.  Then the same through the model's own loss."""
+    16 a launch of ``eml_l1_pairs_*`` takes: they run as two launches whose sums add up; an empty list of pairs is
+    the reference's zero loss (pix2pix_model.py:101-117), not an error.  Then the same through the model's own loss."""
     from emlight_amd.GenProjector import l1_terms
     torch.manual_seed(5)
     B, num_D = 2, 5
@@ -1151,15 +1151,15 @@ def test_fused_l1_terms_with_more_pairs_than_one_launch_takes_and_with_none():
     assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
     zero = l1_terms.feature_matching([], [], 2)
     assert zero.shape == () and float(zero) == 0.0 and zero.is_cuda
-    # the model's generator loss at those settings: 18 pairs, and none
+    # the model's generator loss at such settings: 18 pairs, and the smallest discriminators (one intermediate map each)
     from emlight_amd.GenProjector import networks
     from emlight_amd.GenProjector.data import projector_batch
     from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
-    for num_d, n_layers, pairs in ((3, 6, 18), (2, 1, 0)):
+    for num_d, n_layers, pairs in ((3, 6, 18), (2, 1, 2)):
         model = Pix2PixModel(networks.default_options(ngf=4, ndf=4, num_D=num_d, n_layers_D=n_layers)).cuda()
         losses, _ = model(projector_batch(2, "cuda:0"), mode="generator")
         assert bool(torch.isfinite(losses["GAN_Feat"]).all()) and losses["GAN_Feat"].shape == (1,)
-        assert (float(losses["GAN_Feat"]) == 0.0) == (pairs == 0)
+        assert float(losses["GAN_Feat"]) > 0.0
         sum(losses.values()).mean().backward()
 
 
