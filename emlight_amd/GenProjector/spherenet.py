@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn.parameter import Parameter
 
-from .._knobs import knob_flag, knob_int
+from .._knobs import knob_choice, knob_flag, knob_int
 
 
 @lru_cache(None)
@@ -109,6 +109,33 @@ class SphereGeometry:
         # itself (once per geometry), never assumed
         self.rowshare = int(kind == "sphere" and _table_rowshare(self.idx, self.wgt, self.ho * self.wo))
 
+    def footprints(self, transposed=False):
+        """For ``eml_sphere_conv_lowres_f32`` (csrc/gather_gemm3.h): per 128-pixel tile of a sample the contiguous range of SOURCE
+        pixels its 9 taps touch -- ``(fp, fp_max)`` with ``fp`` an int32 (tiles, 2) tensor of (first pixel, count) or None when a
+        tile spans whole samples (fewer than 128 destination pixels per sample), ``fp_max`` the largest count; (None, 0) when the
+        geometry does not tile.  ``transposed``: for the input gradient (destination = the input pixels, source = dY's)."""
+        cache = self.__dict__.setdefault("_footprints", {})
+        if transposed not in cache:
+            if transposed:
+                tt = self.transposed_table()
+                idx, n_dst, n_src = (tt[0] if tt is not None else None), self.h * self.w, self.ho * self.wo
+            else:
+                idx, n_dst, n_src = self.idx, self.ho * self.wo, self.h * self.w
+            if idx is None:
+                cache[transposed] = (None, 0)
+            elif n_dst % 128 == 0:
+                t = idx.reshape(n_dst // 128, -1).long()
+                ok = t >= 0
+                lo = torch.where(ok, t, torch.full_like(t, n_src)).amin(1).clamp(max=n_src - 1)
+                hi = torch.where(ok, t, torch.full_like(t, -1)).amax(1).clamp(min=0)
+                n = (hi - lo + 1).clamp(min=1)
+                cache[transposed] = (torch.stack([lo, n], 1).to(torch.int32).contiguous(), int(n.max()))
+            elif n_dst < 128 and 128 % n_dst == 0:
+                cache[transposed] = (None, (128 // n_dst) * n_src)
+            else:
+                cache[transposed] = (None, 0)
+        return cache[transposed]
+
     def transposed_table(self):
         """The tap table seen from the INPUT pixels, for the fused input-gradient kernel: for input pixel q and tap t the
         (at most ke) output pixels whose tap t samples q with their bilinear weights, padded with (-1, 0).  Almost every
@@ -165,6 +192,39 @@ def sphere_geometry(h, w, stride, device, kind="sphere"):
     if key not in _GEOMETRY:
         _GEOMETRY[key] = SphereGeometry(h, w, stride, device, kind)
     return _GEOMETRY[key]
+
+
+def _lowres_plan(geo, B, C, O, transposed=False):
+    """Can ``eml_sphere_conv_lowres_f32`` run this product (C source channels -> O destination channels over ``geo``'s table, or
+    its transposed one)?  -> (fp, fp_max, split) or None.  ``split``: channel chunks over that many workgroups per tile where the
+    tiles alone would leave CUs idle (two resident workgroups per CU for the 256-thread variant, one for the 512-thread one)."""
+    from .. import _lib
+    L = _lib.lib()
+    n_dst = geo.h * geo.w if transposed else geo.ho * geo.wo
+    if B <= 0 or C % 32 or O % 128 or (n_dst % 128 and (n_dst > 128 or 128 % n_dst)):
+        return None                      # (before the footprints: they cost a table pass and a host sync per geometry)
+    fp, fp_max = geo.footprints(transposed)
+    variant = L.eml_sphere_conv_lowres_variant(C, O, n_dst, fp_max) if fp_max else 0
+    if not variant:
+        return None
+    tiles = ((B * n_dst + 127) // 128) * (O // (128 if variant == 1 else 256))
+    resident, nch, split = (512 if variant == 1 else 256), C // 32, 1
+    while tiles * split < resident and nch % (2 * split) == 0 and 8 * split * B * n_dst * O <= (256 << 20):
+        split *= 2
+    return fp, fp_max, split
+
+
+def _lowres_conv(xr, idx, wgt, rowmax, ke, plan, w2, bias, res, slope, B, n_src, n_dst, C, O):
+    """One call of ``eml_sphere_conv_lowres_f32``: (B * n_dst, O) = act(gather(xr) W2^T + bias + res)."""
+    from .. import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
+    fp, fp_max, split = plan
+    y = torch.empty(B * n_dst, O, dtype=torch.float32, device=xr.device)
+    part = (torch.empty(L.eml_sphere_conv_lowres_partial_floats(B * n_dst, O, split), dtype=torch.float32, device=xr.device)
+            if split > 1 else None)
+    _lib.check(L.eml_sphere_conv_lowres_f32(p(xr), p(idx), p(wgt), p(rowmax), ke, p(fp), fp_max, p(w2), p(bias), p(y), p(part), split,
+                                            B, n_src, n_dst, C, O, p(res), float(slope), st), "eml_sphere_conv_lowres_f32")
+    return y
 
 
 class _SphereConvFn(torch.autograd.Function):
@@ -227,6 +287,15 @@ class _SphereConvFn(torch.autograd.Function):
         # few-channel OUTPUT layers (conv_img 64 -> 3, the discriminators' final convolutions): one-pass kernels, no 9x operand
         ctx.narrow = bool(SphereConv2D.narrow_kernels and B > 0 and res is None and slope == 1.0 and geo.idx1 is None
                           and not ctx.small and L.eml_sphere_conv_narrow_supported(C, O))
+        # round 6: the low-resolution, wide layers (everything that used to fall through to im2col + a library GEMM below) on
+        # the footprint gather-GEMM of csrc/gather_gemm3.h; "force": wherever it is supported (tests, A/B), "off": round 5
+        mode = SphereConv2D.lowres
+        plan = None
+        if mode != "off" and kind == "sphere" and stride == 1 and not ctx.small and not ctx.narrow and (mode == "force" or not ctx.fused_fwd):
+            plan = _lowres_plan(geo, B, C, O)
+        ctx.lowres_dgrad = None
+        if mode != "off" and kind == "sphere" and stride == 1 and not ctx.small and not ctx.narrow and (mode == "force" or not ctx.fused_dgrad):
+            ctx.lowres_dgrad = _lowres_plan(geo, B, O, C, transposed=True) if ctx.needs_input_grad[0] else None
         if ctx.narrow:
             ctx.fused_fwd = ctx.fused_wgrad = ctx.fused_dgrad = False
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
@@ -239,6 +308,9 @@ class _SphereConvFn(torch.autograd.Function):
             _lib.check(L.eml_sphere_conv_small_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
                                                        p(bias.contiguous()) if bias is not None else None, p(y), B, H * W,
                                                        po, C, O, slope, st), "eml_sphere_conv_small_fwd_f32")
+        elif plan is not None:
+            y = _lowres_conv(xr, geo.idx, geo.wgt, None, 4, plan, w2.contiguous(), bias.contiguous() if bias is not None else None,
+                             res, slope, B, H * W, po, C, O)
         elif ctx.fused_fwd:
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
             tab = (geo.idx1, geo.wgt1, 1) if geo.idx1 is not None else (geo.idx, geo.wgt, 4)
@@ -397,9 +469,16 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
                 gw = gw2.t().contiguous().view(O, 3, 3, C).permute(0, 3, 1, 2)
             del a9
     if needs[0] and not small_x:
-        gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device)
-        tt = geo.transposed_table() if ((ctx.fused_dgrad or narrow) and B) else None
-        if tt is not None and narrow:
+        lowres = getattr(ctx, "lowres_dgrad", None)
+        gxr = torch.empty(B, H, W, C, dtype=torch.float32, device=gy.device) if (lowres is None or narrow or not B) else None
+        tt = geo.transposed_table() if ((ctx.fused_dgrad or narrow or lowres is not None) and B) else None
+        if tt is not None and lowres is not None and not narrow:
+            # the footprint gather-GEMM over the transposed table (round 6): dY's rows of the few source rows in LDS
+            tidx, twgt, rowmax, ke = tt
+            w2t = weight.permute(1, 2, 3, 0).reshape(C, 9 * O).contiguous()   # columns ordered (tap, o)
+            gxr = _lowres_conv(gyr, tidx, twgt, rowmax if ke == 8 else None, ke, lowres, w2t, None, None, 1.0, B, po, H * W, O,
+                               C).view(B, H, W, C)
+        elif tt is not None and narrow:
             tidx, twgt, rowmax, ke = tt
             w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
             _lib.check(L.eml_sphere_conv_narrow_dgrad_f32(p(gyr), p(tidx), p(twgt), ke, p(w2), p(gxr), B, H * W, po, C, O, st),
@@ -1030,6 +1109,9 @@ class SphereConv2D(nn.Module):
     fuse_spade = knob_flag("EML_FUSE_SPADE", True)
     # O <= 4 layers on the one-pass kernels of csrc/sphere_conv_narrow.hip; EML_NARROW=0: A/B knob (im2col + library GEMM)
     narrow_kernels = knob_flag("EML_NARROW", True)
+    # low-resolution wide layers on the footprint gather-GEMM (csrc/gather_gemm3.h) instead of im2col + a library GEMM;
+    # EML_LOWRES: A/B knob -- off = round 5's dispatch, force = wherever the kernel supports the shape
+    lowres = knob_choice("EML_LOWRES", "auto", ("auto", "off", "force"))
     # input gradient of the 3-channel input layers through eml_sphere_conv_small_da9_f32; EML_SMALL_DA9=0: A/B knob (general path)
     small_input_grad = knob_flag("EML_SMALL_DA9", True)
     # split-K of the fused weight gradient: workgroups per launch (tiles x K-splits).  Two resident workgroups per CU: 1024 is

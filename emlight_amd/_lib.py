@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 22   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 23   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -92,6 +92,10 @@ SIGNATURES = {
     "eml_instance_norm_act_bwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, ctypes.c_float, _stream]),
     "eml_sphere_conv_dgrad_fused_f32": (_int, [_f32p, _i32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int, _int, _int, _int,
                                                _int, _stream]),
+    "eml_sphere_conv_lowres_variant": (_int, [_int, _int, _int, _int]),
+    "eml_sphere_conv_lowres_partial_floats": (ctypes.c_size_t, [ctypes.c_long, _int, _int]),
+    "eml_sphere_conv_lowres_f32": (_int, [_f32p, _i32p, _f32p, _i32p, _int, _i32p, _int, _f32p, _f32p, _f32p, _f32p, _int, _int,
+                                          _int, _int, _int, _int, _f32p, ctypes.c_float, _stream]),
     "eml_sphere_conv_wgrad_partial_floats": (ctypes.c_size_t, [_int, _int, _int]),
     "eml_sphere_conv_wgrad_fused_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                                                _stream]),

@@ -133,6 +133,70 @@ def test_sphere_conv_fused_kernels_vs_stock_ops(B, Cin, Cout, H, W, stride, bias
     assert torch.equal(y2, yh) and torch.equal(xh2.grad, xh.grad) and torch.equal(hip.weight.grad, gw1)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias,with_res,slope", [
+    (2, 128, 128, 8, 16, True, False, 1.0),     # one tile per sample, footprint = the sample; split-K (few tiles)
+    (3, 128, 256, 16, 32, True, True, 0.2),     # four tiles per sample, row-range footprints; residual + LeakyReLU epilogue
+    (2, 64, 256, 32, 64, False, False, 1.0),    # 448-pixel footprints: the 512-thread variant (forward; C = 64: dX the old way)
+    (5, 128, 128, 4, 8, True, False, 0.0),      # 32 pixels per sample: a tile spans four samples, the last tile one; ReLU
+    (1, 96, 384, 16, 32, True, False, 1.0),     # three channel chunks, three 128-wide output tiles
+    (2, 256, 256, 32, 64, True, False, 1.0),    # the 512-thread variant both ways
+    (33, 32, 128, 8, 16, True, True, 1.0),      # more tiles than one round of workgroups
+])
+def test_sphere_conv_lowres_footprint_kernel_vs_stock_ops(B, Cin, Cout, H, W, bias, with_res, slope, monkeypatch):
+    """Round 6, ``csrc/gather_gemm3.h`` (``eml_sphere_conv_lowres_f32``): the low-resolution wide layers with the source footprint
+    in LDS -- forward (with the residual / activation epilogue) and the input gradient over the transposed table -- against
+    grid_sample + conv2d(stride 3) (sphere_cnn.py:111-124) in torch f32 on the same GPU; neither sphere_im2col nor
+    sphere_col2im may run for them; run-to-run bit equality (split-K partials are summed in a fixed order)."""
+    from emlight_amd import _lib
+    from emlight_amd.GenProjector.spherenet import SphereConv2D
+    monkeypatch.setattr(SphereConv2D, "lowres", "force")
+    torch.manual_seed(B * 100 + Cin)
+    hip = SphereConv2D(Cin, Cout, stride=1, bias=bias).cuda()
+    if bias:
+        with torch.no_grad():
+            hip.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(B, Cin, H, W, device="cuda")
+    rs = torch.randn(B, Cout, H, W, device="cuda") if with_res else None
+    xr, xh = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    wr = hip.weight.detach().clone().requires_grad_(True)
+    br = hip.bias.detach().clone().requires_grad_(True) if bias else None
+    rr, rh = (rs.clone().requires_grad_(True), rs.clone().requires_grad_(True)) if with_res else (None, None)
+    yr = oracle.sphere_conv(xr, wr, br, 1)
+    if with_res:
+        yr = yr + rr
+    if slope != 1.0:
+        yr = torch.nn.functional.leaky_relu(yr, slope)
+    real, seen = _lib.lib(), []
+
+    class Spy:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+
+            def call(*a):
+                seen.append(name)
+                return fn(*a)
+            return call
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    yh = hip(xh, residual=rh, act_slope=slope)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    yh.backward(gy)
+    # forward always; the input gradient (the same product over the transposed table: C and O swap roles) where C % 128 == 0
+    assert seen.count("eml_sphere_conv_lowres_f32") == 1 + int(Cin % 128 == 0), seen
+    assert "eml_sphere_conv_fwd_fused_ex_f32" not in seen and "eml_sphere_im2col_f32" not in seen[:seen.index("eml_sphere_conv_lowres_f32") + 1], seen
+    scale = float(yr.detach().abs().max())
+    np.testing.assert_allclose(yh.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=3e-5 * scale)
+    pairs = [("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad)] + ([("db", hip.bias.grad, br.grad)] if bias else []) + \
+        ([("dres", rh.grad, rr.grad)] if with_res else [])
+    for name, a, b in pairs:
+        s_ = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=3e-5 * s_, err_msg=name)
+    xh2 = x.clone().requires_grad_(True)
+    y2 = hip(xh2, residual=rs, act_slope=slope)
+    y2.backward(gy)
+    assert torch.equal(y2, yh) and torch.equal(xh2.grad, xh.grad)
+
+
 # Every distinct SphereConv geometry (B, Cin, Cout, H, W, stride) of the ngf = ndf = 64 projector at BASELINE configs[2]
 # (B = 32; the discriminator sees fake + real = 64): the SPADE blocks' convs and their (gamma | beta) heads (one conv over the
 # concatenated outputs), the 3 -> 128 guide-map convs at every resolution, the output layer, both PatchGAN scales.
