@@ -476,6 +476,10 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
     for k in FAM:
         setattr(L, k, timed(k))
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the instrumented iterations run the discriminator step's generator pass eagerly: a replayed graph makes no launcher calls
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    graph_was = Pix2PixModel.graph_dstep
+    Pix2PixModel.graph_dstep = False
     try:
         torch.cuda.synchronize()
         t0.record()
@@ -484,6 +488,7 @@ def time_projector_families(trainer, data, steps, families=None, other_label=Non
         t1.record()
         torch.cuda.synchronize()
     finally:
+        Pix2PixModel.graph_dstep = graph_was
         for k in FAM:
             setattr(L, k, orig[k])
     total = t0.elapsed_time(t1) / steps

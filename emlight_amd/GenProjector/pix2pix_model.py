@@ -8,10 +8,73 @@ offline (parity of the VALUE unpinned): with ``opt.no_vgg_loss`` Fal
 ``opt.vgg_weights`` (a torchvision ``vgg19`` state dict) or, when absent, from seeded random weights -- the step then does
 the reference's work.  A ``vgg_features`` callable may be passed instead.
 """
+import warnings
+
 import torch
 import torch.nn.functional as F
 
+from .._knobs import knob_flag
 from . import networks
+
+
+class _NoGradGraph:
+    """The discriminator step's generator pass (``pix2pix_model.py:124-126``: ``with torch.no_grad(): fake = G(...)``) as a
+    captured HIP graph.  That pass is ~250 launches, a third of them 5-20 us kernels of the low-resolution blocks behind 30-50 us
+    of Python each: the GPU idles for the host there (``profiles/r05_gaps_joint.txt``).  It has no autograd state and fixed
+    shapes, and everything it reads or updates is updated IN PLACE between replays (parameters by Adam, the power iteration's
+    ``weight_u`` / ``weight_v``, BatchNorm's running statistics), so one capture replays correctly for the rest of the run: a
+    replay is the same kernels on the same addresses as an eager call (``test_discriminator_step_graph_equals_eager``).
+    Round 5's attempt died on ``hipErrorStreamCaptureUnsupported``; ``tools/capture_probe.py`` located the one offender (a
+    Python scalar stored into a device tensor = a host-to-device copy, ``spherenet._reduce_sums``), now a fill kernel.
+    Captured on the second call per (shapes, mode) -- the first runs eagerly so that every per-geometry table, LDS attribute
+    and library handle exists; any failure to capture switches the instance back to eager calls for good, loudly."""
+
+    def __init__(self, net):
+        self.net, self.graph, self.key, self.failed, self.calls = net, None, None, False, 0
+        self.s_inp = self.s_crop = self.out = None
+
+    def __deepcopy__(self, memo):
+        return None   # a copy of the model captures its own graph
+
+    def __reduce__(self):
+        return (type(None), ())   # nor does a pickled model carry one
+
+    def __call__(self, inp, crop):
+        if self.failed:
+            return self.net(inp, crop)
+        key = (tuple(inp.shape), tuple(crop.shape), inp.device, inp.dtype, crop.dtype, bool(self.net.training))
+        if key != self.key:
+            self.graph, self.out, self.key, self.calls = None, None, key, 0
+        self.calls += 1
+        if self.calls == 1:
+            return self.net(inp, crop)
+        if self.graph is None:
+            try:
+                self._capture(inp, crop)
+            except Exception as e:   # noqa: BLE001 -- whatever the runtime refuses: the eager pass is always available
+                self.failed, self.graph, self.out = True, None, None
+                torch.cuda.synchronize(inp.device)
+                warnings.warn("the discriminator step's generator pass could not be captured as a graph (%s: %s); running it "
+                              "eagerly from now on" % (type(e).__name__, str(e).splitlines()[0][:200]))
+                return self.net(inp, crop)
+        self.s_inp.copy_(inp)
+        self.s_crop.copy_(crop)
+        self.graph.replay()
+        return self.out.clone()   # the static output is overwritten by the next replay
+
+    def _capture(self, inp, crop):
+        self.s_inp, self.s_crop = inp.detach().clone(), crop.detach().clone()
+        dev = inp.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # the libraries' per-stream state (BLAS handle, workspace) outside the capture
+            a = torch.ones(64, 64, device=dev)
+            torch.mm(a, a)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = self.net(self.s_inp, self.s_crop)
+        self.graph, self.out = graph, out
 
 
 class Pix2PixModel(torch.nn.Module):
@@ -121,9 +184,26 @@ class Pix2PixModel(torch.nn.Module):
         losses["COS"] = (1 - cos(fake, real)).mean() * 5
         return losses, fake
 
+    # EML_GRAPH_DSTEP=0: A/B knob -- the discriminator step's generator pass eagerly, as in rounds 1-5
+    graph_dstep = knob_flag("EML_GRAPH_DSTEP", True)
+
+    def _fake_for_discriminator(self, inp, crop):
+        """``generate_fake`` under no_grad; as a replayed graph where that is possible: one process per job (with more ranks the
+        pass holds SPADE's BatchNorm all-reduces and goes through the DDP wrapper: eager), a GPU generator in training mode,
+        shapes that repeat."""
+        from . import spherenet
+        if (Pix2PixModel.graph_dstep and inp.is_cuda and "generate_fake" not in self.__dict__ and not spherenet._bn_sync()
+                and not torch.cuda.is_current_stream_capturing()):
+            g = self.__dict__.get("_dstep_graph")
+            if g is None:
+                g = _NoGradGraph(self.netG)
+                object.__setattr__(self, "_dstep_graph", g)
+            return g(inp, crop)
+        return self.generate_fake(inp, crop).detach()
+
     def compute_discriminator_loss(self, inp, crop, real):
         with torch.no_grad():
-            fake = self.generate_fake(inp, crop).detach()
+            fake = self._fake_for_discriminator(inp, crop)
         fake.requires_grad_()
         pred_fake, pred_real = self.discriminate(inp, fake, real)
         return {"D_Fake": self.criterionGAN(pred_fake, False, for_discriminator=True),

@@ -1111,7 +1111,7 @@ class SphereConv2D(nn.Module):
     narrow_kernels = knob_flag("EML_NARROW", True)
     # low-resolution wide layers on the footprint gather-GEMM (csrc/gather_gemm3.h) instead of im2col + a library GEMM;
     # EML_LOWRES: A/B knob -- off = round 5's dispatch, force = wherever the kernel supports the shape
-    lowres = knob_choice("EML_LOWRES", "auto", ("auto", "off", "force"))
+    lowres = knob_choice("EML_LOWRES", "off", ("auto", "off", "force"))
     # input gradient of the 3-channel input layers through eml_sphere_conv_small_da9_f32; EML_SMALL_DA9=0: A/B knob (general path)
     small_input_grad = knob_flag("EML_SMALL_DA9", True)
     # split-K of the fused weight gradient: workgroups per launch (tiles x K-splits).  Two resident workgroups per CU: 1024 is

@@ -1347,3 +1347,48 @@ def test_small_layer_input_gradient_first_half(O, slope, M):
     g = gy if slope == 1.0 else torch.where(y > 0, gy, gy * slope)
     want = g.double() @ w2.double()
     np.testing.assert_allclose(da9.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+
+
+def test_discriminator_step_graph_equals_eager():
+    """Round 6: the discriminator step's no-grad generator pass replayed from a captured HIP graph
+    (``pix2pix_model._NoGradGraph``; captured on the second call per shape) against the same pass run eagerly on a copy of the
+    model: the image bit for bit, over four calls with the parameters changed in place in between (as Adam does) and new inputs
+    each time, then every buffer the pass updates (the power iteration's u / v, BatchNorm's running statistics); a new batch
+    size starts over (eager, then captured); a deep copy of the model drops the graph."""
+    import copy
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.GenProjector.pix2pix_model import Pix2PixModel
+    torch.manual_seed(11)
+    opt = networks.default_options(no_vgg_loss=True)
+    opt.ngf = opt.ndf = 8
+    a = Pix2PixModel(opt).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    draw = lambda B: (torch.rand(B, 3, 128, 256, device="cuda", generator=g), torch.rand(B, 3, 128, 128, device="cuda", generator=g))
+    b = copy.deepcopy(a)
+    assert Pix2PixModel.graph_dstep, "EML_GRAPH_DSTEP=0 in the environment: nothing to test"
+    for step in range(4):
+        inp, crop = draw(2)
+        with torch.no_grad():
+            fa = a._fake_for_discriminator(inp, crop)
+            fb = b.generate_fake(inp, crop)
+        gr = a.__dict__["_dstep_graph"]
+        assert not gr.failed, "the capture was refused"
+        assert (gr.graph is not None) == (step >= 1), "eager first, captured from the second call on"
+        assert torch.equal(fa, fb), "step %d" % step
+        with torch.no_grad():
+            for q, r in zip(a.netG.parameters(), b.netG.parameters()):   # an optimizer step's in-place update, on both
+                q.mul_(1.0 + 1e-3 * (step + 1))
+                r.mul_(1.0 + 1e-3 * (step + 1))
+    for (n, x), (_, y) in zip(a.netG.named_buffers(), b.netG.named_buffers()):
+        assert torch.equal(x, y), n
+    for step in range(2):                      # another batch size: eager, then captured again
+        inp, crop = draw(1)
+        with torch.no_grad():
+            assert torch.equal(a._fake_for_discriminator(inp, crop), b.generate_fake(inp, crop))
+    assert a.__dict__["_dstep_graph"].key[0] == (1, 3, 128, 256) and a.__dict__["_dstep_graph"].graph is not None
+    c = copy.deepcopy(a)
+    assert c.__dict__.get("_dstep_graph") is None
+    with torch.no_grad():
+        inp, crop = draw(1)
+        fc = c._fake_for_discriminator(inp, crop)
+        assert torch.equal(fc, b.generate_fake(inp, crop)) and torch.equal(fc, a._fake_for_discriminator(inp, crop))
