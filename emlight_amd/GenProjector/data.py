@@ -9,12 +9,25 @@ from ..RegressionNetwork.data import synthetic_batch
 from ..RegressionNetwork.util import convert_to_panorama, sphere_points
 
 
+_ANCHORS = {}
+
+
+def anchor_dirs(ln, dev):
+    """The Fibonacci anchors as a (1, 3 ln) device tensor, built once per (ln, device): the joint step calls ``gaussian_map`` every
+    iteration, and a fresh ``torch.from_numpy(...).to(dev)`` there is a pageable host-to-device copy -- a host synchronisation
+    in the middle of the step (round 6: every such copy on the iteration's path is gone, ``tools/capture_probe.py``)."""
+    key = (int(ln), str(dev))
+    if key not in _ANCHORS:
+        _ANCHORS[key] = torch.from_numpy(sphere_points(ln)).float().view(1, ln * 3).to(dev)
+    return _ANCHORS[key]
+
+
 def gaussian_map(distribution, intensity, rgb_ratio, ambient, alpha=None, ln=128, pano_hw=(128, 256)):
     """``data.py:86-102``: light = dist * (intensity*0.01) * rgb per anchor, SG lobes of width .0025 on the
     Fibonacci anchors, + ambient / (H*W), * alpha.  All arguments are batched device tensors."""
     B = distribution.shape[0]
     dev = distribution.device
-    dirs = torch.from_numpy(sphere_points(ln)).float().view(1, ln * 3).to(dev).expand(B, -1).contiguous()
+    dirs = anchor_dirs(ln, dev).expand(B, -1).contiguous()
     size = torch.full((B, ln), 0.0025, device=dev)
     light = (distribution.view(B, ln, 1) * (intensity.view(B, 1, 1) * 0.01) * rgb_ratio.view(B, 1, 3))
     env = convert_to_panorama(dirs, size, light.reshape(B, ln * 3).contiguous(), pano_hw=pano_hw)
