@@ -317,3 +317,61 @@ def test_collective_counts_of_a_projector_iteration(tmp_path):
         fwd, 2 * blocks + shortcuts, n_g)
     assert widest == 2 * 64 + 1 and other <= 4       # (2C+1) f64 sums, C <= 16 * ngf = 64 here; DDP's own small reductions
     assert gG >= 1 and gD == 0 and dG == 0 and dD >= 1
+
+
+def _rccl_single_worker(rank, dry_run, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    os.environ.pop("EML_DIST_BACKEND", None)           # the default backend on a GPU: "nccl" = RCCL
+    if dry_run:
+        os.environ["EML_DIST_SINGLE"] = "1"
+    else:
+        os.environ.pop("EML_DIST_SINGLE", None)
+    import torch.distributed as dist
+    from emlight_amd import _dist
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.RegressionNetwork.engine import init_distributed
+    from emlight_amd.joint import JointTrainer, joint_batch
+    r, local, w = init_distributed()
+    assert dist.is_initialized() == bool(dry_run) and _dist.dp_active() == bool(dry_run)
+    if dry_run:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    calls = {"n": 0}
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls["n"] += 1
+        return orig(t, *a, **k)
+    dist.all_reduce = counting
+    torch.manual_seed(0)
+    tr = JointTrainer(networks.default_options(ngf=4, ndf=4), anchors=32, crop_hw=(64, 96), device="cuda:0", world=w)
+    assert (tr.reg.ddp is not None) == bool(dry_run) and hasattr(tr.proj, "_ddpG") == bool(dry_run)
+    batch = joint_batch(2, "cuda:0", 32, (64, 96), seed=9)
+    for _ in range(2):
+        losses = tr.step(batch)
+    flat = torch.cat([q.detach().reshape(-1) for net in (tr.reg.model, tr.proj.model.netG, tr.proj.model.netD) for q in net.parameters()])
+    vals = np.array([float(v.mean()) for v in losses.values()] + [float(flat.double().sum()), float(flat.abs().max()), calls["n"]])
+    np.save(os.path.join(out_dir, "s%d.npy" % int(dry_run)), vals)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_dry_run_of_the_data_parallel_path(tmp_path):
+    """``EML_DIST_SINGLE=1`` (emlight_amd/_dist.py): the whole data-parallel machinery of a joint
+    iteration -- process group on RCCL ("nccl"), DistributedDataParallel around encoder / generator / discriminator, SPADE's
+    synchronised BatchNorm all-reduces, the Sinkhorn diameter's -- with ONE rank on the one GPU of the test box (RCCL refuses two
+    ranks per device: "Duplicate GPU detected", profiles/r06_rccl_probe.txt).  A one-rank all-reduce is the identity, so two
+    iterations must give exactly the losses and parameters of the plain single-process run; and the collectives really ran."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for dry in (0, 1):
+        mp.spawn(_rccl_single_worker, args=(dry, port + dry, str(tmp_path)), nprocs=1, join=True)
+    plain, dry = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
+    assert plain[-1] == 0 and dry[-1] >= 2 * (14 + 18 + 14), (plain[-1], dry[-1])   # sync-BN sums of two iterations (+ diameters)
+    assert np.isfinite(dry).all()
+    # DDP hands the optimizer gradients from its buckets: the same numbers (a one-rank mean), summed in the same kernels
+    np.testing.assert_allclose(dry[:-1], plain[:-1], rtol=1e-6, atol=1e-7)

@@ -24,13 +24,21 @@ batch = joint_batch(B, "cuda:0")
 for _ in range(4):
     tr.step(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, experimental_config=None) as prof:
     tr.step(batch)
     torch.cuda.synchronize()
 calls = collections.Counter()
 where = collections.defaultdict(collections.Counter)
+dev_copies, sync_ops = collections.Counter(), collections.defaultdict(collections.Counter)
 for e in prof.events():
     n = e.name
+    if n.startswith("Memcpy") or n.startswith("Memset"):
+        dev_copies[n] += 1
+    if n in ("aten::item", "aten::_local_scalar_dense", "aten::is_nonzero", "aten::copy_", "aten::to", "aten::_to_copy", "aten::fill_"):
+        st = [f.strip() for f in (e.stack or [])]
+        mine = [f for f in st if "emlight_amd" in f or "bench.py" in f]
+        if n in ("aten::item", "aten::_local_scalar_dense", "aten::is_nonzero"):
+            sync_ops[n][mine[0][:140] if mine else (st[0][:100] if st else "?")] += 1
     if not (n.startswith("hip") or n.startswith("cuda")):
         continue
     if "LaunchKernel" in n or "GetLastError" in n or "hipGetDevice" in n or "PeekAtLastError" in n or "hipSetDevice" in n:
@@ -38,7 +46,13 @@ for e in prof.events():
     calls[n] += 1
     if "Memcpy" in n or "Synchronize" in n or "Memset" in n or "EventQuery" in n:
         frames = [f for f in (e.stack or []) if "emlight_amd" in f or "bench" in f or "joint" in f]
-        where[n][frames[0].strip()[:150] if frames else "(no frame of this repo: %s)" % ((e.stack or ["?"])[0].strip()[:100])] += 1
+        st = [f.strip()[:90] for f in (e.stack or [])][:4]
+        where[n][frames[0].strip()[:150] if frames else "(no frame of this repo: %s)" % " <- ".join(st)] += 1
+print("device-side copies / memsets of one joint iteration:", dict(dev_copies))
+for n, c in sync_ops.items():
+    print("host-synchronising op %s:" % n)
+    for w, k in c.most_common(10):
+        print("     %4d  %s" % (k, w))
 print("runtime calls of one joint iteration (B = %d) other than kernel launches:" % B)
 for n, c in calls.most_common():
     print("  %5d  %s" % (c, n))

@@ -11,6 +11,14 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = dry ]; then
   cd $REPO && exec python -m pytest tests/test_gpu_ddp_two_ranks.py -q -m gpu -k "collective_counts or sync_bn_two_ranks"
 fi
+# `tools/scale_check.sh rccl`: no node needed either -- the FIRST RCCL run of this code need not be the 8-GPU one: one rank on the
+# one GPU with EML_DIST_SINGLE=1 (emlight_amd/_dist.py) initialises the "nccl" process group, wraps the three networks in DDP
+# and issues every collective of an iteration through RCCL; then the bench's joint leg the same way, which prints what it saw
+# (`collectives`: ranks, explicit all-reduces, DDP buckets).  (Two ranks on one device: RCCL answers "Duplicate GPU detected".)
+if [ "$1" = rccl ]; then
+  cd $REPO && python -m pytest tests/test_gpu_ddp_two_ranks.py -q -m gpu -k "one_rank_rccl" || exit 1
+  EML_DIST_SINGLE=1 exec python bench.py --gpus 1 --steps 5 --warmup 2 --no_cpu_baseline --legs joint
+fi
 LEGS=${1:-joint}
 shift
 NS=${@:-1 2 4 8}
