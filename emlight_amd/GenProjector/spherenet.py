@@ -111,9 +111,10 @@ class SphereGeometry:
 
     def footprints(self, transposed=False):
         """For ``eml_sphere_conv_lowres_f32`` (csrc/gather_gemm3.h): per 128-pixel tile of a sample the contiguous range of SOURCE
-        pixels its 9 taps touch -- ``(fp, fp_max)`` with ``fp`` an int32 (tiles, 2) tensor of (first pixel, count) or None when a
-        tile spans whole samples (fewer than 128 destination pixels per sample), ``fp_max`` the largest count; (None, 0) when the
-        geometry does not tile.  ``transposed``: for the input gradient (destination = the input pixels, source = dY's)."""
+        pixels its 9 taps touch -- ``(fp, fp_max, lidx)`` with ``fp`` an int32 (tiles, 2) tensor of (first pixel, count) or None
+        when a tile spans whole samples (fewer than 128 destination pixels per sample), ``fp_max`` the largest count and ``lidx``
+        the table's indices made footprint-local (``eml_sphere_conv_lowres_table_i32``); (None, 0, None) when the geometry does
+        not tile.  ``transposed``: for the input gradient (destination = the input pixels, source = dY's)."""
         cache = self.__dict__.setdefault("_footprints", {})
         if transposed not in cache:
             if transposed:
@@ -121,19 +122,26 @@ class SphereGeometry:
                 idx, n_dst, n_src = (tt[0] if tt is not None else None), self.h * self.w, self.ho * self.wo
             else:
                 idx, n_dst, n_src = self.idx, self.ho * self.wo, self.h * self.w
+            fp, fp_max = None, 0
             if idx is None:
-                cache[transposed] = (None, 0)
+                pass
             elif n_dst % 128 == 0:
                 t = idx.reshape(n_dst // 128, -1).long()
                 ok = t >= 0
                 lo = torch.where(ok, t, torch.full_like(t, n_src)).amin(1).clamp(max=n_src - 1)
                 hi = torch.where(ok, t, torch.full_like(t, -1)).amax(1).clamp(min=0)
                 n = (hi - lo + 1).clamp(min=1)
-                cache[transposed] = (torch.stack([lo, n], 1).to(torch.int32).contiguous(), int(n.max()))
+                fp, fp_max = torch.stack([lo, n], 1).to(torch.int32).contiguous(), int(n.max())
             elif n_dst < 128 and 128 % n_dst == 0:
-                cache[transposed] = (None, (128 // n_dst) * n_src)
-            else:
-                cache[transposed] = (None, 0)
+                fp_max = (128 // n_dst) * n_src
+            lidx = None
+            if fp_max:
+                from .. import _lib
+                idx = idx.contiguous()
+                lidx = torch.empty_like(idx)
+                _lib.check(_lib.lib().eml_sphere_conv_lowres_table_i32(_lib.ptr(idx), _lib.ptr(fp), _lib.ptr(lidx), n_dst, idx.shape[-1],
+                                                                       _lib.current_stream()), "eml_sphere_conv_lowres_table_i32")
+            cache[transposed] = (fp, fp_max, lidx)
         return cache[transposed]
 
     def transposed_table(self):
@@ -203,7 +211,7 @@ def _lowres_plan(geo, B, C, O, transposed=False):
     n_dst = geo.h * geo.w if transposed else geo.ho * geo.wo
     if B <= 0 or C % 32 or O % 128 or (n_dst % 128 and (n_dst > 128 or 128 % n_dst)):
         return None                      # (before the footprints: they cost a table pass and a host sync per geometry)
-    fp, fp_max = geo.footprints(transposed)
+    fp, fp_max, lidx = geo.footprints(transposed)
     variant = L.eml_sphere_conv_lowres_variant(C, O, n_dst, fp_max) if fp_max else 0
     if not variant:
         return None
@@ -211,14 +219,15 @@ def _lowres_plan(geo, B, C, O, transposed=False):
     resident, nch, split = (512 if variant == 1 else 256), C // 32, 1
     while tiles * split < resident and nch % (2 * split) == 0 and 8 * split * B * n_dst * O <= (256 << 20):
         split *= 2
-    return fp, fp_max, split
+    return fp, fp_max, split, lidx
 
 
 def _lowres_conv(xr, idx, wgt, rowmax, ke, plan, w2, bias, res, slope, B, n_src, n_dst, C, O):
-    """One call of ``eml_sphere_conv_lowres_f32``: (B * n_dst, O) = act(gather(xr) W2^T + bias + res)."""
+    """One call of ``eml_sphere_conv_lowres_f32``: (B * n_dst, O) = act(gather(xr) W2^T + bias + res).  (``idx``: the raw table the
+    plan's footprint-local one was made from -- kept in the signature for the callers' symmetry, the kernel takes the plan's.)"""
     from .. import _lib
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream()
-    fp, fp_max, split = plan
+    fp, fp_max, split, idx = plan
     y = torch.empty(B * n_dst, O, dtype=torch.float32, device=xr.device)
     part = (torch.empty(L.eml_sphere_conv_lowres_partial_floats(B * n_dst, O, split), dtype=torch.float32, device=xr.device)
             if split > 1 else None)

@@ -93,6 +93,7 @@ SIGNATURES = {
     "eml_sphere_conv_dgrad_fused_f32": (_int, [_f32p, _i32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int, _int, _int, _int,
                                                _int, _stream]),
     "eml_sphere_conv_lowres_variant": (_int, [_int, _int, _int, _int]),
+    "eml_sphere_conv_lowres_table_i32": (_int, [_i32p, _i32p, _i32p, _int, _int, _stream]),
     "eml_sphere_conv_lowres_partial_floats": (ctypes.c_size_t, [ctypes.c_long, _int, _int]),
     "eml_sphere_conv_lowres_f32": (_int, [_f32p, _i32p, _f32p, _i32p, _int, _i32p, _int, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                           _int, _int, _int, _int, _f32p, ctypes.c_float, _stream]),

@@ -120,11 +120,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
   };
 
   // ---- this lane's two pixels (tiles mi = 0, 1 of the wave's 32) and where their table entries point inside the footprint
+  // (the table this kernel takes is FOOTPRINT-LOCAL and pre-multiplied: entry = kLdF * (source pixel - the tile's first
+  // footprint pixel), 0 for an empty slot -- eml_sphere_conv_lowres_table_i32 builds it once per geometry; what is left to add
+  // per tap is the sample's offset when a tile spans several samples, and the lane's 8 kk: one add per corner)
   int loc[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = min(m0 + 32 * wm + 16 * mi + r, M - 1);
-    loc[mi] = (m / Po - sb0) * HW - lo;
+    loc[mi] = (fp ? 0 : (m / Po - sb0) * HW * kLdF) + 8 * kk;
   }
   // ---- table DMA role: lanes 0..31 the indices, 32..63 the weights of pixel 32 wm + (lane & 31)
   const int tpix = min(m0 + 32 * wm + (lane & 31), M - 1) % Po;
@@ -180,12 +183,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int4 id = tid4[mi];
-      // an empty entry (-1) carries weight 0: any row of the footprint will do -- row 0, by masking (id >> 31 is all ones for
-      // -1): written as a select the compiler turns the eight of them into divergent branches inside the tap loop
-      co[mi][0] = ((id.x + loc[mi]) & ~(id.x >> 31)) * kLdF + 8 * kk;
-      co[mi][1] = ((id.y + loc[mi]) & ~(id.y >> 31)) * kLdF + 8 * kk;
-      co[mi][2] = ((id.z + loc[mi]) & ~(id.z >> 31)) * kLdF + 8 * kk;
-      co[mi][3] = ((id.w + loc[mi]) & ~(id.w >> 31)) * kLdF + 8 * kk;
+      // (round 6, first build: raw indices here -- eight selects for the empty slots, which the compiler turned into divergent
+      // branches inside the tap loop, and eight quarter-rate v_mul_lo_u32 by the row stride)
+      co[mi][0] = id.x + loc[mi];
+      co[mi][1] = id.y + loc[mi];
+      co[mi][2] = id.z + loc[mi];
+      co[mi][3] = id.w + loc[mi];
     }
   };
   auto read_corners = [&](float4 (&cv)[MI][4], int h) {
@@ -193,6 +196,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int e = 0; e < 4; ++e) cv[mi][e] = *reinterpret_cast<const float4*>(Fp + co[mi][e] + 4 * h);
+  };
+  auto combine1 = [&](float4 (&af)[MI], const float4 (&cv)[MI][4], int mi) {   // one pixel tile (experiment builds place the two apart)
+    const float4 w = wv[mi];
+#ifndef GG3_SCALARCOMBINE   // on register pairs (v_pk_mul_f32 / v_pk_fma_f32): half the VALU instructions, same sums in the same order
+                           // (experiment build GG3_SCALARCOMBINE: scalar fmaf chains; pairs + spread placement measured +2 %)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f lo = v2f{cv[mi][0].x, cv[mi][0].y} * v2f{w.x, w.x}, hi = v2f{cv[mi][0].z, cv[mi][0].w} * v2f{w.x, w.x};
+    lo += v2f{cv[mi][1].x, cv[mi][1].y} * v2f{w.y, w.y};
+    hi += v2f{cv[mi][1].z, cv[mi][1].w} * v2f{w.y, w.y};
+    lo += v2f{cv[mi][2].x, cv[mi][2].y} * v2f{w.z, w.z};
+    hi += v2f{cv[mi][2].z, cv[mi][2].w} * v2f{w.z, w.z};
+    lo += v2f{cv[mi][3].x, cv[mi][3].y} * v2f{w.w, w.w};
+    hi += v2f{cv[mi][3].z, cv[mi][3].w} * v2f{w.w, w.w};
+    af[mi] = make_float4(lo.x, lo.y, hi.x, hi.y);
+#else
+    af[mi].x = fmaf(cv[mi][3].x, w.w, fmaf(cv[mi][2].x, w.z, fmaf(cv[mi][1].x, w.y, cv[mi][0].x * w.x)));
+    af[mi].y = fmaf(cv[mi][3].y, w.w, fmaf(cv[mi][2].y, w.z, fmaf(cv[mi][1].y, w.y, cv[mi][0].y * w.x)));
+    af[mi].z = fmaf(cv[mi][3].z, w.w, fmaf(cv[mi][2].z, w.z, fmaf(cv[mi][1].z, w.y, cv[mi][0].z * w.x)));
+    af[mi].w = fmaf(cv[mi][3].w, w.w, fmaf(cv[mi][2].w, w.z, fmaf(cv[mi][1].w, w.y, cv[mi][0].w * w.x)));
+#endif
   };
   auto combine = [&](float4 (&af)[MI], const float4 (&cv)[MI][4]) {   // grid_sample's order: nw, ne, sw, se (= gg2's commit)
 #pragma unroll
@@ -278,7 +301,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
             if (ni < NBD) b_dma(ni, n_tap, n_ch * kBK, buf ^ 1);
 #endif
 #ifndef GG3_NOCORNER
+#ifndef GG3_BUNCHED   // the two pixel tiles' combines behind different MFMA groups (experiment build GG3_BUNCHED: both behind one)
+            if (ni == 4) combine1(af1, cv, 0);
+            if (ni == 6) combine1(af1, cv, 1);
+#else
             if (ni == 5) combine(af1, cv);
+#endif
 #endif
           } else {
 #ifndef GG3_NOTAB
@@ -290,7 +318,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
 #endif
 #ifndef GG3_NOCORNER
             if (ni == 3) read_corners(cv, 0);
+#ifndef GG3_BUNCHED
+            if (ni == 5) combine1(af0, cv, 0);
+            if (ni == 7) combine1(af0, cv, 1);
+#else
             if (ni == 6) combine(af0, cv);
+#endif
 #endif
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -338,6 +371,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gather_gemm3_kernel(
       }
     }
   }
+}
+
+// lidx[i] = kLdF * (idx[i] - lo(tile of i's destination pixel)), 0 for an empty slot (-1): the footprint-local table of the kernel
+__global__ __launch_bounds__(256) void gg3_table_kernel(const int* __restrict__ idx, const int* __restrict__ fp, int* __restrict__ lidx,
+                                                        long n, int per_pixel) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = idx[i];
+  const int lo = fp ? fp[2 * (int)((i / per_pixel) >> 7)] : 0;
+  lidx[i] = v < 0 ? 0 : (v - lo) * kLdF;
 }
 
 // Y = act(bias + res + sum_s partial[s]) in the fixed order s = 0, 1, ...: the second pass of the split-K launches

@@ -20,15 +20,24 @@ extern "C" int eml_sphere_conv_lowres_variant(int C, int O, int Po, int fp_max) 
   return 0;
 }
 
+extern "C" int eml_sphere_conv_lowres_table_i32(const int* idx, const int* fp, int* lidx, int Po, int ke, eml_stream_t stream) {
+  if (!idx || !lidx || Po < 1 || (ke != 4 && ke != 8) || ((Po % 128 == 0) != (fp != nullptr)))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_lowres_table_i32: bad arguments (Po=%d, ke=%d; fp exactly when Po %% 128 == 0)", Po, ke);
+  const long n = (long)Po * 9 * ke;
+  hipLaunchKernelGGL(gg3::gg3_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, fp, lidx, n, 9 * ke);
+  return eml::check_launch("eml_sphere_conv_lowres_table_i32");
+}
+
 extern "C" size_t eml_sphere_conv_lowres_partial_floats(long M, int O, int split) {
   return split > 1 ? (size_t)split * (size_t)M * (size_t)O : 0;
 }
 
-extern "C" int eml_sphere_conv_lowres_f32(const float* X, const int* idx, const float* wgt, const unsigned char* rowmax, int ke,
+extern "C" int eml_sphere_conv_lowres_f32(const float* X, const int* lidx, const float* wgt, const unsigned char* rowmax, int ke,
                                           const int* fp, int fp_max, const float* W2, const float* bias, float* Y,
                                           float* partial, int split, int B, int HW, int Po, int C, int O,
                                           const float* residual, float act_slope, eml_stream_t stream) {
   const char* what = "eml_sphere_conv_lowres_f32";
+  const int* idx = lidx;   // the FOOTPRINT-LOCAL table of eml_sphere_conv_lowres_table_i32, not the raw tap table
   if (!X || !idx || !wgt || !W2 || !Y || B < 0 || HW < 1) return eml::fail(EML_EINVAL, "%s: null pointer / empty grid", what);
   const int variant = eml_sphere_conv_lowres_variant(C, O, Po, fp_max);
   if (!variant) return eml::fail(EML_EINVAL, "%s: unsupported shape (C=%d, O=%d, Po=%d, footprint %d)", what, C, O, Po, fp_max);

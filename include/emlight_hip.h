@@ -475,18 +475,21 @@ int eml_sphere_conv_dgrad_fused_f32(const float* dY, const int* tidx, const floa
  * taps of a 128-pixel tile touch (its FOOTPRINT, a contiguous pixel range of the sample) are staged in LDS once per 32-channel
  * chunk and serve all 9 taps; a lane builds its MFMA fragments straight from them (4 corner reads + the bilinear combine in
  * grid_sample's order: bit-identical to the kernels above); no gathered global load, no operand tile, no 9x tensor.
- *   X (B*HW, C) pixel-major; idx / wgt (Po*9*ke): a forward tap table (ke = 4) or a transposed one (ke = 4 / 8 with rowmax):
- *       the input gradient is this entry on (dY, tidx, twgt, W2t) with the roles of HW / Po and C / O swapped, as above.
+ *   X (B*HW, C) pixel-major; wgt (Po*9*ke): the weights of a forward tap table (ke = 4) or a transposed one (ke = 4 / 8 with
+ *       rowmax): the input gradient is this entry on (dY, tidx, twgt, W2t) with the roles of HW / Po and C / O swapped, as above.
  *   fp (2 ints per 128-pixel tile of a sample: first source pixel, count) when Po % 128 == 0, NULL when Po divides 128 (a
  *       tile then spans 128 / Po whole samples); fp_max = the largest count (resp. (128 / Po) * HW): selects the variant.
+ *   lidx (Po*9*ke): the table's indices made FOOTPRINT-LOCAL by eml_sphere_conv_lowres_table_i32 (once per geometry): row offset
+ *       into the tile's staged footprint, 0 for an empty slot (weight 0) -- the tap loop then adds, it does not select or multiply.
  *   split >= 1 divides the C / 32 channel chunks over that many workgroups per tile (layers with too few tiles for 256 CUs):
  *       raw sums go to partial (eml_sphere_conv_lowres_partial_floats) and a second launch adds them in a fixed order and
  *       applies the epilogue  Y = leaky_relu(conv + bias + residual, act_slope).  Deterministic, no atomics.
  * eml_sphere_conv_lowres_variant: 0 = shape not supported (C % 32, O % 128, Po % 128 == 0 or Po | 128, footprint <= 256
  * pixels -- or <= 448 with O % 256 == 0), else the tile variant that will run. */
 int eml_sphere_conv_lowres_variant(int C, int O, int Po, int fp_max);
+int eml_sphere_conv_lowres_table_i32(const int* idx, const int* fp, int* lidx, int Po, int ke, eml_stream_t stream);
 size_t eml_sphere_conv_lowres_partial_floats(long M, int O, int split);
-int eml_sphere_conv_lowres_f32(const float* X, const int* idx, const float* wgt, const unsigned char* rowmax, int ke,
+int eml_sphere_conv_lowres_f32(const float* X, const int* lidx, const float* wgt, const unsigned char* rowmax, int ke,
                                const int* fp, int fp_max, const float* W2, const float* bias, float* Y, float* partial,
                                int split, int B, int HW, int Po, int C, int O, const float* residual, float act_slope,
                                eml_stream_t stream);

@@ -55,7 +55,7 @@ def run(name, B, C, O, H, W, split_override=None):
     x = torch.randn(B, H, W, C, device=dev)
     w2 = torch.randn(O, 9 * C, device=dev) * 0.05
     bias = torch.randn(O, device=dev)
-    fp, fp_max, split = _lowres_plan(geo, B, C, O)
+    fp, fp_max, split, lidx = _lowres_plan(geo, B, C, O)
     if split_override:
         split = split_override
     y = torch.empty(B * po, O, device=dev)
@@ -65,7 +65,7 @@ def run(name, B, C, O, H, W, split_override=None):
     row = {"layer": name, "B": B, "gflop": round(gflop, 1), "split": split, "fp_max": fp_max}
     for vname, h in LIBS.items():
         def call():
-            rc = h.eml_sphere_conv_lowres_f32(p(x), p(geo.idx), p(geo.wgt), None, 4, p(fp), fp_max, p(w2), p(bias), p(y), p(part), split,
+            rc = h.eml_sphere_conv_lowres_f32(p(x), p(lidx), p(geo.wgt), None, 4, p(fp), fp_max, p(w2), p(bias), p(y), p(part), split,
                                               B, po, po, C, O, None, 1.0, st)
             assert rc == 0, rc
         ms = events(call)
@@ -110,12 +110,12 @@ def run_bwd(name, B, C, O, H, W):
     plan = _lowres_plan(geo, B, O, C, transposed=True)
     tidx, twgt, rowmax, ke = geo.transposed_table()
     if plan is not None:
-        fp, fp_max, split = plan
+        fp, fp_max, split, tlidx = plan
         gx = torch.empty(B * po, C, device=dev)
         part = torch.empty(max(1, split * B * po * C if split > 1 else 1), device=dev)
 
         def dgrad3():
-            rc = L.eml_sphere_conv_lowres_f32(p(gy), p(tidx), p(twgt), p(rowmax) if ke == 8 else None, ke, p(fp), fp_max, p(w2t), None, p(gx),
+            rc = L.eml_sphere_conv_lowres_f32(p(gy), p(tlidx), p(twgt), p(rowmax) if ke == 8 else None, ke, p(fp), fp_max, p(w2t), None, p(gx),
                                               p(part), split, B, po, po, O, C, None, 1.0, st)
             assert rc == 0
         ms = events(dgrad3)
