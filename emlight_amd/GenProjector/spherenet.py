@@ -960,6 +960,9 @@ class _FusedSpectralNormHook:
         self.inner = inner
         self.pre = None   # (key, (w2, uv, sigma)) left by spectral_precompute for this module's NEXT call
 
+    def __getstate__(self):   # torch.save(model) / deepcopy carry the hook, never the GPU scratch of a pending result
+        return {"inner": self.inner, "pre": None}
+
     @staticmethod
     def eligible(sn, w):
         return (w.is_cuda and w.dtype == torch.float32 and sn.dim == 0 and sn.n_power_iterations == 1 and w.dim() == 4
@@ -994,6 +997,8 @@ class _FusedSpectralNormHook:
 
 # EML_SN_BATCH=0: A/B knob -- every hook launches its own five kernels again
 _sn_batch = knob_flag("EML_SN_BATCH", True)
+import weakref  # noqa: E402
+_SN_PLANS = weakref.WeakKeyDictionary()   # network -> [(module, fused hook)] of spectral_precompute
 
 
 def spectral_precompute(root):
@@ -1005,10 +1010,10 @@ def spectral_precompute(root):
     and falls back to its own launches otherwise -- a module called twice in one forward iterates twice, as the reference's."""
     if not _sn_batch:
         return
-    plan = root.__dict__.get("_eml_sn_plan")
+    plan = _SN_PLANS.get(root)   # kept beside the module, not in its __dict__: a pickled / copied network does not carry it
     if plan is None:
         plan = [(m, h) for m in root.modules() for h in m._forward_pre_hooks.values() if isinstance(h, _FusedSpectralNormHook)]
-        root.__dict__["_eml_sn_plan"] = plan
+        _SN_PLANS[root] = plan
     groups = {}
     for m, h in plan:
         sn = h.inner

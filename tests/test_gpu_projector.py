@@ -970,8 +970,9 @@ def test_generator_with_batched_spectral_norm_equals_per_module_hooks(monkeypatc
             assert torch.equal(ga[n], gb[n]), n
     for n in ba:
         assert torch.equal(ba[n], bb[n]), n
-    plan = a.__dict__["_eml_sn_plan"]
+    plan = spherenet._SN_PLANS[a]
     assert len(plan) == 23 and all(h.pre is None for _, h in plan)   # 18 SphereConvs of the blocks + the crop encoder's 5; all consumed
+    assert "_eml_sn_plan" not in a.__dict__   # (kept beside the network: a pickled / copied one does not carry it)
 
 
 @pytest.mark.parametrize("fin,fout,H,W,train", [(64, 32, 8, 16, True), (128, 64, 16, 32, True), (32, 16, 4, 8, False)])
