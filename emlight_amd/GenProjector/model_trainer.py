@@ -22,8 +22,10 @@ class Trainer:
         from .._dist import dp_wrap
         if dp_wrap(world):
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
-            self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, device_ids=ids, bucket_cap_mb=25)
-            self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, device_ids=ids, bucket_cap_mb=25)
+            # gradients live IN the all-reduce buckets (views): no copy of the reduced 473 MB back into .grad
+            kw = dict(device_ids=ids, bucket_cap_mb=25, gradient_as_bucket_view=True)
+            self._ddpG = torch.nn.parallel.DistributedDataParallel(self.model.netG, **kw)
+            self._ddpD = torch.nn.parallel.DistributedDataParallel(self.model.netD, **kw)
             # the model calls generate_fake / the discriminator step's D: route those through the DDP wrappers (the
             # generator step calls the bare D with its parameters held out of the graph: nothing to reduce)
             self.model.generate_fake = lambda inp, crop: self._ddpG(inp, crop)

@@ -52,6 +52,7 @@ class _Workspace:
                     "zmean": torch.zeros(enc.inter, **f32), "zvar": torch.ones(enc.inter, **f32),
                     "zistd": torch.ones(enc.inter, **f32),
                     "W1p": torch.empty(kp * 48, **f32), "W2p": torch.empty(9 * 3 * 4 * 16 * 4, **f32),
+                    "W2t": torch.empty(7 * 3 * 64 * 4, **f32),   # tap-packed conv3x3 weights (csrc/dense_fwd_tp.hip)
                     # ReLU mask of BN1's output as bits (training only): one 64-bit word per (16-pixel group, 16-channel
                     # K-step, t), whole 256-pixel tiles -- what the data-gradient pass reads instead of X
                     "mask": (torch.empty(((B * h * w + 255) // 256) * 16 * (kp // 16) * 4, dtype=torch.int64, device=dev)
@@ -75,6 +76,7 @@ class _Workspace:
                 "tmean": torch.zeros(cout, **f32), "tvar": torch.ones(cout, **f32), "tistd": torch.ones(cout, **f32),
                 "scaleL": torch.zeros(cout, **f32), "shiftL": torch.zeros(cout, **f32),
             }
+            blk["tp"] = enc.tap_packed_plan(B, h, w, dev)
             self.blocks.append(blk)
             h, w = h // 2, w // 2
         self.hf, self.wf = h, w
@@ -243,6 +245,26 @@ class HipDenseEncoder:
         self._grid(dev)
         return self._tuned("EML_GRID3", self._cu)
 
+    def tap_packed_plan(self, B, H, W, dev):
+        """(band_rows, grid) when the conv3x3 forward of a block of (B, H, W) runs the tap-packed kernel
+        (csrc/dense_fwd_tp.hip: 84 MFMAs per 16 pixels instead of 108, no halo tile), else None.  Measured per geometry
+        (tools/bench_c3tp.py, profiles/r06_c3tp_*): it wins where four wavefronts side by side cover the image width
+        (W = 320 or 256: block 1, 0.81 -> 0.62 ms per layer at B = 64), ties at two (block 2) and loses at one (block 3),
+        where the bands needed to fill the chip get too short for their halo rows.  Train-mode BatchNorm only (the mode the
+        reference runs this network in, train.py:42 / test.py:36-37): with untrained running statistics the eval-mode
+        logits are O(100) and f32 round-off is 1e-4 there -- the reference's own f32 result is 8.8e-5 from the f64 one
+        (profiles/r06_c3tp_golden_err.txt) -- so eval mode keeps the summation order its golden outputs were pinned with.
+        EML_C3_TP=off: the halo-tile kernel everywhere (A/B)."""
+        from .._knobs import knob_choice
+        if knob_choice("EML_C3_TP", "auto", ("auto", "off")) == "off":
+            return None
+        if _lib.lib().eml_dense_conv3x3_fwd_tp_supported(B, H, W) != 4 or H < 8:
+            return None
+        self._grid(dev)
+        bands = max(1, min(H // 4, -(-2 * self._cu // B)))       # ~2 workgroups per CU, bands of >= 4 rows
+        band = -(-H // bands)
+        return band, min(self.grid_max, B * (-(-H // band)))
+
     def workspace(self, B, H, W, dev, keep_all):
         """Buffers for this shape.  A workspace still owned by a live graph (a second grad-enabled forward of the same
         shape before the first backward: summed losses, gradient accumulation, GAN-style double forward) is never
@@ -314,7 +336,10 @@ class HipDenseEncoder:
             for l, lay in enumerate(blk["layers"]):
                 Lm = getattr(mod, "denselayer%d" % (l + 1))
                 items.append((Lm.conv1.weight, lay["W1p"], 0, 48, lay["Cin"], lay["Kp"], 0))
-                items.append((Lm.conv2.weight, lay["W2p"], 1, 12, 48, 48, 0))
+                if blk["tp"] is None or not training:
+                    items.append((Lm.conv2.weight, lay["W2p"], 1, 12, 48, 48, 0))
+                else:
+                    items.append((Lm.conv2.weight, lay["W2t"], 3, 12, 48, 48, 0))
             T, tr = getattr(f, "transition%d" % (bi + 1)), blk["trans"]
             items.append((T.conv.weight, tr["Wp"], 0, tr["Cout"], blk["Ctot"], tr["Kp"], 0))
         ws.fwd_permutes.launch(L, st, items)
@@ -332,11 +357,12 @@ class HipDenseEncoder:
             mod = getattr(f, "denseblock%d" % (bi + 1))
             P, Hb, Wb, ld = blk["P"], blk["H"], blk["W"], blk["ld"]
             pending = False  # partial stats of the previous layer's 12 new channels wait in `part`
+            Gc = G3          # ... in that many rows (the grid of the conv3x3 kernel that wrote them)
             for l, lay in enumerate(blk["layers"]):
                 Lm = getattr(mod, "denselayer%d" % (l + 1))
                 cin, kp = lay["Cin"], lay["Kp"]
                 z = blk["Z"][l if keep_all else 0]
-                self._prepare(L, st, part if pending else None, G3, 32, 12, cin - 12, P, blk["mean"], blk["var"],
+                self._prepare(L, st, part if pending else None, Gc, 32, 12, cin - 12, P, blk["mean"], blk["var"],
                               blk["istd"], Lm.norm1, cin, kp, training, lay["scale1"], lay["shift1"])
                 _lib.check(L.eml_dense_conv1x1_fwd_f32(p(blk["X"]), ld, P, Hb, Wb, 0, kp, p(lay["scale1"]),
                                                        p(lay["shift1"]), p(lay["W1p"]), 48, p(z), 48, p(part), Gf,
@@ -344,15 +370,22 @@ class HipDenseEncoder:
                            "eml_dense_conv1x1_fwd_f32")
                 self._prepare(L, st, part, Gf, 96, 48, 0, P, lay["zmean"], lay["zvar"], lay["zistd"], Lm.norm2, 48, 48,
                               training, lay["scale2"], lay["shift2"])
-                _lib.check(L.eml_dense_conv3x3_fwd_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2p"]),
-                                                       p(blk["X"]), ld, cin, B, Hb, Wb, p(part), G3, st),
-                           "eml_dense_conv3x3_fwd_f32")
+                if blk["tp"] is None or not training:
+                    Gc = G3
+                    _lib.check(L.eml_dense_conv3x3_fwd_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2p"]),
+                                                           p(blk["X"]), ld, cin, B, Hb, Wb, p(part), G3, st),
+                               "eml_dense_conv3x3_fwd_f32")
+                else:
+                    band, Gc = blk["tp"]
+                    _lib.check(L.eml_dense_conv3x3_fwd_tp_f32(p(z), p(lay["scale2"]), p(lay["shift2"]), p(lay["W2t"]),
+                                                              p(blk["X"]), ld, cin, B, Hb, Wb, band, p(part), Gc, st),
+                               "eml_dense_conv3x3_fwd_tp_f32")
                 pending = True
             # ---- transition (BN-ReLU-1x1-avgpool2, DenseNet.py:14-21) + last_norm (DenseNet.py:122)
             tr, T = blk["trans"], getattr(f, "transition%d" % (bi + 1))
             LN = getattr(f, "last_norm%d" % (bi + 1))
             ctot, cout, kpt = blk["Ctot"], tr["Cout"], tr["Kp"]
-            self._prepare(L, st, part if pending else None, G3, 32, 12, ctot - 12, P, blk["mean"], blk["var"],
+            self._prepare(L, st, part if pending else None, Gc, 32, 12, ctot - 12, P, blk["mean"], blk["var"],
                           blk["istd"], T.norm, ctot, kpt, training, tr["scale"], tr["shift"])
             Pn = B * (Hb // 2) * (Wb // 2)
             # pool first (it commutes with the 1x1 conv): the conv's output chunks then read A, a quarter of X

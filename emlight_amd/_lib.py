@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 23   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 24   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -125,6 +125,10 @@ SIGNATURES = {
                                          _int, _f32p, _int, _f32p, _int, ctypes.c_void_p, _stream]),
     "eml_dense_conv3x3_fwd_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p,
                                          _int, _stream]),
+    "eml_dense_permute_w2_tp_f32": (_int, [_f32p, _f32p, _stream]),
+    "eml_dense_conv3x3_fwd_tp_supported": (_int, [_int, _int, _int]),
+    "eml_dense_conv3x3_fwd_tp_f32": (_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _f32p,
+                                            _int, _stream]),
     "eml_dense_pool_act_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _f32p, _f32p, _f32p, _int, ctypes.c_void_p,
                                       _stream]),
     "eml_dense_head_pool_fwd_f32": (_int, [_f32p, _int, _int, _int, _int, _int, _int, _f32p, _stream]),

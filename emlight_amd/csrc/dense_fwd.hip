@@ -688,7 +688,7 @@ __global__ void permute_w2_kernel(const float* __restrict__ W2, int Cout, float*
 
 // All weight re-layouts of a pass in ONE launch (blockIdx.y = descriptor): the per-layer permutes are 4-5 us kernels, 150 of
 // them per training step, each one a launch boundary between two big kernels.  kind 0: permute_w1 (1x1 forward),
-// 1: permute_w2 (3x3 forward), 2: the data-gradient layout of dense_bwd.hip's permute_w1_bwd_kernel.
+// 1: permute_w2 (3x3 forward), 2: the data-gradient layout of dense_bwd.hip's permute_w1_bwd_kernel, 3: permute_w2_tp.
 __global__ __launch_bounds__(256) void permute_batch_kernel(const eml_permute_desc* __restrict__ descs) {
   const eml_permute_desc d = descs[blockIdx.y];
   const float* __restrict__ W = d.src;
@@ -714,6 +714,8 @@ __global__ __launch_bounds__(256) void permute_batch_kernel(const eml_permute_de
       const int rest = ei >> 8, j = rest % 3, tap = rest / 3;
       out[e] = (o < d.Cout) ? W[((size_t)o * 48 + 16 * j + 4 * kk + t) * 9 + tap] : 0.f;
     }
+  } else if (d.kind == 3) {   // tap-packed conv3x3 weights (dense_fwd_tp.hip)
+    for (size_t e = e0; e < (size_t)eml::kW2tFloats; e += stride) out[e] = eml::w2t_value(W, (int)e);
   } else {
     const int njo = d.Ko >> 4;
     const size_t total = (size_t)d.Kp * d.Ko;

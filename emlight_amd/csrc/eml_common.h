@@ -134,4 +134,16 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Tap-packed conv3x3 weights (dense_fwd_tp.hip): W2 [12][48][3][3] -> W2t[tile 7][J 3][lane 64][t 4].  lane = 16 kq + i; row i =
+// 4 kkD + g of row tile `tile` is slot s = 4 tile + g of accumulator lane group kkD: tap = s / 3, o = 3 kkD + s % 3 (slot 27:
+// zero); element e holds W2[o][16J + 4kq + t][tap].
+__host__ __device__ __forceinline__ float w2t_value(const float* __restrict__ W2, int e) {
+  const int t = e & 3, ln = (e >> 2) & 63, rest = e >> 8, J = rest % 3, tile = rest / 3;
+  const int i = ln & 15, kq = ln >> 4, kkD = i >> 2, g = i & 3, s = 4 * tile + g;
+  if (s >= 27) return 0.f;
+  const int tap = s / 3, o = 3 * kkD + s % 3, c = 16 * J + 4 * kq + t;
+  return W2[((size_t)o * 48 + c) * 9 + tap];
+}
+constexpr int kW2tFloats = 7 * 3 * 64 * 4;
+
 }  // namespace eml

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 23
+#define EML_ABI_VERSION 24
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -182,7 +182,8 @@ int eml_dense_permute_w2_f32(const float* W2, int Cout, float* W2p, eml_stream_t
 
 /* All re-layouts of a pass in one launch: descs is a DEVICE array of n descriptors (the caller uploads it once; it stays
  * valid while the weight and workspace pointers do).  kind 0 = eml_dense_permute_w1_f32 (Cout, Cin, Kp), 1 =
- * eml_dense_permute_w2_f32 (Cout), 2 = eml_dense_permute_w1_bwd_f32 (Cout, Cin, Kp, Ko); same outputs, bit for bit. */
+ * eml_dense_permute_w2_f32 (Cout), 2 = eml_dense_permute_w1_bwd_f32 (Cout, Cin, Kp, Ko), 3 = eml_dense_permute_w2_tp_f32;
+ * same outputs, bit for bit. */
 typedef struct eml_permute_desc {
   const float* src;
   float* dst;
@@ -207,6 +208,19 @@ int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hin, int Win,
 int eml_dense_conv3x3_fwd_f32(const float* Z, const float* scale2, const float* shift2,
                               const float* W2p, float* X, int ldx, int c_out0, int B, int H, int W,
                               double* partials, int grid, eml_stream_t stream);
+
+/* The same layer (DenseNet.py:38-43) TAP-PACKED: the 9 taps x 12 output channels are the 108 rows of the MFMA product of one
+ * INPUT pixel (7 row tiles, 84 MFMAs per 16 pixels instead of 108; no padded rows, no halo tile) and the 3x3 sum is a
+ * shift-and-add of accumulator registers (csrc/dense_fwd_tp.hip).  Same operands and results (f32 round-off of the summation
+ * order) as eml_dense_conv3x3_fwd_f32 except the weight layout W2t (7*3*64*4 floats, eml_dense_permute_w2_tp_f32 or kind 3
+ * of eml_dense_permute_batch_f32).  A workgroup owns `band_rows` output rows of one image at full width; `grid` workgroups
+ * walk the B * ceil(H / band_rows) bands; partials [grid][16][2] (a workgroup without a band writes zeros).
+ * eml_dense_conv3x3_fwd_tp_supported: 0, or the number of wavefronts side by side (1, 2, 4) when W = 16 * {4, 5} * that. */
+int eml_dense_permute_w2_tp_f32(const float* W2, float* W2t, eml_stream_t stream);
+int eml_dense_conv3x3_fwd_tp_supported(int B, int H, int W);
+int eml_dense_conv3x3_fwd_tp_f32(const float* Z, const float* scale2, const float* shift2,
+                                 const float* W2t, float* X, int ldx, int c_out0, int B, int H, int W,
+                                 int band_rows, double* partials, int grid, eml_stream_t stream);
 
 /* Transition operand: A[p'][c] = 2x2 mean of relu(scale[c]*X + shift[c]), p' over (B, Hin/2, Win/2), c < Kp
  * (Kp % 4 == 0; padded channels have scale = shift = 0).  The transition's 1x1 conv and its weight gradient

@@ -66,6 +66,27 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     assert all(p.grad is not None for p in net.parameters())
 
 
+def test_tap_packed_conv3x3_calls_match_the_abi(recorder):
+    """Blocks whose width the tap-packed conv3x3 forward supports (the library says so) take that entry with its own weight
+    layout (kind 3 of the batched re-layout), a band height and a grid that bn_prepare is then told about."""
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    from emlight_amd.RegressionNetwork.dense_engine import HipDenseEncoder
+    recorder.returns["eml_dense_conv3x3_fwd_tp_supported"] = 4
+    net = DenseNet(anchors=8, crop_hw=(32, 320)).train()
+    net._hip = HipDenseEncoder(net)
+    net._hip._cu = 256
+    sum(v.sum() for v in net(torch.rand(2, 3, 32, 320)).values()).backward()
+    tp = [a for n, a in recorder.args if n == "eml_dense_conv3x3_fwd_tp_f32"]
+    assert len(tp) == 48 and "eml_dense_conv3x3_fwd_f32" not in recorder.calls   # (the stub says "4 wavefronts" for every block)
+    for a in tp:
+        B, H, band, grid = a[7], a[8], a[10], a[12]
+        assert 4 <= band <= H and grid == B * (-(-H // band))
+    # the statistics of a tap-packed layer are folded over ITS grid
+    i = recorder.calls.index("eml_dense_conv3x3_fwd_tp_f32")
+    nxt = recorder.args[i + 1]
+    assert nxt[0] == "eml_dense_bn_prepare_f32" and nxt[1][1] == recorder.args[i][1][12]
+
+
 def test_permute_table_is_rebuilt_only_when_a_pointer_moves(recorder):
     """One batched re-layout launch per pass; its device descriptor table follows the weights' data pointers."""
     import numpy as np

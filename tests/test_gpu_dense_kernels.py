@@ -167,6 +167,54 @@ def test_conv3x3_fwd(lib, B, H, W, c_out0, ld):
     close(q[:12], (want ** 2).sum(0), what="sq", rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,c_out0,ld,band,grid", [
+    (2, 20, 64, 24, 64, 7, 64),      # TX = 4, one wave: no edge exchange; ragged last band
+    (1, 9, 80, 150, 176, 4, 64),     # TX = 5, one wave
+    (2, 13, 160, 108, 128, 5, 3),    # TX = 5, two waves; fewer workgroups than bands (persistent loop)
+    (1, 11, 320, 36, 224, 30, 64),   # TX = 5, four waves (block 1's width); one band taller than the image
+    (2, 7, 256, 24, 64, 1, 64),      # TX = 4, four waves; one-row bands: every row is a top AND a bottom neighbour
+    (3, 6, 128, 48, 64, 3, 7),       # TX = 4, two waves
+])
+def test_conv3x3_fwd_tap_packed(lib, B, H, W, c_out0, ld, band, grid):
+    """eml_dense_conv3x3_fwd_tp_f32 (csrc/dense_fwd_tp.hip): the 9 taps x 12 channels as MFMA rows, the 3x3 sum as a
+    shift-and-add of accumulators -- against F.conv2d in f64 and bit for bit against itself across band sizes."""
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    assert L.eml_dense_conv3x3_fwd_tp_supported(B, H, W) in (1, 2, 4)
+    assert L.eml_dense_conv3x3_fwd_tp_supported(B, H, W + 8) == 0 and L.eml_dense_conv3x3_fwd_tp_supported(B, H, 48) == 0
+    P = B * H * W
+    Z = rnd(P, 48)
+    s2, t2 = torch.rand(48, device=DEV) + 0.5, rnd(48, scale=0.3)
+    W2 = rnd(12, 48, 3, 3, scale=0.05)
+    W2t = torch.empty(7 * 3 * 64 * 4, device=DEV)
+    lib.check(L.eml_dense_permute_w2_tp_f32(p(W2), p(W2t), st), "permute2 tp")
+    outs = []
+    for bd in (band, H):
+        X = torch.full((P, ld), 5.0, device=DEV)
+        part = torch.full((grid * 32,), 3.0, dtype=torch.float64, device=DEV)
+        lib.check(L.eml_dense_conv3x3_fwd_tp_f32(p(Z), p(s2), p(t2), p(W2t), p(X), ld, c_out0, B, H, W, bd, p(part), grid,
+                                                 st), "c3 tp")
+        zn = nchw(Z.double() * s2.double() + t2.double(), B, H, W)
+        want = nhwc(F.conv2d(zn, W2.double(), padding=1))  # zero padding applies to the BN output
+        close(X[:, c_out0:c_out0 + 12], want, what="conv3x3 tp out")
+        assert bool((X[:, :c_out0] == 5.0).all()) and bool((X[:, c_out0 + 12:] == 5.0).all())
+        s, q = fold_partials(part, grid, 16)
+        close(s[:12], want.sum(0), what="sum", rtol=1e-6, atol=1e-4)
+        close(q[:12], (want ** 2).sum(0), what="sq", rtol=1e-5)
+        assert float(s[12:].abs().max()) == 0.0 and float(q[12:].abs().max()) == 0.0
+        outs.append(X[:, c_out0:c_out0 + 12].clone())
+    assert torch.equal(outs[0], outs[1])   # the band split does not change a single bit
+    # the batched re-layout (kind 3) writes the same W2t
+    import ctypes
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("kind", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"), ("Kp", "<i4"),
+                   ("Ko", "<i4"), ("reserved", "<i4")])
+    host = np.zeros(1, dtype=dt)
+    dst = torch.full((7 * 3 * 64 * 4,), 7.0, device=DEV)
+    host[0] = (W2.data_ptr(), dst.data_ptr(), 3, 12, 48, 48, 0, 0)
+    descs = torch.from_numpy(host.view(np.uint8).copy()).to(DEV)
+    lib.check(L.eml_dense_permute_batch_f32(p(descs), 1, st), "permute batch kind 3")
+    assert torch.equal(dst, W2t)
+
+
 def test_head_pool_fwd_bwd(lib):
     L, p, st = lib.lib(), lib.ptr, lib.current_stream()
     B, H, W, C, k, ld = 2, 8, 12, 171, 4, 176
