@@ -842,6 +842,358 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_kernel(
 }
 
 
+// =============================================================================== conv3x3 backward, one pass, weight gradient TAP-PACKED
+// Round 6.  conv3x3_bwd_fused_kernel's weight gradient deals the 27 (tap, 16 input channels) accumulator tiles of
+//     dW2[o][c][tap] = sum_p g[p][o] * zn[p + d_tap][c]
+// to 2 halves x 4 waves with the 12 output channels as the MFMA columns (12 of 16 used) and one of the 28 slots empty: 224
+// MFMAs per wave and 256-pixel tile, and its operand is the BN2(z) HALO tile (10 x 34 pixels, each read 9 times).  Here the
+// sum runs over the pixel p' = p + d that zn is taken at:
+//     dW2[(tap, o)][c] = sum_{p'} g[p' - d_tap][o] * zn[p'][c]
+// rows (tap, o) = 108 of 112 in 7 row tiles, columns c = 48 in 3: 21 accumulator tiles instead of 27; every wave keeps all 21
+// (84 registers) and takes the k-steps of its OWN tile row (32 pixels = 8 k-steps): 168 MFMAs per wave and tile, balanced,
+// against 224 (-25 %; the kernel: 330 against 386, -14.5 %).  The operand that needs neighbours is now g, whose halo tile the
+// data gradient stages anyway (a per-lane offset into it per row tile: ds_read_b32, as before); z is needed at the tile's own
+// 256 pixels only and is staged RAW (no halo: -25 % of the z loads and LDS writes): BN2's affine is one fma on the fragment, and
+// the data gradient's BatchNorm statistics read the same raw rows from LDS instead of a second time from L2 (6 x 16-byte
+// global loads per lane and tile gone).  The eight waves' accumulators are summed through LDS once, after the last tile (fixed
+// order): one partial row of 21 x 256 floats per workgroup (it was 2 x 27 x 256).  Data gradient, g staging and the phase
+// structure (A: data gradient, barrier, B: weight gradient with the data gradient's epilogue riding on it, barrier) are
+// conv3x3_bwd_fused_kernel's.
+template <bool A16>
+__global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
+    const float* __restrict__ G, int ldg, int c0, const float* __restrict__ W2, const float* __restrict__ Z,
+    const float* __restrict__ zmean, const float* __restrict__ zistd, float* __restrict__ DZ, int B, int H, int W,
+    double* __restrict__ partials /*[grid][48][2]*/, const float* __restrict__ Xb, int ldx, int cx,
+    const float* __restrict__ sB, const float* __restrict__ sC, float* __restrict__ GF,
+    const float* __restrict__ scale2, const float* __restrict__ shift2, float* __restrict__ partialW /*[grid][21][16][16]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kGT = kHH * kHW * kPSG;                 // floats of a g halo tile
+  constexpr int kZS = 48;                               // pixel stride of the raw z tile (ds_read_b32 over 4 pixels x 16 channels)
+  float* g_l = smem;                                    // [2][kGT]
+  float* z_l = g_l + 2 * kGT;                           // [2][kTH * kTW][kZS] raw z of the tile's own pixels, double-buffered
+  float* w_l = z_l + 2 * kTH * kTW * kZS;               // [27][3][64]         data-gradient A fragments
+  float* coef_l = w_l + 27 * 3 * 64;                    // [24 (+8)]           sB | sC of the layer's 12 channels
+  double* red = reinterpret_cast<double*>(coef_l + 32); // [8][48][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+
+  // data-gradient fragments (D^T form): entry ((tap*3 + s)*3 + n)*64 + (kk*16 + r) = W2[o = 4s + kk][c = 16n + r][tap]
+  for (int e = tid; e < 27 * 3 * 64; e += 512) {
+    const int l = e & 63, g3 = e >> 6, n = g3 % 3, ts = g3 / 3, s3 = ts % 3, tap = ts / 3;
+    w_l[e] = W2[((size_t)(4 * s3 + (l >> 4)) * 48 + 16 * n + (l & 15)) * 9 + tap];
+  }
+  if (tid < 24) coef_l[tid] = tid < 12 ? sB[cx + tid] : sC[cx + tid - 12];
+
+  // weight gradient: accumulator tile (t, n) = rows 16t .. 16t + 15 of (tap, o) = (row / 12, row % 12), columns 16n .. + 15 of c.
+  // Lane (i = r, k = kk) of an A fragment reads g of halo pixel (own pixel k) - d_tap, channel o: a per-lane offset per row tile.
+  // Waves j and j + 4 (the two waves of SIMD j) share the 64 pixels of tile rows 2j, 2j + 1 (16 k-steps): wave j keeps row
+  // tiles 0..2 (9 accumulator tiles), wave j + 4 row tiles 3..6 (12): 21 tiles x 16 k-steps of MFMAs per SIMD, and 48
+  // accumulator registers instead of the 84 of "every wave keeps all 21 tiles of its own row" (which spilled: every reload in
+  // phase A was an s_waitcnt vmcnt(0) on the z DMA in flight, profiles/r06_c3bwd_tp_stamps.txt).
+  const int role = __builtin_amdgcn_readfirstlane(wave >> 2), pairj = wave & 3;
+  f32x4 accw[4][3];
+  int goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int n = 0; n < 3; ++n) accw[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t = min(3 * role + i, 6);
+    const int row = min(16 * t + r, 107), tap = row / 12, o = row - 12 * tap;
+    goff[i] = (-(tap / 3 - 1) * kHW - (tap % 3 - 1)) * kPSG + o;
+  }
+  float scb[3], shb[3];   // BN2 of the B fragment's channel 16n + r
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    scb[n] = scale2[16 * n + r];
+    shb[n] = shift2[16 * n + r];
+  }
+  const int tx_n = (W + kTW - 1) / kTW, ty_n = (H + kTH - 1) / kTH;
+  const int ntiles = B * ty_n * tx_n;
+  for (int e = tid; e < 8 * 48 * 2; e += 512) red[e] = 0.0;
+
+  // ---- g halo staging (the WIDE map of conv3x3_bwd_data_kernel): item t = tid + 512*it, halo pixel t / 3, float4 t % 3
+  constexpr int kWideItems = kHH * kHW * 3;
+  int w_hy[2], w_hx[2], w_q[2], w_pix[2];
+  bool w_ok[2], w_own[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = min(tid + 512 * it, kWideItems - 1), hp = t / 3;
+    w_q[it] = t - 3 * hp;
+    w_hy[it] = hp / kHW;
+    w_hx[it] = hp - w_hy[it] * kHW;
+  }
+  float4 gt4[2], xt4[2];
+  // ---- raw z of the own pixels: 256 pixels x 12 float4 = 6 items per thread, item t = tid + 512*it = pixel t / 12, slice t % 12
+  // (consecutive threads walk a pixel's 192 bytes, then the next pixel of the tile row: whole cache lines)
+  constexpr int kZI = kTH * kTW * 12 / 512;   // 6
+  int z_pq[kZI];                              // pixel << 4 | slice
+#pragma unroll
+  for (int it = 0; it < kZI; ++it) {
+    const int t = tid + 512 * it;
+    z_pq[it] = ((t / 12) << 4) | (t % 12);
+  }
+  auto stage_begin = [&](int tile) {
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int gy = ty * kTH - 1 + w_hy[it], gx = tx * kTW - 1 + w_hx[it];
+      w_ok[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      w_pix[it] = (b * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1);
+      w_own[it] = w_ok[it] && w_hy[it] >= 1 && w_hy[it] <= kTH && w_hx[it] >= 1 && w_hx[it] <= kTW;
+    }
+  };
+  auto g_load = [&](int it) {   // unconditional, clamped
+    const float* gp = G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it];
+    const float* xp = Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it];
+    if constexpr (A16) {
+      gt4[it] = *reinterpret_cast<const float4*>(gp);
+      xt4[it] = *reinterpret_cast<const float4*>(xp);
+    } else {
+      const float2 g0 = *reinterpret_cast<const float2*>(gp), g1 = *reinterpret_cast<const float2*>(gp + 2);
+      const float2 x0 = *reinterpret_cast<const float2*>(xp), x1 = *reinterpret_cast<const float2*>(xp + 2);
+      gt4[it] = make_float4(g0.x, g0.y, g1.x, g1.y);
+      xt4[it] = make_float4(x0.x, x0.y, x1.x, x1.y);
+    }
+  };
+  auto g_commit = [&](int it, float* dst) {
+    const float4 fb4 = *reinterpret_cast<const float4*>(coef_l + 4 * w_q[it]);
+    const float4 fc4 = *reinterpret_cast<const float4*>(coef_l + 12 + 4 * w_q[it]);
+    float4 v;
+    v.x = fmaf(fb4.x, xt4[it].x, gt4[it].x) + fc4.x;
+    v.y = fmaf(fb4.y, xt4[it].y, gt4[it].y) + fc4.y;
+    v.z = fmaf(fb4.z, xt4[it].z, gt4[it].z) + fc4.z;
+    v.w = fmaf(fb4.w, xt4[it].w, gt4[it].w) + fc4.w;
+    if (!w_ok[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = dst + (w_hy[it] * kHW + w_hx[it]) * kPSG + 4 * w_q[it];   // 56-byte pixel stride: 8-byte aligned
+    *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    if (w_own[it]) *reinterpret_cast<float4*>(GF + (size_t)w_pix[it] * 12 + 4 * w_q[it]) = v;
+  };
+  // z goes HBM -> LDS by DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear: item t lands at z_l + 4 t floats, which
+  // IS [pixel][48] for t = 12 pixel + slice): no staging registers (held across a barrier they were spilled, each load with
+  // its own vmcnt(0)), no ds_write.  The NEXT tile's z is requested at the top of a tile's phase B into the other buffer and
+  // has a phase B, a barrier and a phase A to land (requested at the top of its own phase A it cost that phase 10 000 cycles
+  // of waiting: profiles/r06_c3bwd_tp_stamps.txt); s_waitcnt vmcnt(0) in front of the barrier that ends phase A.  Through an asm statement
+  // (cdna_hip_programming.md 5.7): the compiler keeps no record of it and neither drains the VM counter in front of LDS reads
+  // nor reorders around the explicit wait.  Pixels outside the image are read from a clamped address and masked where the
+  // fragments are built.
+  auto z_dma = [&](int it, int b, int y0, int x0, int buf) {
+    const int pix = z_pq[it] >> 4, q = z_pq[it] & 15;
+    const int gy = min(y0 + (pix >> 5), H - 1), gx = min(x0 + (pix & 31), W - 1);
+    const float* src = Z + ((size_t)(b * H + gy) * W + gx) * 48 + 4 * q;
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(z_l + buf * (kTH * kTW * kZS) + 4 * (64 * wave + 512 * it)));
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+
+  int tile = blockIdx.x, cur = 0;
+  __syncthreads();   // coef_l, w_l, red
+  if (tile < ntiles) {
+    stage_begin(tile);
+    g_load(0);
+    g_load(1);
+    {
+      const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+#pragma unroll
+      for (int it = 0; it < kZI; ++it) z_dma(it, b, (rem / tx_n) * kTH, (rem % tx_n) * kTW, 0);
+    }
+    g_commit(0, g_l);
+    g_commit(1, g_l);
+  }
+  __syncthreads();
+#ifdef EML_STAMPS
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const float* gc = g_l + cur * kGT;
+    float* gn = g_l + (cur ^ 1) * kGT;
+    const int b = tile / (ty_n * tx_n), rem = tile - b * (ty_n * tx_n);
+    const int ty = rem / tx_n, tx = rem - ty * tx_n;
+    const int gy = ty * kTH + wave;
+    size_t prow[2];
+    bool pv[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int gx = tx * kTW + 16 * m + r;
+      pv[m] = gy < H && gx < W;
+      prow[m] = ((size_t)(b * H + min(gy, H - 1)) * W + min(gx, W - 1)) * 48;
+    }
+    stage_begin(nxt < ntiles ? nxt : tile);   // (the last tile re-stages itself: loads stay unconditional)
+    // ------------------------------------------------------------------ phase A: data gradient (162 MFMAs per wave)
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float aq[2][2], wq[2][3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) wq[0][n] = w_l[n * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aq[0][m] = gc[((wave + 2) * kHW + 16 * m + r + 2) * kPSG + kk];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int gi = tap * 3 + s3;
+        if (gi < 2) {
+          g_load(gi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (gi + 1 < 27) {
+          const int tn = (gi + 1) / 3, sn = (gi + 1) - 3 * tn, dyn = tn / 3, dxn = tn - 3 * dyn;
+#pragma unroll
+          for (int n = 0; n < 3; ++n) wq[(gi + 1) & 1][n] = w_l[((gi + 1) * 3 + n) * 64 + lane];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            aq[(gi + 1) & 1][m] = gc[((wave + 2 - dyn) * kHW + 16 * m + r + 2 - dxn) * kPSG + 4 * sn + kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(wq[gi & 1][n], aq[gi & 1][m], acc[m][n]);  // D[channel][pixel]
+        if (gi >= 25) {
+          __builtin_amdgcn_sched_barrier(0);
+          g_commit(gi - 25, gn);
+        }
+      }
+    }
+    EML_C3_STAMP(0);
+#ifndef EML_C3_NOZWAIT   // experiment build: what the wait costs (stale z: wrong results)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the z tile has landed
+#endif
+    eml::lds_barrier();          // this tile's z is in place (and g_l[cur ^ 1] complete)
+    EML_C3_STAMP(1);
+    // ------------------------------------------------------------------ phase B: weight gradient (144 / 192 MFMAs per wave)
+    // k = pixel x = 4 (ks % 8) + kk of tile row 2 pairj + ks / 8: A = g at that pixel minus the row's tap offset, B = BN2(z) there
+    const float* ga = gc + ((2 * pairj + 1) * kHW + kk + 1) * kPSG;
+    const float* zc = z_l + cur * (kTH * kTW * kZS);
+    const float* zb = zc + (kTW * 2 * pairj + kk) * kZS + r;
+    // B-fragment pixels of the pair's two tile rows that lie in the image: x = 4 (ks % 8) + kk < xl[ks / 8]
+    const int xl0 = ty * kTH + 2 * pairj < H ? W - tx * kTW - kk : 0, xl1 = ty * kTH + 2 * pairj + 1 < H ? W - tx * kTW - kk : 0;
+    auto phase_b = [&](auto nt_tag) {
+      constexpr int NT = decltype(nt_tag)::value;   // row tiles of this wave: 3 (tiles 0..2) or 4 (tiles 3..6)
+      float av[2][NT], bz[2][3];                    // both operands are read one k-step ahead of their MFMAs
+#pragma unroll
+      for (int i = 0; i < NT; ++i) av[0][i] = ga[goff[i]];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bz[0][n] = zb[16 * n];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 1 < 16) {
+          const int k1 = ks + 1, go = ((k1 >> 3) * kHW + 4 * (k1 & 7)) * kPSG, zo = ((k1 >> 3) * kTW + 4 * (k1 & 7)) * kZS;
+#pragma unroll
+          for (int i = 0; i < NT; ++i) av[k1 & 1][i] = ga[go + goff[i]];
+#pragma unroll
+          for (int n = 0; n < 3; ++n) bz[k1 & 1][n] = zb[zo + 16 * n];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 1) {   // the next tile's raw z -> the other buffer (the last tile re-requests itself: the loop stays branch-free).
+                         // Behind the phase's address set-up: the compiler reloads a few spilled loop invariants there, each
+                         // with s_waitcnt vmcnt(0) -- issued in front of them, every tile waited out its own request here.
+          const int t2 = nxt < ntiles ? nxt : tile;
+          const int b2 = t2 / (ty_n * tx_n), rem2 = t2 - b2 * (ty_n * tx_n);
+#ifndef EML_C3_NOZDMA   // experiment build: no z traffic at all (wrong results)
+#pragma unroll
+          for (int it = 0; it < kZI; ++it) z_dma(it, b2, (rem2 / tx_n) * kTH, (rem2 % tx_n) * kTW, cur ^ 1);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool pin = 4 * (ks & 7) < (ks < 8 ? xl0 : xl1);
+        float bv[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bv[n] = pin ? fmaf(bz[ks & 1][n], scb[n], shb[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float a = (i < 3 || r < 12) ? av[ks & 1][i] : 0.f;   // rows 108..111 of row tile 6 do not exist
+#pragma unroll
+          for (int n = 0; n < 3; ++n) accw[i][n] = mfma16(a, bv[n], accw[i][n]);
+        }
+        // the data gradient's epilogue (this wave's OWN tile row `wave`), piecewise behind these MFMAs: statistics of channel
+        // group n at k-steps 2, 4, 6 (raw z rows from LDS), then one 16-byte dzn store per k-step
+        if (ks == 2 || ks == 4 || ks == 6) {
+          const int n = (ks - 2) >> 1;
+          float l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const float4 z = *reinterpret_cast<const float4*>(zc + (kTW * wave + 16 * m + r) * kZS + 16 * n + 4 * kk);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float v = pv[m] ? acc[m][n][g] : 0.f;
+              l1[g] += v;
+              l2[g] = fmaf(v, f4c(z, g), l2[g]);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float t1 = eml::row16_sum(l1[g]), t2 = eml::row16_sum(l2[g]);   // over this tile row's 32 pixels
+            if (r == 0) {   // wave-private slots: no other lane touches them
+              double* d = red + (wave * 48 + 16 * n + 4 * kk + g) * 2;
+              d[0] += (double)t1;
+              d[1] += (double)t2;
+            }
+          }
+        } else if (ks >= 8 && ks < 14) {
+          const int si = ks - 8, m = si / 3, n = si - 3 * m;
+          if (pv[m])
+            *reinterpret_cast<float4*>(DZ + prow[m] + 16 * n + 4 * kk) =
+                make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (role == 0) phase_b(std::integral_constant<int, 3>{});
+    else phase_b(std::integral_constant<int, 4>{});
+    EML_C3_STAMP(2);
+    eml::lds_barrier();          // everyone is done with z_l[cur] and g_l[cur]
+    EML_C3_STAMP(3);
+#ifdef EML_STAMPS
+    st_acc[4] += 1;
+#endif
+    cur ^= 1;
+  }
+#ifdef EML_STAMPS
+  if (tid == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&eml_c3_stamps[i], st_acc[i]);
+#endif
+  // ---- outputs: the eight waves' weight-gradient accumulators summed through LDS in wave order, one partial row per workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last tile's look-ahead request still writes z_l)
+  __syncthreads();
+  float* wsum = smem;            // [21][16][16] (the g / z tiles are dead)
+  for (int w8 = 0; w8 < 8; ++w8) {   // waves 0..3 hold row tiles 0..2, waves 4..7 row tiles 3..6: four contributions per tile
+    if (wave == w8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < 3 + role) {
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float* q = wsum + ((((3 * role + i) * 3 + n) * 16 + 4 * kk + g) * 16 + r);
+              *q = ((w8 & 3) == 0 ? 0.f : *q) + accw[i][n][g];
+            }
+        }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 21 * 256; e += 512) partialW[(size_t)blockIdx.x * (21 * 256) + e] = wsum[e];
+  if (tid < 48) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) {
+      t1 += red[(w8 * 48 + tid) * 2 + 0];
+      t2 += red[(w8 * 48 + tid) * 2 + 1];
+    }
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 0] = t1;
+    partials[(size_t)blockIdx.x * 96 + 2 * tid + 1] = (double)zistd[tid] * (t2 - (double)zmean[tid] * t1);
+  }
+}
+
+
 // =============================================================================== BN backward: finalize
 // From the partial (S1 = sum dy, S2 = sum dy*xhat) of C channels: dgamma = S2, dbeta = S1 and the
 // per-channel affine of the input gradient  dx = cA*dy + cB*x + cC  where
@@ -920,6 +1272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 // mode 0: dW1  src k*48+o (k<dim0=Cin, o<dim1=n_valid)     -> dW[(n0+o)*Cin + k]
 // mode 1: dW2  src ((tap*3+mc)*16+ci)*16+o (o<12)            -> dW2[(o*48 + 16mc+ci)*9 + tap]
 // mode 2: dW0  src t*32+o (t<27, o<dim1=C0)                  -> dW0[o*27 + t]
+// mode 3: dW2, tap-packed rows: src ((t*3+n)*16+i)*16+j, row 16t+i = 12 tap + o (< 108), c = 16n+j -> dW2[(o*48 + c)*9 + tap]
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, size_t row_stride,
                                                           int mode, int dim0, int dim1, int n0,
                                                           float* __restrict__ out) {
@@ -937,6 +1290,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     valid = pair < 27 && o < 12;
     src = (size_t)e;
     dst = (size_t)(o * 48 + 16 * mc + ci) * 9 + tap;
+  } else if (mode == 3) {
+    const int j = e & 15, i = (e >> 4) & 15, tn = e >> 8, t = tn / 3, n = tn - 3 * t, row = 16 * t + i;
+    valid = tn < 21 && row < 108;
+    src = (size_t)e;
+    dst = (size_t)((row % 12) * 48 + 16 * n + j) * 9 + row / 12;
   } else {
     const int t = e >> 5, o = e & 31;
     valid = t < 27 && o < dim1;
@@ -2365,6 +2723,26 @@ extern "C" int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, 
       !al16(shift2))
     return eml::fail(EML_EINVAL, "eml_dense_conv3x3_bwd_fused_f32: needs even ldg, c0, ldx, cx and 16-byte aligned buffers");
   const bool a16 = (ldg & 3) == 0 && (c0 & 3) == 0 && (ldx & 3) == 0 && (cx & 3) == 0;
+#ifndef EML_C3_WTP   // experiment builds (tools/exp_build.sh nowtp -DEML_C3_WTP=0): round 4's weight gradient (27 tiles, z halo)
+#define EML_C3_WTP 1
+#endif
+#if EML_C3_WTP
+  const size_t lds = (size_t)(2 * kHH * kHW * kPSG + 2 * kTH * kTW * 48 + 27 * 3 * 64 + 32) * sizeof(float) + 8 * 48 * 2 * sizeof(double);   // 163 392 of 163 840 bytes
+  if (a16) {
+    EML_ENSURE_LDS((&conv3x3_bwd_fused_tp_kernel<true>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_fused_tp_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z,
+                       zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  } else {
+    EML_ENSURE_LDS((&conv3x3_bwd_fused_tp_kernel<false>), lds);
+    hipLaunchKernelGGL(conv3x3_bwd_fused_tp_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, G, ldg, c0, W2, Z,
+                       zmean, zistd, DZ, B, H, W, partials, X, ldx, cx, sB, sC, GF, scale2, shift2, partialW);
+  }
+  int rc = eml::check_launch("eml_dense_conv3x3_bwd_fused_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(21 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partialW, grid,
+                     (size_t)21 * 256, 3, 0, 0, 0, dW2);
+  return eml::check_launch("eml_dense_conv3x3_bwd_fused_f32(reduce)");
+#else
   const size_t lds = (size_t)(2 * kHH * kHW * kPSG + kHH * kHW * kPSW + 27 * 3 * 64 + 32) * sizeof(float) + 8 * 48 * 2 * sizeof(double);
   if (a16) {
     EML_ENSURE_LDS((&conv3x3_bwd_fused_kernel<true>), lds);
@@ -2380,6 +2758,7 @@ extern "C" int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, 
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 256 / 64), dim3(256), 0, (hipStream_t)stream, partialW, 2 * grid,
                      (size_t)27 * 256, 1, 0, 0, 0, dW2);
   return eml::check_launch("eml_dense_conv3x3_bwd_fused_f32(reduce)");
+#endif
 }
 
 extern "C" int eml_dense_bn_bwd_finalize_f32(const double* partials, int R, int pstride, double count,
