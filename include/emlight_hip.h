@@ -255,11 +255,15 @@ int eml_dense_conv3x3_bwd_data_f32(const float* G, int ldg, int c0, const float*
 
 /* The two launches around this comment as ONE pass over the tiles (round 4): the data gradient with the fused BN1 affine
  * (X, sB, sC, GF as in eml_dense_conv3x3_bwd_data_f32 with X != NULL) and the weight gradient of the same layer,
- * dW2 = sum_p g[p] (x) (scale2*Z + shift2)[p+tap], whose g and z tiles the data gradient has just staged: the BN2(z) halo
- * tile is read once for both (autograd of DenseNet.py:38-43: conv2's backward w.r.t. its input and its weight).
+ * dW2 = sum_p g[p] (x) (scale2*Z + shift2)[p+tap], on the g tile the data gradient has just staged (autograd of
+ * DenseNet.py:38-43: conv2's backward w.r.t. its input and its weight).  Round 6: the weight gradient is summed over the
+ * pixel the BN2(z) operand is taken at, with the 9 taps x 12 output channels as the MFMA rows (21 accumulator tiles instead
+ * of 27; z at the tile's own pixels only, csrc/dense_bwd.hip: conv3x3_bwd_fused_tp_kernel).
  * Needs even ldg, c0, ldx, cx and 16-byte aligned buffers (eml_dense_conv3x3_bwd_fused_supported; otherwise EML_EINVAL:
- * issue the two launches); offsets that are multiples of 4 get 16-byte staging loads, the others pairs of 8-byte ones.  partials / grid as the data gradient's, partialW (2*grid*27*256 floats) / dW2 as
- * the weight gradient's: for the same grid the weight gradient is bitwise what the separate launch returns. */
+ * issue the two launches); offsets that are multiples of 4 get 16-byte staging loads, the others pairs of 8-byte ones.
+ * partials / grid as the data gradient's; partialW: grid*21*256 floats of scratch (sized as the weight gradient's
+ * 2*grid*27*256 it always fits); dzn, GF and the statistics are what the separate launches return, dW2 agrees with the
+ * separate launch to f32 round-off of the summation order. */
 int eml_dense_conv3x3_bwd_fused_supported(int ldg, int c0, int ldx, int cx);
 int eml_dense_conv3x3_bwd_fused_f32(const float* G, int ldg, int c0, const float* W2, const float* Z,
                                     const float* zmean, const float* zistd, float* DZ, int B, int H, int W,
