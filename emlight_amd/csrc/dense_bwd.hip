@@ -922,7 +922,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
     w_hy[it] = hp / kHW;
     w_hx[it] = hp - w_hy[it] * kHW;
   }
-  float4 gt4[2], xt4[2];
+  f32x4 gt4[2], xt4[2];   // (the native vector type: written by asm statements, see g_load)
   // ---- raw z of the own pixels: 256 pixels x 12 float4 = 6 items per thread, item t = tid + 512*it = pixel t / 12, slice t % 12
   // (consecutive threads walk a pixel's 192 bytes, then the next pixel of the tile row: whole cache lines)
   constexpr int kZI = kTH * kTW * 12 / 512;   // 6
@@ -947,28 +947,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
     const float* gp = G + (size_t)w_pix[it] * ldg + c0 + 4 * w_q[it];
     const float* xp = Xb + (size_t)w_pix[it] * ldx + cx + 4 * w_q[it];
     if constexpr (A16) {
-      gt4[it] = *reinterpret_cast<const float4*>(gp);
-      xt4[it] = *reinterpret_cast<const float4*>(xp);
+      // through asm statements: as ordinary loads from read-only memory the second pair was REMATERIALISED by the register
+      // allocator -- issued again at MFMA 146 of the phase's 162, an HBM round trip in front of every tile's barrier (the
+      // first copy, at the top of the phase, deleted).  The compiler keeps no count of these: g_wait() before the commits.
+      // Straight into the variables the commit reads, and nothing touches them before g_wait(): a COPY made while the load is
+      // in flight moves the register's old contents (the first version copied into a float4 struct: NaNs in the step).
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(gt4[it]) : "v"(gp) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xt4[it]) : "v"(xp) : "memory");
     } else {
       const float2 g0 = *reinterpret_cast<const float2*>(gp), g1 = *reinterpret_cast<const float2*>(gp + 2);
       const float2 x0 = *reinterpret_cast<const float2*>(xp), x1 = *reinterpret_cast<const float2*>(xp + 2);
-      gt4[it] = make_float4(g0.x, g0.y, g1.x, g1.y);
-      xt4[it] = make_float4(x0.x, x0.y, x1.x, x1.y);
+      gt4[it] = f32x4{g0.x, g0.y, g1.x, g1.y};
+      xt4[it] = f32x4{x0.x, x0.y, x1.x, x1.y};
     }
+  };
+  // the LDS half of a commit; the compact GF copy of the tile's own pixels leaves separately (g_store): its exec-masked
+  // store opens a new basic block, and with the second item's commit behind the first item's store the compiler SANK the second
+  // pair of staging loads from the top of phase A to its end (MachineSink: the values are only used in that later block) --
+  // an HBM round trip exposed in front of the barrier of every tile
+  auto g_wait = [&]() {   // the staging loads have landed (ties the registers to the wait: nothing is read before it)
+    if constexpr (A16)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gt4[0]), "+v"(xt4[0]), "+v"(gt4[1]), "+v"(xt4[1]) :: "memory");
   };
   auto g_commit = [&](int it, float* dst) {
     const float4 fb4 = *reinterpret_cast<const float4*>(coef_l + 4 * w_q[it]);
     const float4 fc4 = *reinterpret_cast<const float4*>(coef_l + 12 + 4 * w_q[it]);
     float4 v;
-    v.x = fmaf(fb4.x, xt4[it].x, gt4[it].x) + fc4.x;
-    v.y = fmaf(fb4.y, xt4[it].y, gt4[it].y) + fc4.y;
-    v.z = fmaf(fb4.z, xt4[it].z, gt4[it].z) + fc4.z;
-    v.w = fmaf(fb4.w, xt4[it].w, gt4[it].w) + fc4.w;
+    v.x = fmaf(fb4.x, xt4[it][0], gt4[it][0]) + fc4.x;
+    v.y = fmaf(fb4.y, xt4[it][1], gt4[it][1]) + fc4.y;
+    v.z = fmaf(fb4.z, xt4[it][2], gt4[it][2]) + fc4.z;
+    v.w = fmaf(fb4.w, xt4[it][3], gt4[it][3]) + fc4.w;
     if (!w_ok[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
     float* d = dst + (w_hy[it] * kHW + w_hx[it]) * kPSG + 4 * w_q[it];   // 56-byte pixel stride: 8-byte aligned
     *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
     *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
-    if (w_own[it]) *reinterpret_cast<float4*>(GF + (size_t)w_pix[it] * 12 + 4 * w_q[it]) = v;
+    gt4[it] = f32x4{v.x, v.y, v.z, v.w};   // (kept for g_store)
+  };
+  auto g_store = [&](int it) {
+    // 32-bit element offset from the uniform base (P * 12 < 2^31): as a 64-bit per-lane pointer its loop-invariant part was
+    // spilled and reloaded (s_waitcnt vmcnt(0)) in front of every store
+    if (w_own[it]) *reinterpret_cast<float4*>(GF + ((unsigned)w_pix[it] * 12u + 4u * (unsigned)w_q[it])) = make_float4(gt4[it][0], gt4[it][1], gt4[it][2], gt4[it][3]);
   };
   // z goes HBM -> LDS by DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear: item t lands at z_l + 4 t floats, which
   // IS [pixel][48] for t = 12 pixel + slice): no staging registers (held across a barrier they were spilled, each load with
@@ -1000,8 +1018,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
 #pragma unroll
       for (int it = 0; it < kZI; ++it) z_dma(it, b, (rem / tx_n) * kTH, (rem % tx_n) * kTW, 0);
     }
+    g_wait();
     g_commit(0, g_l);
     g_commit(1, g_l);
+    g_store(0);
+    g_store(1);
   }
   __syncthreads();
 #ifdef EML_STAMPS
@@ -1041,6 +1062,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
         const int gi = tap * 3 + s3;
         if (gi < 2) {
           g_load(gi);
+          // a compiler-level memory barrier: with no store left in this phase (round 4's kernel committed the z halo here) LLVM
+          // sank the second pair of staging loads from here to their use at the end of the phase -- an HBM round trip in
+          // front of every tile's barrier (ISA: global_load at MFMA 150 of 162, s_waitcnt vmcnt(0) at 156)
+          asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
         if (gi + 1 < 27) {
@@ -1058,17 +1083,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd_fused_tp_kernel(
           for (int n = 0; n < 3; ++n) acc[m][n] = mfma16(wq[gi & 1][n], aq[gi & 1][m], acc[m][n]);  // D[channel][pixel]
         if (gi >= 25) {
           __builtin_amdgcn_sched_barrier(0);
+          if (gi == 25) g_wait();
           g_commit(gi - 25, gn);
         }
       }
     }
+    g_store(0);
+    g_store(1);
     EML_C3_STAMP(0);
 #ifndef EML_C3_NOZWAIT   // experiment build: what the wait costs (stale z: wrong results)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the z tile has landed
 #endif
     eml::lds_barrier();          // this tile's z is in place (and g_l[cur ^ 1] complete)
     EML_C3_STAMP(1);
-    // ------------------------------------------------------------------ phase B: weight gradient (144 / 192 MFMAs per wave)
+    // ------------------------------------------------------------------ phase B: weight gradient (144 / 192 MFMAs per wave; row tile 3 shared between the pair -- 168 each -- measured slower: 14 spills)
     // k = pixel x = 4 (ks % 8) + kk of tile row 2 pairj + ks / 8: A = g at that pixel minus the row's tap offset, B = BN2(z) there
     const float* ga = gc + ((2 * pairj + 1) * kHW + kk + 1) * kPSG;
     const float* zc = z_l + cur * (kTH * kTW * kZS);
