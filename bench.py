@@ -130,7 +130,7 @@ FAMILIES = {
                                   "MFMAs per 16 pixels, shift-and-add of accumulators) + conv3x3_fwd_kernel (blocks 2, 3: halo tile, 108)", 1),
     "eml_dense_conv3x3_bwd_data_f32": ("conv3x3_bwd_data_kernel", 1),
     "eml_dense_conv3x3_bwd_weight_f32": ("conv3x3_bwd_weight_kernel", 1),
-    "eml_dense_conv3x3_bwd_fused_f32": ("conv3x3_bwd_fused_kernel (data gradient + weight gradient of a layer in one pass over "
+    "eml_dense_conv3x3_bwd_fused_f32": ("conv3x3_bwd_fused_tp_kernel (data gradient + weight gradient of a layer in one pass over "
                                         "the tiles: replaces the two rows above, whose algorithmic bytes / FLOPs then count "
                                         "for launches that did not happen)", 4),
 }
@@ -451,7 +451,7 @@ ENCODER_FAMILIES = {
     "eml_dense_conv3x3_fwd_tp_f32": ("encoder conv3x3 forward (tap-packed in block 1)", lambda a: 2.0 * a[7] * a[8] * a[9] * 9 * 48 * 12),
     "eml_dense_conv3x3_bwd_data_f32": ("encoder conv3x3_bwd_data_kernel", lambda a: 2.0 * a[8] * a[9] * a[10] * 9 * 48 * 12),
     "eml_dense_conv3x3_bwd_weight_f32": ("encoder conv3x3_bwd_weight_kernel", lambda a: 2.0 * a[6] * a[7] * a[8] * 9 * 48 * 12),
-    "eml_dense_conv3x3_bwd_fused_f32": ("encoder conv3x3_bwd_fused_kernel (data + weight gradient in one pass)",
+    "eml_dense_conv3x3_bwd_fused_f32": ("encoder conv3x3_bwd_fused_tp_kernel (data + weight gradient in one pass, taps packed into the MFMA rows)",
                                         lambda a: 4.0 * a[8] * a[9] * a[10] * 9 * 48 * 12),
 }
 

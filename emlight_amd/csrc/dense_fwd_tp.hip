@@ -35,7 +35,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
-__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 
 constexpr int kNWMax = 4;
 
@@ -87,7 +86,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_tp_kernel(
 
   const int nbands = (H + band - 1) / band, nitems = B * nbands;
   const int xcol = 16 * TX * wave + x;                  // this lane's pixel column in tile 0
-  double ssum[3] = {0.0, 0.0, 0.0}, ssq[3] = {0.0, 0.0, 0.0};
+  // BatchNorm statistics: f64 running sums per (wave, channel) in LDS, updated once per stored row by the lane that owns the
+  // channel after a DPP reduction over the 16 pixel lanes.  As 12 VGPRs of doubles they were spilled across the row's MFMA
+  // stream, and the reload at the end of every row (s_waitcnt vmcnt, in order) waited for the next row's z prefetch as well.
+  if (tid < kNWMax * 12 * 2) (&red[0][0][0])[tid] = 0.0;
+  __syncthreads();
 
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / nbands, bd = item - b * nbands;
@@ -260,8 +263,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_tp_kernel(
         }
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-          ssum[o] += (double)ls[o];
-          ssq[o] += (double)lq[o];
+          const float t1 = eml::row16_sum(ls[o]), t2 = eml::row16_sum(lq[o]);   // over the wave's 16 TX pixels of the row
+          if (x == 0) {   // wave-private slots: no other lane touches them
+            red[wave][3 * kk + o][0] += (double)t1;
+            red[wave][3 * kk + o][1] += (double)t2;
+          }
         }
       }
 #pragma unroll
@@ -274,19 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_tp_kernel(
         }
     }
   }
-  // channel statistics of the 12 new channels: channel 3kk + o over the 16 pixel lanes, then the waves
-#pragma unroll
-  for (int o = 0; o < 3; ++o) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-      ssum[o] += shfl_xor_d(ssum[o], m);
-      ssq[o] += shfl_xor_d(ssq[o], m);
-    }
-    if (x == 0) {
-      red[wave][3 * kk + o][0] = ssum[o];
-      red[wave][3 * kk + o][1] = ssq[o];
-    }
-  }
+  // channel statistics of the 12 new channels: the waves' running sums
   __syncthreads();
   if (tid < 32) {
     double t = 0.0;
