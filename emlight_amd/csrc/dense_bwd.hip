@@ -1619,6 +1619,10 @@ __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd
         }
       }
       if constexpr (NARROW) {
+        // an unmasked use of the narrow operands HERE: their only other use feeds the exec-masked N12 store, and the compiler
+        // sank the G-slice load from the top of the chunk into that masked block -- issued after the chunk's MFMAs and waited
+        // for at once (s_waitcnt vmcnt(0): behind every x request in flight as well), an HBM round trip per 64-pixel chunk
+        asm volatile("" ::"v"(ng[0].x), "v"(ng[0].y), "v"(ng[1].x), "v"(ng[1].y), "v"(nx[0].x), "v"(nx[0].y), "v"(nx[1].x), "v"(nx[1].y));
         f32x4 an = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < 12; ++st) an = mfma16(wn_l[st * 64 + lane], dzb[(16 * wave + r) * 48 + 4 * st + kk], an);
@@ -1631,7 +1635,8 @@ __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd
           o4[g] = fmaf(nsk[g], dam, gg[g]);
           ns1[g] += (double)dam;
         }
-        if (nv) *reinterpret_cast<float4*>(na.N12 + (size_t)pn * 12 + 4 * kk) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        // (32-bit offset off the uniform base, P * 12 < 2^31: the 64-bit per-lane pointer was spilled -- a reload + vmcnt(0) here)
+        if (nv) *reinterpret_cast<float4*>(na.N12 + ((unsigned)pn * 12u + 4u * (unsigned)kk)) = make_float4(o4[0], o4[1], o4[2], o4[3]);
       }
       stage_write(dz_l[(it + 1) & 1]);
       // LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the x operands of the NEXT chunk's first
