@@ -137,7 +137,9 @@ FAMILIES = {
 
 
 # launchers whose calls are booked to another launcher's family (same layer, another kernel)
-FAMILY_ALIASES = {"eml_dense_conv3x3_fwd_tp_f32": "eml_dense_conv3x3_fwd_f32"}
+FAMILY_ALIASES = {"eml_dense_conv3x3_fwd_tp_f32": "eml_dense_conv3x3_fwd_f32",
+                  # the same pass with its top 24 columns leaving as compact tensors (same bytes, other addresses)
+                  "eml_dense_conv1x1_bwd_data_multi_top_f32": "eml_dense_conv1x1_bwd_data_multi_f32"}
 
 
 def time_kernel_families(trainer, batch, steps, B, crop_hw):
@@ -446,6 +448,8 @@ ENCODER_FAMILIES = {
     "eml_dense_conv1x1_bwd_weight_f32": ("encoder conv1x1_bwd_weight_kernel", lambda a: 2.0 * a[2] * a[7] * a[17]),  # P * Cin * Cout
     "eml_dense_conv1x1_bwd_data_multi_f32": ("encoder conv1x1_bwd_data_multi_kernel (two layers per pass)",
                                              lambda a: 2.0 * a[0] * a[15] * (a[17] - a[16]) * 48),      # layers * P * channels * 48
+    "eml_dense_conv1x1_bwd_data_multi_top_f32": ("encoder conv1x1_bwd_data_multi_kernel (two layers per pass)",
+                                                 lambda a: 2.0 * 2 * a[6] * a[7] * 48),                   # layers * P * k_hi * 48
     "eml_dense_conv1x1_bwd_data_f32": ("encoder transition_bwd_data_kernel", lambda a: 2.0 * a[15] * a[19] * a[7]),  # P * Kp * Ko
     "eml_dense_conv3x3_fwd_f32": ("encoder conv3x3 forward (tap-packed in block 1)", lambda a: 2.0 * a[7] * a[8] * a[9] * 9 * 48 * 12),
     "eml_dense_conv3x3_fwd_tp_f32": ("encoder conv3x3 forward (tap-packed in block 1)", lambda a: 2.0 * a[7] * a[8] * a[9] * 9 * 48 * 12),

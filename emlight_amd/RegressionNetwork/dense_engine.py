@@ -19,10 +19,22 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .._knobs import knob_int
 
 
 def _r16(v):
     return (v + 15) // 16 * 16
+
+
+def _row_floats(ctot):
+    """Row length of a block buffer: whole 128-byte lines (32 floats), so that every pixel row starts on a line.  The
+    1x1 kernels read the prefix [0, k) of every row and HBM serves whole lines (FETCH_SIZE per layer,
+    profiles/r06_perlayer_1x1.txt): with 304-float rows (block 2) every second row started in the middle of a line and its
+    prefix pulled the previous row's unused tail along.  EML_ROW_ALIGN=16: the earlier rounding (A/B)."""
+    a = knob_int("EML_ROW_ALIGN", 32, 16, 64)
+    if a not in (16, 32, 64):
+        raise ValueError("EML_ROW_ALIGN must be 16, 32 or 64")
+    return (ctot + a - 1) // a * a
 
 
 class _Workspace:
@@ -36,8 +48,8 @@ class _Workspace:
         for bi, (c0, nl) in enumerate(zip(enc.block_c0, enc.block_layers)):
             ctot = c0 + nl * enc.growth
             blk = {
-                "H": h, "W": w, "P": B * h * w, "C0": c0, "Ctot": ctot, "ld": _r16(ctot),
-                "X": torch.zeros(B * h * w, _r16(ctot), **f32),  # zeros: padded / not-yet-written channels stay finite
+                "H": h, "W": w, "P": B * h * w, "C0": c0, "Ctot": ctot, "ld": _row_floats(ctot),
+                "X": torch.zeros(B * h * w, _row_floats(ctot), **f32),  # zeros: padded / not-yet-written channels stay finite
                 "Z": torch.empty(nl if keep_all else 1, B * h * w, enc.inter, **f32),
                 "mean": torch.zeros(_r16(ctot), **f32), "var": torch.ones(_r16(ctot), **f32),
                 "istd": torch.ones(_r16(ctot), **f32),

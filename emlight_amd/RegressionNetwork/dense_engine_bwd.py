@@ -63,6 +63,9 @@ class _BwdBuffers:
         self.ring = max(1, int(os.environ.get("EML_WGRAD_RING", 4))) if enc.overlap_wgrad(dev) else 1
         self.GF12 = [torch.empty(maxP, 12, **f32) for _ in range(self.ring)]
         self.N12 = torch.empty(maxP, 12, **f32)     # narrow pass: finished gradient of the lower layer's 12 channels
+        # the two-layer data-gradient pass's top 24 channels (the next pair's output channels) as two compact tensors: their
+        # readers then fetch 48 bytes per pixel instead of one or two 128-byte lines of a wide G row (EML_DGRAD_TOP=0: A/B)
+        self.TOP = torch.empty(2 * maxP * 12, **f32) if knob_flag("EML_DGRAD_TOP", True) else None   # (2, P, 12) per block
         # scratch sized from the network (widest block Kp, widest transition Ko) and the largest grid, not for
         # EMLight's default only
         kp, ko, g = enc.kp_max, max(enc.ko_max, 48), enc.grid_max
@@ -217,6 +220,7 @@ def _run_backward(enc, ws, x, gpooled):
         cout, Ko, kpt = tr["Cout"], tr["Ko"], tr["Kp"]
         Pn = B * (Hb // 2) * (Wb // 2)
         Gbuf = bw.G[bi]
+        top2 = bw.TOP[:2 * P * 12].view(2, P, 12) if bw.TOP is not None else None
         # ---- last_norm backward (affine folded into the transition kernels' dz operand)
         _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(tr["T"]), Ko, None, 0, 0, cout, Pn, p(tr["tmean"]),
                                                 p(tr["tistd"]), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
@@ -237,18 +241,20 @@ def _run_backward(enc, ws, x, gpooled):
                       bw.condT[bi], T.norm)   # before the dense layers reuse coefficient set 0
         # ---- dense layers, last to first, two per pass of the block gradient (see dense_bwd.hip:
         #      "dense layers: 1 or 2 layers per pass")
-        def conv2_backward(l, slot, n12=False, narrow_lo=None):
+        def conv2_backward(l, slot, n12=False, narrow_lo=None, top=False):
             """conv3x3 backward of layer l -> DZ[slot], dW2, BN2 backward -> coefficient set `slot`; conv1 wgrad, which
             also materialises dz = cA*dzn + cB*z + cC in place over DZ[slot] for the data-gradient passes.
             n12: the layer above left the finished gradient of this layer's channels in the compact bw.N12.
             narrow_lo: this is the upper layer of a pair -- its narrow data pass over the lower layer's 12 output channels
-            [narrow_lo, narrow_lo + 12) rides on the weight-gradient kernel's dz tile (-> bw.N12, S1 -> bw.part2[slot])."""
+            [narrow_lo, narrow_lo + 12) rides on the weight-gradient kernel's dz tile (-> bw.N12, S1 -> bw.part2[slot]).
+            top: the pair above left this pair's gradient columns in the compact bw.TOP (its data-gradient pass wrote them
+            there instead of into G): [1] = this (upper) layer's 12 channels, [0] = the lower layer's (the narrow operand)."""
             lay = blk["layers"][l]
             Lm = getattr(mod, "denselayer%d" % (l + 1))
             cin, kp, z, dz = lay["Cin"], lay["Kp"], blk["Z"][l], bw.DZ[slot]
             # the gradient of this layer's 12 output channels is complete: its deferred BN1 affine (sB, sC) is
             # applied inside the conv3x3 dgrad's tile staging, which also leaves the finished gradient in GF12
-            gsrc = (p(bw.N12), 12, 0) if n12 else (p(Gbuf), ld, cin)
+            gsrc = (p(bw.N12), 12, 0) if n12 else (p(top2[1]), 12, 0) if top else (p(Gbuf), ld, cin)
             r = ring[0] = (ring[0] + 1) % bw.ring
             if bw.side is not None and bw.ev_done[r] is not None:
                 main.wait_event(bw.ev_done[r])   # the side stream's weight gradient that last read this slot
@@ -290,13 +296,23 @@ def _run_backward(enc, ws, x, gpooled):
             _lib.check(L.eml_dense_conv1x1_bwd_weight_f32(
                 p(blk["X"]), ld, P, Hb, Wb, 0, kp, cin, p(lay["scale1"]), p(lay["shift1"]), p(dz), 48, p(z), 48,
                 p(a), p(b), p(c), 48, p(bw.partW), gr(Lm.conv1.weight), Gw, p(dz),
-                *((p(Lm.conv1.weight), narrow_lo, p(Gbuf), ld, p(bw.N12), p(bw.part2[slot])) if narrow_lo is not None
+                *((p(Lm.conv1.weight), narrow_lo, *((p(top2[0]), 12) if top else (p(Gbuf), ld)), p(bw.N12),
+                   p(bw.part2[slot])) if narrow_lo is not None
                   else (None, 0, None, 0, None, None)), st), "eml_dense_conv1x1_bwd_weight_f32")
             return Lm
 
-        def dgrad(layers, slots, k_lo, k_hi):
-            """G[:, k_lo:k_hi] += sum over `layers` of scale1*dam; BN1 partial sums -> bw.part2[slot]."""
+        def dgrad(layers, slots, k_lo, k_hi, top=False):
+            """G[:, k_lo:k_hi] += sum over `layers` of scale1*dam; BN1 partial sums -> bw.part2[slot].
+            top: columns [k_hi - 24, k_hi) -- the next pair's output channels -- go to bw.TOP instead of G."""
             lays = [blk["layers"][l] for l in layers]
+            if top:
+                _lib.check(L.eml_dense_conv1x1_bwd_data_multi_top_f32(
+                    parr([bw.DZ[s_] for s_ in slots]), parr([bw.Wd[bi][l_] for l_ in layers]),
+                    parr([y["scale1"] for y in lays]), parr([y["shift1"] for y in lays]),
+                    parr([bw.part2[s_] for s_ in slots]), (ctypes.c_int * len(layers))(*[y["Kp"] for y in lays]),
+                    P, k_hi, p(Gbuf), ld, Gd, parr([y["mask"] for y in lays]), p(top2), st),
+                    "eml_dense_conv1x1_bwd_data_multi_top_f32")
+                return
             _lib.check(L.eml_dense_conv1x1_bwd_data_multi_f32(
                 len(layers), parr([bw.DZ[s_] for s_ in slots]), None, None, None, None,   # DZ holds the materialised dz
                 parr([bw.Wd[bi][l_] for l_ in layers]),
@@ -319,14 +335,20 @@ def _run_backward(enc, ws, x, gpooled):
                           lay["shift1"], bw.cond[bi][l], Lm.norm1)
 
         l = len(blk["layers"]) - 1
+        have_top = False   # the pair above left this pair's 24 gradient columns in top2
         while l >= 0:
             if l >= 1:
                 la, lb = l, l - 1
                 cin_a, cin_b = blk["layers"][la]["Cin"], blk["layers"][lb]["Cin"]
-                Lma = conv2_backward(la, 0, narrow_lo=cin_b)   # + narrow pass: layer lb's output channels only -> N12
+                Lma = conv2_backward(la, 0, narrow_lo=cin_b, top=have_top)   # + narrow pass: layer lb's output channels only -> N12
                 bn1_finalize(la, Lma, 0, cin_b, cin_a, rows=Gw)
                 Lmb = conv2_backward(lb, 1, n12=True)
-                dgrad([la, lb], [0, 1], 0, cin_b)              # both layers, X read once, G updated once
+                # the next pair (lb - 1, lb - 2) owns columns [cin_b - 24, cin_b): masked passes only (the bits the forward
+                # kept), and only where the fused conv3x3 backward / the narrow epilogue are what reads them
+                to_top = (top2 is not None and lb >= 2 and blk["layers"][la]["mask"] is not None and bw.side is None
+                          and cin_b >= 24 and cin_b % 4 == 0)   # (block 3 starts at channel 150: quads straddle)
+                dgrad([la, lb], [0, 1], 0, cin_b, top=to_top)  # both layers, X read once, G updated once
+                have_top = to_top
                 bn1_finalize(la, Lma, 0, 0, cin_b)
                 bn1_finalize(lb, Lmb, 1, 0, blk["layers"][lb]["Kp"])
                 bn1_direct(la, Lma, 0)

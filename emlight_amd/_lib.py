@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 24   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 25   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -158,6 +158,8 @@ SIGNATURES = {
     "eml_dense_conv1x1_bwd_data_multi_f32": (_int, [_int] + [ctypes.c_void_p] * 10 + [_f32p, _int, _f32p, _f32p,
                                                     ctypes.c_long, _int, _int, _f32p, _int, _int, ctypes.c_void_p,
                                                     _stream]),
+    "eml_dense_conv1x1_bwd_data_multi_top_f32": (_int, [ctypes.c_void_p] * 6 + [ctypes.c_long, _int, _f32p, _int, _int,
+                                                        ctypes.c_void_p, _f32p, _stream]),
     "eml_dense_grad_materialize_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _int, _int, ctypes.c_long,
                                               _stream]),
     "eml_dense_bn_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _int, _int, ctypes.c_long, _f32p,

@@ -1558,7 +1558,8 @@ __global__ __launch_bounds__(256, (NARROW || VEC == 4) ? 2 : 1) void conv1x1_bwd
       if constexpr (NARROW) {
         const size_t pc = (size_t)min(pn, P - 1);
         const float* xs = X + pc * ldx + na.k_lo + 4 * kq;
-        const float* gs = na.G + pc * na.ldg + na.k_lo + 4 * kq;
+        // ldg == 12: G is a compact (P, 12) tensor of exactly these channels (the data-gradient pass's `top` output)
+        const float* gs = na.G + pc * na.ldg + (na.ldg == 12 ? 0 : na.k_lo) + 4 * kq;
         nx[0] = *reinterpret_cast<const float2*>(xs);
         nx[1] = *reinterpret_cast<const float2*>(xs + 2);
         ng[0] = *reinterpret_cast<const float2*>(gs);
@@ -2083,8 +2084,14 @@ struct BwdLayer {
 // MASKED: the ReLU mask of every layer comes from the bits the forward stored (BwdLayer::mask); X, mean, istd and the
 // layers' shift1 are not read at all and only S1 = sum dam is accumulated (BN1's S2 follows from the weight gradient,
 // bn_bwd_finalize_kernel) -- the pass moves old G, new G and dz only: (2k + 96) instead of (3k + 96) floats per pixel.
+// TOP (round 6): the pass's top 24 channels [k_hi - 24, k_hi) -- the output channels of the NEXT pair of layers, whose
+// backward reads them next and nobody else ever again -- leave as two compact (P, 12) tensors instead of going back into
+// the wide G rows: Top[0] = channels [k_hi - 24, k_hi - 12) (the lower layer of that pair: the narrow pass's G operand),
+// Top[1] = [k_hi - 12, k_hi) (the upper layer: conv3x3_bwd's g).  A 48-byte slice of a 896-byte row costs its reader one
+// or two whole 128-byte lines per pixel (FETCH_SIZE per layer: 128 / 256 bytes fetched for 48 used,
+// profiles/r06_perlayer_1x1.txt); a compact tensor is read line for line.  Same values, same bytes written.
 template <int NL, int MT /* 16-pixel tiles per wave */, bool RAW = false /* DZ already holds dz (materialised) */,
-          bool MASKED = false>
+          bool MASKED = false, bool TOP = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer L0, BwdLayer L1,
                                                                         const float* __restrict__ X, int ldx,
                                                                         const float* __restrict__ mean,
@@ -2092,7 +2099,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
                                                                         int k_lo, int k_hi, float* __restrict__ Gd,
                                                                         int ldg, int KpMax,
                                                                         const unsigned long long* __restrict__ M0,
-                                                                        const unsigned long long* __restrict__ M1) {
+                                                                        const unsigned long long* __restrict__ M1,
+                                                                        float* __restrict__ Top) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   double* sacc = reinterpret_cast<double*>(smem);                         // [NL][4 waves][KpMax][2]
   float* vec_l = reinterpret_cast<float*>(sacc + (size_t)NL * 4 * KpMax * 2);  // [2 + 2*NL][KpMax]: mean, istd, (scale1, shift1) per layer
@@ -2292,9 +2300,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_data_multi_kernel(BwdLayer
         if (nt < nt_hi) {
           const int k4 = 16 * nt + 4 * kk;
           const bool act = k4 + 3 >= k_lo && k4 < k_hi;
+          if constexpr (TOP) {
+            // quads of the top 24 channels go to the compact tensors (k_hi is a multiple of 4: a quad lies on one side)
+            const int t = k4 - (k_hi - 24);
+            float* cdst = Top + (t >= 12 ? (size_t)P * 12 + (t - 12) : (size_t)max(t, 0));
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            if (pv[m] && act) *reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4) = gs[m][n];  // gs = old G + updates
+            for (int m = 0; m < MT; ++m) {
+              float* dst = t >= 0 ? cdst + prow[m] * 12 : Gd + prow[m] * ldg + k4;
+              if (pv[m] && act) *reinterpret_cast<float4*>(dst) = gs[m][n];
+            }
+          } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              if (pv[m] && act) *reinterpret_cast<float4*>(Gd + prow[m] * ldg + k4) = gs[m][n];  // gs = old G + updates
+            }
           }
         }
       }
@@ -2840,7 +2859,7 @@ extern "C" int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P,
   if (dz_out && (Cout != 48 || pool))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: dz_out is for dense layers (Cout == 48, no pool)");
   if (N12 && (Cout != 48 || pool || !W1 || !G || !partials_n || k_lo < 0 || (k_lo & 1) || k_lo + 12 > Cin || (ldg & 1) ||
-              k_lo + 12 > ldg))
+              (ldg != 12 && k_lo + 12 > ldg)))   // ldg == 12: G is the compact (P, 12) tensor of exactly those channels
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_weight_f32: fused narrow pass needs a dense layer, W1, G, partials_n "
                                  "and an even k_lo with k_lo + 12 <= Cin (k_lo=%d, Cin=%d)", k_lo, Cin);
   if (!X || !scale1 || !shift1 || !DY || !Zr || !cA || !cB || !cC || !partial || !dW || P < 1 || grid < 1 || Kp < 32 ||
@@ -2959,14 +2978,16 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
 // Dense-layer data gradient for 1 or 2 consecutive layers in one pass over channels [k_lo, k_hi).
 // Arrays of length n_layers (1 or 2): DZ/Zr (P,48), cA/cB/cC (48), Wd, scale1/shift1 (Kp_j), partials
 // ([grid][Kp_j][2]), Kp.  G[p][k] += sum_j scale1_j[k]*dam_j[p][k] for k in range.
-extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
-                                                    const float* const* cA, const float* const* cB,
-                                                    const float* const* cC, const float* const* Wd,
-                                                    const float* const* scale1, const float* const* shift1,
-                                                    double* const* partials, const int* Kp, const float* X, int ldx,
-                                                    const float* mean, const float* istd, long P, int k_lo, int k_hi,
-                                                    float* G, int ldg, int grid,
-                                                    const unsigned long long* const* relu_masks, eml_stream_t stream) {
+namespace {
+int launch_bwd_data_multi(int n_layers, const float* const* DZ, const float* const* Zr, const float* const* cA,
+                          const float* const* cB, const float* const* cC, const float* const* Wd,
+                          const float* const* scale1, const float* const* shift1, double* const* partials, const int* Kp,
+                          const float* X, int ldx, const float* mean, const float* istd, long P, int k_lo, int k_hi,
+                          float* G, int ldg, int grid, const unsigned long long* const* relu_masks, float* top,
+                          eml_stream_t stream) {
+  if (top && (n_layers != 2 || !relu_masks || Zr || k_lo != 0 || k_hi < 24 || (k_hi & 3) || P * 12 > 2147483647L))
+    return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_top_f32: the compact top-24 output needs two layers, "
+                                 "relu_masks, materialised dz, k_lo == 0 and k_hi >= 24, a multiple of 4 (k_hi=%d)", k_hi);
   if (n_layers < 1 || n_layers > 2 || !DZ || !Wd || !scale1 || !shift1 || !partials ||
       !Kp || (!relu_masks && (!X || !mean || !istd)) || !G || P < 1 || grid < 1 || k_lo < 0 || k_hi <= k_lo ||
       (ldx & 3) || (ldg & 3))
@@ -2999,13 +3020,18 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
     EML_ENSURE_LDS((&conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>), lds);                                 \
     hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<NLV, MTV, RAWV, MSKV>), dim3(grid), dim3(256), lds,            \
                        (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax,        \
-                       Mk[0], Mk[1]);                                                                               \
+                       Mk[0], Mk[1], (float*)nullptr);                                                              \
   } while (0)
   // two layers: 32 pixels per wave keeps both layers' dz fragments resident at 2 waves/SIMD
   if (n_layers == 1) {
     if (relu_masks) EML_LAUNCH_MULTI(1, 4, true, true);
     else if (raw) EML_LAUNCH_MULTI(1, 4, true, false);
     else EML_LAUNCH_MULTI(1, 4, false, false);
+  } else if (top) {
+    EML_ENSURE_LDS((&conv1x1_bwd_data_multi_kernel<2, 2, true, true, true>), lds);
+    hipLaunchKernelGGL((conv1x1_bwd_data_multi_kernel<2, 2, true, true, true>), dim3(grid), dim3(256), lds,
+                       (hipStream_t)stream, L[0], L[1], X, ldx, mean, istd, (int)P, k_lo, k_hi, G, ldg, kmax, Mk[0], Mk[1],
+                       top);
   } else {
     if (relu_masks) EML_LAUNCH_MULTI(2, 2, true, true);
     else if (raw) EML_LAUNCH_MULTI(2, 2, true, false);
@@ -3013,6 +3039,34 @@ extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* c
   }
 #undef EML_LAUNCH_MULTI
   return eml::check_launch("eml_dense_conv1x1_bwd_data_multi_f32");
+}
+}  // namespace
+
+extern "C" int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, const float* const* Zr,
+                                                    const float* const* cA, const float* const* cB,
+                                                    const float* const* cC, const float* const* Wd,
+                                                    const float* const* scale1, const float* const* shift1,
+                                                    double* const* partials, const int* Kp, const float* X, int ldx,
+                                                    const float* mean, const float* istd, long P, int k_lo, int k_hi,
+                                                    float* G, int ldg, int grid,
+                                                    const unsigned long long* const* relu_masks, eml_stream_t stream) {
+  return launch_bwd_data_multi(n_layers, DZ, Zr, cA, cB, cC, Wd, scale1, shift1, partials, Kp, X, ldx, mean, istd, P, k_lo,
+                               k_hi, G, ldg, grid, relu_masks, nullptr, stream);
+}
+
+// The two-layer masked pass with its top 24 channels [k_hi - 24, k_hi) written to `top` (2, P, 12) instead of G: top[0] =
+// channels [k_hi - 24, k_hi - 12), top[1] = [k_hi - 12, k_hi) -- the finished-but-for-their-own-pair gradients the next
+// pair of layers reads (eml_dense_conv3x3_bwd_*'s G operand with ldg = 12, c0 = 0; eml_dense_conv1x1_bwd_weight_f32's
+// narrow G operand with ldg = 12).  G keeps its old values in those 24 columns.
+extern "C" int eml_dense_conv1x1_bwd_data_multi_top_f32(const float* const* DZ, const float* const* Wd,
+                                                        const float* const* scale1, const float* const* shift1,
+                                                        double* const* partials, const int* Kp, long P, int k_hi,
+                                                        float* G, int ldg, int grid,
+                                                        const unsigned long long* const* relu_masks, float* top,
+                                                        eml_stream_t stream) {
+  if (!top) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_bwd_data_multi_top_f32: top is NULL");
+  return launch_bwd_data_multi(2, DZ, nullptr, nullptr, nullptr, nullptr, Wd, scale1, shift1, partials, Kp, nullptr, 0,
+                               nullptr, nullptr, P, 0, k_hi, G, ldg, grid, relu_masks, top, stream);
 }
 
 // Narrow pass: N12 (P,12) = G[:, k_lo:k_lo+12] + scale1 * relu-mask * (dz W1[:, k_lo:k_lo+12]) and the BN1 partial sums

@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 24
+#define EML_ABI_VERSION 25
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -318,7 +318,8 @@ int eml_dense_bn_dgamma_direct_f32(const float* X, int ldx, long P, int Hin, int
  * N12 != NULL (dense layers): the narrow data pass of eml_dense_conv1x1_bwd_narrow_f32 rides on the dz tile this
  * kernel holds in LDS -- N12 (P,12) = G[:, k_lo:k_lo+12] + scale1*relu-mask*(dz W1[:, k_lo:k_lo+12]) with W1 (48,Cin)
  * the conv's weight (PyTorch layout), G (P, ldg) read only, k_lo even, and partials_n [grid][Kp][2] receiving S1 of
- * those 12 channels (S2 slot 0: see eml_dense_bn_bwd_finalize_f32). */
+ * those 12 channels (S2 slot 0: see eml_dense_bn_bwd_finalize_f32).  ldg == 12: G is the COMPACT (P,12) tensor of
+ * exactly those channels (eml_dense_conv1x1_bwd_data_multi_top_f32's top[0]), read from column 0. */
 int eml_dense_conv1x1_bwd_weight_f32(const float* X, int ldx, long P, int Hin, int Win, int pool,
                                      int Kp, int Cin, const float* scale1, const float* shift1,
                                      const float* DY, int ld_dy, const float* Zr, int ld_z,
@@ -360,6 +361,20 @@ int eml_dense_conv1x1_bwd_data_multi_f32(int n_layers, const float* const* DZ, c
                                          const float* mean, const float* istd, long P, int k_lo,
                                          int k_hi, float* G, int ldg, int grid,
                                          const unsigned long long* const* relu_masks, eml_stream_t stream);
+
+/* The two-layer masked pass above (n_layers = 2, relu_masks, materialised dz, channel range [0, k_hi)) with its top 24
+ * channels leaving as two COMPACT (P,12) tensors instead of going back into the wide rows of G (round 6; same reference
+ * lines: DenseNet.py:50-55 under autograd): top[0] = the updated gradient of channels [k_hi - 24, k_hi - 12), top[1] =
+ * [k_hi - 12, k_hi) -- the output channels of the NEXT pair of layers down the block, which are read by that pair's
+ * backward (eml_dense_conv3x3_bwd_*_f32 with (G, ldg, c0) = (top[1], 12, 0); eml_dense_conv1x1_bwd_weight_f32's narrow
+ * operand with (G, ldg) = (top[0], 12)) and by nothing else.  A 48-byte slice of an 896-byte row costs its reader one or
+ * two whole 128-byte lines per pixel; the compact tensors are read line for line.  G's columns [k_hi - 24, k_hi) keep
+ * their OLD values.  k_hi >= 24 and a multiple of 4; top: (2, P, 12) floats. */
+int eml_dense_conv1x1_bwd_data_multi_top_f32(const float* const* DZ, const float* const* Wd,
+                                             const float* const* scale1, const float* const* shift1,
+                                             double* const* partials, const int* Kp, long P, int k_hi, float* G,
+                                             int ldg, int grid, const unsigned long long* const* relu_masks,
+                                             float* top, eml_stream_t stream);
 
 /* Narrow data pass (autograd of DenseNet.py:50-55 restricted to 12 channels): the data gradient of a dense layer
  * over the 12 output channels [k_lo, k_lo+12) of the layer below it, added to what G holds there and written as the

@@ -62,7 +62,13 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     # from the end, is set) and 8 two-layer passes per block of 16 layers
     narrow = [a for n, a in recorder.args if n == "eml_dense_conv1x1_bwd_weight_f32" and a[-3] is not None]
     assert len(narrow) == 24 and all(a[-6] % 2 == 0 for a in narrow)
-    assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 24
+    # the last pair of a block updates G; in blocks 1 and 2 (first channel a multiple of 4) every pair above it hands the next
+    # pair's 24 columns over as compact tensors
+    assert recorder.calls.count("eml_dense_conv1x1_bwd_data_multi_f32") == 2 + 8
+    top = [a for n, a in recorder.args if n == "eml_dense_conv1x1_bwd_data_multi_top_f32"]
+    assert len(top) == 14 and all(a[7] >= 48 and a[7] % 4 == 0 for a in top)    # k_hi = Cin of the pair's lower layer
+    # ... which that pair then reads with a row length of 12: the upper layer's narrow operand (G, ldg) and conv3x3's (G, ldg, c0)
+    assert sum(1 for a in narrow if a[-4] == 12) == 14
     assert all(p.grad is not None for p in net.parameters())
 
 

@@ -497,6 +497,14 @@ def test_conv1x1_bwd_weight_and_data(lib, pool, Cin, Cout, B, H, W):
             S1n, S2n = fold_partials(pn, G, Kp)
             close(S1n[k_lo:Cin], dam_n.sum(0), what="fused narrow S1", rtol=1e-5, atol=1e-4)
             assert float(S2n.abs().max()) == 0.0 and float(S1n[:k_lo].abs().max()) == 0.0
+            # the narrow pass's G operand as the COMPACT (P, 12) tensor of those channels (ldg == 12: the two-layer data
+            # pass's `top` output): bit for bit the wide-row result
+            Gc, N12c = Gn[:, k_lo:Cin].contiguous(), torch.full((P, 12), 5.0, device=DEV)
+            pn2 = torch.zeros_like(pn)
+            lib.check(L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
+                                                         p(cA), p(cB), p(cC), Cout, p(partW), p(dW_n), G, p(dz_n), p(Wt), k_lo,
+                                                         p(Gc), 12, p(N12c), p(pn2), st), "wgrad + narrow, compact G")
+            assert torch.equal(N12c, N12) and torch.equal(pn2, pn)
             # odd k_lo / range past Cin are refused
             assert L.eml_dense_conv1x1_bwd_weight_f32(p(X), ld, P, H, W, pool, Kp, Cin, p(s1), p(t1), p(DY), ld_dy, p(Zr), Ko,
                                                       p(cA), p(cB), p(cC), Cout, p(partW), p(dW_n), G, p(dz_n), p(Wt), k_lo + 1,
@@ -710,7 +718,8 @@ def test_conv1x1_bwd_narrow_and_raw_dz_passes(lib, Cin_a, B, H, W):
                                               p(istd), P, p(Gd), ld, p(N12), p(A["part"]), Kpa, G, st) == -1
 
 
-@pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 16, 32), (330, 1, 16, 16), (162, 3, 16, 16), (174, 2, 9, 7)])
+@pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 16, 32), (330, 1, 16, 16), (162, 3, 16, 16), (174, 2, 9, 7),
+                                         (216, 2, 16, 16), (132, 3, 9, 7)])
 def test_conv1x1_bwd_masked_pass_and_bn1_from_weight_gradient(lib, Cin_a, B, H, W):
     """The X-free data-gradient pass: the forward kernel's ReLU bits replace relu(bn1(x)) > 0, the pass accumulates S1
     only, and BN1's S2 = sum dy*xhat is recovered from the conv's weight gradient:
@@ -772,6 +781,23 @@ def test_conv1x1_bwd_masked_pass_and_bn1_from_weight_gradient(lib, Cin_a, B, H, 
         scale = float(S2.abs().max())
         close(dg[:Cin_b], S2, what="dgamma from the weight gradient", rtol=2e-4, atol=2e-5 * max(scale, 1.0))
         close(db[:Cin_b], y["dam"][:, :Cin_b].sum(0), what="dbeta", rtol=1e-5, atol=1e-4)
+    # the same pass with its top 24 columns leaving as two compact (P, 12) tensors: bit for bit the values the plain pass
+    # writes into G, G's own top 24 columns untouched, the statistics identical
+    if Cin_b % 4 == 0:
+        Gt, top = G0.clone(), torch.full((2, P, 12), float("nan"), device=DEV)
+        parts = [y["part"].clone() for y in layers]
+        for y in layers:
+            y["part"].zero_()
+        lib.check(L.eml_dense_conv1x1_bwd_data_multi_top_f32(
+            arr("dz"), arr("Wd"), arr("s1"), arr("t1"), arr("part"), (ctypes.c_int * 2)(Kpa, Kpb), P, Cin_b, p(Gt), ld, G,
+            arr("mask"), p(top), st), "multi masked, compact top")
+        assert torch.equal(Gt[:, :Cin_b - 24], Gd[:, :Cin_b - 24]) and torch.equal(Gt[:, Cin_b - 24:], G0[:, Cin_b - 24:])
+        assert torch.equal(top[0], Gd[:, Cin_b - 24:Cin_b - 12]) and torch.equal(top[1], Gd[:, Cin_b - 12:Cin_b])
+        for y, q in zip(layers, parts):
+            assert torch.equal(y["part"], q)
+        assert L.eml_dense_conv1x1_bwd_data_multi_top_f32(
+            arr("dz"), arr("Wd"), arr("s1"), arr("t1"), arr("part"), (ctypes.c_int * 2)(Kpa, Kpb), P, Cin_b - 2, p(Gt), ld, G,
+            arr("mask"), p(top), st) == -1                                # a range that would split a channel quad
     # single-layer form
     Gd1 = G0.clone()
     A["part"].zero_()
