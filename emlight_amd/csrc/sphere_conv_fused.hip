@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_fwd_fused_kernel(
 template <int BN, int BMO, bool VR>
 __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     const float* __restrict__ X, const int* __restrict__ idx, const float* __restrict__ wgt,
-    const float* __restrict__ dY /*[M][O]*/, float* __restrict__ partial, int M, int HW, int Po, int C, int O) {
+    const float* __restrict__ dY /*[M][O]*/, float* __restrict__ partial, int M, int HW, int Po, int C, int O,
+    int xcd_group) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                       // [2][kBK][kLdW]  dY tile   [pixel][o]
   float* Gs = smem + 2 * kBK * kLdW;      // [2][kBK][kLdW]  Ag tile   [pixel][c]
@@ -315,8 +316,21 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
   const int tiles_per_tap = C / BN;
   // (natural 3-D grid order: sending all (tap, c-tile, O-tile) workgroups of a K-split to one XCD, the forward
   // kernel's trick, made this kernel 10 % slower -- measured)
-  const int tap = blockIdx.x / tiles_per_tap, c0 = (blockIdx.x - tap * tiles_per_tap) * BN;
-  const int o0 = blockIdx.y * BMO;
+  // xcd_group (the launcher decides): workgroups are dealt round-robin to the 8 XCDs by their linear id; all (tap, c-tile, O-tile)
+  // tiles of a K-split then run on ONE XCD (splits z = k, k + 8, ... on XCD k; gridDim.z is a multiple of 8): the dY chunk
+  // and the source rows the 9 taps share are fetched into one L2 instead of eight
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_group) {
+    const int T = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int zq = slot / T, t = slot - zq * T;
+    bz = 8 * zq + xcd;
+    by = t / (int)gridDim.x;
+    bx = t - by * (int)gridDim.x;
+  }
+  const int tap = bx / tiles_per_tap, c0 = (bx - tap * tiles_per_tap) * BN;
+  const int o0 = by * BMO;
   const int S = gridDim.z;
   const int nchunks_all = (M + kBK - 1) / kBK;
 
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int chunk = blockIdx.z;
+  int chunk = bz;
   Tap t0, t1;
   size_t x0 = 0, x1 = 0;
   if (chunk < nchunks_all) {
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_wgrad_fused_kernel(
     eml::lds_barrier();
   }
   // partial[z][o][tap*C + c]: lane (r, kk) holds rows o = 4kk + g, column c = r of each 16x16 tile
-  float* out = partial + (size_t)blockIdx.z * O * 9 * C;
+  float* out = partial + (size_t)bz * O * 9 * C;
   if constexpr (VR) {
     // tile (mi, ni): row index i = 4kk + g is output channel MI*i + mi, column index r is input channel NI*r + ni
 #pragma unroll
@@ -660,6 +674,13 @@ extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, c
   const int bn = (C % 128 == 0) ? 128 : 64;
   const int bmo = (O % 128 == 0 || O > 192) ? 128 : 64;   // 64-wide row tiles when a 128-row tile would be mostly padding
   const size_t lds = (size_t)(4 * kBK * kLdW) * sizeof(float);
+  // The tiles of a K-split on one XCD (see the kernel) where a split has at most 18 of them -- then the 7 splits an XCD
+  // holds at a time are all resident: +1.6 ... 2.6 % on the 128 x 256 layers, +-0 at 64 x 128; with 36 / 72 tiles per split
+  // (128 -> 512, 512 -> 256) the same order LOSES 12 / 22 % (profiles/r06_wgrad_xcd.txt).  Needs a multiple of 8 splits: the
+  // remainder of the caller's split_k is not used (partial rows past it are never summed).  EML_WG_XCD=0: natural order (A/B).
+  static const bool xcd_env = [] { const char* v = getenv("EML_WG_XCD"); return !(v && v[0] == '0'); }();
+  const int xg = (xcd_env && split_k >= 8 && 9 * (C / bn) * ((O + bmo - 1) / bmo) <= 18) ? 1 : 0;
+  if (xg) split_k &= ~7;
   const dim3 grid(9 * (C / bn), (O + bmo - 1) / bmo, split_k);
   static const bool scalar_reads = [] { const char* v = getenv("EML_WG_V1"); return v && v[0] == '1'; }();   // A/B switch
 #define EML_LAUNCH_WGRAD(BNV, BMV)                                                                                   \
@@ -667,11 +688,11 @@ extern "C" int eml_sphere_conv_wgrad_fused_f32(const float* X, const int* idx, c
     if (scalar_reads) {                                                                                             \
       EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV, false>), lds);                                      \
       hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV, false>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
-                         wgt, dY, partial, (int)M, HW, Po, C, O);                                                    \
+                         wgt, dY, partial, (int)M, HW, Po, C, O, xg);                                                \
     } else {                                                                                                        \
       EML_ENSURE_LDS((&sphere_conv_wgrad_fused_kernel<BNV, BMV, true>), lds);                                       \
       hipLaunchKernelGGL((sphere_conv_wgrad_fused_kernel<BNV, BMV, true>), grid, dim3(256), lds, (hipStream_t)stream, X, idx, \
-                         wgt, dY, partial, (int)M, HW, Po, C, O);                                                    \
+                         wgt, dY, partial, (int)M, HW, Po, C, O, xg);                                                \
     }                                                                                                               \
   } while (0)
   if (bn == 128) {
