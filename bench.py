@@ -895,6 +895,13 @@ def main():
                                "traffic_over_algorithmic": (round(traffic / (dom["algorithmic_GB_per_step"] * 1e9 /
                                                                              max(dom["dispatches_per_step"], 1)), 3)
                                                             if traffic else None),
+                               # what the kernel actually moves (PMC traffic per dispatch over the live dispatch duration): the
+                               # 1x1 kernels stream at the part's ceiling on THIS count; the gap to `achieved` is whole-line
+                               # fetches of row prefixes that end inside a 128-byte line
+                               "traffic_GBps": (round(traffic / (dom["avg_dispatch_ms"] * 1e-3) / 1e9, 1)
+                                                if traffic and dom.get("avg_dispatch_ms") else None),
+                               "frac_on_traffic": (round(traffic / (dom["avg_dispatch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                                   if traffic and dom.get("avg_dispatch_ms") and hbm else None),
                                "dispatches_per_step": dom["dispatches_per_step"],
                                # the strict count: only what the family's arithmetic needs (for the 1x1 weight gradient x and
                                # dz once, without the BN2-backward rebuild fused into it), and the fraction of the roof on it
