@@ -172,14 +172,17 @@ class HipDenseEncoder:
         if model.bn_size * model.growth_rate != 48 or model.growth_rate != 12:
             raise NotImplementedError("the HIP engine is built for growth_rate=12, bn_size=4 (EMLight's DenseNet)")
         c = f.conv0.out_channels
-        if c > 32 or c % 2 or c < 8:
-            raise NotImplementedError("num_init_features must be even and in [8, 32] (got %d)" % c)
+        if c != 24:   # conv0_fwd_kernel / conv0_bwd_weight_kernel are instantiated for EMLight's 24 only
+            raise NotImplementedError("the HIP engine is built for num_init_features=24 (got %d)" % c)
         for bi, nl in enumerate(model.block_config):
             ctot = c + nl * model.growth_rate
             if nl < 1 or _r16(ctot) > 384:
                 raise NotImplementedError("dense block %d would be %d channels wide; the HIP kernels hold per-channel "
                                           "vectors of at most 384 (EMLight: 216/300/342)" % (bi + 1, ctot))
             c = getattr(f, "transition%d" % (bi + 1)).conv.out_channels
+            if _r16(c) == 48:   # the 1x1 launchers tell a dense layer (48 outputs) from a transition by that width
+                raise NotImplementedError("transition %d has %d output channels: widths that pad to 48 collide with the "
+                                          "dense layers' bottleneck in the 1x1 launchers (EMLight: 108/150/171)" % (bi + 1, c))
             if c % 2 and bi + 1 < len(model.block_config):   # the next block's channel offsets must stay 8-byte aligned
                 raise NotImplementedError("transition %d feeds a dense block with an odd channel count (%d)" % (bi + 1, c))
 

@@ -252,6 +252,42 @@ def test_backward_small_vs_oracle(crop_hw, B):
     _grad_check(net, ref)
 
 
+@pytest.mark.parametrize("block_config,num_init", [((8, 5, 4), 24), ((2, 7, 4), 24), ((2, 2, 2), 24)])
+def test_other_block_configs_vs_oracle(block_config, num_init):
+    """The class signature's other depths (DenseNet.py:82-83: block_config) through the same schedule logic:
+    pairs of layers with the compact top-24 hand-over where a next pair exists and the block's first channel is a multiple
+    of 4, a single leftover layer for odd counts, blocks that start at channels which are not -- forward values and every
+    parameter gradient of a train-mode step against the oracle's autograd (CPU)."""
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    crop_hw, B, anchors = (32, 64), 2, 32
+    ref = oracle.OracleDenseNet(block_config=block_config, num_init_features=num_init, anchors=anchors, crop_hw=crop_hw)
+    sd = oracle.deterministic_state_dict(ref.state_dict(), seed=11)
+    ref.load_state_dict(sd)
+    net = DenseNet(block_config=block_config, num_init_features=num_init, anchors=anchors, crop_hw=crop_hw).cuda()
+    net.load_state_dict(sd)
+    ref.train(), net.train()
+    g = np.random.default_rng([9, len(block_config), num_init])
+    x = torch.from_numpy(g.random((B, 3) + crop_hw, dtype=np.float32))
+    w = {k: torch.from_numpy(g.standard_normal(s).astype(np.float32))
+         for k, s in (("distribution", (B, anchors)), ("intensity", (B, 1)), ("rgb_ratio", (B, 3)), ("ambient", (B, 3)))}
+    po = ref(x)
+    sum((po[k] * w[k]).sum() for k in KEYS).backward()
+    pg = net(x.cuda())
+    sum((pg[k] * w[k].cuda()).sum() for k in KEYS).backward()
+    for k in KEYS:
+        np.testing.assert_allclose(pg[k].detach().cpu().numpy(), po[k].detach().numpy(), rtol=1e-5, atol=OUT_ATOL)
+    _grad_check(net, ref)
+
+
+def test_configurations_outside_the_envelope_are_refused_up_front():
+    """What the kernels are not built for raises when the engine is made -- not in the middle of a backward pass."""
+    from emlight_amd.RegressionNetwork.DenseNet import DenseNet
+    for kw in (dict(num_init_features=32), dict(num_init_features=16), dict(block_config=(4, 5, 2)),   # transition 2: 96 -> 48
+               dict(growth_rate=16), dict(bn_size=2), dict(block_config=(32, 16, 16))):
+        with pytest.raises(NotImplementedError):
+            DenseNet(anchors=8, crop_hw=(32, 64), **kw)     # the constructor asks HipDenseEncoder.check_supported
+
+
 def test_properties_at_full_baseline_size():
     """BASELINE configs[1] (B=64, 240x320, 128 anchors) is too large for the oracle, so the full-size check uses
     properties of the encoder that do not depend on size: bitwise run-to-run determinism, sample independence in eval
