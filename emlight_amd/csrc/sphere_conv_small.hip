@@ -195,47 +195,125 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_small_wgrad_kernel(const f
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[G][t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // 4 pixels per MFMA k-step; U k-steps per iteration so that U sets of gathers are in flight before the first MFMA needs one
+  // 4 pixels per MFMA k-step, U k-steps per step, and a step's operands are requested a whole step AHEAD of its MFMAs
+  // (round 6).  A step is a two-level dependent chain -- the tap-table entry, then the four corners it names -- of ~2 us, in front
+  // of 32 MFMAs: run step after step (round 4's loop, U sets of gathers in flight) every wave spent its time waiting for one
+  // chain after the other: 331 us for the 1 M pixels of a 128 x 256 layer, and 67 us for the 1 K pixels of a 4 x 8 one (one
+  // workgroup: see small_wgrad_grid).  Now the table entries of step i + 2 and the corners / dY / Y of step i + 1 are in
+  // flight while step i's MFMAs run: two operand buffers (native vectors: arrays of HIP float4 structs that live across a
+  // rolled loop are parked in scratch), the loop body written out for both, every load unconditional from a clamped pixel.
   constexpr int U = 2;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  struct Tables {   // entries of one step: (u, nt) -> this lane's pixel (st * U + u) * 4 + g, column 16 nt + r
+    i32x4 id[U][NT];
+    int xoff[U];    // sample offset into X (elements)
+    int trow[U];    // row of the pixel in the tap table: the weights need no index and travel with the operands
+    int okb;        // bit u: the pixel exists
+  };
+  struct Operands {
+    f32x4 xr[U][NT];   // the four corners' values
+    f32x4 we[U][NT];   // their weights (0 where the corner is off the map)
+    f32x4 gq[U][NG], yq[U][NG];
+    int okb;
+  };
   const int nsteps = (M + 4 * U - 1) / (4 * U);
-  for (int st = wave; st < nsteps; st += nwaves) {
-    float bv[U][NT];
-    float4 gq[U][NG];
+  int ccol[NT];     // this lane's column of tile nt -> channel of its tap (clamped column: padding lanes gather a valid address)
+  int ctap[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int k = min(16 * nt + r, K - 1);
+    ctap[nt] = k / CIN;
+    ccol[nt] = k - ctap[nt] * CIN;
+  }
+  auto load_tables = [&](int st, Tables& t) {
+    t.okb = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int m = (st * U + u) * 4 + g;        // this lane's pixel of the k-step
-      const bool ok = m < M;
-      const int b = ok ? m / Po : 0, p = ok ? m - b * Po : 0;
-      const float* xb = X + (size_t)b * HW * CIN;
+      const int m = (st * U + u) * 4 + g;
+      const bool ok = st < nsteps && m < M;
+      const int mc = ok ? m : 0;
+      const int b = mc / Po, pp = mc - b * Po;
+      t.xoff[u] = b * HW * CIN;
+      t.trow[u] = pp * 9;
+      t.okb |= ok ? (1 << u) : 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        t.id[u][nt] = *reinterpret_cast<const i32x4*>(idx + ((size_t)pp * 9 + ctap[nt]) * 4);
+    }
+  };
+  auto issue_operands = [&](int st, const Tables& t, Operands& o) {
+    o.okb = t.okb;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* xb = X + t.xoff[u] + 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const i32x4 id = t.id[u][nt];
+        // (a corner off the map has index -1 AND weight 0 in the table -- eml_sphere_tap_table_f32 writes both; the clamped
+        // address reads a finite value that the zero weight removes)
+        o.we[u][nt] = *reinterpret_cast<const f32x4*>(wgt + ((size_t)(t.trow[u] + ctap[nt])) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.xr[u][nt][e] = xb[(size_t)max(id[e], 0) * CIN + ccol[nt]];
+      }
+      const int m = (st * U + u) * 4 + g;
+      const size_t row = (size_t)(((t.okb >> u) & 1) ? m : 0) * O;
+#pragma unroll
+      for (int G = 0; G < NG; ++G) {
+        o.gq[u][G] = *reinterpret_cast<const f32x4*>(dY + row + 64 * G + 4 * r);
+        if (Yact) o.yq[u][G] = *reinterpret_cast<const f32x4*>(Yact + row + 64 * G + 4 * r);   // wave-uniform
+      }
+    }
+  };
+  auto run_step = [&](const Operands& o) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = (o.okb >> u) & 1;
+      float bv[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int k = 16 * nt + r;
-        const float v = tap_value<CIN>(xb, idx, wgt, p, min(k, K - 1));
-        bv[u][nt] = !ok ? 0.f : k < K ? v : k == K ? 1.f : 0.f;
+        float v = o.xr[u][nt][0] * o.we[u][nt][0];     // grid_sampler's corner order, as tap_value
+        v += o.xr[u][nt][1] * o.we[u][nt][1];
+        v += o.xr[u][nt][2] * o.we[u][nt][2];
+        v += o.xr[u][nt][3] * o.we[u][nt][3];
+        bv[nt] = !ok ? 0.f : k < K ? v : k == K ? 1.f : 0.f;
       }
 #pragma unroll
       for (int G = 0; G < NG; ++G) {
-        const size_t off = (size_t)(ok ? m : 0) * O + 64 * G + 4 * r;
-        float4 q = *reinterpret_cast<const float4*>(dY + off);
-        if (Yact) {   // wave-uniform
-          const float4 yq = *reinterpret_cast<const float4*>(Yact + off);
-          q.x = yq.x > 0.f ? q.x : q.x * slope; q.y = yq.y > 0.f ? q.y : q.y * slope;
-          q.z = yq.z > 0.f ? q.z : q.z * slope; q.w = yq.w > 0.f ? q.w : q.w * slope;
+        f32x4 q = o.gq[u][G];
+        if (Yact) {
+          const f32x4 yq = o.yq[u][G];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = yq[e] > 0.f ? q[e] : q[e] * slope;
         }
-        gq[u][G] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int G = 0; G < NG; ++G)
+        if (!ok) q = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[G][0][nt] = mfma16(gq[u][G].x, bv[u][nt], acc[G][0][nt]);
-          acc[G][1][nt] = mfma16(gq[u][G].y, bv[u][nt], acc[G][1][nt]);
-          acc[G][2][nt] = mfma16(gq[u][G].z, bv[u][nt], acc[G][2][nt]);
-          acc[G][3][nt] = mfma16(gq[u][G].w, bv[u][nt], acc[G][3][nt]);
+          acc[G][0][nt] = mfma16(q[0], bv[nt], acc[G][0][nt]);
+          acc[G][1][nt] = mfma16(q[1], bv[nt], acc[G][1][nt]);
+          acc[G][2][nt] = mfma16(q[2], bv[nt], acc[G][2][nt]);
+          acc[G][3][nt] = mfma16(q[3], bv[nt], acc[G][3][nt]);
         }
+      }
+    }
+  };
+  Tables tab;
+  Operands opA, opB;
+  load_tables(wave, tab);
+  issue_operands(wave, tab, opA);
+  load_tables(wave + nwaves, tab);
+  for (int st = wave; st < nsteps; st += 2 * nwaves) {
+    // steps past the end have no pixel: their loads go to pixel 0 and their MFMAs add zeros (the tail of a wave's last turn)
+    issue_operands(st + nwaves, tab, opB);
+    load_tables(st + 2 * nwaves, tab);
+    __builtin_amdgcn_sched_barrier(0);
+    run_step(opA);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_operands(st + 2 * nwaves, tab, opA);
+    load_tables(st + 3 * nwaves, tab);
+    __builtin_amdgcn_sched_barrier(0);
+    run_step(opB);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // D element i of tile (G, t, nt): row 4g + i <-> channel 64G + 4(4g + i) + t, column 16nt + r
   if (wv > 0) {
@@ -303,7 +381,9 @@ void launch_small_wgrad(const float* X, const int* idx, const float* wgt, const 
 
 int small_kp(int C) { return 16 * ((9 * C + 1 + 15) / 16); }
 bool small_supported(int C, int O) { return C == 3 && (O == 64 || O == 128); }
-int small_wgrad_grid(long M) { return (int)std::min<long>(kSmallGrid, std::max<long>(1, (M + 1023) / 1024)); }
+// one workgroup per 128 pixels up to the persistent grid (round 6; it was one per 1024: the 1 K pixels of a 4 x 8 layer ran on
+// ONE workgroup, 32 dependent steps per wave = 67 us of latency for 26 MFLOP)
+int small_wgrad_grid(long M) { return (int)std::min<long>(kSmallGrid, std::max<long>(1, (M + 127) / 128)); }
 
 }  // namespace
 
