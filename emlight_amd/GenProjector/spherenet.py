@@ -308,9 +308,16 @@ class _SphereConvFn(torch.autograd.Function):
         if ctx.narrow:
             ctx.fused_fwd = ctx.fused_wgrad = ctx.fused_dgrad = False
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
-            _lib.check(L.eml_sphere_conv_narrow_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
-                                                        p(bias.contiguous()) if bias is not None else None, p(y), B, H * W, po,
-                                                        C, O, st), "eml_sphere_conv_narrow_fwd_f32")
+            if SphereConv2D.narrow_project:   # round 6: project onto the 9 x O columns per SOURCE pixel, then gather 16 bytes per corner
+                scratch = torch.empty(L.eml_sphere_conv_narrow_scratch_floats(B, H * W), dtype=torch.float32, device=x.device)
+                _lib.check(L.eml_sphere_conv_narrow_fwd2_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+                                                             p(bias.contiguous()) if bias is not None else None, p(y), p(scratch),
+                                                             B, H * W, po, C, O, st), "eml_sphere_conv_narrow_fwd2_f32")
+                del scratch
+            else:
+                _lib.check(L.eml_sphere_conv_narrow_fwd_f32(p(xr), p(geo.idx), p(geo.wgt), p(w2.contiguous()),
+                                                            p(bias.contiguous()) if bias is not None else None, p(y), B, H * W, po,
+                                                            C, O, st), "eml_sphere_conv_narrow_fwd_f32")
         elif ctx.small:
             ctx.fused_fwd = ctx.fused_wgrad = False
             y = torch.empty(B * po, O, dtype=torch.float32, device=x.device)
@@ -436,7 +443,20 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             gres._eml_colsum = (gb, gres.data_ptr(), gres._version)
     narrow = getattr(ctx, "narrow", False)
     if needs[1] and not small_w:
-        if narrow:
+        ttn = geo.transposed_table() if (narrow and SphereConv2D.narrow_project and B) else None
+        if narrow and ttn is not None:
+            # round 6: what every output pixel sends back to a source pixel through each tap (the transposed table), (B*HW, 36),
+            # then a 36 x C product over the pixels -- nothing is gathered at full channel width
+            tidx, twgt, rowmax, ke = ttn
+            scratch = torch.empty(L.eml_sphere_conv_narrow_scratch_floats(B, H * W), dtype=torch.float32, device=gy.device)
+            part = torch.empty(L.eml_sphere_conv_narrow_wgrad2_partial_floats(B, H * W, C), dtype=torch.float32, device=gy.device)
+            gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
+            _lib.check(L.eml_sphere_conv_narrow_wgrad2_f32(p(xr), p(tidx), p(twgt), ke, p(rowmax) if ke == 8 else None, p(gyr),
+                                                           p(scratch), p(part), p(gw2), B, H * W, po, C, O, st),
+                       "eml_sphere_conv_narrow_wgrad2_f32")
+            gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
+            del part, scratch
+        elif narrow:
             part = torch.empty(L.eml_sphere_conv_narrow_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
             gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
             _lib.check(L.eml_sphere_conv_narrow_wgrad_f32(p(xr), p(geo.idx), p(geo.wgt), p(gyr), p(part), p(gw2), B, H * W, po, C,
@@ -1123,6 +1143,8 @@ class SphereConv2D(nn.Module):
     fuse_spade = knob_flag("EML_FUSE_SPADE", True)
     # O <= 4 layers on the one-pass kernels of csrc/sphere_conv_narrow.hip; EML_NARROW=0: A/B knob (im2col + library GEMM)
     narrow_kernels = knob_flag("EML_NARROW", True)
+    # round 6: those layers as project-then-gather (csrc/sphere_conv_narrow2.hip); EML_NARROW_PROJECT=0: the one-pass kernels (A/B)
+    narrow_project = knob_flag("EML_NARROW_PROJECT", True)
     # low-resolution wide layers on the footprint gather-GEMM (csrc/gather_gemm3.h) instead of im2col + a library GEMM;
     # EML_LOWRES: A/B knob -- off = round 5's dispatch, force = wherever the kernel supports the shape
     lowres = knob_choice("EML_LOWRES", "off", ("auto", "off", "force"))

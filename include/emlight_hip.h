@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 25
+#define EML_ABI_VERSION 26
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -493,6 +493,26 @@ int eml_sphere_conv_narrow_dgrad_f32(const float* dY, const int* tidx, const flo
 size_t eml_sphere_conv_narrow_wgrad_partial_floats(int B, int Po, int C, int O);
 int eml_sphere_conv_narrow_wgrad_f32(const float* X, const int* idx, const float* wgt, const float* dY, float* partial, float* dW2,
                                      int B, int HW, int Po, int C, int O, eml_stream_t stream);
+
+/* The same layers, project-then-gather (round 6, csrc/sphere_conv_narrow2.hip; same reference lines: sphere_cnn.py:111-124).
+ * With O <= 4 the 36 gathers per pixel at full channel width (9.2 KB of L1 traffic per pixel of conv_img) are what bounds the
+ * kernels above; the convolution is linear and the bilinear weights do not depend on the channel, so
+ *   forward:  P[q][tap][o] = sum_c W2[o][tap*C + c] X[q][c] for every SOURCE pixel (f32-MFMA GEMM), then
+ *             Y[m][o] = bias[o] + sum_{tap,e} wgt[p,tap,e] P[idx[p,tap,e]][tap][o]   (36 16-byte gathers per pixel);
+ *   wgrad  :  V[q][tap][o] = sum_s twgt[q,tap,s] dY[tidx[q,tap,s]][o] over the TRANSPOSED tap table (tidx / twgt / ke as for
+ *             eml_sphere_conv_narrow_dgrad_f32; rowmax (HW bytes, may be NULL): the largest entry count of a tap of source
+ *             pixel q -- pixels with <= 4 skip slots 4..7 of a ke = 8 table), then dW2[o][tap*C + c] = sum_q V[q][tap][o] X[q][c] (split-K f32-MFMA GEMM,
+ *             fixed-order second pass).
+ * scratch: eml_sphere_conv_narrow_scratch_floats(B, HW) floats (P or V: (B*HW, 36)); partial:
+ * eml_sphere_conv_narrow_wgrad2_partial_floats(B, HW, C) floats.  Same supported widths (eml_sphere_conv_narrow_supported).
+ * Results agree with the first generation to f32 round-off (the order of the sums differs). */
+size_t eml_sphere_conv_narrow_scratch_floats(int B, int HW);
+int eml_sphere_conv_narrow_fwd2_f32(const float* X, const int* idx, const float* wgt, const float* W2, const float* bias,
+                                    float* Y, float* scratch, int B, int HW, int Po, int C, int O, eml_stream_t stream);
+size_t eml_sphere_conv_narrow_wgrad2_partial_floats(int B, int HW, int C);
+int eml_sphere_conv_narrow_wgrad2_f32(const float* X, const int* tidx, const float* twgt, int ke,
+                                      const unsigned char* rowmax, const float* dY, float* scratch, float* partial, float* dW2, int B, int HW, int Po, int C, int O,
+                                      eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the

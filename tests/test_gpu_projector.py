@@ -392,15 +392,20 @@ def test_spade_norm_modulate_hip_vs_stock_ops(slope, B, C, H, W, mode):
     assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("project", [True, False])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride", [(2, 64, 3, 16, 32, 1), (3, 128, 1, 10, 20, 1), (2, 512, 3, 8, 16, 1),
-                                                    (1, 64, 4, 6, 12, 1), (2, 192, 2, 12, 24, 2), (1, 64, 3, 2, 4, 1)])
-def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, stride, monkeypatch):
+                                                    (1, 64, 4, 6, 12, 1), (2, 192, 2, 12, 24, 2), (1, 64, 3, 2, 4, 1),
+                                                    (5, 64, 3, 9, 19, 1)])
+def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, stride, project, monkeypatch):
     """conv_img 64 -> 3 and the discriminators' final convolutions (csrc/sphere_conv_narrow.hip: forward, input gradient by the
     transposed tap table, weight gradient) against grid_sample + conv2d(stride 3) (sphere_cnn.py:111-124): pixel counts that do
     not fill a workgroup, several 64-channel groups, stride 2, and a geometry so small that a (pixel, tap) has more than 8
     sources (the input gradient then falls back to dA9 + col2im)."""
     from emlight_amd.GenProjector.spherenet import SphereConv2D
     torch.manual_seed(Cin + Cout)
+    # project = the round-6 form (csrc/sphere_conv_narrow2.hip: a (pixels, 36) projection, then 16-byte gathers; the weight
+    # gradient through the transposed table) -- False: the one-pass kernels, which stay behind EML_NARROW_PROJECT=0
+    monkeypatch.setattr(SphereConv2D, "narrow_project", project)
     hip = SphereConv2D(Cin, Cout, stride=stride, bias=True).cuda()
     with torch.no_grad():
         hip.bias.uniform_(-0.5, 0.5)
@@ -413,7 +418,13 @@ def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, st
     gy = torch.randn_like(yr)
     yh.backward(gy)
     yr.backward(gy)
-    assert "eml_sphere_conv_narrow_fwd_f32" in seen and "eml_sphere_conv_narrow_wgrad_f32" in seen
+    if project:
+        assert "eml_sphere_conv_narrow_fwd2_f32" in seen and "eml_sphere_conv_narrow_fwd_f32" not in seen
+        # (the 2 x 4 geometry has a (pixel, tap) with more than 8 sources: no transposed table, the one-pass weight gradient)
+        assert ("eml_sphere_conv_narrow_wgrad2_f32" in seen) != ("eml_sphere_conv_narrow_wgrad_f32" in seen)
+        assert ("eml_sphere_conv_narrow_wgrad2_f32" in seen) == ("eml_sphere_conv_narrow_dgrad_f32" in seen)
+    else:
+        assert "eml_sphere_conv_narrow_fwd_f32" in seen and "eml_sphere_conv_narrow_wgrad_f32" in seen
     assert "eml_sphere_im2col_f32" not in seen
     assert ("eml_sphere_conv_narrow_dgrad_f32" in seen) != ("eml_sphere_col2im_f32" in seen)
     for name, h, r in (("y", yh, yr), ("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad), ("db", hip.bias.grad, br.grad)):
