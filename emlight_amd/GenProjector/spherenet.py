@@ -442,6 +442,7 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
             # is the same column sum -- handed over on the tensor, under the same storage / version check as above
             gres._eml_colsum = (gb, gres.data_ptr(), gres._version)
     narrow = getattr(ctx, "narrow", False)
+    narrow_v = None   # the few-output-channel layers' V (B*HW, 36), left by the weight gradient for the input gradient
     if needs[1] and not small_w:
         ttn = geo.transposed_table() if (narrow and SphereConv2D.narrow_project and B) else None
         if narrow and ttn is not None:
@@ -455,7 +456,8 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
                                                            p(scratch), p(part), p(gw2), B, H * W, po, C, O, st),
                        "eml_sphere_conv_narrow_wgrad2_f32")
             gw = gw2.view(O, 3, 3, C).permute(0, 3, 1, 2)
-            del part, scratch
+            del part
+            narrow_v = scratch     # V stays for the input gradient below
         elif narrow:
             part = torch.empty(L.eml_sphere_conv_narrow_wgrad_partial_floats(B, po, C, O), dtype=torch.float32, device=gy.device)
             gw2 = torch.empty(O, 9 * C, dtype=torch.float32, device=gy.device)
@@ -510,8 +512,20 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
         elif tt is not None and narrow:
             tidx, twgt, rowmax, ke = tt
             w2 = weight.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
-            _lib.check(L.eml_sphere_conv_narrow_dgrad_f32(p(gyr), p(tidx), p(twgt), ke, p(w2), p(gxr), B, H * W, po, C, O, st),
-                       "eml_sphere_conv_narrow_dgrad_f32")
+            # round 6: dX = V W2 on the matrix unit, V shared with the weight gradient -- for conv_img's width (372 -> 86 us); the
+            # discriminators' 512-channel heads keep the one-pass kernel (a workgroup would stage 74 KB of weights for a few
+            # thousand pixels: 35 -> 31 us at 15 x 31, 12 -> 20 us at 7 x 15; tools/bench_narrow.py)
+            if SphereConv2D.narrow_project and C <= 128:
+                has_v = narrow_v is not None
+                scratch = narrow_v if has_v else torch.empty(L.eml_sphere_conv_narrow_scratch_floats(B, H * W), dtype=torch.float32,
+                                                             device=gy.device)
+                _lib.check(L.eml_sphere_conv_narrow_dgrad2_f32(p(gyr), p(tidx), p(twgt), ke, p(rowmax) if ke == 8 else None, p(w2),
+                                                               p(gxr), p(scratch), int(has_v), B, H * W, po, C, O, st),
+                           "eml_sphere_conv_narrow_dgrad2_f32")
+                del scratch
+            else:
+                _lib.check(L.eml_sphere_conv_narrow_dgrad_f32(p(gyr), p(tidx), p(twgt), ke, p(w2), p(gxr), B, H * W, po, C, O, st),
+                           "eml_sphere_conv_narrow_dgrad_f32")
         elif tt is not None:
             # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
             tidx, twgt, rowmax, ke = tt

@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 26   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 27   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -76,6 +76,8 @@ SIGNATURES = {
     "eml_sphere_conv_narrow_scratch_floats": (ctypes.c_size_t, [_int, _int]),
     "eml_sphere_conv_narrow_fwd2_f32": (_int, [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _stream]),
     "eml_sphere_conv_narrow_wgrad2_partial_floats": (ctypes.c_size_t, [_int, _int, _int]),
+    "eml_sphere_conv_narrow_dgrad2_f32": (_int, [_f32p, _i32p, _f32p, _int, ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _int, _int,
+                                                 _int, _int, _int, _stream]),
     "eml_sphere_conv_narrow_wgrad2_f32": (_int, [_f32p, _i32p, _f32p, _int, ctypes.c_void_p, _f32p, _f32p, _f32p, _f32p, _int, _int,
                                                  _int, _int, _int, _stream]),
     "eml_sphere_conv_spade_supported": (_int, [_int, _int, ctypes.c_long]),

@@ -298,7 +298,75 @@ __global__ __launch_bounds__(256) void narrow_wgrad2_reduce_kernel(const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------- input gradient: V, then V W
+// dX[q][c] = sum_n V[q][n] * Wn[n][c],  Wn[4 tap + o][c] = W2[o][tap * C + c]: D^T form again -- MFMA rows = 16 channels,
+// columns = 16 source pixels, k = the 36 columns of V: two groups of four steps fed from the lane's float4 V[q][16 j + 4 kk ..]
+// (step t of group j uses column 16 j + 4 kk + t on both operands) and a ninth step for columns 32 .. 35.  Weights in LDS in
+// fragment order; a lane holds 4 consecutive channels of its pixel: 16-byte stores.
+__global__ __launch_bounds__(256, 2) void narrow_expand_kernel(const float* __restrict__ V, const float* __restrict__ W2,
+                                                               float* __restrict__ dX, int Mq, int C, int O) {
+  extern __shared__ __attribute__((aligned(16))) float Wl[];   // [(2 * CT + ...)]: main [2][CT][4][64], tail [CT][64]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
+  const int CT = C >> 4;
+  float* Wt = Wl + 2 * CT * 4 * 64;
+  auto wn = [&](int n, int c) {
+    const int tap = n >> 2, o = n & 3;
+    return (n < kCols && o < O) ? W2[(size_t)o * 9 * C + (size_t)tap * C + c] : 0.f;
+  };
+  for (int e = tid; e < 2 * CT * 4 * 64; e += 256) {
+    const int l = e & 63, t = (e >> 6) & 3, rest = e >> 8, ct = rest % CT, j = rest / CT;
+    Wl[e] = wn(16 * j + 4 * (l >> 4) + t, 16 * ct + (l & 15));
+  }
+  for (int e = tid; e < CT * 64; e += 256) {
+    const int l = e & 63, ct = e >> 6;
+    Wt[e] = wn(32 + (l >> 4), 16 * ct + (l & 15));
+  }
+  __syncthreads();
+  const int wave = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+  const int ntiles = (Mq + 15) >> 4;
+  struct Tile {
+    f32x4 v0, v1;
+    float vt;
+  };
+  auto fetch = [&](int tile, Tile& t) {
+    const int q = min(min(tile, ntiles - 1) * 16 + r, Mq - 1);
+    const float* vp = V + (size_t)q * kCols;
+    t.v0 = *reinterpret_cast<const f32x4*>(vp + 4 * kk);
+    t.v1 = *reinterpret_cast<const f32x4*>(vp + 16 + 4 * kk);
+    t.vt = vp[32 + kk];
+  };
+  auto compute = [&](int tile, const Tile& t) {
+    const int q = tile * 16 + r;
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* w0 = Wl + (size_t)(ct * 4) * 64 + lane;
+      const float* w1 = Wl + (size_t)((CT + ct) * 4) * 64 + lane;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc = mfma16(w0[tt * 64], t.v0[tt], acc);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc = mfma16(w1[tt * 64], t.v1[tt], acc);
+      acc = mfma16(Wt[ct * 64 + lane], t.vt, acc);
+      if (q < Mq) *reinterpret_cast<f32x4*>(dX + (size_t)q * C + 16 * ct + 4 * kk) = acc;
+    }
+  };
+  Tile ta, tb;
+  fetch(wave, ta);
+  for (int tile = wave; tile < ntiles; tile += 2 * nwaves) {
+    fetch(tile + nwaves, tb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tile, ta);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(tile + 2 * nwaves, ta);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + nwaves < ntiles) compute(tile + nwaves, tb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 int narrow2_wgrad_blocks(long Mq) { return (int)std::max<long>(1, std::min<long>(512, (Mq + 255) / 256)); }
+
+int launch_vgather(const char* what, const float* dY, const int* tidx, const float* twgt, int ke, const unsigned char* rowmax,
+                   float* V, long Mq, int HW, int Po, int O, eml_stream_t stream);
 
 #define EML_NARROW2_DISPATCH(O_, STMT)             \
   switch (O_) {                                    \
@@ -307,6 +375,18 @@ int narrow2_wgrad_blocks(long Mq) { return (int)std::max<long>(1, std::min<long>
     case 3: { constexpr int OV = 3; STMT; } break; \
     default: { constexpr int OV = 4; STMT; } break; \
   }
+
+int launch_vgather(const char* what, const float* dY, const int* tidx, const float* twgt, int ke, const unsigned char* rowmax,
+                   float* V, long Mq, int HW, int Po, int O, eml_stream_t stream) {
+  const long nv = Mq * 9;
+  const long gridv = 8 * (((nv + 255) / 256 + 7) / 8);
+  if (gridv > 2147483647L) return eml::fail(EML_EINVAL, "%s: too many pixels", what);
+  EML_NARROW2_DISPATCH(O, {
+    hipLaunchKernelGGL((narrow_vgather_kernel<OV>), dim3((unsigned)gridv), dim3(256), 0, (hipStream_t)stream, dY, tidx, twgt, ke,
+                       rowmax, V, nv, HW, Po);
+  })
+  return eml::check_launch(what);
+}
 
 }  // namespace
 
@@ -351,14 +431,7 @@ extern "C" int eml_sphere_conv_narrow_wgrad2_f32(const float* X, const int* tidx
     return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_wgrad2_f32: need C %% 64 == 0, C <= %d, 1 <= O <= 4 (C=%d, O=%d)", kMaxC, C, O);
   const long Mq = (long)B * HW;
   if (Mq * kCols > 2147483647L || (long)B * Po > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_wgrad2_f32: too many pixels");
-  const long nv = Mq * 9;
-  const long gridv = 8 * (((nv + 255) / 256 + 7) / 8);
-  if (gridv > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_wgrad2_f32: too many pixels");
-  EML_NARROW2_DISPATCH(O, {
-    hipLaunchKernelGGL((narrow_vgather_kernel<OV>), dim3((unsigned)gridv), dim3(256), 0, (hipStream_t)stream, dY, tidx, twgt, ke,
-                       rowmax, scratch, nv, HW, Po);
-  })
-  int rc = eml::check_launch("eml_sphere_conv_narrow_wgrad2_f32(V)");
+  int rc = launch_vgather("eml_sphere_conv_narrow_wgrad2_f32(V)", dY, tidx, twgt, ke, rowmax, scratch, Mq, HW, Po, O, stream);
   if (rc) return rc;
   const int blocks = narrow2_wgrad_blocks(Mq);
   const size_t lds = (size_t)3 * 64 * 48 * sizeof(float);
@@ -368,4 +441,27 @@ extern "C" int eml_sphere_conv_narrow_wgrad2_f32(const float* X, const int* tidx
   hipLaunchKernelGGL(narrow_wgrad2_reduce_kernel, dim3((C * 48 + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, O,
                      dW2);
   return eml::check_launch("eml_sphere_conv_narrow_wgrad2_f32(reduce)");
+}
+
+// dX (B*HW, C) = V W: `scratch` holds V when scratch_has_v != 0 (eml_sphere_conv_narrow_wgrad2_f32 of the SAME dY left it there),
+// else it is computed first.
+extern "C" int eml_sphere_conv_narrow_dgrad2_f32(const float* dY, const int* tidx, const float* twgt, int ke,
+                                                 const unsigned char* rowmax, const float* W2, float* dX, float* scratch,
+                                                 int scratch_has_v, int B, int HW, int Po, int C, int O, eml_stream_t stream) {
+  if (!dY || !tidx || !twgt || !W2 || !dX || !scratch || B < 0 || HW < 1 || Po < 1 || ke < 1 || ke > 8)
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_dgrad2_f32: null pointer, empty shape or ke outside 1..8");
+  if (!narrow2_supported(C, O))
+    return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_dgrad2_f32: need C %% 64 == 0, C <= %d, 1 <= O <= 4 (C=%d, O=%d)", kMaxC, C, O);
+  const long Mq = (long)B * HW;
+  if (Mq * kCols > 2147483647L || (long)B * Po > 2147483647L) return eml::fail(EML_EINVAL, "eml_sphere_conv_narrow_dgrad2_f32: too many pixels");
+  if (Mq == 0) return EML_OK;
+  if (!scratch_has_v) {
+    const int rc = launch_vgather("eml_sphere_conv_narrow_dgrad2_f32(V)", dY, tidx, twgt, ke, rowmax, scratch, Mq, HW, Po, O, stream);
+    if (rc) return rc;
+  }
+  const size_t lds = (size_t)C * kCols * sizeof(float);
+  const int grid = (int)std::min<long>(512, (Mq + 63) / 64);
+  EML_ENSURE_LDS((&narrow_expand_kernel), lds);
+  hipLaunchKernelGGL(narrow_expand_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, scratch, W2, dX, (int)Mq, C, O);
+  return eml::check_launch("eml_sphere_conv_narrow_dgrad2_f32(expand)");
 }

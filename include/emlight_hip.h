@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 26
+#define EML_ABI_VERSION 27
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -499,7 +499,7 @@ int eml_sphere_conv_narrow_wgrad_f32(const float* X, const int* idx, const float
  * kernels above; the convolution is linear and the bilinear weights do not depend on the channel, so
  *   forward:  P[q][tap][o] = sum_c W2[o][tap*C + c] X[q][c] for every SOURCE pixel (f32-MFMA GEMM), then
  *             Y[m][o] = bias[o] + sum_{tap,e} wgt[p,tap,e] P[idx[p,tap,e]][tap][o]   (36 16-byte gathers per pixel);
- *   wgrad  :  V[q][tap][o] = sum_s twgt[q,tap,s] dY[tidx[q,tap,s]][o] over the TRANSPOSED tap table (tidx / twgt / ke as for
+ *   wgrad / dgrad:  V[q][tap][o] = sum_s twgt[q,tap,s] dY[tidx[q,tap,s]][o] over the TRANSPOSED tap table (tidx / twgt / ke as for
  *             eml_sphere_conv_narrow_dgrad_f32; rowmax (HW bytes, may be NULL): the largest entry count of a tap of source
  *             pixel q -- pixels with <= 4 skip slots 4..7 of a ke = 8 table), then dW2[o][tap*C + c] = sum_q V[q][tap][o] X[q][c] (split-K f32-MFMA GEMM,
  *             fixed-order second pass).
@@ -513,6 +513,11 @@ size_t eml_sphere_conv_narrow_wgrad2_partial_floats(int B, int HW, int C);
 int eml_sphere_conv_narrow_wgrad2_f32(const float* X, const int* tidx, const float* twgt, int ke,
                                       const unsigned char* rowmax, const float* dY, float* scratch, float* partial, float* dW2, int B, int HW, int Po, int C, int O,
                                       eml_stream_t stream);
+/* dX (B*HW, C) = V W2 in the (tap, o) x c arrangement (f32 MFMA, K = 36): the same V.  scratch_has_v != 0: `scratch` still
+ * holds the V that eml_sphere_conv_narrow_wgrad2_f32 built from this dY; else it is built first. */
+int eml_sphere_conv_narrow_dgrad2_f32(const float* dY, const int* tidx, const float* twgt, int ke,
+                                      const unsigned char* rowmax, const float* W2, float* dX, float* scratch,
+                                      int scratch_has_v, int B, int HW, int Po, int C, int O, eml_stream_t stream);
 /* Input gradient with the same kernel: dX (B*HW, C) = sum_{tap,o} Dg[q][tap][o] * W2t[c][tap*O + o], Dg = dY gathered through
  * the TRANSPOSED tap table tidx / twgt (HW*9*ke ints / floats: for input pixel q and tap t, the output pixels whose tap t
  * samples q, -1 / weight 0 = empty slot; ke = 4 or 8 slots).  rowmax (HW bytes, required for ke = 8) = per input pixel the

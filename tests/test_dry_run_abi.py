@@ -218,10 +218,13 @@ def test_one_launch_spade_and_few_output_channel_calls_match_the_abi(recorder, m
     xi = torch.rand(2, 64, 4, 8, requires_grad=True)
     conv(xi).sum().backward()
     for name in ("eml_sphere_conv_narrow_scratch_floats", "eml_sphere_conv_narrow_fwd2_f32", "eml_sphere_conv_narrow_wgrad2_partial_floats",
-                 "eml_sphere_conv_narrow_wgrad2_f32", "eml_sphere_conv_narrow_dgrad_f32"):   # round 6: project, then gather
+                 "eml_sphere_conv_narrow_wgrad2_f32", "eml_sphere_conv_narrow_dgrad2_f32"):   # round 6: project, then gather
         assert name in recorder.calls[n:], name
     assert "eml_sphere_im2col_f32" not in recorder.calls[n:] and "eml_sphere_col2im_f32" not in recorder.calls[n:]
     assert xi.grad.shape == xi.shape and conv.weight.grad.shape == conv.weight.shape
+    # the input gradient reuses the V the weight gradient left in the scratch tensor (scratch_has_v = 1)
+    dg = [a for nme, a in recorder.args[n:] if nme == "eml_sphere_conv_narrow_dgrad2_f32"][-1]
+    assert dg[8] == 1
     # EML_NARROW_PROJECT=0: the one-pass kernels
     monkeypatch.setattr(spherenet.SphereConv2D, "narrow_project", False)
     n = len(recorder.calls)

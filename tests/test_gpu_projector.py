@@ -422,11 +422,13 @@ def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, st
         assert "eml_sphere_conv_narrow_fwd2_f32" in seen and "eml_sphere_conv_narrow_fwd_f32" not in seen
         # (the 2 x 4 geometry has a (pixel, tap) with more than 8 sources: no transposed table, the one-pass weight gradient)
         assert ("eml_sphere_conv_narrow_wgrad2_f32" in seen) != ("eml_sphere_conv_narrow_wgrad_f32" in seen)
-        assert ("eml_sphere_conv_narrow_wgrad2_f32" in seen) == ("eml_sphere_conv_narrow_dgrad_f32" in seen)
+        narrow_dgrad = "eml_sphere_conv_narrow_dgrad2_f32" if Cin <= 128 else "eml_sphere_conv_narrow_dgrad_f32"   # (wide heads: one pass)
+        assert ("eml_sphere_conv_narrow_wgrad2_f32" in seen) == (narrow_dgrad in seen)
+        assert (narrow_dgrad in seen) != ("eml_sphere_col2im_f32" in seen)
     else:
         assert "eml_sphere_conv_narrow_fwd_f32" in seen and "eml_sphere_conv_narrow_wgrad_f32" in seen
+        assert ("eml_sphere_conv_narrow_dgrad_f32" in seen) != ("eml_sphere_col2im_f32" in seen)
     assert "eml_sphere_im2col_f32" not in seen
-    assert ("eml_sphere_conv_narrow_dgrad_f32" in seen) != ("eml_sphere_col2im_f32" in seen)
     for name, h, r in (("y", yh, yr), ("dx", xh.grad, xr.grad), ("dW", hip.weight.grad, wr.grad), ("db", hip.bias.grad, br.grad)):
         np.testing.assert_allclose(h.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=1e-4,
                                    atol=1e-4 * float(r.detach().abs().max()), err_msg=name)
@@ -436,6 +438,10 @@ def test_sphere_conv_few_output_channels_one_pass_kernels(B, Cin, Cout, H, W, st
     y2 = hip(x2)
     y2.backward(gy)
     assert torch.equal(y2, yh) and torch.equal(x2.grad, xh.grad)
+    # the input gradient on its own (frozen weights: the discriminators in the generator step) builds its own V: same values
+    x3 = x.clone().requires_grad_(True)
+    (gx3,) = torch.autograd.grad(hip(x3), x3, gy)
+    assert torch.equal(gx3, xh.grad)
 
 
 def _spy_on_lib(monkeypatch):

@@ -53,7 +53,11 @@ for B, C, O, H, W in [(32, 64, 3, 128, 256), (64, 512, 1, 15, 31), (64, 512, 1, 
                                                                     H * W, po, C, O, st), "fwd2"))
     g2 = timed(lambda: _lib.check(L.eml_sphere_conv_narrow_wgrad2_f32(p(x), p(tidx), p(twgt), ke, p(rowmax) if ke == 8 else None, p(gy), p(scr), p(part2), p(gw3), B,
                                                                       H * W, po, C, O, st), "wgrad2"))
+    gx2 = torch.empty_like(gx)
+    d2 = timed(lambda: _lib.check(L.eml_sphere_conv_narrow_dgrad2_f32(p(gy), p(tidx), p(twgt), ke, p(rowmax) if ke == 8 else None, p(w2),
+                                                                      p(gx2), p(scr), 1, B, H * W, po, C, O, st), "dgrad2"))
+    ex = float((gx2 - gx).abs().max() / gx.abs().max())
     ey = float((y2 - y).abs().max() / y.abs().max())
     ew = float((gw3 - gw2).abs().max() / gw2.abs().max())
-    print("B%d %d -> %d @%dx%d: fwd %7.1f -> %7.1f us  wgrad %7.1f -> %7.1f us  dgrad %7.1f us   (x = %.0f MB; max rel diff y %.1e, dW %.1e)"
-          % (B, C, O, H, W, f, f2, g, g2, d, x.numel() * 4 / 1e6, ey, ew))
+    print("B%d %d -> %d @%dx%d: fwd %7.1f -> %7.1f us  wgrad %7.1f -> %7.1f us  dgrad %7.1f -> %7.1f us (V reused)   (x = %.0f MB; max rel diff y %.1e, dW %.1e, dX %.1e)"
+          % (B, C, O, H, W, f, f2, g, g2, d, d2, x.numel() * 4 / 1e6, ey, ew, ex))
