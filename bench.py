@@ -710,12 +710,28 @@ def leg_joint(args, rank, world, dev, steps, warmup):
     from emlight_amd.GenProjector.networks import default_options
     batch = joint_batch(B, dev, args.anchors, crop_hw, seed=1234 + rank)
 
+    host_cpu = [None]
+
     def run(no_vgg):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             tr = JointTrainer(default_options(no_vgg_loss=no_vgg, vgg_random=True), anchors=args.anchors, crop_hw=crop_hw, blur=args.blur,
                               device=dev, world=world)
         dt = run_timed(lambda: tr.step(batch), steps, warmup, world, dev)
+        # host CPU seconds (all threads of this process) an iteration costs: the 2 500 launches of an iteration leave the host
+        # ~110 us each on the clock but it must never fall behind -- on a loaded host it does, and the step time follows
+        # (measured from a drained GPU: how long the host takes to enqueue one iteration, and how much GPU work is still queued
+        #  when it is done -- the margin the host has per iteration before the GPU would wait for it)
+        enq = tail = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            tr.step(batch)
+            h1 = time.perf_counter()
+            torch.cuda.synchronize()
+            enq += h1 - h0
+            tail += time.perf_counter() - h1
+        host_cpu[0] = (enq / 3 * 1e3, tail / 3 * 1e3)
         # every rank runs the instrumented iteration (collectives inside); rank 0 reports
         fams = None if no_vgg else time_projector_families(
             tr, batch, 1, {**ENCODER_FAMILIES, **PROJECTOR_FAMILIES},
@@ -729,6 +745,7 @@ def leg_joint(args, rank, world, dev, steps, warmup):
         _free_gpu()
         return dt, peak, fams, other, coll
     dt, peak, fams, other, coll = run(False)     # the generator losses include the VGG19 perceptual term, as in the reference (random weights)
+    host_cpu_ms = host_cpu[0]
     dt0 = run(True)[0]
     value, value0 = B * world * steps / dt, B * world * steps / dt0
     enc_gflop = STEP_GFLOP_240x320 if crop_hw == (240, 320) else 0.0
@@ -748,6 +765,8 @@ def leg_joint(args, rank, world, dev, steps, warmup):
                            "frac_of_f32_mfma_peak": round((enc_gflop + PROJECTOR_STEP_GFLOP) * value0 / world / 1e3
                                                           / F32_MFMA_PEAK_TFLOPS, 4)},
            "peak_hbm_GB": peak,
+           "host_enqueue_ms_per_step": round(host_cpu_ms[0], 1) if host_cpu_ms else None,
+           "gpu_still_queued_when_host_is_done_ms": round(host_cpu_ms[1], 1) if host_cpu_ms else None,
            "algorithmic_gflop_per_image": round(gflop, 1), "executed_gflop_per_image": round(gflop_exec, 1),
            "step_frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
            "step_frac_executed": round(gflop_exec * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
