@@ -684,6 +684,36 @@ def test_vgg19_features_and_loss_vs_stock_ops():
         VGG19Features()
 
 
+def test_frozen_weight_layouts_are_remembered_and_follow_the_weight():
+    """The (O, 9C) / (C, 9O) operands of a weight that takes no gradient (the VGG19 stack) are built once per (Parameter,
+    version, storage) -- and again when the weight is rewritten."""
+    from emlight_amd.GenProjector import spherenet
+    from emlight_amd.GenProjector.vgg import PlanarConv3x3
+    torch.manual_seed(0)
+    conv = PlanarConv3x3(64, 64).cuda()
+    for q in conv.parameters():
+        q.requires_grad = False
+    x = torch.randn(2, 64, 16, 32, device="cuda", requires_grad=True)
+    spherenet._FROZEN.clear()
+    y1 = conv(x)
+    y1.sum().backward()
+    held = {k[1]: v[2].data_ptr() for k, v in spherenet._FROZEN.items()}
+    assert set(held) >= {"w2"}
+    y2 = conv(x)
+    assert torch.equal(y1, y2) and {k[1]: v[2].data_ptr() for k, v in spherenet._FROZEN.items()} == held   # no new copies
+    want = torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1)
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    with torch.no_grad():
+        conv.weight.mul_(-0.5)
+    y3 = conv(x)
+    np.testing.assert_allclose(y3.detach().cpu().numpy(), (-0.5 * (want - conv.bias.view(1, -1, 1, 1)) + conv.bias.view(1, -1, 1, 1)).detach().cpu().numpy(),
+                               rtol=1e-4, atol=1e-4)
+    trainable = PlanarConv3x3(64, 64).cuda()
+    n = len(spherenet._FROZEN)
+    trainable(x)
+    assert len(spherenet._FROZEN) == n                                   # a weight that takes a gradient is never remembered
+
+
 def test_vgg_stack_construction_leaves_the_global_rng_alone():
     """building the (random) feature stack must not reseed the CPU or the CUDA generators."""
     from emlight_amd.GenProjector.vgg import VGG19Features
