@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
     const float* __restrict__ X, int ldx, int P, int Hin, int Win, int Kp,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ Wp,
     float* __restrict__ out, int ldo, int n_valid, double* __restrict__ partials,
-    unsigned long long* __restrict__ relu_mask) {
+    unsigned long long* __restrict__ relu_mask, int staged) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                 // [Kp/16][4][48][4]
   float* sl = wl + (size_t)Kp * 48; // [Kp]
@@ -91,6 +91,11 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
   // store to reach memory.  Through LDS (lgkmcnt) the loop holds loads only; the words leave once per tile, as one
   // contiguous 128*Kp/16-byte run per wave.
   unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(red + 4 * 48 * 2);
+  // staged (round 6; dense layers, compact 48-wide output): a 16-pixel group's 16 x 48 results go through a wave-private LDS
+  // tile (row stride 52 floats: conflict-free 16-byte writes) and leave as three stores of 1 KB of CONSECUTIVE addresses.  The
+  // D^T epilogue stores 16 x 64 bytes per instruction -- half lines, which a write-only stream pays for: 3.3 TB/s against
+  // 5.5 for whole lines on this very shape (profiles/r06_write_pattern.txt).
+  float* stg = reinterpret_cast<float*>(mask_l + (MASK ? (size_t)4 * 16 * (Kp >> 4) : 0)) + (size_t)(threadIdx.x >> 6) * 16 * 52;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
 
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
           ls[g] += v;
           lq[g] = fmaf(v, v, lq[g]);
         }
-        if (pv) {
+        if (pv && !staged) {
           float* dst = out + (size_t)p * ldo + c4;
           if (vec_ok && c4 + 4 <= n_valid) {
             *reinterpret_cast<float4*>(dst) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
@@ -253,6 +258,27 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
       for (int g = 0; g < 4; ++g) {
         ssum[n][g] += (double)ls[g];
         ssq[n][g] += (double)lq[g];
+      }
+    }
+    if (staged) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(stg + r * 52 + 16 * n + 4 * kk) = acc[m][n];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private tile, LDS runs a wave's accesses in order
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int pg = p0 + 16 * m;
+        float* dst = out + (size_t)pg * 48;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int f = lane + 64 * i, px = f / 12, piece = f - 12 * px;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * 52 + 4 * piece);
+          if (pg + px < P) *reinterpret_cast<f32x4*>(dst + 4 * f) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
@@ -857,8 +883,15 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
   if (relu_mask && (pool || Cout > 48))
     return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: relu_mask is for dense layers (no pool, Cout <= 48)");
   if (pool && ((Hin & 1) || (Win & 1))) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: pool needs even H, W");
-  const size_t lds = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double) +
-                     (relu_mask ? (size_t)4 * 16 * (Kp / 16) * sizeof(unsigned long long) : 0);
+  // dense layers with a compact 48-wide output leave through a staging tile (whole-line stores): EML_FWD_STAGED=0 for the A/B
+  static const bool staged_env = [] { const char* v = getenv("EML_FWD_STAGED"); return !(v && v[0] == '0'); }();
+  const size_t lds0 = ((size_t)Kp * 48 + 2 * Kp) * sizeof(float) + 4 * 48 * 2 * sizeof(double) +
+                      (relu_mask ? (size_t)4 * 16 * (Kp / 16) * sizeof(unsigned long long) : 0);
+  const size_t stg_bytes = (size_t)4 * 16 * 52 * sizeof(float);
+  // (only where two workgroups per CU still fit with the tile: the widest layers of blocks 2 and 3 keep the direct stores)
+  const int staged = (staged_env && !pool && Cout == 48 && ldo == 48 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                      lds0 + stg_bytes <= 80 * 1024) ? 1 : 0;
+  const size_t lds = lds0 + (staged ? stg_bytes : 0);
   if (lds > 160 * 1024) return eml::fail(EML_EINVAL, "eml_dense_conv1x1_fwd_f32: Kp=%d does not fit LDS", Kp);
   const int nchunks = (Cout + 47) / 48;
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -868,15 +901,15 @@ extern "C" int eml_dense_conv1x1_fwd_f32(const float* X, int ldx, long P, int Hi
     if (pool) {
       EML_ENSURE_LDS((&conv1x1_fwd_kernel<true, false>), lds);
       hipLaunchKernelGGL((conv1x1_fwd_kernel<true, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P, Hin,
-                         Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
+                         Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr, 0);
     } else if (relu_mask) {
       EML_ENSURE_LDS((&conv1x1_fwd_kernel<false, true>), lds);
       hipLaunchKernelGGL((conv1x1_fwd_kernel<false, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
-                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, relu_mask);
+                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, relu_mask, staged);
     } else {
       EML_ENSURE_LDS((&conv1x1_fwd_kernel<false, false>), lds);
       hipLaunchKernelGGL((conv1x1_fwd_kernel<false, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, ldx, (int)P,
-                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr);
+                         Hin, Win, Kp, scale, shift, wp, out + ch * 48, ldo, nv, pp, nullptr, staged);
     }
     int rc = eml::check_launch("eml_dense_conv1x1_fwd_f32");
     if (rc) return rc;
