@@ -1860,6 +1860,7 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
   double* sacc = reinterpret_cast<double*>(smem);                  // [4 waves][Kp][2]
   float* vec_l = reinterpret_cast<float*>(sacc + (size_t)4 * Kp * 2);  // scale1, shift1, mean, istd [Kp]; cA, cB, cC [Ko]
   float* co_l = vec_l + 4 * Kp;
+  float* stg = co_l + 3 * Ko + (size_t)(threadIdx.x >> 6) * 16 * 36;   // [4 waves][16][36]: MASKED && !ACC only
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
   for (int e = tid; e < 4 * Kp * 2; e += 256) sacc[e] = 0.0;
@@ -1893,6 +1894,19 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
       const int b = (int)(prow[m] / (Ho * Wo)), rem = (int)(prow[m] - (long)b * (Ho * Wo));
       const int oy = rem / Wo, ox = rem - oy * Wo;
       pin[m] = (size_t)(b * Hin + 2 * oy) * Win + 2 * ox;   // top-left input pixel of the pooling window
+    }
+    // staged stores (MASKED && !ACC): the rows lane l writes are those of lanes l >> 3 and (l >> 3) + 8
+    size_t pinx[MT][2];
+    bool pvx[MT][2];
+    if constexpr (MASKED && !ACC) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int src = (lane >> 3) + 8 * h;
+          pinx[m][h] = (size_t)__shfl((unsigned long long)pin[m], src, 64);
+          pvx[m][h] = __shfl((int)pv[m], src, 64) != 0;
+        }
     }
     float4 dzr[NJO > 0 ? NJO : 1][MT];
     if constexpr (NJO > 0) {
@@ -1987,6 +2001,64 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
           group_step(jo, dz);
         }
       }
+      if constexpr (MASKED && !ACC) {
+        // (round 6) G is write-only here: 16 rows x 64 bytes per store instruction are HALF lines into rows nobody holds in
+        // L2 -- 2.15 TB/s on this shape against 3.9 for whole lines (profiles/r06_write_pattern.txt).  The two column tiles of
+        // a (pooled pixel group, sub-pixel) go through a wave-private LDS tile (16 rows x 32 channels, stride 36) and leave as
+        // two stores of 8 rows x one whole 128-byte line each: lane l -> row l >> 3 (+ 8), 16-byte piece l & 7.
+        float l1n[NCH][4];
+        float4 skn[NCH];
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+          skn[n] = *reinterpret_cast<const float4*>(vec_l + 16 * min(nt0 + n, nnt - 1) + 4 * kk);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) l1n[n][g] = 0.f;
+        }
+        const int piece = lane & 7;
+        const bool col_ok = nt0 + (piece >> 2) < nnt;             // the lane's column tile exists
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+            for (int n = 0; n < NCH; ++n) {
+              const unsigned b = pv[m] ? mk[m][n] >> (4 * sub) : 0u;
+              const float d0 = (b & 1u) ? 0.25f * acc[m][n][0] : 0.f, d1 = (b & 2u) ? 0.25f * acc[m][n][1] : 0.f;
+              const float d2 = (b & 4u) ? 0.25f * acc[m][n][2] : 0.f, d3 = (b & 8u) ? 0.25f * acc[m][n][3] : 0.f;
+              *reinterpret_cast<f32x4*>(stg + r * 36 + 16 * n + 4 * kk) = f32x4{skn[n].x * d0, skn[n].y * d1, skn[n].z * d2, skn[n].w * d3};
+              if (nt0 + n < nnt) {
+                l1n[n][0] += d0;
+                l1n[n][1] += d1;
+                l1n[n][2] += d2;
+                l1n[n][3] += d3;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private tile: LDS runs a wave's accesses in order
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const size_t suboff = ((size_t)(sub >> 1) * Win + (sub & 1)) * (size_t)ldg + 16 * nt0 + 4 * piece;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(stg + ((lane >> 3) + 8 * h) * 36 + 4 * piece);
+              if (pvx[m][h] && col_ok) *reinterpret_cast<f32x4*>(Gd + pinx[m][h] * ldg + suboff) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+          if (nt0 + n < nnt) {
+            const int k4 = 16 * (nt0 + n) + 4 * kk;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float t1 = eml::row16_sum(l1n[n][g]);
+              if (r == 0) my[2 * (k4 + g)] += (double)t1;
+            }
+          }
+        }
+      } else {
       // epilogue: lane owns channels k4..k4+3 of the 4 input pixels under each of its MT pooled pixels
 #pragma unroll
       for (int n = 0; n < NCH; ++n) {
@@ -2051,6 +2123,7 @@ __global__ __launch_bounds__(256, 2) void transition_bwd_data_kernel(
             }
           }
         }
+      }
       }
     }
   }
@@ -2940,7 +3013,7 @@ extern "C" int eml_dense_conv1x1_bwd_data_f32(const float* DY, int ld_dy, const 
     if (Ko == 48) {
       EML_LAUNCH_BWD_DATA(true, true, 4);
     } else {  // transitions
-      const size_t lds_t = lds + (size_t)(4 * Kp + 3 * Ko) * sizeof(float);
+      const size_t lds_t = lds + (size_t)(4 * Kp + 3 * Ko + 4 * 16 * 36) * sizeof(float);   // + the staged stores' wave tiles
 #define EML_LAUNCH_TRANSITION(ACCV, MSKV)                                                                              \
   do {                                                                                                                \
     EML_ENSURE_LDS((&transition_bwd_data_kernel<2, 2, ACCV, MSKV>), lds_t);                                 \
