@@ -51,62 +51,122 @@ __global__ __launch_bounds__(256, 2) void sphere_conv_small_fwd_kernel(const flo
                                                                     const float* __restrict__ W2 /*[O][9*CIN]*/,
                                                                     const float* __restrict__ bias, float* __restrict__ Y,
                                                                     int M, int HW, int Po, float slope) {
-  constexpr int K = 9 * CIN, KS = (K + 3) / 4, MT = O / 16;
+  // Round 6.  16 pixels per step; the four lanes (r, g = 0..3) of a pixel share its 9 taps (lane g: taps g, g + 4, g + 8) and
+  // load a corner's CIN channels TOGETHER; the interpolated values go through a wave-private LDS tile A_l[pixel][9 CIN (+1)] into
+  // the MFMA operand layout.  Round 4 gave every lane its own (tap, channel) COLUMNS: 28 scattered 4-byte gathers + 14 table
+  // loads per lane and tile -- the texture-address unit, not HBM and not the matrix unit, bound the kernel (254 us for a
+  // 128 x 256 layer whose 537 MB of output stream out in 100); now 12 + 6.  And a step's operands are requested a whole step
+  // ahead of its MFMAs (table entries two ahead; two operand buffers of native vectors), W2 sits in LDS in fragment order:
+  // Wl[(s * MT + mt) * 64 + lane] = W2[16 mt + r][4 s + g].
+  constexpr int K = 9 * CIN, KS = (K + 3) / 4, MT = O / 16, LDA = 4 * KS;
+  static_assert(CIN == 3, "a corner is loaded as three floats");
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  __shared__ float Wl[KS * MT * 64];
+  __shared__ float A_all[4 * 16 * LDA];
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  float* A_l = A_all + (threadIdx.x >> 6) * 16 * LDA;
+  for (int e = threadIdx.x; e < KS * MT * 64; e += 256) {
+    const int l = e & 63, rest = e >> 6, mt = rest % MT, s_ = rest / MT;
+    const int k = 4 * s_ + (l >> 4);
+    Wl[e] = k < K ? W2[(size_t)(16 * mt + (l & 15)) * K + k] : 0.f;
+  }
+  for (int e = threadIdx.x; e < 4 * 16 * LDA; e += 256) A_all[e] = 0.f;   // (the padding columns K .. LDA - 1 stay zero)
+  __syncthreads();
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  float wreg[MT][KS];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 4 * s + g;
-      wreg[mt][s] = k < K ? W2[(size_t)(16 * mt + r) * K + k] : 0.f;
-    }
   float4 bq[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     bq[mt] = bias ? *reinterpret_cast<const float4*>(bias + 16 * mt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int ntiles = (M + 31) / 32;
-  for (int t = wave; t < ntiles; t += nwaves) {
-    const int m0 = t * 32;
-    f32x4 acc[MT][2];
+  const int ntiles = (M + 15) / 16;
+  constexpr int NJ = 3;   // taps per lane: g, g + 4, g + 8 (the last exists for g == 0 only)
+  struct Tables {
+    i32x4 id[NJ];
+    int xoff, trow, ok;
+  };
+  struct Operands {
+    f32x3 xr[NJ][4];
+    f32x4 we[NJ];
+    int ok;
+  };
+  auto tap_of = [&](int j) { return min(g + 4 * j, 8); };   // clamped: lanes without a third tap re-read tap 8 (not written)
+  auto load_tables = [&](int t, Tables& tb) {
+    const int m = t * 16 + r;
+    tb.ok = (t < ntiles && m < M) ? 1 : 0;
+    const int mc = tb.ok ? m : 0;
+    const int b = mc / Po, p = mc - b * Po;
+    tb.xoff = b * HW * CIN;
+    tb.trow = p * 9;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float av[2][KS];
+    for (int j = 0; j < NJ; ++j) tb.id[j] = *reinterpret_cast<const i32x4*>(idx + ((size_t)p * 9 + tap_of(j)) * 4);
+  };
+  auto issue = [&](const Tables& tb, Operands& o) {
+    o.ok = tb.ok;
+    const float* xb = X + tb.xoff;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int m = m0 + 16 * nt + r;
-      const bool ok = m < M;
-      const int b = ok ? m / Po : 0, p = ok ? m - b * Po : 0;
-      const float* xb = X + (size_t)b * HW * CIN;
+    for (int j = 0; j < NJ; ++j) {
+      o.we[j] = *reinterpret_cast<const f32x4*>(wgt + ((size_t)(tb.trow + tap_of(j))) * 4);   // 0 where the corner is off the map
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int k = 4 * s + g;
-        const float v = tap_value<CIN>(xb, idx, wgt, p, min(k, K - 1));   // padding lanes gather a valid address too
-        av[nt][s] = (ok && k < K) ? v : 0.f;
+      for (int e = 0; e < 4; ++e) o.xr[j][e] = *reinterpret_cast<const f32x3*>(xb + (size_t)max(tb.id[j][e], 0) * CIN);
+    }
+  };
+  auto run = [&](int t, const Operands& o) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int tap = g + 4 * j;
+      f32x3 v = o.xr[j][0] * o.we[j][0];     // grid_sampler's corner order, as tap_value
+      v += o.xr[j][1] * o.we[j][1];
+      v += o.xr[j][2] * o.we[j][2];
+      v += o.xr[j][3] * o.we[j][3];
+      if (!o.ok) v = f32x3{0.f, 0.f, 0.f};
+      if (tap < 9) {
+        A_l[r * LDA + CIN * tap + 0] = v[0];
+        A_l[r * LDA + CIN * tap + 1] = v[1];
+        A_l[r * LDA + CIN * tap + 2] = v[2];
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private tile: LDS runs a wave's accesses in order
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 acc[MT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const float av = A_l[r * LDA + 4 * s_ + g];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(Wl[(s_ * MT + mt) * 64 + lane], av, acc[mt]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int m = t * 16 + r;
+    if (o.ok) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][0] = mfma16(wreg[mt][s], av[0][s], acc[mt][0]);
-        acc[mt][1] = mfma16(wreg[mt][s], av[1][s], acc[mt][1]);
-      }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int m = m0 + 16 * nt + r;
-      if (m < M) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float4 v = make_float4(acc[mt][nt][0] + bq[mt].x, acc[mt][nt][1] + bq[mt].y, acc[mt][nt][2] + bq[mt].z,
-                                 acc[mt][nt][3] + bq[mt].w);
-          v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
-          v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
-          *reinterpret_cast<float4*>(Y + (size_t)m * O + 16 * mt + 4 * g) = v;
-        }
+        float4 v = make_float4(acc[mt][0] + bq[mt].x, acc[mt][1] + bq[mt].y, acc[mt][2] + bq[mt].z, acc[mt][3] + bq[mt].w);
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(Y + (size_t)m * O + 16 * mt + 4 * g) = v;
       }
     }
+  };
+  Tables tab;
+  Operands oa, ob;
+  load_tables(wave, tab);
+  issue(tab, oa);
+  load_tables(wave + nwaves, tab);
+  for (int t = wave; t < ntiles; t += 2 * nwaves) {
+    issue(tab, ob);
+    load_tables(t + 2 * nwaves, tab);
+    __builtin_amdgcn_sched_barrier(0);
+    run(t, oa);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(tab, oa);
+    load_tables(t + 3 * nwaves, tab);
+    __builtin_amdgcn_sched_barrier(0);
+    run(t + nwaves, ob);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
