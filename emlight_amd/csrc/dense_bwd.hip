@@ -2594,6 +2594,61 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
         (red[e] + red[CP * 2 + e]) + (red[2 * CP * 2 + e] + red[3 * CP * 2 + e]);
 }
 
+// The same sums for FEW channels (C <= 32, a multiple of 4: norm0's 24 at the full resolution; see bn_apply_small_kernel): a
+// lane owns 4 consecutive channels of a pixel, 16-byte loads, 64 / (C / 4) pixels per wave instruction.
+__global__ __launch_bounds__(256) void bn_bwd_stats_small_kernel(const float* __restrict__ DY, int ld_dy,
+                                                                 const float* __restrict__ raw, int ld_raw,
+                                                                 const float* __restrict__ out, int ld_out, int relu, int C,
+                                                                 size_t P, const float* __restrict__ mean,
+                                                                 const float* __restrict__ istd,
+                                                                 double* __restrict__ partials /*[grid][C][2]*/) {
+  __shared__ double red[4][64][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CQ = C >> 2, PW = 64 / CQ;
+  const int slot = lane / CQ, quad = lane - slot * CQ;
+  const bool live = slot < PW;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * quad), is = *reinterpret_cast<const float4*>(istd + 4 * quad);
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int kUN = 4;
+  const size_t step = (size_t)gridDim.x * 4 * kUN * PW;
+  for (size_t p0 = ((size_t)blockIdx.x * 4 + wave) * kUN * PW; p0 < P; p0 += step) {
+    float4 dy[kUN], rw[kUN], ou[kUN];
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const size_t p = p0 + (size_t)u * PW + slot;
+      const size_t pc = p < P ? p : P - 1;
+      dy[u] = *reinterpret_cast<const float4*>(DY + pc * ld_dy + 4 * quad);
+      rw[u] = *reinterpret_cast<const float4*>(raw + pc * ld_raw + 4 * quad);
+      ou[u] = relu ? *reinterpret_cast<const float4*>(out + pc * ld_out + 4 * quad) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const bool ok = live && p0 + (size_t)u * PW + slot < P;
+      const float d[4] = {(ok && ou[u].x > 0.f) ? dy[u].x : 0.f, (ok && ou[u].y > 0.f) ? dy[u].y : 0.f,
+                          (ok && ou[u].z > 0.f) ? dy[u].z : 0.f, (ok && ou[u].w > 0.f) ? dy[u].w : 0.f};
+      const float xh[4] = {(rw[u].x - mu.x) * is.x, (rw[u].y - mu.y) * is.y, (rw[u].z - mu.z) * is.z, (rw[u].w - mu.w) * is.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        a1[g] += (double)d[g];
+        a2[g] += (double)(d[g] * xh[g]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    red[wave][lane][2 * g] = live ? a1[g] : 0.0;
+    red[wave][lane][2 * g + 1] = live ? a2[g] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    const int c = e >> 1, k = e & 1, q = c >> 2, g = c & 3;
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int sl = 0; sl < PW; ++sl) t += red[w][sl * CQ + q][2 * g + k];
+    partials[(size_t)blockIdx.x * C * 2 + e] = t;
+  }
+}
+
 // =============================================================================== conv0 backward: weight
 // dW0[o][c][ky][kx] = sum_p dY0[p][o] * x[b][c][y+ky-1][x+kx-1],
 // dY0 = cA*(G*(X1>0)) + cB*Y0 + cC (norm0 + relu0 backward folded into the operand).
@@ -3172,6 +3227,13 @@ extern "C" int eml_dense_bn_bwd_stats_f32(const float* DY, int ld_dy, const floa
                                           double* partials, int grid, eml_stream_t stream) {
   if (!DY || !raw || !mean || !istd || !partials || (relu && !out) || C < 1 || C > 384 || P < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_bn_bwd_stats_f32: bad arguments");
+  auto a16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+  if (C <= 32 && (C & 3) == 0 && ((ld_dy | ld_raw | (relu ? ld_out : 0)) & 3) == 0 && a16(DY) && a16(raw) && (!relu || a16(out)) &&
+      a16(mean) && a16(istd)) {
+    hipLaunchKernelGGL(bn_bwd_stats_small_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, DY, ld_dy, raw, ld_raw, out, ld_out,
+                       relu, C, (size_t)P, mean, istd, partials);
+    return eml::check_launch("eml_dense_bn_bwd_stats_f32");
+  }
   const size_t lds = (size_t)4 * ((C + 63) / 64) * 64 * 2 * sizeof(double);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, DY, ld_dy, raw, ld_raw, out,
                      ld_out, relu, C, (size_t)P, mean, istd, partials);

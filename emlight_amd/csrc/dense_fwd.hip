@@ -618,6 +618,62 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         (red[e] + red[CP * 2 + e]) + (red[2 * CP * 2 + e] + red[3 * CP * 2 + e]);
 }
 
+// The same pass for FEW channels (C <= 32, a multiple of 4: norm0's 24 -- the only call at the full resolution).  The kernel
+// above gives a lane a channel: with 24 channels 24 of 64 lanes work, every access is 4 bytes and a wave instruction moves 96
+// bytes (and the six channel slots are loaded whether they exist or not): 4.9 M pixels were 14.7 M wave instructions, bound by
+// the texture-address unit at 2.6 TB/s.  Here a lane owns 4 consecutive channels of a pixel (16-byte accesses), a wave
+// instruction covers 64 / (C / 4) pixels, kUN of them in flight; the per-lane f64 sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void bn_apply_small_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                             int ldd, int C, size_t P, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu,
+                                                             double* __restrict__ partials /*[G][C][2]*/) {
+  __shared__ double red[4][64][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CQ = C >> 2, PW = 64 / CQ;                 // channel quads per pixel, pixels per wave instruction
+  const int slot = lane / CQ, quad = lane - slot * CQ;
+  const bool live = slot < PW;
+  const float4 s4 = *reinterpret_cast<const float4*>(scale + 4 * quad), t4 = *reinterpret_cast<const float4*>(shift + 4 * quad);
+  double as[4] = {0.0, 0.0, 0.0, 0.0}, aq[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int kUN = 4;
+  const size_t step = (size_t)gridDim.x * 4 * kUN * PW;
+  for (size_t p0 = ((size_t)blockIdx.x * 4 + wave) * kUN * PW; p0 < P; p0 += step) {
+    float4 v[kUN];
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const size_t p = p0 + (size_t)u * PW + slot;
+      v[u] = *reinterpret_cast<const float4*>(src + (p < P ? p : P - 1) * lds_ + 4 * quad);
+    }
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const size_t p = p0 + (size_t)u * PW + slot;
+      if (live && p < P) {
+        float w[4] = {fmaf(v[u].x, s4.x, t4.x), fmaf(v[u].y, s4.y, t4.y), fmaf(v[u].z, s4.z, t4.z), fmaf(v[u].w, s4.w, t4.w)};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (relu) w[g] = fmaxf(w[g], 0.f);
+          const double wd = (double)w[g];
+          as[g] += wd;
+          aq[g] = fma(wd, wd, aq[g]);
+        }
+        *reinterpret_cast<float4*>(dst + p * ldd + 4 * quad) = make_float4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    red[wave][lane][2 * g] = live ? as[g] : 0.0;
+    red[wave][lane][2 * g + 1] = live ? aq[g] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    const int c = e >> 1, k = e & 1, q = c >> 2, g = c & 3;
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int sl = 0; sl < PW; ++sl) t += red[w][sl * CQ + q][2 * g + k];
+    partials[(size_t)blockIdx.x * C * 2 + e] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------ BN prepare
 // (1) fold the f64 partial stats of n_new freshly produced channels [c_new0, c_new0+n_new)
 //     into the block's per-channel mean / biased var / invstd arrays;
@@ -830,6 +886,12 @@ extern "C" int eml_dense_bn_apply_f32(const float* src, int ld_src, float* dst, 
                                       eml_stream_t stream) {
   if (!src || !dst || !scale || !shift || !partials || C < 1 || C > 384 || P < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_bn_apply_f32: bad arguments (C<=384)");
+  if (C <= 32 && (C & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst) |
+                                                                             reinterpret_cast<size_t>(scale) | reinterpret_cast<size_t>(shift)) & 15) == 0) {
+    hipLaunchKernelGGL(bn_apply_small_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, C, (size_t)P,
+                       scale, shift, relu, partials);
+    return eml::check_launch("eml_dense_bn_apply_f32");
+  }
   const size_t lds = (size_t)4 * ((C + 63) / 64) * 64 * 2 * sizeof(double);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, src, ld_src, dst, ld_dst, C,
                      (size_t)P, scale, shift, relu, partials);
