@@ -273,7 +273,7 @@ class _SphereConvFn(torch.autograd.Function):
         po = geo.ho * geo.wo
         xr = x.permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C); a view when x is channels-last
         O = weight.shape[0]
-        w2 = _frozen_layout(weight, "w2")                         # columns ordered (tap, c) like A9
+        w2 = _frozen_layout(weight, "w2", kind == "planar")       # columns ordered (tap, c) like A9
         # which layers take the fused kernels: measured per shape (tools/sphere_layers.py, profiles/r02_sphere_layers.jsonl).
         # They run at 85-115 TF/s; im2col + the library GEMM is faster only where the GEMM is wide (O >= 512) and the
         # operand small -- there the library's 115-125 TF/s wins and A9 costs little memory.
@@ -529,7 +529,7 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
         elif tt is not None:
             # gather-GEMM over the transposed tap table: neither dA9 (B*Po, 9C) nor its col2im pass exist
             tidx, twgt, rowmax, ke = tt
-            w2t = _frozen_layout(weight, "w2t")                                # columns ordered (tap, o)
+            w2t = _frozen_layout(weight, "w2t", geo.idx1 is not None)          # columns ordered (tap, o)
             _lib.check(L.eml_sphere_conv_dgrad_fused_f32(p(gyr), p(tidx), p(twgt), p(rowmax), ke, p(w2t), p(gxr), B,
                                                          H * W, po, C, O, getattr(geo, "t_rowshare", 0), st),
                        "eml_sphere_conv_dgrad_fused_f32")
@@ -555,7 +555,7 @@ def sphere_conv(x, weight, bias, stride=1, residual=None, act_slope=1.0):
 _FROZEN = {}   # (id, kind) -> (weakref to the Parameter, its version, re-laid-out copy): frozen Parameters only
 
 
-def _frozen_layout(weight, kind):
+def _frozen_layout(weight, kind, remember=False):
     """``weight`` (O, C, 3, 3) as the (O, 9C) operand of the forward ("w2": columns (tap, c)) or the (C, 9O) operand of the
     fused input gradient ("w2t": columns (tap, o)).  A trainable weight changes every step and is re-laid-out per call (a
     view here, made contiguous where it is used); a FROZEN one -- the VGG19 stack of the perceptual loss: 13 convolutions, two
@@ -565,7 +565,11 @@ def _frozen_layout(weight, kind):
     view = (weight.permute(0, 2, 3, 1).reshape(O, 9 * C) if kind == "w2" else weight.permute(1, 2, 3, 0).reshape(C, 9 * O))
     # only a Parameter object that takes no gradient is remembered, and only while it is THAT object at THAT version (a
     # computed weight -- spectral norm under no_grad -- is a new tensor every call whose address the allocator reuses)
-    if weight.requires_grad or not isinstance(weight, torch.nn.Parameter):
+    # ... and only for the planar convolutions (``remember``: the VGG19 stack, which no optimizer holds).  A discriminator frozen
+    # for the generator step is a Parameter without requires_grad too, and the fused Adam that updates it a moment later does
+    # not bump its version counter: remembered by version, its head kept last step's weights (the joint reproducibility test
+    # caught it: GAN term off by 0.017).
+    if not remember or weight.requires_grad or not isinstance(weight, torch.nn.Parameter):
         return view if kind == "w2" else view.contiguous()
     key = (id(weight), kind)
     hit = _FROZEN.get(key)
