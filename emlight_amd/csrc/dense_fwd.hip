@@ -106,15 +106,20 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
     sl[e] = scale[e];
     tl[e] = shift[e];
   }
+#ifdef EML_FWD_STATS_LDS   // experiment build: the 24 f64 statistics accumulators in wave-private LDS slots (48 registers less)
+  for (int e = tid; e < 4 * 48 * 2; e += 256) red[e] = 0.0;
+#endif
   __syncthreads();
 
   // D^T form (weights as the MFMA A operand): lane (r, kk) owns output channels 16n + 4kk .. +3 of pixel
   // p0 + 16m + r -> 16-byte stores; per-lane statistics of those 12 channels.
+#ifndef EML_FWD_STATS_LDS
   double ssum[3][4], ssq[3][4];
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
     for (int g = 0; g < 4; ++g) ssum[n][g] = ssq[n][g] = 0.0;
+#endif
   const int nj = Kp >> 4;
   const int ntiles = (P + 255) >> 8;
   const int Wo = Win >> 1, Ho = Hin >> 1;
@@ -256,8 +261,17 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+#ifdef EML_FWD_STATS_LDS
+        const float t1 = eml::row16_sum(ls[g]), t2 = eml::row16_sum(lq[g]);
+        if (r == 0) {
+          double* d = red + (wave * 48 + 16 * n + 4 * kk + g) * 2;
+          d[0] += (double)t1;
+          d[1] += (double)t2;
+        }
+#else
         ssum[n][g] += (double)ls[g];
         ssq[n][g] += (double)lq[g];
+#endif
       }
     }
     if (staged) {
@@ -283,6 +297,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
     }
   }
   // channel statistics: over the 16 pixel lanes r, then the 4 waves
+#ifndef EML_FWD_STATS_LDS
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(256, EML_FWD_MIN_WG) void conv1x1_fwd_kernel(
         red[(wave * 48 + 16 * n + 4 * kk + g) * 2 + 1] = ssq[n][g];
       }
     }
+#endif
   __syncthreads();
   for (int e = tid; e < 96; e += 256)
     partials[(size_t)blockIdx.x * 96 + e] = (red[e] + red[96 + e]) + (red[192 + e] + red[288 + e]);
