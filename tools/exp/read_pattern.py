@@ -1,4 +1,5 @@
-"""Read-pattern probe (tools/exp/read_pattern.hip, build_exp/librp.so): TB/s of reading the first `cols` columns of a (P, LD) f32 matrix
+"""(build first: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/exp/read_pattern.hip -o build_exp/librp.so)
+Read-pattern probe (tools/exp/read_pattern.hip, build_exp/librp.so): TB/s of reading the first `cols` columns of a (P, LD) f32 matrix
 in the access shapes the 1x1 kernels use against whole lines / whole rows."""
 import ctypes, os, torch
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "build_exp", "librp.so"))

@@ -1,4 +1,5 @@
-"""Write-pattern probe (tools/exp/write_pattern.hip, build_exp/libwp.so): TB/s of writing a (P, LD) f32 matrix in the D^T epilogue
+"""(build first: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/exp/write_pattern.hip -o build_exp/libwp.so)
+Write-pattern probe (tools/exp/write_pattern.hip, build_exp/libwp.so): TB/s of writing a (P, LD) f32 matrix in the D^T epilogue
 pattern (16 rows x 64 B per instruction), row by row (whole lines), and flat."""
 import ctypes, os, torch
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "build_exp", "libwp.so"))
