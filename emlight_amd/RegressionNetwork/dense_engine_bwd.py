@@ -361,17 +361,31 @@ def _run_backward(enc, ws, x, gpooled):
                 bn1_direct(l, Lm0, 0)
                 l -= 1
         c0b = blk["C0"]
-        materialize(Gbuf, blk, 0, c0b)  # block input channels: every layer has contributed
+        # block input channels: every layer has contributed.  Block 1's are norm0 + relu0's output: their deferred affine is
+        # applied inside the two kernels that read them (round 6: no pass over G, no read of the block buffer's first line)
+        norm0_fused = bi == 0 and knob_flag("EML_NORM0_FUSED", True) and c0b % 4 == 0 and c0b <= 32
+        if not norm0_fused:
+            materialize(Gbuf, blk, 0, c0b)
         dY, ld_dy = Gbuf, ld
     # ---- relu0 / norm0 / conv0
     b0 = ws.blocks[0]
     c0 = enc.c_init
-    _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(ws.Y0), c0, p(b0["X"]), b0["ld"], 1, c0, b0["P"],
-                                            p(ws.mean0), p(ws.istd0), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
+    if norm0_fused:
+        _lib.check(L.eml_dense_norm0_bwd_stats_f32(p(dY), ld_dy, p(ws.Y0), c0, p(ws.scale0), p(ws.shift0), p(sB), p(sC), c0,
+                                                   b0["P"], p(ws.mean0), p(ws.istd0), p(part), Gb, st),
+                   "eml_dense_norm0_bwd_stats_f32")
+    else:
+        _lib.check(L.eml_dense_bn_bwd_stats_f32(p(dY), ld_dy, p(ws.Y0), c0, p(b0["X"]), b0["ld"], 1, c0, b0["P"],
+                                                p(ws.mean0), p(ws.istd0), p(part), Gb, st), "eml_dense_bn_bwd_stats_f32")
     finalize(Gb, 2 * c0, b0["P"], f.norm0, ws.mean0, ws.istd0, c0, _r16(c0), coef=0)
-    _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
-                                                p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
-               "eml_dense_conv0_bwd_weight_f32")
+    if norm0_fused:
+        _lib.check(L.eml_dense_conv0_bwd_weight_fused_f32(p(x), p(dY), ld_dy, p(ws.Y0), c0, p(ws.scale0), p(ws.shift0), p(sB),
+                                                          p(sC), p(cA), p(cB), p(cC), B, H, W, p(bw.partW),
+                                                          gr(f.conv0.weight), G, st), "eml_dense_conv0_bwd_weight_fused_f32")
+    else:
+        _lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(dY), ld_dy, p(b0["X"]), b0["ld"], p(ws.Y0), c0, p(cA), p(cB),
+                                                    p(cC), B, H, W, p(bw.partW), gr(f.conv0.weight), G, st),
+                   "eml_dense_conv0_bwd_weight_f32")
     if bw.side is not None:
         main.wait_stream(bw.side)   # every dW2 is complete before the gradients leave
     return [grads[id(q)] for q in params]

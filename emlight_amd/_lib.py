@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 27   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 28   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -171,6 +171,10 @@ SIGNATURES = {
                                               _stream]),
     "eml_dense_bn_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _int, _int, _int, ctypes.c_long, _f32p,
                                           _f32p, _f32p, _int, _stream]),
+    "eml_dense_norm0_bwd_stats_f32": (_int, [_f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p, _int, ctypes.c_long, _f32p, _f32p,
+                                             ctypes.c_void_p, _int, _stream]),
+    "eml_dense_conv0_bwd_weight_fused_f32": (_int, [_f32p, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                                    _int, _int, _int, _f32p, _f32p, _int, _stream]),
     "eml_dense_conv0_bwd_weight_f32": (_int, [_f32p, _f32p, _int, _f32p, _int, _f32p, _int, _f32p, _f32p, _f32p,
                                               _int, _int, _int, _f32p, _f32p, _int, _stream]),
     "eml_dense_head_pool_bwd_f32": (_int, [_f32p, _f32p, _int, _int, _int, _int, _int, _int, _f32p, _int, _stream]),

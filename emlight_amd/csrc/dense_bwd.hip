@@ -2649,14 +2649,80 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_small_kernel(const float* __
   }
 }
 
+// norm0 + relu0 backward statistics with the block's deferred BN1 affine folded in and WITHOUT the block buffer (round 6): the
+// incoming gradient of block 1's C0 input channels is G + sB*x + sC with x = relu(scale0*y0 + shift0) -- the value the forward's
+// bn_apply wrote into the block buffer, recomputed from the raw conv0 output y0 with the same expression -- so neither the
+// grad_materialize pass over G (a read-modify-write of 96 bytes per 896-byte row) nor the read of X's first line happens.
+__global__ __launch_bounds__(256) void norm0_bwd_stats_kernel(const float* __restrict__ Gd, int ldg, const float* __restrict__ Y0,
+                                                              int ld_y0, const float* __restrict__ scale0,
+                                                              const float* __restrict__ shift0, const float* __restrict__ sB,
+                                                              const float* __restrict__ sC, int C, size_t P,
+                                                              const float* __restrict__ mean, const float* __restrict__ istd,
+                                                              double* __restrict__ partials /*[grid][C][2]*/) {
+  __shared__ double red[4][64][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CQ = C >> 2, PW = 64 / CQ;
+  const int slot = lane / CQ, quad = lane - slot * CQ;
+  const bool live = slot < PW;
+  auto ld4 = [&](const float* q) { return *reinterpret_cast<const float4*>(q + 4 * quad); };
+  const float4 mu = ld4(mean), is = ld4(istd), s0 = ld4(scale0), t0 = ld4(shift0), b4 = ld4(sB), c4 = ld4(sC);
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int kUN = 4;
+  const size_t step = (size_t)gridDim.x * 4 * kUN * PW;
+  for (size_t p0 = ((size_t)blockIdx.x * 4 + wave) * kUN * PW; p0 < P; p0 += step) {
+    float4 gv[kUN], yv[kUN];
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const size_t p = p0 + (size_t)u * PW + slot;
+      const size_t pc = p < P ? p : P - 1;
+      gv[u] = *reinterpret_cast<const float4*>(Gd + pc * ldg + 4 * quad);
+      yv[u] = *reinterpret_cast<const float4*>(Y0 + pc * ld_y0 + 4 * quad);
+    }
+#pragma unroll
+    for (int u = 0; u < kUN; ++u) {
+      const bool ok = live && p0 + (size_t)u * PW + slot < P;
+      const float y[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      const float sc[4] = {s0.x, s0.y, s0.z, s0.w}, sh[4] = {t0.x, t0.y, t0.z, t0.w};
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = fmaxf(fmaf(y[e], sc[e], sh[e]), 0.f);            // bn_apply's expression
+        const float dy = g[e] + fmaf(bb[e], x, cc[e]);                   // grad_materialize's expression
+        const float d = (ok && x > 0.f) ? dy : 0.f;
+        a1[e] += (double)d;
+        a2[e] += (double)(d * ((y[e] - mm[e]) * ii[e]));
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    red[wave][lane][2 * g] = live ? a1[g] : 0.0;
+    red[wave][lane][2 * g + 1] = live ? a2[g] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    const int c = e >> 1, k = e & 1, q = c >> 2, g = c & 3;
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int sl = 0; sl < PW; ++sl) t += red[w][sl * CQ + q][2 * g + k];
+    partials[(size_t)blockIdx.x * C * 2 + e] = t;
+  }
+}
+
 // =============================================================================== conv0 backward: weight
 // dW0[o][c][ky][kx] = sum_p dY0[p][o] * x[b][c][y+ky-1][x+kx-1],
 // dY0 = cA*(G*(X1>0)) + cB*Y0 + cC (norm0 + relu0 backward folded into the operand).
 // D[i=(c,ky,kx) 27->32][j=o 24->32], MFMA-k = pixel.
+// FUSED (round 6): X1 is not read -- the block buffer's value is recomputed from Y0 (relu(scale0*y0 + shift0), bn_apply's
+// expression) and the block's deferred BN1 affine is applied to G here (g = G + sB*x + sC, grad_materialize's expression).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
     const float* __restrict__ x, const float* __restrict__ Gd, int ldg, const float* __restrict__ X1, int ldx,
     const float* __restrict__ Y0, int C0, const float* __restrict__ cA, const float* __restrict__ cB,
-    const float* __restrict__ cC, int B, int H, int W, float* __restrict__ partial /*[grid*4][32][32]*/) {
+    const float* __restrict__ cC, int B, int H, int W, float* __restrict__ partial /*[grid*4][32][32]*/,
+    const float* __restrict__ scale0, const float* __restrict__ shift0, const float* __restrict__ sB,
+    const float* __restrict__ sC) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
   f32x4 acc[2][2];
@@ -2664,7 +2730,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ca[2], cb[2], cc[2];
+  float ca[2], cb[2], cc[2], fs0[2] = {0.f, 0.f}, ft0[2] = {0.f, 0.f}, fb[2] = {0.f, 0.f}, fc[2] = {0.f, 0.f};
   bool ov[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
@@ -2672,6 +2738,12 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
     ca[n] = ov[n] ? cA[16 * n + r] : 0.f;
     cb[n] = ov[n] ? cB[16 * n + r] : 0.f;
     cc[n] = ov[n] ? cC[16 * n + r] : 0.f;
+    if constexpr (FUSED) {
+      fs0[n] = ov[n] ? scale0[16 * n + r] : 0.f;
+      ft0[n] = ov[n] ? shift0[16 * n + r] : 0.f;
+      fb[n] = ov[n] ? sB[16 * n + r] : 0.f;
+      fc[n] = ov[n] ? sC[16 * n + r] : 0.f;
+    }
   }
   int ci[2], dyi[2], dxi[2];
   bool iv[2];
@@ -2709,7 +2781,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
       for (int n = 0; n < 2; ++n) {
         const int o = ov[n] ? 16 * n + r : 0;
         gv[u][n] = Gd[pc * ldg + o];
-        xv[u][n] = X1[pc * ldx + o];
+        if constexpr (!FUSED) xv[u][n] = X1[pc * ldx + o];
         yv[u][n] = Y0[pc * C0 + o];
       }
     }
@@ -2720,7 +2792,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(
       for (int i = 0; i < 2; ++i) a[i] = inb[u][i] ? av[u][i] : 0.f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const float g = xv[u][n] > 0.f ? gv[u][n] : 0.f;
+        float g;
+        if constexpr (FUSED) {
+          const float xx = fmaxf(fmaf(yv[u][n], fs0[n], ft0[n]), 0.f);
+          g = xx > 0.f ? gv[u][n] + fmaf(fb[n], xx, fc[n]) : 0.f;
+        } else {
+          g = xv[u][n] > 0.f ? gv[u][n] : 0.f;
+        }
         const float v = fmaf(ca[n], g, fmaf(cb[n], yv[u][n], cc[n]));
         d[n] = (pvu[u] && ov[n]) ? v : 0.f;
       }
@@ -3266,8 +3344,8 @@ extern "C" int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, in
                                               int grid, eml_stream_t stream) {
   if (!x || !G || !X1 || !Y0 || !cA || !cB || !cC || !partial || !dW0 || C0 < 1 || C0 > 32 || B < 1 || grid < 1)
     return eml::fail(EML_EINVAL, "eml_dense_conv0_bwd_weight_f32: bad arguments");
-  hipLaunchKernelGGL(conv0_bwd_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, G, ldg, X1, ldx, Y0, C0,
-                     cA, cB, cC, B, H, W, partial);
+  hipLaunchKernelGGL(conv0_bwd_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, G, ldg, X1, ldx, Y0, C0,
+                     cA, cB, cC, B, H, W, partial, nullptr, nullptr, nullptr, nullptr);
   int rc = eml::check_launch("eml_dense_conv0_bwd_weight_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 32 / 64 + 1), dim3(256), 0, (hipStream_t)stream, partial, grid * 4,
@@ -3283,4 +3361,38 @@ extern "C" int eml_dense_head_pool_bwd_f32(const float* gpooled, const float* F,
   hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gpooled, F, ldf, C, B, H, W, k,
                      dF, ldd);
   return eml::check_launch("eml_dense_head_pool_bwd_f32");
+}
+
+// Block 1's input channels without the grad_materialize pass and without the block buffer (round 6): the statistics of
+// norm0 + relu0's backward and conv0's weight gradient take G as the data-gradient passes left it (the deferred BN1 affine
+// sB, sC still outstanding) and the raw conv0 output Y0; x = relu(scale0*Y0 + shift0) is what eml_dense_bn_apply_f32 wrote
+// into the block buffer (same expression), g = G + sB*x + sC what eml_dense_grad_materialize_f32 would have written.
+extern "C" int eml_dense_norm0_bwd_stats_f32(const float* G, int ldg, const float* Y0, int ld_y0, const float* scale0,
+                                             const float* shift0, const float* sB, const float* sC, int C, long P,
+                                             const float* mean, const float* istd, double* partials, int grid,
+                                             eml_stream_t stream) {
+  auto a16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+  if (!G || !Y0 || !scale0 || !shift0 || !sB || !sC || !mean || !istd || !partials || C < 4 || C > 32 || (C & 3) || P < 1 ||
+      grid < 1 || ((ldg | ld_y0) & 3) || !a16(G) || !a16(Y0) || !a16(scale0) || !a16(shift0) || !a16(sB) || !a16(sC) || !a16(mean) ||
+      !a16(istd))
+    return eml::fail(EML_EINVAL, "eml_dense_norm0_bwd_stats_f32: bad arguments (C a multiple of 4 <= 32, 16-byte aligned operands)");
+  hipLaunchKernelGGL(norm0_bwd_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G, ldg, Y0, ld_y0, scale0, shift0, sB,
+                     sC, C, (size_t)P, mean, istd, partials);
+  return eml::check_launch("eml_dense_norm0_bwd_stats_f32");
+}
+
+extern "C" int eml_dense_conv0_bwd_weight_fused_f32(const float* x, const float* G, int ldg, const float* Y0, int C0,
+                                                    const float* scale0, const float* shift0, const float* sB, const float* sC,
+                                                    const float* cA, const float* cB, const float* cC, int B, int H, int W,
+                                                    float* partial, float* dW0, int grid, eml_stream_t stream) {
+  if (!x || !G || !Y0 || !scale0 || !shift0 || !sB || !sC || !cA || !cB || !cC || !partial || !dW0 || C0 < 1 || C0 > 32 || B < 1 ||
+      grid < 1)
+    return eml::fail(EML_EINVAL, "eml_dense_conv0_bwd_weight_fused_f32: bad arguments");
+  hipLaunchKernelGGL(conv0_bwd_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, G, ldg, nullptr, 0, Y0, C0, cA,
+                     cB, cC, B, H, W, partial, scale0, shift0, sB, sC);
+  int rc = eml::check_launch("eml_dense_conv0_bwd_weight_fused_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(27 * 32 / 64 + 1), dim3(256), 0, (hipStream_t)stream, partial, grid * 4,
+                     (size_t)1024, 2, 0, C0, 0, dW0);
+  return eml::check_launch("eml_dense_conv0_bwd_weight_fused_f32(reduce)");
 }

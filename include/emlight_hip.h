@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 27
+#define EML_ABI_VERSION 28
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -403,6 +403,20 @@ int eml_dense_conv0_bwd_weight_f32(const float* x, const float* G, int ldg, cons
                                    const float* Y0, int C0, const float* cA, const float* cB,
                                    const float* cC, int B, int H, int W, float* partial, float* dW0,
                                    int grid, eml_stream_t stream);
+
+/* Block 1's input channels without the eml_dense_grad_materialize_f32 pass and without the block buffer (round 6; same
+ * reference lines: DenseNet.py:88-92 under autograd): G is taken as the data-gradient passes left it -- the deferred BN1 affine
+ * (sB, sC) still outstanding -- and Y0 is the raw conv0 output.  x = relu(scale0*Y0 + shift0) is what eml_dense_bn_apply_f32
+ * wrote into the block buffer (the same expression, so the same bits), g = G + (sB*x + sC) what grad_materialize would have
+ * written: the statistics of norm0 + relu0's backward (partials [grid][C][2], as eml_dense_bn_bwd_stats_f32 with relu = 1) and
+ * conv0's weight gradient (as eml_dense_conv0_bwd_weight_f32) from those.  C a multiple of 4, <= 32; 16-byte aligned vectors. */
+int eml_dense_norm0_bwd_stats_f32(const float* G, int ldg, const float* Y0, int ld_y0, const float* scale0,
+                                  const float* shift0, const float* sB, const float* sC, int C, long P,
+                                  const float* mean, const float* istd, double* partials, int grid, eml_stream_t stream);
+int eml_dense_conv0_bwd_weight_fused_f32(const float* x, const float* G, int ldg, const float* Y0, int C0,
+                                         const float* scale0, const float* shift0, const float* sB, const float* sC,
+                                         const float* cA, const float* cB, const float* cC, int B, int H, int W,
+                                         float* partial, float* dW0, int grid, eml_stream_t stream);
 
 /* dF = relu-mask(F) * unpool_k(gpooled) / k^2 : backward of DenseNet.py:136-137. */
 int eml_dense_head_pool_bwd_f32(const float* gpooled, const float* F, int ldf, int C, int B, int H,

@@ -55,8 +55,8 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     for name in ("eml_dense_conv0_fwd_f32", "eml_dense_conv1x1_fwd_f32", "eml_dense_conv3x3_fwd_f32", "eml_dense_pool_act_f32",
                  "eml_dense_conv3x3_bwd_data_f32", "eml_dense_conv3x3_bwd_weight_f32", "eml_dense_conv1x1_bwd_weight_f32",
                  "eml_dense_conv1x1_bwd_data_multi_f32", "eml_dense_conv1x1_bwd_data_f32",
-                 "eml_dense_bn_bwd_finalize_f32", "eml_dense_grad_materialize_f32", "eml_dense_conv0_bwd_weight_f32",
-                 "eml_dense_head_pool_bwd_f32"):
+                 "eml_dense_bn_bwd_finalize_f32", "eml_dense_grad_materialize_f32", "eml_dense_norm0_bwd_stats_f32",
+                 "eml_dense_conv0_bwd_weight_fused_f32", "eml_dense_head_pool_bwd_f32"):
         assert name in recorder.calls, name
     # the pair schedule: 8 narrow passes (riding on the upper layer's weight-gradient launch: its N12 argument, fifth
     # from the end, is set) and 8 two-layer passes per block of 16 layers
@@ -69,6 +69,8 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     assert len(top) == 14 and all(a[7] >= 48 and a[7] % 4 == 0 for a in top)    # k_hi = Cin of the pair's lower layer
     # ... which that pair then reads with a row length of 12: the upper layer's narrow operand (G, ldg) and conv3x3's (G, ldg, c0)
     assert sum(1 for a in narrow if a[-4] == 12) == 14
+    # block 1's input channels: no materialize pass (blocks 2 and 3 only), its affine rides on norm0's two backward kernels
+    assert recorder.calls.count("eml_dense_grad_materialize_f32") == 2 and "eml_dense_conv0_bwd_weight_f32" not in recorder.calls
     assert all(p.grad is not None for p in net.parameters())
 
 

@@ -605,6 +605,51 @@ def test_conv0_bwd_weight(lib):
     close(dW0, w.grad, what="dW0", rtol=1e-4)
 
 
+def test_norm0_backward_without_materialize_and_block_buffer(lib):
+    """``eml_dense_norm0_bwd_stats_f32`` / ``eml_dense_conv0_bwd_weight_fused_f32`` (round 6) against the three launches they replace
+    -- grad_materialize on block 1's input columns, then bn_bwd_stats / conv0_bwd_weight reading the block buffer: the
+    statistics bit for bit (same expressions, same summation layout), dW0 bit for bit."""
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    B, H, W, ld, C = 3, 20, 44, 224, 24
+    P = B * H * W
+    x = torch.rand(B, 3, H, W, device=DEV)
+    Y0 = rnd(P, C)
+    s0, t0 = torch.rand(C, device=DEV) + 0.5, rnd(C, scale=0.3)
+    X1 = torch.zeros(P, ld, device=DEV)
+    fp = torch.zeros(G * C * 2, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_bn_apply_f32(p(Y0), C, p(X1), ld, C, P, p(s0), p(t0), 1, p(fp), G, st), "bn_apply")   # the forward's x
+    Gd = rnd(P, ld)
+    sB, sC = rnd(ld, scale=0.1), rnd(ld, scale=0.1)
+    mean, istd = rnd(C, scale=0.1), torch.rand(C, device=DEV) + 0.5
+    cA, cB, cC = (torch.zeros(32, device=DEV) for _ in range(3))
+    cA[:C], cB[:C], cC[:C] = rnd(C), rnd(C, scale=0.1), rnd(C, scale=0.1)
+    partW = torch.empty(G * 4 * 1024, device=DEV)
+    # the three launches
+    Gm = Gd.clone()
+    lib.check(L.eml_dense_grad_materialize_f32(p(Gm), ld, p(X1), ld, p(sB), p(sC), 0, C, P, st), "materialize")
+    part_a = torch.zeros(G * C * 2, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_bn_bwd_stats_f32(p(Gm), ld, p(Y0), C, p(X1), ld, 1, C, P, p(mean), p(istd), p(part_a), G, st), "stats")
+    dW_a = torch.empty(C, 3, 3, 3, device=DEV)
+    lib.check(L.eml_dense_conv0_bwd_weight_f32(p(x), p(Gm), ld, p(X1), ld, p(Y0), C, p(cA), p(cB), p(cC), B, H, W, p(partW), p(dW_a),
+                                               G, st), "conv0 bwd")
+    # the two fused ones, on the un-materialised G and without X1
+    part_b = torch.zeros(G * C * 2, dtype=torch.float64, device=DEV)
+    lib.check(L.eml_dense_norm0_bwd_stats_f32(p(Gd), ld, p(Y0), C, p(s0), p(t0), p(sB), p(sC), C, P, p(mean), p(istd), p(part_b), G,
+                                              st), "norm0 stats")
+    dW_b = torch.empty(C, 3, 3, 3, device=DEV)
+    lib.check(L.eml_dense_conv0_bwd_weight_fused_f32(p(x), p(Gd), ld, p(Y0), C, p(s0), p(t0), p(sB), p(sC), p(cA), p(cB), p(cC), B, H,
+                                                     W, p(partW), p(dW_b), G, st), "conv0 bwd fused")
+    assert torch.equal(part_a, part_b) and torch.equal(dW_a, dW_b)
+    # and against f64 torch
+    xq = torch.clamp(Y0.double() * s0.double() + t0.double(), min=0)
+    dy = torch.where(xq > 0, Gd[:, :C].double() + sB[:C].double() * xq + sC[:C].double(), torch.zeros_like(xq))
+    S1, S2 = fold_partials(part_b, G, C)
+    close(S1, dy.sum(0), what="S1", atol=1e-4)
+    close(S2, (dy * (Y0.double() - mean.double()) * istd.double()).sum(0), what="S2", atol=1e-4)
+    assert L.eml_dense_norm0_bwd_stats_f32(p(Gd), ld, p(Y0), C, p(s0), p(t0), p(sB), p(sC), 22, P, p(mean), p(istd), p(part_b), G,
+                                           st) == -1                        # a channel count that is not a multiple of 4
+
+
 @pytest.mark.parametrize("Cin_a,B,H,W", [(48, 2, 20, 44), (330, 1, 12, 20), (162, 3, 6, 10)])
 def test_conv1x1_bwd_data_two_layers_per_pass(lib, Cin_a, B, H, W):
     """Layers (a, b = a-1) of a dense block: the narrow pass of layer a over b's 12 output channels, then
