@@ -183,3 +183,34 @@ def test_joint_step_properties_at_cfg4_size():
     assert any(float(g.abs().max()) > 0 for g in g_only), "the generator losses must reach the encoder"
     want = predicted_gaussian_map({k: v.detach() for k, v in pred.items()}, ln)
     assert torch.equal(want, gmap)   # the rasteriser itself is bitwise reproducible
+
+
+def test_two_iterations_are_bit_reproducible():
+    """Run-to-run: two trainers from the same seed, two joint iterations each -- every loss term and every parameter of the
+    encoder, the generator and the discriminator must agree BIT FOR BIT.  The HIP kernels of this package use no atomics and no
+    timing-dependent split; the only run-to-run differences of a joint step come from the library's planar convolutions of the
+    generator's crop encoder (``nn.Conv2d`` -> MIOpen, whose default weight-gradient algorithm sums with atomics: measured
+    spread 5e-6 on ``GAN_Feat`` over four runs, tools/exp/ddp_flake_probe.py), so MIOpen is asked for its deterministic
+    algorithms here (``torch.backends.cudnn.deterministic``).  With that, eight fresh processes gave identical numbers."""
+    from emlight_amd.GenProjector import networks
+    from emlight_amd.joint import JointTrainer, joint_batch
+    before = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        runs = []
+        for _ in range(2):
+            torch.manual_seed(0)
+            tr = JointTrainer(networks.default_options(ngf=4, ndf=4), anchors=32, crop_hw=(64, 96), device="cuda:0")
+            batch = joint_batch(2, "cuda:0", 32, (64, 96), seed=9)
+            for _ in range(2):
+                losses = tr.step(batch)
+            nets = (tr.reg.model, tr.proj.model.netG, tr.proj.model.netD)
+            runs.append(({k: v.detach().clone() for k, v in losses.items()},
+                         [(n, q.detach().clone()) for net in nets for n, q in net.named_parameters()]))
+            del tr
+    finally:
+        torch.backends.cudnn.deterministic = before
+    for k in runs[0][0]:
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), (k, runs[0][0][k], runs[1][0][k])
+    for (n, a), (_, b) in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
