@@ -594,15 +594,16 @@ def other_breakdown(step_fn, world):
 def collectives_of_a_step(step_fn, ddps):
     """What ONE iteration puts on the wire, observed in this run: the ranks RCCL sees, every explicit
     ``dist.all_reduce`` of the step (SPADE's synchronised BatchNorm sums, the Sinkhorn diameter: count and bytes) and DDP's gradient
-    buckets per wrapped network (count and bytes from the reducer's own record).  None without a process group."""
+    buckets per network (count and bytes from the reducer's own record: ``GradientBuckets.describe`` or DDP's logging data).  None without a process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return None
     seen = {"calls": 0, "bytes": 0}
     orig = dist.all_reduce
 
     def counting(t, *a, **k):
-        seen["calls"] += 1
-        seen["bytes"] += t.numel() * t.element_size()
+        if not k.get("async_op"):    # the asynchronous ones are GradientBuckets' gradient buckets: reported per network below
+            seen["calls"] += 1
+            seen["bytes"] += t.numel() * t.element_size()
         return orig(t, *a, **k)
     dist.all_reduce = counting
     try:
@@ -616,6 +617,9 @@ def collectives_of_a_step(step_fn, ddps):
         if d is None:
             continue
         try:
+            if hasattr(d, "describe"):    # emlight_amd._dist.GradientBuckets (the default reducer)
+                out["ddp"][name] = d.describe()
+                continue
             info = d._get_ddp_logging_data()
             sizes = [int(x) for x in str(info.get("rebuilt_bucket_sizes") or info.get("bucket_sizes") or "").replace(",", " ").split()]
             out["ddp"][name] = {"buckets": len(sizes), "bytes": sum(sizes), "backend": info.get("backend_name"),
@@ -738,8 +742,9 @@ def leg_joint(args, rank, world, dev, steps, warmup):
             "other (encoder BN / pooling / head passes, Sinkhorn, rasteriser, library GEMMs of the unfused layers, ATen glue, Adam)")
         other = None if no_vgg else other_breakdown(lambda: tr.step(batch), world)
         coll = None if no_vgg else collectives_of_a_step(
-            lambda: tr.step(batch), [("encoder", tr.reg.ddp), ("generator", getattr(tr.proj, "_ddpG", None)),
-                                     ("discriminator", getattr(tr.proj, "_ddpD", None))])
+            lambda: tr.step(batch), [("encoder", tr.reg.buckets or tr.reg.ddp),
+                                     ("generator", tr.proj.bucketsG or getattr(tr.proj, "_ddpG", None)),
+                                     ("discriminator", tr.proj.bucketsD or getattr(tr.proj, "_ddpD", None))])
         peak = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del tr
         _free_gpu()
@@ -854,7 +859,7 @@ def main():
     # live per-kernel timing: EVERY rank runs the instrumented steps (they contain DDP's all-reduce)
     fams = time_kernel_families(tr, batch, 2, args.batch, crop_hw) if "families" in legs else None
     peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
-    reg_coll = collectives_of_a_step(lambda: tr.step(batch), [("encoder", tr.ddp)])   # every rank steps; rank 0 reports
+    reg_coll = collectives_of_a_step(lambda: tr.step(batch), [("encoder", tr.buckets or tr.ddp)])   # every rank steps; rank 0 reports
     del tr, batch
     _free_gpu()
     # the other legs of BASELINE's metric; every rank takes part (DDP collectives inside), rank 0 reports

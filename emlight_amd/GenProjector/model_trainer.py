@@ -1,8 +1,8 @@
 """``Trainer`` of the projector (reference ``GenProjector/model_trainer.py``): one G step + one D step.
 
 The reference wraps the model in a single-process multi-thread ``DataParallelWithCallback``; here each GPU is
-its own process: G and D are wrapped in DistributedDataParallel (gradient all-reduce over RCCL/xGMI, G's
-473 MB in 25 MB buckets overlapped with backward); SPADE's param-free BatchNorm all-reduces its (2C+1)-float sums
+its own process: G's and D's gradients are all-reduced over RCCL/xGMI in 25 MB buckets overlapped with backward
+(``_dist.GradientBuckets``; ``EML_DP_BUCKETS=0``: DistributedDataParallel wrappers); SPADE's param-free BatchNorm all-reduces its (2C+1)-float sums
 itself (``spherenet.spade_batch_stats`` / the modulation's backward), which is what the vendored ``sync_batchnorm``
 package did."""
 import os
@@ -19,8 +19,15 @@ class Trainer:
         self.opt = opt
         self.model = Pix2PixModel(opt, vgg_features=vgg_features).to(device)
         self.world = world
-        from .._dist import dp_wrap
-        if dp_wrap(world):
+        from .._dist import dp_wrap, own_buckets, GradientBuckets
+        self.bucketsG = self.bucketsD = None
+        if dp_wrap(world) and own_buckets():
+            # the package's own reducer: a bucket is packed by one multi-tensor copy and all-reduced while backward continues
+            self.bucketsG = GradientBuckets(self.model.netG.parameters(), world, cap_mb=25, name="generator",
+                                            buffers=list(self.model.netG.buffers()))
+            self.bucketsD = GradientBuckets(self.model.netD.parameters(), world, cap_mb=25, name="discriminator",
+                                            buffers=list(self.model.netD.buffers()))
+        elif dp_wrap(world):
             ids = [torch.device(device).index] if str(device).startswith("cuda") else None
             # gradients live IN the all-reduce buckets (views): no copy of the reduced 473 MB back into .grad
             kw = dict(device_ids=ids, bucket_cap_mb=25, gradient_as_bucket_view=True)
@@ -34,10 +41,16 @@ class Trainer:
         self.old_lr = opt.lr
         self.g_losses, self.d_losses, self.generated = {}, {}, None
 
+    def reduce_gradients(self, which):
+        b = self.bucketsG if which == "G" else self.bucketsD
+        if b is not None:
+            b.finish()
+
     def run_generator_one_step(self, data):
         self.optimizer_G.zero_grad()
         g_losses, generated = self.model(data, mode="generator")
         sum(g_losses.values()).mean().backward()
+        self.reduce_gradients("G")
         self.optimizer_G.step()
         self.g_losses, self.generated = g_losses, generated
 
@@ -45,6 +58,7 @@ class Trainer:
         self.optimizer_D.zero_grad()
         d_losses = self.model(data, mode="discriminator")
         sum(d_losses.values()).mean().backward()
+        self.reduce_gradients("D")
         self.optimizer_D.step()
         self.d_losses = d_losses
 

@@ -69,7 +69,7 @@ class RegressionTrainer:
         ``sync_diameter``: derive the Sinkhorn eps-schedule from the range of the GLOBAL batch (2-float all-reduce per
         step) so that N ranks x B reproduce the single-process run with N*B samples (sinkhorn_divergence.py:9-18);
         default: on when world > 1 and no fixed ``diameter`` is given."""
-        from .._dist import dp_wrap
+        from .._dist import dp_wrap, own_buckets, GradientBuckets
         if sync_diameter is None:
             sync_diameter = dp_wrap(world) and diameter is None
         self.ln = anchors
@@ -78,8 +78,13 @@ class RegressionTrainer:
         self.model.train()
         self.sam_loss = sam_loss or SamplesLoss("sinkhorn", p=2, blur=blur, diameter=diameter, anchors=anchors,
                                                 sync_diameter=sync_diameter)
-        self.ddp = None
-        if dp_wrap(world):
+        self.ddp = self.buckets = None
+        if dp_wrap(world) and own_buckets():
+            # 37.3 MB of f32 gradients: the encoder's backward is ONE autograd node, so its one bucket is packed and reduced
+            # when that node returns (GradientBuckets: no per-parameter copies)
+            self.buckets = GradientBuckets(self.model.parameters(), world, cap_mb=bucket_cap_mb, name="encoder",
+                                           buffers=list(self.model.buffers()))
+        elif dp_wrap(world):
             # DenseNet BN stays per-rank (plain nn.BatchNorm2d in the reference); only the
             # 37.3 MB of f32 gradients cross xGMI, in one bucket overlapped with backward.
             self.ddp = torch.nn.parallel.DistributedDataParallel(
@@ -88,12 +93,18 @@ class RegressionTrainer:
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas,
                                           fused=self.device.type == "cuda")   # one launch instead of the foreach passes
 
+    def reduce_gradients(self):
+        """Between backward and the optimizer step: the gradients' all-reduce is complete (DDP: its hooks have done it)."""
+        if self.buckets is not None:
+            self.buckets.finish()
+
     def step(self, batch):
         net = self.ddp if self.ddp is not None else self.model
         pred = net(batch["crop"])
         loss, terms = regression_loss(pred, batch, self.sam_loss, self.ln)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        self.reduce_gradients()
         self.optimizer.step()
         self.last_pred = pred   # train.py visualises the training batch's own prediction (train.py:110-145)
         return loss, terms

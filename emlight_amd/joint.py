@@ -67,6 +67,8 @@ class JointTrainer:
         self.reg.optimizer.zero_grad(set_to_none=True)
         self.proj.optimizer_G.zero_grad()
         (l_reg + sum(g_losses.values()).mean()).backward()
+        self.reg.reduce_gradients()
+        self.proj.reduce_gradients("G")
         self.reg.optimizer.step()
         self.proj.optimizer_G.step()
         self.losses = {**terms, **g_losses}
@@ -80,6 +82,7 @@ class JointTrainer:
         self.proj.optimizer_D.zero_grad()
         d_losses = pm(data_d, mode="discriminator")
         sum(d_losses.values()).mean().backward()
+        self.proj.reduce_gradients("D")
         self.proj.optimizer_D.step()
         self.losses = {**self.losses, **d_losses}
         return d_losses

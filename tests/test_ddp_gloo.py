@@ -26,9 +26,10 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, buckets="1"):
     import sys
     sys.path.insert(0, ROOT)
+    os.environ["EML_DP_BUCKETS"] = buckets   # "1": the package's GradientBuckets; "0": torch's DistributedDataParallel
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -58,11 +59,13 @@ def _worker(rank, world, port, out_dir):
         dist.all_reduce(g)
         want.append(g / w)
 
-    # DDP step with lr = 0 grads inspection: run forward/backward through DDP, then compare
-    pred = tr.ddp(batch["crop"])
+    # forward / backward through the data-parallel path (DDP's wrapper or the model with GradientBuckets' hooks), then compare
+    assert (tr.ddp is None) == (buckets == "1") and (tr.buckets is not None) == (buckets == "1")
+    pred = (tr.ddp if tr.ddp is not None else tr.model)(batch["crop"])
     loss2, _ = regression_loss(pred, batch, tr.sam_loss, anchors)
     tr.optimizer.zero_grad(set_to_none=True)
     loss2.backward()
+    tr.reduce_gradients()
     worst = 0.0
     for q, g in zip(tr.model.parameters(), want):
         worst = max(worst, float((q.grad - g).abs().max() / (g.abs().max() + 1e-12)))
@@ -80,18 +83,20 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_training_step(tmp_path):
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_two_rank_gloo_training_step(tmp_path, buckets):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), buckets), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     assert r0[0] < 1e-5 and r1[0] < 1e-5, "DDP gradient != mean of per-rank gradients: %s %s" % (r0, r1)
     assert r0[1] == 0.0 and r1[1] == 0.0, "replicas diverged after one step"
     assert abs(r0[2] - r1[2]) < 1e-9 and r0[2] >= 0.2 - 1e-3, "timing must be the max over ranks: %s %s" % (r0, r1)
 
 
-def _projector_worker(rank, world, port, out_dir):
+def _projector_worker(rank, world, port, out_dir, buckets="1"):
     import sys
     sys.path.insert(0, ROOT)
+    os.environ["EML_DP_BUCKETS"] = buckets   # "1": the package's GradientBuckets; "0": torch's DistributedDataParallel
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -120,19 +125,21 @@ def _projector_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_gloo_projector_step(tmp_path):
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_two_rank_gloo_projector_step(tmp_path, buckets):
     """GenProjector trainer under DDP (G and D wrapped separately, model_trainer.py): one G step + one D step on two
     ranks with different shards leaves both replicas of both networks identical."""
     port = _free_port()
-    mp.spawn(_projector_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_projector_worker, args=(2, port, str(tmp_path), buckets), nprocs=2, join=True)
     p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
     assert p0[0] == 1.0 and p1[0] == 1.0, "non-finite projector losses"
     assert p0[1] == 0.0 and p0[2] == 0.0, "projector replicas diverged after one DDP step: %s" % p0
 
 
-def _joint_worker(rank, world, port, out_dir):
+def _joint_worker(rank, world, port, out_dir, buckets="1"):
     import sys
     sys.path.insert(0, ROOT)
+    os.environ["EML_DP_BUCKETS"] = buckets   # "1": the package's GradientBuckets; "0": torch's DistributedDataParallel
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -164,12 +171,13 @@ def _joint_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_gloo_joint_step(tmp_path):
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_two_rank_gloo_joint_step(tmp_path, buckets):
     """Joint regression+projector trainer (BASELINE configs[3]) under DDP on two ranks with different shards: the
     encoder, generator and discriminator replicas are identical after the iteration (three DDP-wrapped networks,
     the encoder's and the generator's gradients all-reduced inside ONE backward)."""
     port = _free_port()
-    mp.spawn(_joint_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_joint_worker, args=(2, port, str(tmp_path), buckets), nprocs=2, join=True)
     j0, j1 = np.load(tmp_path / "j0.npy"), np.load(tmp_path / "j1.npy")
     assert j0[0] == 1.0 and j1[0] == 1.0, "non-finite joint losses"
     assert j0[1] > 0 and j0[1] == j1[1], "DDP-averaged encoder gradients must be identical and non-zero on both ranks"

@@ -259,7 +259,8 @@ def _count_worker(rank, world, port, out_dir):
     real = dist.all_reduce
 
     def counting(t, *a, **k):
-        log.append((phase[0], str(t.dtype), t.numel()))
+        if not k.get("async_op"):          # (the asynchronous ones are GradientBuckets' gradient buckets, counted below)
+            log.append((phase[0], str(t.dtype), t.numel()))
         return real(t, *a, **k)
 
     def hook(name):
@@ -267,8 +268,20 @@ def _count_worker(rank, world, port, out_dir):
             buckets[name] += 1
             return default_hooks.allreduce_hook(state, bucket)
         return h
-    tr._ddpG.register_comm_hook(None, hook("G"))
-    tr._ddpD.register_comm_hook(None, hook("D"))
+
+    def counted_launch(name, red):
+        inner = red._launch
+
+        def launch(b):
+            buckets[name] += 1
+            return inner(b)
+        red._launch = launch
+    if tr.bucketsG is not None:            # the package's reducer (default) ...
+        counted_launch("G", tr.bucketsG)
+        counted_launch("D", tr.bucketsD)
+    else:                                  # ... or torch's DistributedDataParallel (EML_DP_BUCKETS=0)
+        tr._ddpG.register_comm_hook(None, hook("G"))
+        tr._ddpD.register_comm_hook(None, hook("D"))
     phase = ["warm"]
     tr.step(data)                      # builds DDP's buckets (the first iteration may rebuild them)
     dist.all_reduce = counting
@@ -350,7 +363,8 @@ def _rccl_single_worker(rank, dry_run, port, out_dir):
     dist.all_reduce = counting
     torch.manual_seed(0)
     tr = JointTrainer(networks.default_options(ngf=4, ndf=4), anchors=32, crop_hw=(64, 96), device="cuda:0", world=w)
-    assert (tr.reg.ddp is not None) == bool(dry_run) and hasattr(tr.proj, "_ddpG") == bool(dry_run)
+    assert (tr.reg.buckets is not None or tr.reg.ddp is not None) == bool(dry_run)
+    assert (tr.proj.bucketsG is not None or hasattr(tr.proj, "_ddpG")) == bool(dry_run)
     batch = joint_batch(2, "cuda:0", 32, (64, 96), seed=9)
     for _ in range(2):
         losses = tr.step(batch)
