@@ -997,6 +997,7 @@ class _SpectralW2Fn(torch.autograd.Function):
                                                   p(scratch), O, C, st), "eml_spectral_norm_w2_f32")
         ctx.save_for_backward(w2, uv, sigma)
         ctx.shape = (O, C)
+        ctx.wkey = (id(w), w.data_ptr())   # the parameter this gradient belongs to (its place in a gradient bucket, _dist.grad_slot)
         return w2
 
     @staticmethod
@@ -1007,7 +1008,10 @@ class _SpectralW2Fn(torch.autograd.Function):
         O, C = ctx.shape
         gw2 = gw2.contiguous()
         partial = torch.empty(256, dtype=torch.float64, device=gw2.device)
-        dw = torch.empty(O, C, 3, 3, dtype=torch.float32, device=gw2.device)
+        from .._dist import grad_slot
+        dw = grad_slot(ptr=ctx.wkey[1])    # data-parallel runs: straight into the all-reduce bucket (no packing copy)
+        if dw is None or tuple(dw.shape) != (O, C, 3, 3) or dw.device != gw2.device:
+            dw = torch.empty(O, C, 3, 3, dtype=torch.float32, device=gw2.device)
         _lib.check(L.eml_spectral_norm_w2_bwd_f32(p(gw2), p(w2), p(uv[:O]), p(uv[O:]), p(sigma), p(partial), p(dw), O, C, st),
                    "eml_spectral_norm_w2_bwd_f32")
         return dw, None, None, None, None, None

@@ -158,7 +158,11 @@ def _run_backward(enc, ws, x, gpooled):
                       tr_["Kp"], tr_["Ko"]))
     bw.permutes.launch(L, st, items)
     params = enc.param_list()
-    grads = {id(q): torch.empty_like(q) for q in params}
+    from .._dist import grad_slot
+    grads = {}
+    for q in params:   # data-parallel runs: the kernels write straight into the all-reduce bucket (no packing copy)
+        slot = grad_slot(q)
+        grads[id(q)] = slot if slot is not None else torch.empty_like(q)
     gr = lambda q: p(grads[id(q)])
     coefs = [tuple(bw.coef[3 * k + i] for i in range(3)) for k in range(2)]
     cA, cB, cC = coefs[0]

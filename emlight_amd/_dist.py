@@ -35,6 +35,30 @@ def own_buckets():
     return knob_flag("EML_DP_BUCKETS", True)
 
 
+_SLOTS = {}   # id(parameter) and ("ptr", data_ptr) -> (reducer, bucket index, index in the bucket)
+
+
+def grad_slot(param=None, ptr=None):
+    """Where a kernel that PRODUCES the gradient of a parameter may write it: a fresh view of the parameter's place in its
+    gradient bucket (returned by a backward, autograd adopts it as ``.grad`` without a copy and the bucket needs no packing for
+    it), or None -- no reducer, graph-building backward, or the place was already handed out in this backward (a module used
+    twice: autograd has to sum two tensors).  The producer must write every element."""
+    import torch
+    hit = _SLOTS.get(id(param)) if param is not None else None
+    if hit is None and ptr is not None:
+        hit = _SLOTS.get(("ptr", ptr))
+    if hit is None or torch.is_grad_enabled():
+        return None
+    red, bi, pi = hit
+    b = red.buckets[bi]
+    if b["flat"] is None or pi in b["taken"]:
+        return None
+    b["taken"].add(pi)
+    q = b["params"][pi]
+    o = b["offs"][pi]
+    return b["flat"][o:o + q.numel()].view(q.shape)
+
+
 class GradientBuckets:
     """The gradient all-reduce of one network, without DistributedDataParallel's per-parameter copies.
 
@@ -45,7 +69,9 @@ class GradientBuckets:
     (parameters in reverse registration order -- roughly the order their gradients become final -- up to ``cap_mb``) is packed
     by ONE multi-tensor copy when its last gradient has been accumulated (``register_post_accumulate_grad_hook``), divided by
     the world size and all-reduced asynchronously on RCCL's stream while backward continues; ``.grad`` of its parameters
-    then ARE views of the bucket (the optimizer reads the reduced values in place, nothing is copied back).  Buckets are
+    then ARE views of the bucket (the optimizer reads the reduced values in place, nothing is copied back).  The kernels that
+    produce the large gradients (spectral norm's backward, the encoder's backward) write them straight into their places
+    (``grad_slot``): those need no packing at all.  Buckets are
     launched strictly in index order on every rank.  ``finish()`` -- before the optimizer step -- launches what is left
     (a parameter without a gradient in this backward counts as zero: every rank runs the same graph) and makes the current
     stream wait for the collectives.  Like DDP, construction broadcasts rank 0's parameters."""
@@ -66,6 +92,8 @@ class GradientBuckets:
             size += n
         if cur:
             self._add(cur)
+        for b in self.buckets:
+            self._materialise(b)
         self.next = 0          # the next bucket to launch (strictly in order, so that every rank issues the same sequence)
         self.launched = []
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -76,7 +104,11 @@ class GradientBuckets:
 
     def _add(self, ps):
         self.where.update({id(p): len(self.buckets) for p in ps})
-        self.buckets.append({"params": list(ps), "pending": len(ps), "flat": None, "views": None, "work": None})
+        self.buckets.append({"params": list(ps), "pending": len(ps), "flat": None, "views": None, "work": None, "offs": None,
+                             "taken": set()})
+        for i, p in enumerate(ps):
+            if p.is_contiguous():
+                _SLOTS[id(p)] = _SLOTS[("ptr", p.data_ptr())] = (self, len(self.buckets) - 1, i)
 
     def _materialise(self, b):
         import torch
@@ -85,6 +117,7 @@ class GradientBuckets:
             offs.append(n)
             n += (p.numel() + 31) // 32 * 32        # every view starts on a 128-byte line
         p0 = b["params"][0]
+        b["offs"] = offs
         b["flat"] = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         b["views"] = [b["flat"][o:o + p.numel()].view(p.shape) for o, p in zip(offs, b["params"])]
 
@@ -114,9 +147,12 @@ class GradientBuckets:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
             if dp_active():
-                if dist.get_world_size() > 1:
-                    b["flat"].div_(dist.get_world_size())
-                b["work"] = dist.all_reduce(b["flat"], async_op=True)
+                if dist.get_backend() == "nccl":     # RCCL averages inside the collective: no division pass over the bucket
+                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG, async_op=True)
+                else:
+                    if dist.get_world_size() > 1:
+                        b["flat"].div_(dist.get_world_size())
+                    b["work"] = dist.all_reduce(b["flat"], async_op=True)
         self.launched.append(b)
 
     def finish(self):
@@ -132,6 +168,7 @@ class GradientBuckets:
         self.launched, self.next = [], 0
         for b in self.buckets:
             b["pending"] = len(b["params"])
+            b["taken"].clear()
 
     def describe(self):
         import torch.distributed as dist
