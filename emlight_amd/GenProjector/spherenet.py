@@ -540,6 +540,15 @@ def _sphere_conv_backward(ctx, gy, saved, needs):
                 _lib.check(L.eml_sphere_col2im_f32(p(da9), p(geo.csr_ptr), p(geo.csr_src), p(geo.csr_w), p(gxr), B,
                                                    H * W, po, C, st), "eml_sphere_col2im_f32")
         gx = gxr.permute(0, 3, 1, 2)
+    if gw is not None and weight.is_leaf:
+        # data-parallel runs, a weight that is a parameter itself (SPADE's heads, conv_img, the first discriminator layer):
+        # the re-layout to the parameter's own order -- which autograd would make anyway when it adopts a permuted view --
+        # lands in the parameter's place in its gradient bucket (_dist.grad_slot: nothing to pack)
+        from .._dist import grad_slot
+        slot = grad_slot(ptr=weight.data_ptr())
+        if slot is not None and slot.shape == gw.shape and slot.device == gw.device:
+            slot.copy_(gw)
+            gw = slot
     return gx, gw, gb, None, None, gres, None
 
 
