@@ -7,6 +7,7 @@ multi-rank iteration (gradient buckets, SPADE's synchronised BatchNorm sums, the
 device -- same results as without it (a one-rank all-reduce is the identity), but RCCL's initialisation, its kernels on the
 HIP stream and DDP's hooks have then run under this code before an 8-GPU node ever sees it."""
 import os
+import weakref
 
 
 def single_rank_dry_run():
@@ -49,8 +50,12 @@ def grad_slot(param=None, ptr=None):
         hit = _SLOTS.get(("ptr", ptr))
     if hit is None or torch.is_grad_enabled():
         return None
-    red, bi, pi = hit
+    red, bi, pi = hit[0](), hit[1], hit[2]
+    if red is None:          # its trainer is gone (the registry holds weak references; an address can be reused)
+        return None
     b = red.buckets[bi]
+    if param is None and b["params"][pi].data_ptr() != ptr:
+        return None
     if b["flat"] is None or pi in b["taken"]:
         return None
     b["taken"].add(pi)
@@ -79,6 +84,8 @@ class GradientBuckets:
     def __init__(self, params, world, cap_mb=64, name="", buffers=()):
         import torch
         import torch.distributed as dist
+        for k in [k for k, v in _SLOTS.items() if v[0]() is None]:   # places of trainers that no longer exist
+            del _SLOTS[k]
         self.name, self.world = name, int(world)
         self.params = [p for p in params if p.requires_grad]
         self.buckets, self.where = [], {}
@@ -108,7 +115,7 @@ class GradientBuckets:
                              "taken": set()})
         for i, p in enumerate(ps):
             if p.is_contiguous():
-                _SLOTS[id(p)] = _SLOTS[("ptr", p.data_ptr())] = (self, len(self.buckets) - 1, i)
+                _SLOTS[id(p)] = _SLOTS[("ptr", p.data_ptr())] = (weakref.ref(self), len(self.buckets) - 1, i)
 
     def _materialise(self, b):
         import torch
