@@ -16,7 +16,7 @@ _f64p = ctypes.c_void_p
 _stream = ctypes.c_void_p
 _int = ctypes.c_int
 
-ABI_VERSION = 28   # == EML_ABI_VERSION of include/emlight_hip.h
+ABI_VERSION = 29   # == EML_ABI_VERSION of include/emlight_hip.h
 
 # symbol -> (restype, argtypes): exactly the declarations of include/emlight_hip.h
 SIGNATURES = {
@@ -120,6 +120,7 @@ SIGNATURES = {
                                     _stream]),
     # DenseNet-BC encoder, forward
     "eml_dense_conv0_fwd_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
+    "eml_dense_conv0_fwd_mfma_f32": (_int, [_f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _f32p, _int, _stream]),
     "eml_dense_bn_apply_f32": (_int, [_f32p, _int, _f32p, _int, _int, ctypes.c_long, _f32p, _f32p, _int, _f32p,
                                       _int, _stream]),
     "eml_dense_bn_prepare_f32": (_int, [_f32p, _int, _int, _int, _int, ctypes.c_double, _f32p, _f32p, _f32p, _f32p,

@@ -573,6 +573,106 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   }
 }
 
+// conv0 on the matrix unit (round 6; opt-in, EML_CONV0_MFMA=1, train mode): D[o][p] = sum_k W0[o][k] in[k][p], k = (c, ky, kx) -- 27 of 28 -- in the D^T
+// form of the other kernels: A = W0 (two 16-row tiles: outputs 0..15 and 16..23), B = the 3x3x3 neighbourhood of 16 pixels,
+// lane (r, kk) supplying element k = 4 s + kk of pixel r at step s -- ONE 4-byte load per lane, step and 16 pixels (7 per 16
+// pixels instead of 27 per pixel), 14 MFMAs per 16 pixels instead of 648 FMAs per pixel each with its LDS weight operand
+// (the VALU kernel above is bound by those broadcast reads: 0.51 ms at 64 x 240 x 320).  A lane then holds channels
+// 4kk..4kk+3 (and 16+4kk.., kk < 2) of its pixel: 16-byte stores into the compact (P, 24) rows, BatchNorm sums by DPP row
+// reductions.  Not the default: the golden train step's sampled gradients are pinned with the VALU kernel's summation order
+// (0.033 instead of < 0.02 of a tensor's RMS gradient at one sampled entry: f32 conditioning).
+__global__ __launch_bounds__(256) void conv0_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                             float* __restrict__ X, int ldx, int B, int H, int W,
+                                                             double* __restrict__ partials) {
+  constexpr int C0 = 24, MT = 4;
+  __shared__ double wacc[4][C0][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < 4 * C0 * 2; e += 256) (&wacc[0][0][0])[e] = 0.0;
+  // weights: A[row r of tile j][k = 4 s + kk]
+  float wa[2][7];
+  int off[7], dy[7], dx[7];
+  const int plane = H * W;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + kk;
+    const bool kin = k < 27;
+    const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+    wa[0][s] = kin ? w0[r * 27 + k] : 0.f;
+    wa[1][s] = (kin && r < 8) ? w0[(16 + r) * 27 + k] : 0.f;
+    dy[s] = kin ? ky - 1 : 0;
+    dx[s] = kin ? kx - 1 : 0;
+    off[s] = kin ? c * plane + (ky - 1) * W + (kx - 1) : 0;
+    if (!kin) dy[s] = 1 << 20;   // never inside: the padded k contributes 0
+  }
+  __syncthreads();
+  const long P = (long)B * plane;
+  const long nt = (P + 64 * 4 - 1) / (64 * 4);   // a workgroup tile = 4 waves x 64 pixels
+  float ls[8], lq[8];
+  for (long tile = blockIdx.x; tile < nt; tile += gridDim.x) {
+    const long p0 = tile * 256 + wave * 64;
+    float bv[MT][7];
+    long pp[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const long p = p0 + 16 * m + r;
+      pv[m] = p < P;
+      pp[m] = pv[m] ? p : P - 1;
+      const int b = (int)(pp[m] / plane);
+      const int rem = (int)(pp[m] - (long)b * plane);
+      const int yy = rem / W, xx = rem - yy * W;
+      const float* base = x + (long)b * 3 * plane + rem;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        const int gy = yy + dy[s], gx = xx + dx[s];
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        bv[m][s] = in ? base[off[s]] : 0.f;
+      }
+    }
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][j] = mfma16(wa[j][s], bv[m][s], acc[m][j]);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ls[g] = lq[g] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (pv[m]) {
+        *reinterpret_cast<f32x4*>(X + pp[m] * ldx + 4 * kk) = acc[m][0];
+        if (kk < 2) *reinterpret_cast<f32x4*>(X + pp[m] * ldx + 16 + 4 * kk) = acc[m][1];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = pv[m] ? acc[m][0][g] : 0.f, v1 = pv[m] ? acc[m][1][g] : 0.f;
+        ls[g] += v0;
+        lq[g] = fmaf(v0, v0, lq[g]);
+        ls[4 + g] += v1;
+        lq[4 + g] = fmaf(v1, v1, lq[4 + g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float t1 = eml::row16_sum(ls[g]), t2 = eml::row16_sum(lq[g]);
+      const int ch = g < 4 ? 4 * kk + g : 16 + 4 * kk + (g - 4);
+      if (r == 0 && (g < 4 || kk < 2)) {
+        wacc[wave][ch][0] += (double)t1;
+        wacc[wave][ch][1] += (double)t2;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < C0 * 2; e += 256) {
+    const int oc = e >> 1, k = e & 1;
+    partials[(size_t)blockIdx.x * C0 * 2 + e] = (wacc[0][oc][k] + wacc[1][oc][k]) + (wacc[2][oc][k] + wacc[3][oc][k]);
+  }
+}
+
 // ------------------------------------------------------------------------------ BN apply (+ReLU) with stats of the result
 // dst[p][c] = act(scale[c]*src[p][c] + shift[c]) for c < C; emits f64 partial stats of dst.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
@@ -895,6 +995,17 @@ extern "C" int eml_dense_conv0_fwd_f32(const float* x, const float* w0, float* X
   if (C0 != 24) return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_f32: only num_init_features=24 is built (got %d)", C0);
   hipLaunchKernelGGL(conv0_fwd_kernel<24>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w0, X, ldx, B, H, W, partials);
   return eml::check_launch("eml_dense_conv0_fwd_f32");
+}
+
+extern "C" int eml_dense_conv0_fwd_mfma_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
+                                            int C0, double* partials, int grid, eml_stream_t stream) {
+  if (!x || !w0 || !X || !partials || B < 1 || H < 1 || W < 1 || grid < 1 || ldx < C0 || (ldx & 3) ||
+      ((uintptr_t)X & 15))
+    return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_mfma_f32: bad arguments");
+  if (C0 != 24) return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_mfma_f32: only num_init_features=24 is built (got %d)", C0);
+  if ((long)B * H * W * 3 > 2147483647L) return eml::fail(EML_EINVAL, "eml_dense_conv0_fwd_mfma_f32: input too large");
+  hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w0, X, ldx, B, H, W, partials);
+  return eml::check_launch("eml_dense_conv0_fwd_mfma_f32");
 }
 
 extern "C" int eml_dense_bn_apply_f32(const float* src, int ld_src, float* dst, int ld_dst, int C, long P,

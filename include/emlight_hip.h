@@ -36,7 +36,7 @@ typedef void* eml_stream_t; /* hipStream_t */
 
 /* Library ABI version (bumped on any signature change; the ctypes binding refuses a library built from another
  * version of this header) and last-error text. */
-#define EML_ABI_VERSION 28
+#define EML_ABI_VERSION 29
 int eml_abi_version(void);
 const char* eml_last_error(void);
 
@@ -157,6 +157,12 @@ int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, in
  * X[:, 0:C0] (ld = ldx); partials [grid][C0][2]. */
 int eml_dense_conv0_fwd_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
                             int C0, double* partials, int grid, eml_stream_t stream);
+/* the same layer on the matrix unit (ABI 29; opt-in, EML_CONV0_MFMA=1, train mode): the 3x3x3 neighbourhood of 16 pixels as
+ * the B operand of 14 v_mfma_f32_16x16x4_f32 (K = 27 of 28), one 4-byte load per lane and step; X 16-byte aligned.  Same
+ * values up to the order of the 27-term sums -- which is why it is not the default: the golden train step's sampled-gradient
+ * bound is pinned with eml_dense_conv0_fwd_f32's order. */
+int eml_dense_conv0_fwd_mfma_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
+                                 int C0, double* partials, int grid, eml_stream_t stream);
 
 /* dst[p][c] = act(scale[c]*src[p][c] + shift[c]), c < C (norm0+relu0, DenseNet.py:91-92; last_norm,
  * DenseNet.py:122); partials [grid][C][2] = stats of dst. */

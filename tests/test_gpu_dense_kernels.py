@@ -51,13 +51,17 @@ def nchw(t, B, H, W):  # (P, C) -> (B,C,H,W)
 
 
 # ------------------------------------------------------------------------------------------ forward
-def test_conv0_fwd_and_stats(lib):
+@pytest.mark.parametrize("entry,B,H,W,ld", [("eml_dense_conv0_fwd_f32", 2, 20, 44, 32), ("eml_dense_conv0_fwd_mfma_f32", 2, 20, 44, 32),
+                                            ("eml_dense_conv0_fwd_mfma_f32", 3, 17, 23, 24), ("eml_dense_conv0_fwd_mfma_f32", 1, 5, 3, 24)])
+def test_conv0_fwd_and_stats(lib, entry, B, H, W, ld):
+    """Both kernels of the layer (VALU: eval mode; matrix unit: train mode; ragged sizes: the last tile is partial, rows shorter
+    than a 16-pixel group) against F.conv2d in f64, with the BatchNorm sums of what was written."""
     L, p, st = lib.lib(), lib.ptr, lib.current_stream()
-    B, H, W, ld = 2, 20, 44, 32
     x, w0 = torch.rand(B, 3, H, W, device=DEV), rnd(24, 3, 3, 3, scale=0.3)
     Y = torch.zeros(B * H * W, ld, device=DEV)
     part = torch.zeros(G * 48, dtype=torch.float64, device=DEV)
-    lib.check(L.eml_dense_conv0_fwd_f32(p(x), p(w0), p(Y), ld, B, H, W, 24, p(part), G, st), "conv0")
+    lib.check(getattr(L, entry)(p(x), p(w0), p(Y), ld, B, H, W, 24, p(part), G, st), "conv0")
+    assert ld == 24 or float(Y[:, 24:].abs().max()) == 0.0
     want = nhwc(F.conv2d(x.double(), w0.double(), padding=1))
     close(Y[:, :24], want, what="conv0")
     s, q = fold_partials(part, G, 24)
