@@ -72,14 +72,15 @@ class GradientBuckets:
     (encoder 364 parameters, generator ~400, discriminator ~30: +5.9 ms of a 272 ms iteration with one rank,
     ``tools/scale_check.sh rccl``), i.e. a 2 % tax on every multi-GPU run before a byte has crossed xGMI.  Here a bucket
     (parameters in reverse registration order -- roughly the order their gradients become final -- up to ``cap_mb``) is packed
-    by ONE multi-tensor copy when its last gradient has been accumulated (``register_post_accumulate_grad_hook``), divided by
-    the world size and all-reduced asynchronously on RCCL's stream while backward continues; ``.grad`` of its parameters
-    then ARE views of the bucket (the optimizer reads the reduced values in place, nothing is copied back).  The kernels that
-    produce the large gradients (spectral norm's backward, the encoder's backward) write them straight into their places
-    (``grad_slot``): those need no packing at all.  Buckets are
-    launched strictly in index order on every rank.  ``finish()`` -- before the optimizer step -- launches what is left
-    (a parameter without a gradient in this backward counts as zero: every rank runs the same graph) and makes the current
-    stream wait for the collectives.  Like DDP, construction broadcasts rank 0's parameters."""
+    by ONE multi-tensor copy when its last gradient has been accumulated (``register_post_accumulate_grad_hook``) and averaged
+    over the ranks asynchronously on RCCL's stream while backward continues (``ReduceOp.AVG`` inside the collective; gloo: a
+    division pass, then SUM); ``.grad`` of its parameters then ARE views of the bucket (the optimizer reads the reduced values in
+    place, nothing is copied back).  The kernels that produce the large gradients (spectral norm's backward, the encoder's
+    backward) write them straight into their places (``grad_slot``): those need no packing at all.  Buckets are launched
+    strictly in index order on every rank.  ``finish()`` -- before the optimizer step -- launches what is left (a parameter
+    without a gradient in this backward counts as zero: every rank runs the same graph) and makes the current stream wait for
+    the collectives.  Like DDP, construction broadcasts rank 0's parameters (and buffers, once).  One backward per optimizer
+    step with ``zero_grad(set_to_none=True)`` in between, as the trainers do: there is no ``no_sync`` accumulation mode."""
 
     def __init__(self, params, world, cap_mb=64, name="", buffers=()):
         import torch
