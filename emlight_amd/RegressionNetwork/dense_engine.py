@@ -359,10 +359,10 @@ class HipDenseEncoder:
             items.append((T.conv.weight, tr["Wp"], 0, tr["Cout"], blk["Ctot"], tr["Kp"], 0))
         ws.fwd_permutes.launch(L, st, items)
         # ---- conv0 -> norm0 -> relu0 (DenseNet.py:88-93)
-        # EML_CONV0_MFMA=1 (train mode only): the layer on the matrix unit -- built, parity-green, -0.35 ms per step at 64 x 240 x 320,
-        # NOT the default: the other order of its 27-term sums moves one sampled gradient entry of the reference's golden train
-        # step from under 0.02 to 0.033 of the tensor's RMS gradient (f32 conditioning of 100 train-mode BN layers)
-        conv0 = ("eml_dense_conv0_fwd_mfma_f32" if training and knob_flag("EML_CONV0_MFMA", False) else "eml_dense_conv0_fwd_f32")
+        # conv0 on the matrix unit (round 6): outputs and BatchNorm partial sums bit for bit those of the VALU kernel (the MFMA adds
+        # its 27 terms in the fma chain's order; the sums are formed in that kernel's association), -0.35 ms per step;
+        # EML_CONV0_MFMA=0: the VALU kernel (A/B)
+        conv0 = "eml_dense_conv0_fwd_mfma_f32" if knob_flag("EML_CONV0_MFMA", True) else "eml_dense_conv0_fwd_f32"
         _lib.check(getattr(L, conv0)(p(x), p(f.conv0.weight), p(ws.Y0), self.c_init, B, H, W, self.c_init,
                                      p(part), G, st), conv0)
         self._prepare(L, st, part, G, 2 * self.c_init, self.c_init, 0, b0["P"], ws.mean0, ws.var0, ws.istd0, f.norm0,

@@ -573,14 +573,15 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   }
 }
 
-// conv0 on the matrix unit (round 6; opt-in, EML_CONV0_MFMA=1, train mode): D[o][p] = sum_k W0[o][k] in[k][p], k = (c, ky, kx) -- 27 of 28 -- in the D^T
+// conv0 on the matrix unit (round 6; the engine's default): D[o][p] = sum_k W0[o][k] in[k][p], k = (c, ky, kx) -- 27 of 28 -- in the D^T
 // form of the other kernels: A = W0 (two 16-row tiles: outputs 0..15 and 16..23), B = the 3x3x3 neighbourhood of 16 pixels,
 // lane (r, kk) supplying element k = 4 s + kk of pixel r at step s -- ONE 4-byte load per lane, step and 16 pixels (7 per 16
 // pixels instead of 27 per pixel), 14 MFMAs per 16 pixels instead of 648 FMAs per pixel each with its LDS weight operand
 // (the VALU kernel above is bound by those broadcast reads: 0.51 ms at 64 x 240 x 320).  A lane then holds channels
 // 4kk..4kk+3 (and 16+4kk.., kk < 2) of its pixel: 16-byte stores into the compact (P, 24) rows, BatchNorm sums by DPP row
-// reductions.  Not the default: the golden train step's sampled gradients are pinned with the VALU kernel's summation order
-// (0.033 instead of < 0.02 of a tensor's RMS gradient at one sampled entry: f32 conditioning).
+// reductions.  Bit for bit the VALU kernel's outputs and partial sums (v_mfma_f32_16x16x4_f32 adds its k terms in order, like
+// that kernel's fma chain over k = 0..26; the sums below follow its wave_sum's association): a first version whose sums were
+// merely as accurate moved the golden train step's sampled gradients from 0.011 to 0.033 of a tensor's RMS.
 __global__ __launch_bounds__(256) void conv0_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                              float* __restrict__ X, int ldx, int B, int H, int W,
                                                              double* __restrict__ partials) {
@@ -640,25 +641,37 @@ __global__ __launch_bounds__(256) void conv0_fwd_mfma_kernel(const float* __rest
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][j] = mfma16(wa[j][s], bv[m][s], acc[m][j]);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) ls[g] = lq[g] = 0.f;
-#pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (pv[m]) {
         *reinterpret_cast<f32x4*>(X + pp[m] * ldx + 4 * kk) = acc[m][0];
         if (kk < 2) *reinterpret_cast<f32x4*>(X + pp[m] * ldx + 16 + 4 * kk) = acc[m][1];
       }
+    }
+    // BatchNorm sums of the 64 pixels, in EXACTLY the association of the VALU kernel's wave_sum over lane = pixel (xor 32, 16,
+    // 8, 4, 2, 1; squares rounded before they are added): pixel 16 m + r, so xor 32 / 16 pair the m's and the rest runs inside
+    // the 16-lane row -- the partial sums, like the outputs (the MFMA adds its k terms in order), are bit for bit the same
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v0 = pv[m] ? acc[m][0][g] : 0.f, v1 = pv[m] ? acc[m][1][g] : 0.f;
-        ls[g] += v0;
-        lq[g] = fmaf(v0, v0, lq[g]);
-        ls[4 + g] += v1;
-        lq[4 + g] = fmaf(v1, v1, lq[4 + g]);
+    for (int g = 0; g < 8; ++g) {
+      float v[MT], q[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        v[m] = pv[m] ? acc[m][g >> 2][g & 3] : 0.f;
+        q[m] = v[m] * v[m];
       }
+      ls[g] = (v[0] + v[2]) + (v[1] + v[3]);
+      lq[g] = (q[0] + q[2]) + (q[1] + q[3]);
     }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const float t1 = eml::row16_sum(ls[g]), t2 = eml::row16_sum(lq[g]);
+      float t1 = ls[g], t2 = lq[g];
+      t1 += eml::dpp_mov<0x128>(t1);   // row_ror:8 = lane ^ 8 inside the row
+      t2 += eml::dpp_mov<0x128>(t2);
+      t1 += __shfl_xor(t1, 4, 64);
+      t2 += __shfl_xor(t2, 4, 64);
+      t1 += eml::dpp_mov<0x4E>(t1);    // lane ^ 2
+      t2 += eml::dpp_mov<0x4E>(t2);
+      t1 += eml::dpp_mov<0xB1>(t1);    // lane ^ 1
+      t2 += eml::dpp_mov<0xB1>(t2);
       const int ch = g < 4 ? 4 * kk + g : 16 + 4 * kk + (g - 4);
       if (r == 0 && (g < 4 || kk < 2)) {
         wacc[wave][ch][0] += (double)t1;

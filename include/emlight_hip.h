@@ -157,10 +157,10 @@ int eml_sinkhorn_bwd_f32(const float* gloss, const float* gunit, float* gout, in
  * X[:, 0:C0] (ld = ldx); partials [grid][C0][2]. */
 int eml_dense_conv0_fwd_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
                             int C0, double* partials, int grid, eml_stream_t stream);
-/* the same layer on the matrix unit (ABI 29; opt-in, EML_CONV0_MFMA=1, train mode): the 3x3x3 neighbourhood of 16 pixels as
- * the B operand of 14 v_mfma_f32_16x16x4_f32 (K = 27 of 28), one 4-byte load per lane and step; X 16-byte aligned.  Same
- * values up to the order of the 27-term sums -- which is why it is not the default: the golden train step's sampled-gradient
- * bound is pinned with eml_dense_conv0_fwd_f32's order. */
+/* the same layer on the matrix unit (ABI 29; the engine's default, EML_CONV0_MFMA=0: the entry above): the 3x3x3
+ * neighbourhood of 16 pixels as the B operand of 14 v_mfma_f32_16x16x4_f32 (K = 27 of 28), one 4-byte load per lane and step;
+ * X 16-byte aligned.  Outputs AND partials are bit for bit those of eml_dense_conv0_fwd_f32: the MFMA adds its k terms in
+ * order (that kernel's fma chain) and the sums are formed in the association of its wave reduction. */
 int eml_dense_conv0_fwd_mfma_f32(const float* x, const float* w0, float* X, int ldx, int B, int H, int W,
                                  int C0, double* partials, int grid, eml_stream_t stream);
 

@@ -52,7 +52,7 @@ def test_densenet_engine_calls_match_the_abi(recorder):
     net._hip._cu = 256
     out = net(torch.rand(2, 3, 32, 32))
     sum(v.sum() for v in out.values()).backward()
-    for name in ("eml_dense_conv0_fwd_f32", "eml_dense_conv1x1_fwd_f32", "eml_dense_conv3x3_fwd_f32", "eml_dense_pool_act_f32",
+    for name in ("eml_dense_conv0_fwd_mfma_f32", "eml_dense_conv1x1_fwd_f32", "eml_dense_conv3x3_fwd_f32", "eml_dense_pool_act_f32",
                  "eml_dense_conv3x3_bwd_data_f32", "eml_dense_conv3x3_bwd_weight_f32", "eml_dense_conv1x1_bwd_weight_f32",
                  "eml_dense_conv1x1_bwd_data_multi_f32", "eml_dense_conv1x1_bwd_data_f32",
                  "eml_dense_bn_bwd_finalize_f32", "eml_dense_grad_materialize_f32", "eml_dense_norm0_bwd_stats_f32",

@@ -69,6 +69,22 @@ def test_conv0_fwd_and_stats(lib, entry, B, H, W, ld):
     close(q, (want * want).sum(0), what="conv0 sumsq", rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 20, 44), (3, 17, 23), (2, 192, 256)])
+def test_conv0_on_the_matrix_unit_is_bit_identical_to_the_valu_kernel(lib, B, H, W):
+    """The MFMA adds the 27 terms of an output in order -- the VALU kernel's fma chain -- and the BatchNorm partial sums are
+    formed in the association of that kernel's wave_sum: outputs AND partial sums bit for bit."""
+    L, p, st = lib.lib(), lib.ptr, lib.current_stream()
+    x, w0 = torch.rand(B, 3, H, W, device=DEV), rnd(24, 3, 3, 3, scale=0.3)
+    out = []
+    for entry in ("eml_dense_conv0_fwd_f32", "eml_dense_conv0_fwd_mfma_f32"):
+        Y = torch.zeros(B * H * W, 24, device=DEV)
+        part = torch.zeros(G * 48, dtype=torch.float64, device=DEV)
+        lib.check(getattr(L, entry)(p(x), p(w0), p(Y), 24, B, H, W, 24, p(part), G, st), entry)
+        out.append((Y, part))
+    assert torch.equal(out[0][0], out[1][0]), float((out[0][0] - out[1][0]).abs().max())
+    assert torch.equal(out[0][1], out[1][1]), float((out[0][1] - out[1][1]).abs().max())
+
+
 @pytest.mark.parametrize("relu,C", [(1, 24), (0, 171), (0, 150)])
 def test_bn_apply_and_prepare(lib, relu, C):
     L, p, st = lib.lib(), lib.ptr, lib.current_stream()

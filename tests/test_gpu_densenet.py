@@ -252,27 +252,28 @@ def test_backward_small_vs_oracle(crop_hw, B):
     _grad_check(net, ref)
 
 
-def test_conv0_on_the_matrix_unit_opt_in_vs_oracle(monkeypatch):
-    """``EML_CONV0_MFMA=1`` (opt-in): a train-mode step with conv0's forward on the matrix unit against the oracle's
-    autograd -- the same bounds as the default path; the entry really is the one that ran."""
+def test_conv0_kernel_choice_does_not_change_a_training_step(monkeypatch):
+    """``EML_CONV0_MFMA=0 / 1`` (VALU kernel / matrix unit, the default): conv0's outputs and BatchNorm sums are bit-identical
+    (tests/test_gpu_dense_kernels.py), so a whole train-mode step is -- every head and every parameter gradient, bit for bit."""
     from emlight_amd import _lib
-    monkeypatch.setenv("EML_CONV0_MFMA", "1")
-    seen, real = [], _lib.lib().eml_dense_conv0_fwd_mfma_f32
-    ref, net = _pair(32, (64, 96), seed=5)
-    ref.train(), net.train()
-    g = np.random.default_rng([4, 2])
-    x = torch.from_numpy(g.random((2, 3, 64, 96), dtype=np.float32))
-    w = {k: torch.from_numpy(g.standard_normal(s).astype(np.float32))
-         for k, s in (("distribution", (2, 32)), ("intensity", (2, 1)), ("rgb_ratio", (2, 3)), ("ambient", (2, 3)))}
-    po = ref(x)
-    sum((po[k] * w[k]).sum() for k in KEYS).backward()
-    monkeypatch.setattr(_lib.lib(), "eml_dense_conv0_fwd_mfma_f32", lambda *a: (seen.append(1), real(*a))[1])
-    pg = net(x.cuda())
-    sum((pg[k] * w[k].cuda()).sum() for k in KEYS).backward()
-    assert seen == [1]
-    for k in KEYS:
-        np.testing.assert_allclose(pg[k].detach().cpu().numpy(), po[k].detach().numpy(), rtol=1e-5, atol=OUT_ATOL)
-    _grad_check(net, ref)
+    runs = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("EML_CONV0_MFMA", knob)
+        seen = []
+        for name in ("eml_dense_conv0_fwd_f32", "eml_dense_conv0_fwd_mfma_f32"):
+            real = getattr(_lib.lib(), name)
+            monkeypatch.setattr(_lib.lib(), name, (lambda r, n: lambda *a: (seen.append(n), r(*a))[1])(real, name))
+        _, net = _pair(32, (64, 96), seed=5)
+        net.train()
+        g = np.random.default_rng([4, 2])
+        x = torch.from_numpy(g.random((2, 3, 64, 96), dtype=np.float32)).cuda()
+        out = net(x)
+        sum(v.square().sum() for v in out.values()).backward()
+        assert seen == ["eml_dense_conv0_fwd_mfma_f32" if knob == "1" else "eml_dense_conv0_fwd_f32"]
+        runs.append(([out[k].detach().clone() for k in KEYS], [q.grad.clone() for q in net.parameters()]))
+        monkeypatch.undo()
+    for a, b in zip(runs[0][0] + runs[0][1], runs[1][0] + runs[1][1]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("block_config,num_init", [((8, 5, 4), 24), ((2, 7, 4), 24), ((2, 2, 2), 24)])
