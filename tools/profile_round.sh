@@ -27,7 +27,7 @@ rm -rf /tmp/kst
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- python $REPO/bench.py --steps 3 --warmup 1 --no_cpu_baseline --legs families,sinkhorn,rasteriser > $OUT/${TAG}_kst.log 2>&1
 cp $(find /tmp/kst -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # one steady-state iteration (the 3rd of the trace) from the per-dispatch trace: the table to read per-step times from
-python $REPO/tools/steady_step.py $(find /tmp/kst -name '*kernel_trace.csv' | head -1) conv0_fwd_kernel 1 2 > $OUT/${TAG}_bench_steady_step.csv
+python $REPO/tools/steady_step.py $(find /tmp/kst -name '*kernel_trace.csv' | head -1) conv0_fwd_ 1 2 > $OUT/${TAG}_bench_steady_step.csv
 if [ -z "$SKIP_PROJ" ]; then
   for WL in projector joint; do
     rm -rf /tmp/kst_$WL
@@ -35,7 +35,7 @@ if [ -z "$SKIP_PROJ" ]; then
     cp $(find /tmp/kst_$WL -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_${WL}_kernel_stats.csv
     # the 3rd iteration of the trace = the 2nd timed step of the variant WITH the VGG term (markers: the encoder's first kernel /
     # the fold of the fused L1 terms, which a projector step launches twice: feature matching, VGG)
-    if [ $WL = joint ]; then MK="conv0_fwd_kernel 1"; else MK="l1_pairs_fold_kernel 2"; fi
+    if [ $WL = joint ]; then MK="conv0_fwd_ 1"; else MK="l1_pairs_fold_kernel 2"; fi
     python $REPO/tools/steady_step.py $(find /tmp/kst_$WL -name '*kernel_trace.csv' | head -1) $MK 2 > $OUT/${TAG}_${WL}_steady_step.csv
   done
 fi
