@@ -362,7 +362,8 @@ class HipDenseEncoder:
         # conv0 on the matrix unit (round 6): outputs and BatchNorm partial sums bit for bit those of the VALU kernel (the MFMA adds
         # its 27 terms in the fma chain's order; the sums are formed in that kernel's association), -0.35 ms per step;
         # EML_CONV0_MFMA=0: the VALU kernel (A/B)
-        conv0 = "eml_dense_conv0_fwd_mfma_f32" if knob_flag("EML_CONV0_MFMA", True) else "eml_dense_conv0_fwd_f32"
+        conv0 = ("eml_dense_conv0_fwd_mfma_f32" if knob_flag("EML_CONV0_MFMA", True) and 3 * B * H * W < 2 ** 31   # (32-bit offsets)
+                 else "eml_dense_conv0_fwd_f32")
         _lib.check(getattr(L, conv0)(p(x), p(f.conv0.weight), p(ws.Y0), self.c_init, B, H, W, self.c_init,
                                      p(part), G, st), conv0)
         self._prepare(L, st, part, G, 2 * self.c_init, self.c_init, 0, b0["P"], ws.mean0, ws.var0, ws.istd0, f.norm0,
